@@ -1,0 +1,144 @@
+"""Seeded synthetic frame generators for BASELINE.json's configs (own code).
+
+The FSG-2019 recording the reference's demo replays is absent from the checkout
+(/root/reference/.MISSING_LARGE_BLOBS:1-2), so configs 2-4 are built from a closed,
+Fourier-perturbed loop: 3 m track width, ~4.5 m cone spacing.
+
+A *frame* = (cones by type, vehicle position, vehicle direction), i.e. exactly the
+arguments of ``PathPlanner.calculate_path_in_global_frame`` (reference
+full_pipeline/full_pipeline.py:84-101).  The batched layout is the reference's own
+flattened ``(N,3) [x, y, type]`` array (sorting_cones/trace_sorter/core_trace_sorter.py:37-54)
+concatenated frame-major with a CSR ``cone_offsets`` array.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+UNKNOWN, RIGHT, LEFT, ORANGE_SMALL, ORANGE_BIG = 0, 1, 2, 3, 4
+
+
+def closed_track(n_per_side: int, seed: int, width: float = 3.0, spacing: float = 4.5):
+    """Centreline + left/right cone rows of a closed loop.
+
+    Returns (left (n,2), right (n,2), centre_fn) where ``centre_fn(s)`` maps arc
+    fraction s in [0,1) to (position (2,), unit tangent (2,)).
+    """
+    rng = np.random.default_rng(seed)
+    circumference = n_per_side * spacing
+    r0 = circumference / (2 * np.pi)
+    # low-order Fourier perturbation of the radius; amplitudes small enough that the
+    # curvature radius stays > ~9 m (FS rules) for n_per_side >= 48
+    amp = rng.uniform(0.04, 0.10, size=3) * r0
+    phase = rng.uniform(0, 2 * np.pi, size=3)
+    orders = np.array([2, 3, 5])
+
+    def radius(phi):
+        phi = np.asarray(phi, dtype=float)
+        return r0 + (amp * np.cos(np.multiply.outer(phi, orders) + phase)).sum(axis=-1)
+
+    def dradius(phi):
+        phi = np.asarray(phi, dtype=float)
+        return (-amp * orders * np.sin(np.multiply.outer(phi, orders) + phase)).sum(axis=-1)
+
+    def centre(phi):
+        r = radius(phi)
+        dr = dradius(phi)
+        c, s = np.cos(phi), np.sin(phi)
+        pos = np.stack([r * c, r * s], axis=-1)
+        tan = np.stack([dr * c - r * s, dr * s + r * c], axis=-1)
+        tan = tan / np.linalg.norm(tan, axis=-1, keepdims=True)
+        return pos, tan
+
+    # equal-arc-length parameter table (counter-clockwise => left cones are inside)
+    phi_dense = np.linspace(0, 2 * np.pi, 20001)
+    pos_dense, _ = centre(phi_dense)
+    seg = np.linalg.norm(np.diff(pos_dense, axis=0), axis=1)
+    arc = np.concatenate([[0.0], np.cumsum(seg)])
+    total = arc[-1]
+
+    def centre_fn(s):
+        s = np.asarray(s, dtype=float) % 1.0
+        phi = np.interp(s * total, arc, phi_dense)
+        return centre(phi)
+
+    s_cones = np.arange(n_per_side) / n_per_side
+    pos, tan = centre_fn(s_cones)
+    normal = np.stack([-tan[:, 1], tan[:, 0]], axis=-1)  # left of travel direction
+    left = pos + normal * (width / 2)
+    right = pos - normal * (width / 2)
+    return left, right, centre_fn
+
+
+def _pack(frames_cones: List[np.ndarray], poses: np.ndarray):
+    offsets = np.zeros(len(frames_cones) + 1, dtype=np.int32)
+    offsets[1:] = np.cumsum([len(c) for c in frames_cones])
+    cones = np.ascontiguousarray(np.concatenate(frames_cones, axis=0), dtype=np.float64)
+    return offsets, cones, np.ascontiguousarray(poses, dtype=np.float64)
+
+
+def make_replay_batch(
+    n_frames: int,
+    n_per_side: int = 64,
+    track_noise: float = 0.15,
+    seed: int = 1,
+    color: bool = True,
+    frame_noise: float = 0.0,
+    random_pose: bool = False,
+    lateral_noise: float = 0.0,
+    heading_noise: float = 0.0,
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """BASELINE configs 2/3/4.
+
+    cfg 2: ``make_replay_batch(4096, 64, 0.15, seed=1, color=True)``
+    cfg 3: same with ``color=False`` (all cones UNKNOWN, per-frame permutation; mirrors
+           the reference demo's ``remove_color_info``, demo/json_demo.py:266-273)
+    cfg 4: ``make_replay_batch(65536, 100, 0.0, seed=7, frame_noise=0.1, random_pose=True)``
+
+    Returns ``(cone_offsets int32 (F+1,), cones_xyt f64 (total,3), poses f64 (F,4))`` with
+    pose rows ``[px, py, dx, dy]``.
+    """
+    rng = np.random.default_rng(seed)
+    left, right, centre_fn = closed_track(n_per_side, seed)
+    left = left + rng.normal(0, track_noise, left.shape) if track_noise > 0 else left
+    right = right + rng.normal(0, track_noise, right.shape) if track_noise > 0 else right
+
+    if random_pose:
+        s = rng.uniform(0, 1, n_frames)
+    else:
+        s = np.arange(n_frames) / n_frames
+    pos, tan = centre_fn(s)
+    if lateral_noise > 0:
+        normal = np.stack([-tan[:, 1], tan[:, 0]], axis=-1)
+        pos = pos + normal * rng.normal(0, lateral_noise, (n_frames, 1))
+    if heading_noise > 0:
+        a = np.arctan2(tan[:, 1], tan[:, 0]) + rng.normal(0, heading_noise, n_frames)
+        tan = np.stack([np.cos(a), np.sin(a)], axis=-1)
+    poses = np.concatenate([pos, tan], axis=1)
+
+    frames = []
+    for f in range(n_frames):
+        l, r = left, right
+        if frame_noise > 0:
+            l = l + rng.normal(0, frame_noise, l.shape)
+            r = r + rng.normal(0, frame_noise, r.shape)
+        if color:
+            # reference flatten order: UNKNOWN, RIGHT, LEFT, ORANGE_S, ORANGE_B
+            xyt = np.concatenate(
+                [
+                    np.column_stack([r, np.full(len(r), float(RIGHT))]),
+                    np.column_stack([l, np.full(len(l), float(LEFT))]),
+                ]
+            )
+        else:
+            xy = np.concatenate([r, l])
+            xy = xy[rng.permutation(len(xy))]
+            xyt = np.column_stack([xy, np.zeros(len(xy))])
+        frames.append(xyt)
+    return _pack(frames, poses)
+
+
+def split_by_type(xyt: np.ndarray) -> List[np.ndarray]:
+    """(N,3) flattened cones -> list of 5 (n,2) arrays indexed by ConeTypes value."""
+    return [np.ascontiguousarray(xyt[xyt[:, 2] == t, :2]) for t in range(5)]

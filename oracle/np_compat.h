@@ -1,0 +1,178 @@
+// TEST INFRASTRUCTURE — CPU oracle for the PathPlanner hot path.  Never shipped, never
+// imported by the product package (ft-fsd-path-planning_amd/); only tests/, bench.py's
+// cpu_baseline leg and __graft_entry__.smoke() may load the library built from oracle/.
+//
+// np_compat.h: small helpers that restate the NumPy semantics the reference relies on
+// (summation order, arange/linspace fill rules, Python min/max with NaN, floored modulo).
+// Each helper names the NumPy behaviour it mirrors; none of this is reference source.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace fsdo {
+
+struct Vec2 {
+  double x, y;
+};
+
+// Exceptions mirroring the Python control flow of the reference.
+//  PyValueError  : raised where the reference raises ValueError (or a subclass such as
+//                  numpy.linalg.LinAlgError) — caught by the same try/except sites
+//                  (calculate_path/core_calculate_path.py:214-221, :561-570).
+//  RefUndefined  : the reference raises an exception that propagates out of
+//                  calculate_path_in_global_frame (IndexError etc., SURVEY.md §8a quirks
+//                  8/10) or would corrupt memory under numba.  Carries a status code.
+struct PyValueError {
+  int where;
+};
+struct RefUndefined {
+  int code;
+};
+
+static const double PI = 3.14159265358979323846;  // == numpy.pi
+
+inline double deg2rad(double d) { return d * (PI / 180.0); }  // numpy.deg2rad: x * (pi/180)
+
+// numpy pairwise summation (numpy/core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum):
+// n < 8 sequential; n <= 128 eight-way unrolled; otherwise recursive halves.
+inline double np_pairwise(const double* a, long n, long stride = 1) {
+  if (n < 8) {
+    double res = 0.;
+    for (long i = 0; i < n; i++) res += a[i * stride];
+    return res;
+  } else if (n <= 128) {
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j * stride];
+    long i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; j++) r[j] += a[(i + j) * stride];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i * stride];
+    return res;
+  } else {
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2, stride) + np_pairwise(a + n2 * stride, n - n2, stride);
+  }
+}
+// add.reduce over a contiguous/strided 1-D run: identity 0 + pairwise
+inline double np_sum(const double* a, long n, long stride = 1) { return 0.0 + np_pairwise(a, n, stride); }
+inline double np_sum(const std::vector<double>& v) { return np_sum(v.data(), (long)v.size()); }
+
+// Python's builtin max/min on floats (first argument wins unless the other compares
+// strictly greater/smaller) — matters only for NaN propagation.
+inline double py_max(double a, double b) { return (b > a) ? b : a; }
+inline double py_min(double a, double b) { return (b < a) ? b : a; }
+
+// numpy float remainder for positive divisor (npy_divmod): fmod then sign fix-up.
+inline double np_mod(double a, double b) {
+  double m = std::fmod(a, b);
+  if (m != 0.0) {
+    if ((b < 0) != (m < 0)) m += b;
+  } else {
+    m = std::copysign(0.0, b);
+  }
+  return m;
+}
+// utils/math_utils.py:663-676 and trace_sorter/end_configurations.py:303-317
+inline double angle_difference(double a1, double a2) { return np_mod(a1 - a2 + 3 * PI, 2 * PI) - PI; }
+
+inline double np_sign(double v) { return (v > 0) ? 1.0 : ((v < 0) ? -1.0 : (v == 0 ? 0.0 : v)); }
+
+// --- BLAS-backed NumPy calls -----------------------------------------------------------------
+// np.dot (hence utils/math_utils.py rotate / my_cdist_sq_euclidean) and np.linalg.norm of a
+// 1-D vector (sqrt(dot(x,x))) go through OpenBLAS.  On the machine the golden vectors were
+// captured on (AVX-512, OpenBLAS SkylakeX kernels) every such inner product is accumulated
+// as a fused-multiply-add chain in k order:  acc = a0*b0; acc = fma(a_k, b_k, acc)
+// (checked against np.dot on 20k random operands: 100 % agreement for ddot/dgemv/dgemm, see
+// tests/test_oracle_numpy_semantics.py).  fma() is exact by IEEE-754, so the restatement is
+// portable; on a BLAS without FMA the reference itself would differ in the last bit.
+inline double blas_dot2(double a0, double b0, double a1, double b1) { return std::fma(a1, b1, a0 * b0); }
+
+// np.linalg.norm of a 1-D 2-vector: sqrt(x.dot(x))  (BLAS ddot)
+inline double norm2(double x, double y) { return std::sqrt(blas_dot2(x, x, y, y)); }
+// np.linalg.norm(v, axis=-1) on an (n,2) array: sqrt(add.reduce(v*v)) — not BLAS
+inline double norm2_axis(double x, double y) { return std::sqrt(x * x + y * y); }
+
+// utils/math_utils.py:70-100 vec_angle_between for one pair of 2-vectors:
+//   cos = sum(v1*v2); cos /= (sqrt(sum(v1*v1)) * sqrt(sum(v2*v2))); clip; arccos
+inline double vec_angle_between(double ax, double ay, double bx, double by) {
+  double c = ax * bx + ay * by;
+  c /= std::sqrt(ax * ax + ay * ay) * std::sqrt(bx * bx + by * by);
+  if (c < -1) c = -1;
+  if (c > 1) c = 1;
+  return std::acos(c);
+}
+
+// utils/math_utils.py:103-117 rotate: points @ [[c,-s],[s,c]].T
+struct Rot {
+  double c, s;
+  explicit Rot(double theta) : c(std::cos(theta)), s(std::sin(theta)) {}
+  // points @ [[c, s], [-s, c]]  (BLAS gemm/gemv, K = 2)
+  inline Vec2 apply(double x, double y) const { return Vec2{blas_dot2(x, c, y, -s), blas_dot2(x, s, y, c)}; }
+};
+
+// utils/math_utils.py:120-150 my_cdist_sq_euclidean, one entry: the expansion form
+// [1,1,ax,ay,ax^2,ay^2] . [bx^2,by^2,-2bx,-2by,1,1] handed to BLAS dgemm (K = 6): an FMA
+// chain in k order, see the BLAS note above.
+inline double cdist_sq(double ax, double ay, double bx, double by) {
+  double acc = 1.0 * (bx * bx);
+  acc = std::fma(1.0, by * by, acc);
+  acc = std::fma(ax, -2 * bx, acc);
+  acc = std::fma(ay, -2 * by, acc);
+  acc = std::fma(ax * ax, 1.0, acc);
+  acc = std::fma(ay * ay, 1.0, acc);
+  return acc;
+}
+
+// numpy.arange(0, stop, step) for Python floats: length ceil(stop/step), value i*step
+inline long arange_len(double stop, double step) {
+  double q = stop / step;
+  if (!(q > 0)) return 0;
+  return (long)std::ceil(q);
+}
+
+// stable argsort of a short array (NumPy's default sort is insertion sort for n<=16 and
+// otherwise only differs from stable on exact ties)
+inline std::vector<int> argsort(const std::vector<double>& v) {
+  std::vector<int> idx(v.size());
+  for (size_t i = 0; i < v.size(); i++) idx[i] = (int)i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return v[a] < v[b]; });
+  return idx;
+}
+
+// sign of det([[1,x0,y0],[1,x1,y1],[1,x2,y2]]) the way numpy.linalg.det gets it:
+// LAPACK dgetrf (partial pivoting, column-major), product of the diagonal, sign flips.
+inline double det3_lu(const double m_in[3][3]) {
+  double a[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) a[i][j] = m_in[i][j];
+  double det = 1.0;
+  int sign = 1;
+  for (int k = 0; k < 3; k++) {
+    int p = k;
+    double best = std::fabs(a[k][k]);
+    for (int i = k + 1; i < 3; i++)
+      if (std::fabs(a[i][k]) > best) {
+        best = std::fabs(a[i][k]);
+        p = i;
+      }
+    if (a[p][k] == 0.0) return 0.0;
+    if (p != k) {
+      for (int j = 0; j < 3; j++) std::swap(a[p][j], a[k][j]);
+      sign = -sign;
+    }
+    double inv = 1.0 / a[k][k];
+    for (int i = k + 1; i < 3; i++) a[i][k] *= inv;
+    for (int j = k + 1; j < 3; j++)
+      for (int i = k + 1; i < 3; i++) a[i][j] -= a[i][k] * a[k][j];
+  }
+  // numpy: sign * prod(diag) accumulated as acc_sign / acc_logdet-free product for det()
+  for (int k = 0; k < 3; k++) det *= a[k][k];
+  return sign * det;
+}
+
+}  // namespace fsdo

@@ -1,0 +1,188 @@
+// TEST INFRASTRUCTURE (oracle) — C entry points.  Orchestration restates
+// full_pipeline/full_pipeline.py:84-207 (mission without relocalizer: sorting -> matching -> path).
+#include <cstring>
+#include <thread>
+#include <atomic>
+#include <cmath>
+
+#include "oracle_internal.h"
+
+using namespace fsdo;
+
+static Frame make_frame(const double* xyt, int n, const double* pose) {
+  Frame f;
+  f.n = n;
+  f.x.resize(n);
+  f.y.resize(n);
+  f.type.resize(n);
+  for (int i = 0; i < n; i++) {
+    f.x[i] = xyt[3 * i];
+    f.y[i] = xyt[3 * i + 1];
+    f.type[i] = (int)xyt[3 * i + 2];
+  }
+  f.px = pose[0];
+  f.py = pose[1];
+  f.dx = pose[2];
+  f.dy = pose[3];
+  return f;
+}
+
+static void clear_result(fsdo_frame_result* o) {
+  std::memset(o, 0, sizeof(*o));
+  for (int i = 0; i < FSDO_MAX_LEN; i++) o->left_idx[i] = o->right_idx[i] = -1;
+  for (int i = 0; i < FSDO_MAX_MATCH; i++) o->l2r[i] = o->r2l[i] = -1;
+  o->first_k_left[0] = o->first_k_left[1] = o->first_k_right[0] = o->first_k_right[1] = -1;
+  o->best_cost_left = o->best_cost_right = NAN;
+  for (int i = 0; i < FSDO_PATH_POINTS; i++)
+    for (int j = 0; j < 4; j++) o->path[i][j] = NAN;
+}
+
+static void fill_sort(const std::vector<int>& l, const std::vector<int>& r, const SideResult& L, const SideResult& R,
+                      fsdo_frame_result* o) {
+  o->n_left = (int)l.size();
+  o->n_right = (int)r.size();
+  for (size_t i = 0; i < l.size(); i++) o->left_idx[i] = l[i];
+  for (size_t i = 0; i < r.size(); i++) o->right_idx[i] = r[i];
+  o->n_configs_left = L.has ? (int)L.configs.size() : 0;
+  o->n_configs_right = R.has ? (int)R.configs.size() : 0;
+  for (int i = 0; i < 2; i++) {
+    o->first_k_left[i] = L.first_k[i];
+    o->first_k_right[i] = R.first_k[i];
+  }
+  if (L.has) o->best_cost_left = L.costs[0];
+  if (R.has) o->best_cost_right = R.costs[0];
+}
+
+static void fill_match(const Pts& lv, const Pts& rv, const std::vector<int>& l2r, const std::vector<int>& r2l,
+                       fsdo_frame_result* o) {
+  if (lv.size() > FSDO_MAX_MATCH || rv.size() > FSDO_MAX_MATCH) throw RefUndefined{FSDO_REF_UNDEFINED_OTHER};
+  o->n_left_v = (int)lv.size();
+  o->n_right_v = (int)rv.size();
+  for (size_t i = 0; i < lv.size(); i++) {
+    o->left_v[i][0] = lv[i].x;
+    o->left_v[i][1] = lv[i].y;
+    o->l2r[i] = l2r[i];
+  }
+  for (size_t i = 0; i < rv.size(); i++) {
+    o->right_v[i][0] = rv[i].x;
+    o->right_v[i][1] = rv[i].y;
+    o->r2l[i] = r2l[i];
+  }
+}
+
+extern "C" {
+
+void fsdo_sort_frame(const double* xyt, int n, const double* pose, fsdo_frame_result* o) {
+  clear_result(o);
+  try {
+    Frame f = make_frame(xyt, n, pose);
+    std::vector<int> l, r;
+    SideResult L, R;
+    sort_frame(f, l, r, &L, &R);
+    fill_sort(l, r, L, R, o);
+  } catch (RefUndefined& e) {
+    o->status = e.code;
+  }
+}
+
+void fsdo_match(const double* left, int nl, const double* right, int nr, const double* pose, fsdo_frame_result* o) {
+  clear_result(o);
+  try {
+    Pts L(nl), R(nr), lv, rv;
+    for (int i = 0; i < nl; i++) L[i] = Vec2{left[2 * i], left[2 * i + 1]};
+    for (int i = 0; i < nr; i++) R[i] = Vec2{right[2 * i], right[2 * i + 1]};
+    std::vector<int> l2r, r2l;
+    match_cones(L, R, Vec2{pose[0], pose[1]}, lv, rv, l2r, r2l);
+    fill_match(lv, rv, l2r, r2l, o);
+  } catch (RefUndefined& e) {
+    o->status = e.code;
+  }
+}
+
+void fsdo_path(const double* left_v, int nl, const double* right_v, int nr, const int32_t* l2r, const int32_t* r2l,
+               const double* pose, fsdo_frame_result* o) {
+  clear_result(o);
+  try {
+    Pts L(nl), R(nr);
+    for (int i = 0; i < nl; i++) L[i] = Vec2{left_v[2 * i], left_v[2 * i + 1]};
+    for (int i = 0; i < nr; i++) R[i] = Vec2{right_v[2 * i], right_v[2 * i + 1]};
+    std::vector<int> a(l2r, l2r + nl), b(r2l, r2l + nr);
+    PathOut po;
+    calculate_path(L, R, a, b, Vec2{pose[0], pose[1]}, Vec2{pose[2], pose[3]}, po);
+    std::memcpy(o->path, po.p, sizeof(po.p));
+    o->path_fallback = po.fallback;
+  } catch (RefUndefined& e) {
+    o->status = e.code;
+  } catch (PyValueError&) {
+    o->status = FSDO_REF_UNDEFINED_PATH;
+  }
+}
+
+void fsdo_plan_frame(const double* xyt, int n, const double* pose, fsdo_frame_result* o) {
+  clear_result(o);
+  try {
+    Frame f = make_frame(xyt, n, pose);
+    std::vector<int> l, r;
+    SideResult L, R;
+    sort_frame(f, l, r, &L, &R);
+    fill_sort(l, r, L, R, o);
+    Pts sl(l.size()), sr(r.size()), lv, rv;
+    for (size_t i = 0; i < l.size(); i++) sl[i] = Vec2{f.x[l[i]], f.y[l[i]]};
+    for (size_t i = 0; i < r.size(); i++) sr[i] = Vec2{f.x[r[i]], f.y[r[i]]};
+    std::vector<int> l2r, r2l;
+    match_cones(sl, sr, Vec2{f.px, f.py}, lv, rv, l2r, r2l);
+    fill_match(lv, rv, l2r, r2l, o);
+    PathOut po;
+    calculate_path(lv, rv, l2r, r2l, Vec2{f.px, f.py}, Vec2{f.dx, f.dy}, po);
+    std::memcpy(o->path, po.p, sizeof(po.p));
+    o->path_fallback = po.fallback;
+  } catch (RefUndefined& e) {
+    o->status = e.code;
+  } catch (PyValueError&) {
+    o->status = FSDO_REF_UNDEFINED_PATH;
+  }
+}
+
+void fsdo_plan_batch(int n_frames, const int32_t* off, const double* xyt, const double* poses, fsdo_frame_result* out,
+                     int n_threads) {
+  default_previous_path();
+  if (n_threads <= 1) {
+    for (int i = 0; i < n_frames; i++) fsdo_plan_frame(xyt + 3 * (size_t)off[i], off[i + 1] - off[i], poses + 4 * (size_t)i, &out[i]);
+    return;
+  }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++)
+    th.emplace_back([&]() {
+      for (;;) {
+        int i = next.fetch_add(1);
+        if (i >= n_frames) break;
+        fsdo_plan_frame(xyt + 3 * (size_t)off[i], off[i + 1] - off[i], poses + 4 * (size_t)i, &out[i]);
+      }
+    });
+  for (auto& t : th) t.join();
+}
+
+void fsdo_default_path(double* out) { std::memcpy(out, default_previous_path(), sizeof(double) * FSDO_PATH_POINTS * 4); }
+
+int fsdo_side_configs(const double* xyt, int n, const double* pose, int cone_type, int32_t* configs_out, double* costs_out,
+                      int max_configs, int32_t* first_k_out) {
+  try {
+    Frame f = make_frame(xyt, n, pose);
+    SideResult s = configs_for_one_side(f, cone_type);
+    first_k_out[0] = s.first_k[0];
+    first_k_out[1] = s.first_k[1];
+    if (!s.has) return 0;
+    int C = (int)s.configs.size();
+    for (int i = 0; i < C && i < max_configs; i++) {
+      for (int l = 0; l < FSDO_MAX_LEN; l++) configs_out[i * FSDO_MAX_LEN + l] = s.configs[i].v[l];
+      costs_out[i] = s.costs[i];
+    }
+    return C;
+  } catch (RefUndefined& e) {
+    return -e.code;
+  }
+}
+
+int fsdo_result_size(void) { return (int)sizeof(fsdo_frame_result); }
+}

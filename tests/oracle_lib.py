@@ -1,0 +1,162 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke(); never by the
+product package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+LIB_PATH = ORACLE_DIR / "liboracle.so"
+
+MAX_LEN, MAX_MATCH, PATH_POINTS = 12, 24, 40
+
+
+class FrameResult(ctypes.Structure):
+    _fields_ = [
+        ("status", ctypes.c_int32),
+        ("n_left", ctypes.c_int32),
+        ("n_right", ctypes.c_int32),
+        ("left_idx", ctypes.c_int32 * MAX_LEN),
+        ("right_idx", ctypes.c_int32 * MAX_LEN),
+        ("n_left_v", ctypes.c_int32),
+        ("n_right_v", ctypes.c_int32),
+        ("left_v", (ctypes.c_double * 2) * MAX_MATCH),
+        ("right_v", (ctypes.c_double * 2) * MAX_MATCH),
+        ("l2r", ctypes.c_int32 * MAX_MATCH),
+        ("r2l", ctypes.c_int32 * MAX_MATCH),
+        ("path", (ctypes.c_double * 4) * PATH_POINTS),
+        ("n_configs_left", ctypes.c_int32),
+        ("n_configs_right", ctypes.c_int32),
+        ("first_k_left", ctypes.c_int32 * 2),
+        ("first_k_right", ctypes.c_int32 * 2),
+        ("best_cost_left", ctypes.c_double),
+        ("best_cost_right", ctypes.c_double),
+        ("path_fallback", ctypes.c_int32),
+    ]
+
+
+RESULT_DTYPE = np.dtype(
+    [
+        ("status", "<i4"),
+        ("n_left", "<i4"),
+        ("n_right", "<i4"),
+        ("left_idx", "<i4", (MAX_LEN,)),
+        ("right_idx", "<i4", (MAX_LEN,)),
+        ("n_left_v", "<i4"),
+        ("n_right_v", "<i4"),
+        ("left_v", "<f8", (MAX_MATCH, 2)),
+        ("right_v", "<f8", (MAX_MATCH, 2)),
+        ("l2r", "<i4", (MAX_MATCH,)),
+        ("r2l", "<i4", (MAX_MATCH,)),
+        ("path", "<f8", (PATH_POINTS, 4)),
+        ("n_configs_left", "<i4"),
+        ("n_configs_right", "<i4"),
+        ("first_k_left", "<i4", (2,)),
+        ("first_k_right", "<i4", (2,)),
+        ("best_cost_left", "<f8"),
+        ("best_cost_right", "<f8"),
+        ("path_fallback", "<i4"),
+    ],
+    align=True,
+)
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-s", "-C", str(ORACLE_DIR)], check=True)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        _lib = ctypes.CDLL(str(LIB_PATH))
+        assert _lib.fsdo_result_size() == RESULT_DTYPE.itemsize == ctypes.sizeof(FrameResult), (
+            _lib.fsdo_result_size(),
+            RESULT_DTYPE.itemsize,
+            ctypes.sizeof(FrameResult),
+        )
+    return _lib
+
+
+def _p(a, t=ctypes.c_double):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def plan_frame(xyt: np.ndarray, pose: np.ndarray) -> np.ndarray:
+    xyt = np.ascontiguousarray(xyt, dtype=np.float64).reshape(-1, 3)
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    out = np.zeros(1, dtype=RESULT_DTYPE)
+    lib().fsdo_plan_frame(_p(xyt), ctypes.c_int(len(xyt)), _p(pose), ctypes.c_void_p(out.ctypes.data))
+    return out[0]
+
+
+def plan_batch(offsets, xyt, poses, n_threads: int = 1) -> np.ndarray:
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    xyt = np.ascontiguousarray(xyt, dtype=np.float64)
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    n = len(offsets) - 1
+    out = np.zeros(n, dtype=RESULT_DTYPE)
+    lib().fsdo_plan_batch(
+        ctypes.c_int(n), _p(offsets, ctypes.c_int32), _p(xyt), _p(poses), ctypes.c_void_p(out.ctypes.data), ctypes.c_int(n_threads)
+    )
+    return out
+
+
+def default_path() -> np.ndarray:
+    out = np.zeros((PATH_POINTS, 4))
+    lib().fsdo_default_path(_p(out))
+    return out
+
+
+def side_configs(xyt, pose, cone_type: int, max_configs: int = 64):
+    xyt = np.ascontiguousarray(xyt, dtype=np.float64).reshape(-1, 3)
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    cfg = np.full((max_configs, MAX_LEN), -1, dtype=np.int32)
+    costs = np.zeros(max_configs)
+    fk = np.full(2, -1, dtype=np.int32)
+    c = lib().fsdo_side_configs(
+        _p(xyt), ctypes.c_int(len(xyt)), _p(pose), ctypes.c_int(cone_type), _p(cfg, ctypes.c_int32), _p(costs),
+        ctypes.c_int(max_configs), _p(fk, ctypes.c_int32),
+    )
+    return c, cfg[: max(c, 0)], costs[: max(c, 0)], fk
+
+
+def splprep(trace: np.ndarray, s: float, k: int):
+    trace = np.ascontiguousarray(trace, dtype=np.float64)
+    u = np.concatenate(([0.0], np.cumsum(np.linalg.norm(np.diff(trace, axis=0), axis=1))))
+    m = len(trace)
+    x = np.ascontiguousarray(trace[:, 0])
+    y = np.ascontiguousarray(trace[:, 1])
+    t = np.zeros(m + 2 * k + 2)
+    cx = np.zeros_like(t)
+    cy = np.zeros_like(t)
+    n = ctypes.c_int()
+    ier = ctypes.c_int()
+    fp = ctypes.c_double()
+    rc = lib().fsdo_splprep(
+        _p(u), _p(x), _p(y), ctypes.c_int(m), ctypes.c_int(k), ctypes.c_double(s), _p(t), _p(cx), _p(cy),
+        ctypes.byref(n), ctypes.byref(ier), ctypes.byref(fp),
+    )
+    return rc, u, t[: n.value], cx[: n.value], cy[: n.value], ier.value, fp.value
+
+
+def splev(t, cx, cy, k, u_eval):
+    t = np.ascontiguousarray(t)
+    cx = np.ascontiguousarray(cx)
+    cy = np.ascontiguousarray(cy)
+    u_eval = np.ascontiguousarray(u_eval, dtype=np.float64)
+    ox = np.zeros(len(u_eval))
+    oy = np.zeros(len(u_eval))
+    lib().fsdo_splev(_p(t), _p(cx), _p(cy), ctypes.c_int(len(t)), ctypes.c_int(k), _p(u_eval), ctypes.c_long(len(u_eval)), _p(ox), _p(oy))
+    return np.column_stack([ox, oy])
