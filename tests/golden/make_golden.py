@@ -1,0 +1,246 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE
+(/root/reference imported read-only; identity-jit numba stub in _refstubs/).
+
+Build-container only (the reference does not exist on the GPU box).  What is committed are
+the .npz data files: inputs (frames) and the reference's outputs for them.  No reference
+source is stored.  Re-run:  python tests/golden/make_golden.py
+
+Fixture layout (all frame sets share it; arrays are padded, lengths given explicitly):
+  offsets (F+1,) i4, cones (total,3) f8 [x,y,type], poses (F,4) f8 [px,py,dx,dy]
+  ok (F,) bool            reference returned normally (False: it raised, `exc` holds the class name)
+  n_left/n_right (F,) i4, left_idx/right_idx (F,12) i4   = left_config/right_config of
+                          trace_sorter/core_trace_sorter.py:197-214 (the bit-exact parity target)
+  n_left_v/n_right_v (F,) i4, left_v/right_v (F,24,2) f8, l2r/r2l (F,24) i4   (matching outputs)
+  path (F,40,4) f8        [u, x, y, curvature]
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(HERE))
+
+import refharness  # noqa: E402
+
+synth = importlib.import_module("ft-fsd-path-planning_amd.synth")
+
+MAX_LEN, MAX_MATCH = 12, 24
+
+
+def capture(offsets, cones, poses, frames=None):
+    if frames is None:
+        frames = range(len(offsets) - 1)
+    frames = list(frames)
+    F = len(frames)
+    out = dict(
+        ok=np.zeros(F, bool),
+        exc=np.array([""] * F, dtype="U24"),
+        n_left=np.zeros(F, np.int32),
+        n_right=np.zeros(F, np.int32),
+        left_idx=np.full((F, MAX_LEN), -1, np.int32),
+        right_idx=np.full((F, MAX_LEN), -1, np.int32),
+        n_left_v=np.zeros(F, np.int32),
+        n_right_v=np.zeros(F, np.int32),
+        left_v=np.zeros((F, MAX_MATCH, 2)),
+        right_v=np.zeros((F, MAX_MATCH, 2)),
+        l2r=np.full((F, MAX_MATCH), -1, np.int32),
+        r2l=np.full((F, MAX_MATCH), -1, np.int32),
+        path=np.full((F, 40, 4), np.nan),
+    )
+    sub_cones, sub_off = [], [0]
+    for k, f in enumerate(frames):
+        xyt = cones[offsets[f] : offsets[f + 1]]
+        sub_cones.append(xyt)
+        sub_off.append(sub_off[-1] + len(xyt))
+        r = refharness.run_frame(xyt, poses[f])
+        if r["status"] != "ok":
+            out["exc"][k] = r["status"]
+            continue
+        out["ok"][k] = True
+        lc, rc = r["left_config"], r["right_config"]
+        out["n_left"][k], out["n_right"][k] = len(lc), len(rc)
+        out["left_idx"][k, : len(lc)] = lc
+        out["right_idx"][k, : len(rc)] = rc
+        lv, rv = r["left_v"], r["right_v"]
+        assert len(lv) <= MAX_MATCH and len(rv) <= MAX_MATCH
+        out["n_left_v"][k], out["n_right_v"][k] = len(lv), len(rv)
+        out["left_v"][k, : len(lv)] = lv
+        out["right_v"][k, : len(rv)] = rv
+        out["l2r"][k, : len(lv)] = r["l2r"]
+        out["r2l"][k, : len(rv)] = r["r2l"]
+        out["path"][k] = r["path"]
+    out["offsets"] = np.array(sub_off, np.int32)
+    out["cones"] = np.concatenate(sub_cones).reshape(-1, 3) if sub_cones else np.zeros((0, 3))
+    out["poses"] = np.ascontiguousarray(poses[frames])
+    return out
+
+
+def scenario_frames():
+    """The reference's 8 hard-coded demo scenarios, +/- its deterministic shuffle
+    (demo/streamlit_demo/common.py:72-324), plus the notebook variant (Simple Corner with
+    4 coloured cones, rest unknown) and a no-colour variant of each."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    refharness.load()
+    from fsd_path_planning.demo.streamlit_demo.common import get_cones_for_configuration
+
+    frames, names = [], []
+    for name in ["Straight", "Simple Corner", "Corner Missing Blue", "Corner Missing Blue Alt", "Hairpin",
+                 "Hairpin Extreme", "Wrong sort", "Skidpad"]:
+        for sh in (False, True):
+            pos, d, cones = get_cones_for_configuration(name, sh)
+            xyt = np.concatenate([np.column_stack([np.asarray(c, float).reshape(-1, 2), np.full(len(c), float(t))])
+                                  for t, c in enumerate(cones)])
+            frames.append((xyt, np.concatenate([pos, d])))
+            names.append(f"{name}|shuffle={sh}")
+            if not sh:
+                nc = xyt.copy()
+                nc[:, 2] = 0.0
+                frames.append((nc, np.concatenate([pos, d])))
+                names.append(f"{name}|nocolor")
+    # notebook scenario (demo/simple_application.ipynb cells 3-15): 2 coloured per side
+    pos, d, cones = get_cones_for_configuration("Simple Corner", False)
+    left, right = np.asarray(cones[2]), np.asarray(cones[1])
+    unknown = np.concatenate([left[2:], right[2:]])
+    xyt = np.concatenate([np.column_stack([unknown, np.zeros(len(unknown))]),
+                          np.column_stack([right[:2], np.ones(2)]), np.column_stack([left[:2], np.full(2, 2.0)])])
+    frames.append((xyt, np.concatenate([pos, d])))
+    names.append("notebook")
+    off = np.concatenate([[0], np.cumsum([len(f[0]) for f in frames])]).astype(np.int32)
+    return off, np.concatenate([f[0] for f in frames]), np.array([f[1] for f in frames]), names
+
+
+def fuzz_frames(seed, n):
+    """Small irregular frames around the origin (so the previous-path fallbacks are
+    exercised the way the reference's demo scenarios exercise them) + noisy loop frames."""
+    rng = np.random.default_rng(seed)
+    frames = []
+    for _ in range(n):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            m = rng.integers(0, 30)
+            xy = rng.uniform(-15, 25, (m, 2))
+            t = rng.integers(0, 5, m)
+        elif kind == 1:
+            nl, nr = rng.integers(0, 9), rng.integers(0, 9)
+            xl, xr = np.sort(rng.uniform(-6, 30, nl)), np.sort(rng.uniform(-6, 30, nr))
+            curv = rng.uniform(-0.06, 0.06)
+
+            def bend(x, off):
+                return np.column_stack([x, off + 0.5 * curv * x * x]) + rng.normal(0, 0.2, (len(x), 2))
+
+            xy = np.concatenate([bend(xl, 1.5), bend(xr, -1.5)])
+            t = np.concatenate([np.full(nl, 2), np.full(nr, 1)])
+            if rng.random() < 0.4:
+                t[:] = 0
+            if rng.random() < 0.3 and len(t):
+                t[rng.integers(0, len(t))] = rng.integers(0, 5)
+        elif kind == 2:
+            off, cones, poses = synth.make_replay_batch(
+                1, int(rng.integers(8, 40)), float(rng.uniform(0, 0.4)), seed=int(rng.integers(1 << 30)),
+                color=bool(rng.random() < 0.6), random_pose=True, lateral_noise=float(rng.uniform(0, 1)),
+                heading_noise=float(rng.uniform(0, 0.5)))
+            frames.append((cones, poses[0]))
+            continue
+        else:
+            m = rng.integers(2, 12)
+            sp = rng.uniform(2.5, 6)
+            x = np.arange(m) * sp - rng.uniform(0, 8)
+            curv = rng.uniform(-0.05, 0.05)
+            yl, yr = 1.5 + 0.5 * curv * x * x, -1.5 + 0.5 * curv * x * x
+            xy = np.concatenate([np.column_stack([x, yl]), np.column_stack([x + rng.uniform(-1, 1), yr])])
+            xy = xy + rng.normal(0, 0.1, (2 * m, 2))
+            t = np.concatenate([np.full(m, 2), np.full(m, 1)])
+            drop = rng.random(2 * m) < rng.uniform(0, 0.4)
+            xy, t = xy[~drop], t[~drop]
+            if rng.random() < 0.3:
+                t[:] = 0
+        order = np.argsort(t, kind="stable")
+        xyt = np.column_stack([xy[order], t[order].astype(float)]) if len(t) else np.zeros((0, 3))
+        a = rng.normal(0, 0.3)
+        frames.append((xyt, np.array([rng.normal(0, 0.5), rng.normal(0, 0.5), np.cos(a), np.sin(a)])))
+    off = np.concatenate([[0], np.cumsum([len(f[0]) for f in frames])]).astype(np.int32)
+    return off, np.concatenate([f[0].reshape(-1, 3) for f in frames]), np.array([f[1] for f in frames])
+
+
+def spline_fixtures(seed=0, n=90):
+    """scipy.interpolate.splprep/splev outputs (the FITPACK arithmetic the reference reaches
+    through utils/spline_fit.py:117,61) for the three fit shapes of the pipeline."""
+    from scipy.interpolate import splev, splprep
+
+    rng = np.random.default_rng(seed)
+    items = {}
+    for i in range(n):
+        mode = i % 3
+        if mode == 0:
+            m, length, noise, s = int(rng.integers(2, 15)), None, 0.3, 0.2
+            length = m * 3.0
+        elif mode == 1:
+            m, length, noise, s = int(rng.integers(300, 600)), 50.0, 0.004, 0.2
+        else:
+            m, length, noise, s = int(rng.integers(150, 250)), 20.0, 0.001, 0.01
+        ss = np.linspace(0, length, m)
+        th = rng.uniform(-0.08, 0.08) * ss + rng.uniform(-3, 3) + 0.3 * np.sin(ss / 7 + rng.uniform(0, 6))
+        tr = np.column_stack([np.cumsum(np.cos(th)), np.cumsum(np.sin(th))]) * (length / m) + rng.normal(0, noise, (m, 2))
+        k = int(np.clip(m - 1, 1, 3))
+        u = np.concatenate(([0.0], np.cumsum(np.linalg.norm(np.diff(tr, axis=0), axis=1))))
+        (tck, _), fp, ier, _ = splprep(tr.T, s=s, k=k, u=u, full_output=1)
+        ue = np.arange(0, u[-1] * 1.1, u[-1] / 57.0)
+        ev = np.array(splev(ue, tck)).T
+        items[f"trace_{i}"] = tr
+        items[f"s_{i}"] = np.array([s, k, ier, fp])
+        items[f"t_{i}"] = tck[0]
+        items[f"c_{i}"] = np.array(tck[1])
+        items[f"ue_{i}"] = ue
+        items[f"ev_{i}"] = ev
+    items["n"] = np.array(n)
+    return items
+
+
+def main():
+    refharness.load()
+    sets = {}
+    off, cones, poses, names = scenario_frames()
+    sets["scenarios"] = capture(off, cones, poses)
+    sets["scenarios"]["names"] = np.array(names)
+    o, c, p = synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
+    sets["cfg2_color"] = capture(o, c, p, range(0, 4096, 64))
+    o, c, p = synth.make_replay_batch(4096, 64, 0.15, seed=1, color=False)
+    sets["cfg3_nocolor"] = capture(o, c, p, range(0, 4096, 64))
+    o, c, p = synth.make_replay_batch(48, 100, 0.0, seed=7, frame_noise=0.1, random_pose=True)
+    sets["cfg4_200cones"] = capture(o, c, p)
+    o, c, p = synth.make_replay_batch(48, 100, 0.0, seed=8, frame_noise=0.3, random_pose=True, color=False,
+                                      lateral_noise=0.5, heading_noise=0.2)
+    sets["cfg4_noisy_nocolor"] = capture(o, c, p)
+    o, c, p = fuzz_frames(11, 400)
+    sets["fuzz"] = capture(o, c, p)
+    for name, d in sets.items():
+        np.savez_compressed(HERE / f"{name}.npz", **d)
+        print(name, "frames", len(d["ok"]), "ok", int(d["ok"].sum()), "exc", sorted(set(d["exc"].tolist()) - {""}))
+    np.savez_compressed(HERE / "splines.npz", **spline_fixtures())
+    # constant initial previous path (core_calculate_path.py:103-107)
+    m = refharness.load()
+    pp = m["PathPlanner"](m["MissionTypes"].trackdrive)
+    np.savez_compressed(HERE / "default_path.npz", path=np.array(pp.pathing.previous_paths[0]))
+    # numpy/BLAS semantics probes used by the oracle's np_compat.h
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-60, 60, (400, 2))
+    m2 = rng.uniform(-1, 1, (2, 2))
+    from fsd_path_planning.utils.math_utils import my_cdist_sq_euclidean, rotate
+
+    np.savez_compressed(
+        HERE / "numpy_semantics.npz", v=v, m2=m2, dot=np.dot(v, m2), norm1d=np.array([np.linalg.norm(r) for r in v]),
+        cdist=my_cdist_sq_euclidean(v[:40], v[:40]), rot=rotate(v, 0.7), rot_theta=np.array(0.7),
+        sums=np.array([v[:k, 0].sum() for k in range(1, 400)]),
+    )
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""Pin the CPU oracle (oracle/) against golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU-only."""
+import collections
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import parity
+
+SETS = ["scenarios", "cfg2_color", "cfg3_nocolor", "cfg4_200cones", "cfg4_noisy_nocolor", "fuzz"]
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_oracle_matches_reference_golden(golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    res = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=4)
+    cats = collections.Counter()
+    bad = []
+    n_arc = 0
+    for k in range(len(res)):
+        cat, detail = parity.compare_frame(res[k], g, k)
+        cats[cat] += 1
+        n_arc += bool(int(res[k]["path_fallback"]) & parity.ARC_FLAG)
+        if cat in ("IDX", "MATCH", "PATH", "STATUS"):
+            bad.append((k, cat, detail))
+    assert not bad, bad[:5]
+    # sample-count flips only on arc-extension frames, and only a small share of those
+    assert cats["flip"] <= max(1, int(0.10 * n_arc)), (cats, n_arc)
+
+
+def test_default_previous_path(golden_dir):
+    """core_calculate_path.py:103-107: the constant initial previous path."""
+    ref = np.load(golden_dir / "default_path.npz")["path"]
+    assert np.abs(oracle_lib.default_path() - ref).max() < 1e-12
+
+
+def test_empty_and_tiny_frames():
+    """N < 3 cones: both sides have no result (core_trace_sorter.py:272-273) and the path is
+    the previous path run through the MPC step (core_calculate_path.py:531-536)."""
+    for n in range(0, 3):
+        xyt = np.array([[3.0 * i + 2, 1.5, 2.0] for i in range(n)]).reshape(-1, 3)
+        r = oracle_lib.plan_frame(xyt, np.array([0.0, 0, 1, 0]))
+        assert r["status"] == 0 and r["n_left"] == 0 and r["n_right"] == 0
+        assert r["path_fallback"] & 1
+        assert np.isfinite(r["path"]).all()

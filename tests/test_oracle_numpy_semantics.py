@@ -1,0 +1,62 @@
+"""np_compat.h claims about NumPy/BLAS arithmetic, checked against values captured from NumPy
+on the fixture machine (tests/golden/numpy_semantics.npz)."""
+import math
+
+import numpy as np
+
+
+def _fma(a, b, c):
+    from fractions import Fraction
+
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+def test_blas_inner_products_are_fma_chains(golden_dir):
+    z = np.load(golden_dir / "numpy_semantics.npz")
+    v, m2, dot = z["v"], z["m2"], z["dot"]
+    for i in range(len(v)):
+        for j in range(2):
+            assert dot[i, j] == _fma(v[i, 1], m2[1, j], v[i, 0] * m2[0, j])
+        assert z["norm1d"][i] == math.sqrt(_fma(v[i, 1], v[i, 1], v[i, 0] * v[i, 0]))
+    cd = z["cdist"]
+    for i in range(40):
+        for j in range(40):
+            a, b = v[i], v[j]
+            acc = 1.0 * (b[0] * b[0])
+            acc = _fma(1.0, b[1] * b[1], acc)
+            acc = _fma(a[0], -2 * b[0], acc)
+            acc = _fma(a[1], -2 * b[1], acc)
+            acc = _fma(a[0] * a[0], 1.0, acc)
+            acc = _fma(a[1] * a[1], 1.0, acc)
+            assert cd[i, j] == acc
+
+
+def test_pairwise_sum(golden_dir):
+    z = np.load(golden_dir / "numpy_semantics.npz")
+    v = z["v"][:, 0]
+
+    def pw(a):
+        n = len(a)
+        if n < 8:
+            r = 0.0
+            for x in a:
+                r += x
+            return r
+        if n <= 128:
+            r = list(a[:8])
+            i = 8
+            while i < n - (n % 8):
+                for j in range(8):
+                    r[j] += a[i + j]
+                i += 8
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            while i < n:
+                res += a[i]
+                i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pw(a[:n2]) + pw(a[n2:])
+
+    for k in range(1, 400):
+        assert z["sums"][k - 1] == pw(v[:k])
