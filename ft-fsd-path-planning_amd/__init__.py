@@ -1,0 +1,9 @@
+"""MI355X-native batched PathPlanner hot path (host side).
+
+``from fsd_path_planning_amd import PathPlanner, ConeTypes, MissionTypes`` mirrors
+``from fsd_path_planning import ...`` of the reference.  The compute lives in
+lib/libfsdp_hip.so (hand-written HIP kernels, C ABI in include/fsdp.h).
+"""
+from .planner import ConeTypes, MissionTypes, PathPlanner, ReferenceUndefinedError, flatten_cones_by_type_array, pack_frames  # noqa: F401
+from . import synth  # noqa: F401
+from ._capi import Context, FsdpError, RESULT_DTYPE  # noqa: F401

@@ -1,0 +1,188 @@
+"""ctypes binding of libfsdp_hip.so (C ABI: include/fsdp.h).
+
+There is deliberately NO fallback: if the HIP library is missing, or no GPU is visible, the
+calls below raise.  (The CPU oracle under oracle/ is test infrastructure and is never imported
+from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "lib" / "libfsdp_hip.so"
+
+MAX_LEN, MAX_MATCH, PATH_POINTS, MAX_CONES = 12, 24, 40, 256
+
+# numpy mirror of fsdp_frame_result (include/fsdp.h)
+RESULT_DTYPE = np.dtype(
+    [
+        ("status", "<i4"),
+        ("n_left", "<i4"),
+        ("n_right", "<i4"),
+        ("left_idx", "<i4", (MAX_LEN,)),
+        ("right_idx", "<i4", (MAX_LEN,)),
+        ("n_left_v", "<i4"),
+        ("n_right_v", "<i4"),
+        ("left_v", "<f8", (MAX_MATCH, 2)),
+        ("right_v", "<f8", (MAX_MATCH, 2)),
+        ("l2r", "<i4", (MAX_MATCH,)),
+        ("r2l", "<i4", (MAX_MATCH,)),
+        ("path", "<f8", (PATH_POINTS, 4)),
+        ("n_configs_left", "<i4"),
+        ("n_configs_right", "<i4"),
+        ("first_k_left", "<i4", (2,)),
+        ("first_k_right", "<i4", (2,)),
+        ("best_cost_left", "<f8"),
+        ("best_cost_right", "<f8"),
+        ("path_fallback", "<i4"),
+        ("n_dense", "<i4"),
+    ],
+    align=True,
+)
+
+
+class FsdpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libfsdp_hip.so or raise FsdpError (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FsdpError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950); this package has no CPU fallback"
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    lib.fsdp_version.restype = ctypes.c_char_p
+    lib.fsdp_last_error.restype = ctypes.c_char_p
+    lib.fsdp_last_error.argtypes = [ctypes.c_void_p]
+    lib.fsdp_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.fsdp_destroy.argtypes = [ctypes.c_void_p]
+    if lib.fsdp_result_size() != RESULT_DTYPE.itemsize:
+        raise FsdpError(f"fsdp_frame_result layout mismatch: {lib.fsdp_result_size()} != {RESULT_DTYPE.itemsize}")
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
+    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs",
+    "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
+]
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+class Context:
+    """One GPU context (= fsdp_ctx): device buffers + one HIP stream."""
+
+    def __init__(self, device: int | None = None, mission: int = 4):
+        lib = load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(lib.fsdp_device_count(), 1)
+        h = ctypes.c_void_p()
+        rc = lib.fsdp_create(int(device), int(mission), ctypes.byref(h))
+        if rc != 0:
+            raise FsdpError(f"fsdp_create failed ({rc}): {lib.fsdp_last_error(None).decode()}")
+        self._lib, self._h, self.device, self.n_frames = lib, h, device, 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FsdpError(f"{what} failed ({rc}): {self._lib.fsdp_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fsdp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _prep(offsets, cones, poses):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        cones = np.ascontiguousarray(cones, dtype=np.float64).reshape(-1, 3)
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4)
+        n = len(offsets) - 1
+        if n < 0 or len(poses) != n or (n > 0 and int(offsets[-1]) != len(cones)):
+            raise ValueError("inconsistent batch: offsets / cones / poses")
+        return offsets, cones, poses, n
+
+    def plan_batch(self, offsets, cones, poses) -> np.ndarray:
+        offsets, cones, poses, n = self._prep(offsets, cones, poses)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        self._check(self._lib.fsdp_plan_batch(self._h, n, _ip(offsets), _dp(cones), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_plan_batch")
+        self.n_frames = n
+        return out
+
+    def sort_batch(self, offsets, cones, poses) -> np.ndarray:
+        offsets, cones, poses, n = self._prep(offsets, cones, poses)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        self._check(self._lib.fsdp_sort_batch(self._h, n, _ip(offsets), _dp(cones), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_sort_batch")
+        return out
+
+    def match_batch(self, sorted_left, n_left, sorted_right, n_right, poses) -> np.ndarray:
+        sorted_left = np.ascontiguousarray(sorted_left, np.float64).reshape(-1, MAX_LEN, 2)
+        sorted_right = np.ascontiguousarray(sorted_right, np.float64).reshape(-1, MAX_LEN, 2)
+        n_left = np.ascontiguousarray(n_left, np.int32)
+        n_right = np.ascontiguousarray(n_right, np.int32)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 4)
+        n = len(poses)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        self._check(self._lib.fsdp_match_batch(self._h, n, _dp(sorted_left), _ip(n_left), _dp(sorted_right), _ip(n_right), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_match_batch")
+        return out
+
+    def path_batch(self, poses, results: np.ndarray) -> np.ndarray:
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 4)
+        results = np.ascontiguousarray(results)
+        assert results.dtype == RESULT_DTYPE and len(results) == len(poses)
+        self._check(self._lib.fsdp_path_batch(self._h, len(poses), _dp(poses), ctypes.c_void_p(results.ctypes.data)), "fsdp_path_batch")
+        return results
+
+    # resident API
+    def upload(self, offsets, cones, poses):
+        offsets, cones, poses, n = self._prep(offsets, cones, poses)
+        self._check(self._lib.fsdp_upload(self._h, n, _ip(offsets), _dp(cones), _dp(poses)), "fsdp_upload")
+        self._check(self._lib.fsdp_sync(self._h), "fsdp_sync")
+        self.n_frames = n
+
+    def run(self):
+        self._check(self._lib.fsdp_run(self._h), "fsdp_run")
+
+    def sync(self):
+        self._check(self._lib.fsdp_sync(self._h), "fsdp_sync")
+
+    def download(self) -> np.ndarray:
+        out = np.zeros(self.n_frames, dtype=RESULT_DTYPE)
+        self._check(self._lib.fsdp_download(self._h, ctypes.c_void_p(out.ctypes.data)), "fsdp_download")
+        return out
+
+    def time_runs(self, iters: int):
+        tot = ctypes.c_float()
+        st = (ctypes.c_float * 3)()
+        self._check(self._lib.fsdp_time_runs(self._h, int(iters), ctypes.byref(tot), st), "fsdp_time_runs")
+        return float(tot.value), [float(x) for x in st]
+
+    def default_path(self) -> np.ndarray:
+        out = np.zeros((PATH_POINTS, 4))
+        self._check(self._lib.fsdp_default_path(self._h, _dp(out)), "fsdp_default_path")
+        return out

@@ -1,0 +1,199 @@
+// Device-side common definitions for the MI355X (gfx950) PathPlanner kernels.
+//
+// Execution model: ONE WAVEFRONT (64 lanes) PER FRAME, one wavefront per workgroup.  Frame
+// state lives in LDS; wave-uniform control flow drives the inherently serial parts (DFS stack,
+// Givens QR of the smoothing spline) while the data-parallel parts (pairwise distances, kNN,
+// side counting, B-spline evaluation, curvature windows) run one element per lane.  Cross-lane
+// traffic uses ballot / shuffles; LDS hand-offs between lanes are fenced by __syncthreads()
+// (a single-wave workgroup: s_barrier is a no-op in hardware, the fence orders LDS for the
+// compiler).
+//
+// Arithmetic contract: float64 throughout, compiled with -ffp-contract=off so every + - * /
+// sqrt is the IEEE operation the reference performs; fused multiply-adds appear only where
+// the reference's NumPy->BLAS calls fuse them (explicit fma(), see blas_dot2).
+#pragma once
+
+#include <stdint.h>
+
+#ifndef FSDP_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+namespace fsdp {
+
+constexpr int WAVE = 64;
+constexpr int MAX_CONES = 256;   // cones per frame handled in LDS (status OVERFLOW beyond)
+constexpr int MAX_LEN = 12;      // reference config.py:36 max_length
+constexpr int KNN = 5;           // config.py:34 max_n_neighbors
+constexpr int MAX_ENDS = 64;     // raw end configurations kept per side (OVERFLOW beyond)
+constexpr int MAX_STACK = 64;    // DFS stack bound: <= 5 pending siblings per depth * 12 depths
+constexpr int MAX_MATCH = 24;    // cones-with-virtual per side
+constexpr int PATH_POINTS = 40;  // config.py:58 mpc_prediction_horizon
+
+constexpr int T_UNKNOWN = 0, T_RIGHT = 1, T_LEFT = 2;
+
+// per-frame status codes (mirrored in include/fsdp.h)
+constexpr int ST_OK = 0;
+constexpr int ST_REF_UNDEFINED_SET_DIFF = 101;
+constexpr int ST_REF_UNDEFINED_DFS_OOB = 102;
+constexpr int ST_REF_UNDEFINED_PATH = 103;
+constexpr int ST_REF_UNDEFINED_MATCH_IDX = 104;
+constexpr int ST_OVERFLOW_CONES = 201;
+constexpr int ST_OVERFLOW_ENDS = 202;
+constexpr int ST_OVERFLOW_PATH = 203;
+constexpr int ST_OVERFLOW_KNOTS = 204;
+
+#define FSDP_PI 3.14159265358979323846
+#define FSDP_DEG (FSDP_PI / 180.0)
+
+// ---- sorting stage output (one record per frame, HBM) ----
+struct SortOut {
+  int32_t status;
+  int32_t n_left, n_right;
+  int32_t left_idx[MAX_LEN];
+  int32_t right_idx[MAX_LEN];
+  int32_t n_configs_left, n_configs_right;
+  int32_t first_k_left[2], first_k_right[2];
+  double best_cost_left, best_cost_right;
+};
+
+// ---- matching stage output ----
+struct MatchOut {
+  int32_t status;
+  int32_t n_left_v, n_right_v;
+  int32_t pad;
+  double left_v[MAX_MATCH][2];
+  double right_v[MAX_MATCH][2];
+  int32_t l2r[MAX_MATCH];
+  int32_t r2l[MAX_MATCH];
+};
+
+// ---- path stage output ----
+struct PathOut {
+  double path[PATH_POINTS][4];
+  int32_t status;
+  int32_t fallback;
+  int32_t n_dense;   // number of dense samples L the 40 outputs were drawn from
+  int32_t pad;
+};
+
+// ------------------------------------------------------------------------------------------
+// scalar math helpers (NumPy semantics; see DESIGN.md "arithmetic contract")
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double blas_dot2(double a0, double b0, double a1, double b1) {
+  // np.dot / BLAS inner product of length 2 as OpenBLAS evaluates it: acc = a0*b0; acc = fma(a1,b1,acc)
+  return fma(a1, b1, a0 * b0);
+}
+__device__ __forceinline__ double norm_blas(double x, double y) { return sqrt(blas_dot2(x, x, y, y)); }
+__device__ __forceinline__ double norm_axis(double x, double y) { return sqrt(x * x + y * y); }
+
+// reference utils/math_utils.py:120-150 (expansion-form squared distance through dgemm, K=6)
+__device__ __forceinline__ double cdist_sq(double ax, double ay, double bx, double by) {
+  double acc = 1.0 * (bx * bx);
+  acc = fma(1.0, by * by, acc);
+  acc = fma(ax, -2 * bx, acc);
+  acc = fma(ay, -2 * by, acc);
+  acc = fma(ax * ax, 1.0, acc);
+  acc = fma(ay * ay, 1.0, acc);
+  return acc;
+}
+
+// reference utils/math_utils.py:70-100
+__device__ __forceinline__ double angle_between(double ax, double ay, double bx, double by) {
+  double c = ax * bx + ay * by;
+  c /= sqrt(ax * ax + ay * ay) * sqrt(bx * bx + by * by);
+  if (c < -1) c = -1;
+  if (c > 1) c = 1;
+  return acos(c);
+}
+
+// reference utils/math_utils.py:663-676: (a1 - a2 + 3pi) % (2pi) - pi  (NumPy floored modulo)
+__device__ __forceinline__ double angle_difference(double a1, double a2) {
+  double m = fmod(a1 - a2 + 3 * FSDP_PI, 2 * FSDP_PI);
+  if (m != 0.0 && m < 0) m += 2 * FSDP_PI;
+  return m - FSDP_PI;
+}
+
+__device__ __forceinline__ double sign_of(double v) { return (v > 0) ? 1.0 : ((v < 0) ? -1.0 : 0.0); }
+
+// rotation by theta the way utils/math_utils.py:103-117 does it: points @ [[c, s], [-s, c]]
+struct Rot2 {
+  double c, s;
+};
+__device__ __forceinline__ Rot2 make_rot(double theta) { return Rot2{cos(theta), sin(theta)}; }
+__device__ __forceinline__ void rot_apply(const Rot2& r, double x, double y, double& ox, double& oy) {
+  ox = blas_dot2(x, r.c, y, -r.s);
+  oy = blas_dot2(x, r.s, y, r.c);
+}
+
+// cone_matching/match_directions.py:7-20: rotate the chord by +-pi/2 and normalise.
+// cos(+-pi/2) = 6.123233995736766e-17 and sin(+-pi/2) = +-1 are the libm values NumPy uses.
+__device__ __forceinline__ void search_direction(double x0, double y0, double x1, double y1, int cone_type, double& dx,
+                                                 double& dy) {
+  const double c = 6.123233995736766e-17;
+  const double s = (cone_type == T_RIGHT) ? 1.0 : -1.0;
+  double tx = x1 - x0, ty = y1 - y0;
+  double rx = blas_dot2(tx, c, ty, -s);
+  double ry = blas_dot2(tx, s, ty, c);
+  double n = norm_blas(rx, ry);
+  dx = rx / n;
+  dy = ry / n;
+}
+
+// NumPy pairwise summation for short runs (n <= 128): n < 8 sequential, else 8 accumulators
+__device__ __forceinline__ double np_sum_small(const double* a, int n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; i++) r += a[i];
+    return r;
+  }
+  double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+    r0 += a[i];
+    r1 += a[i + 1];
+    r2 += a[i + 2];
+    r3 += a[i + 3];
+    r4 += a[i + 4];
+    r5 += a[i + 5];
+    r6 += a[i + 6];
+    r7 += a[i + 7];
+  }
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < n; i++) res += a[i];
+  return 0.0 + res;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave primitives
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+template <class T>
+__device__ __forceinline__ T wave_bcast(T v, int src) {
+  return __shfl(v, src, WAVE);
+}
+
+// argmin over (value, index) pairs with "first smallest" semantics (lowest index on ties);
+// lanes holding no candidate pass idx = -1.
+__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
+  for (int off = 32; off >= 1; off >>= 1) {
+    double ov = __shfl_xor(v, off, WAVE);
+    int oi = __shfl_xor(idx, off, WAVE);
+    bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && oi < idx));
+    if (take) {
+      v = ov;
+      idx = oi;
+    }
+  }
+}
+
+__device__ __forceinline__ int wave_min_int(int v) {
+  for (int off = 32; off >= 1; off >>= 1) {
+    int o = __shfl_xor(v, off, WAVE);
+    v = (o < v) ? o : v;
+  }
+  return v;
+}
+
+}  // namespace fsdp

@@ -1,0 +1,416 @@
+// libfsdp_hip.so — host side of the C ABI declared in include/fsdp.h.
+// Owns the per-GPU context: device buffers sized for the batch, one HIP stream, HIP events for
+// in-stream timing.  Launch geometry: one 64-lane workgroup (= one wavefront) per frame, so a
+// 4096-frame batch is 4096 workgroups over 256 CUs / 8 XCDs (consecutive frames land on
+// consecutive XCDs; frames are independent, no inter-workgroup traffic).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fsdp.h"
+#include "sort_kernel.h"
+#include "match_kernel.h"
+#include "path_kernel.h"
+
+using namespace fsdp;
+
+static_assert(FSDP_MAX_LEN == MAX_LEN && FSDP_MAX_MATCH == MAX_MATCH && FSDP_PATH_POINTS == PATH_POINTS &&
+                  FSDP_MAX_CONES == MAX_CONES,
+              "header/device constant mismatch");
+
+static thread_local std::string g_create_error;
+
+struct fsdp_ctx {
+  int device = 0;
+  int mission = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  std::string err;
+  // capacities
+  int cap_frames = 0;
+  size_t cap_cones = 0;
+  int n_frames = 0;
+  // device buffers
+  int32_t* d_off = nullptr;
+  double* d_cones = nullptr;
+  double* d_poses = nullptr;
+  SortOut* d_sort = nullptr;
+  MatchOut* d_match = nullptr;
+  PathOut* d_path = nullptr;
+  double* d_default_path = nullptr;  // (40,4)
+  // pinned host staging for results
+  std::vector<SortOut> h_sort;
+  std::vector<MatchOut> h_match;
+  std::vector<PathOut> h_path;
+};
+
+#define HIP_TRY(ctx, call)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+      return 2;                                                                                  \
+    }                                                                                            \
+  } while (0)
+
+static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
+  if (n_frames > c->cap_frames) {
+    if (c->d_off) hipFree(c->d_off);
+    if (c->d_poses) hipFree(c->d_poses);
+    if (c->d_sort) hipFree(c->d_sort);
+    if (c->d_match) hipFree(c->d_match);
+    if (c->d_path) hipFree(c->d_path);
+    c->d_off = nullptr;
+    c->d_poses = nullptr;
+    c->d_sort = nullptr;
+    c->d_match = nullptr;
+    c->d_path = nullptr;
+    c->cap_frames = 0;
+    HIP_TRY(c, hipMalloc(&c->d_off, sizeof(int32_t) * ((size_t)n_frames + 1)));
+    HIP_TRY(c, hipMalloc(&c->d_poses, sizeof(double) * 4 * (size_t)n_frames));
+    HIP_TRY(c, hipMalloc(&c->d_sort, sizeof(SortOut) * (size_t)n_frames));
+    HIP_TRY(c, hipMalloc(&c->d_match, sizeof(MatchOut) * (size_t)n_frames));
+    HIP_TRY(c, hipMalloc(&c->d_path, sizeof(PathOut) * (size_t)n_frames));
+    c->cap_frames = n_frames;
+  }
+  if (n_cones > c->cap_cones) {
+    if (c->d_cones) hipFree(c->d_cones);
+    c->d_cones = nullptr;
+    c->cap_cones = 0;
+    size_t want = n_cones ? n_cones : 1;
+    HIP_TRY(c, hipMalloc(&c->d_cones, sizeof(double) * 3 * want));
+    c->cap_cones = want;
+  }
+  return 0;
+}
+
+static void launch_sort(fsdp_ctx* c) {
+  hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
+                     c->d_sort);
+}
+static void launch_match(fsdp_ctx* c) {
+  hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
+                     c->d_sort, c->d_match);
+}
+static void launch_path(fsdp_ctx* c) {
+  hipLaunchKernelGGL(path_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_poses, c->d_match,
+                     c->d_default_path, c->d_path);
+}
+
+static void assemble(const SortOut* s, const MatchOut* m, const PathOut* p, fsdp_frame_result* r) {
+  // r may already hold fields from earlier stages when only part of the pipeline ran
+  if (s) {
+    r->status = s->status;
+    r->n_left = s->n_left;
+    r->n_right = s->n_right;
+    memcpy(r->left_idx, s->left_idx, sizeof(r->left_idx));
+    memcpy(r->right_idx, s->right_idx, sizeof(r->right_idx));
+    r->n_configs_left = s->n_configs_left;
+    r->n_configs_right = s->n_configs_right;
+    memcpy(r->first_k_left, s->first_k_left, sizeof(r->first_k_left));
+    memcpy(r->first_k_right, s->first_k_right, sizeof(r->first_k_right));
+    r->best_cost_left = s->best_cost_left;
+    r->best_cost_right = s->best_cost_right;
+  }
+  if (m) {
+    if (m->status != 0) r->status = m->status;
+    r->n_left_v = m->n_left_v;
+    r->n_right_v = m->n_right_v;
+    memcpy(r->left_v, m->left_v, sizeof(r->left_v));
+    memcpy(r->right_v, m->right_v, sizeof(r->right_v));
+    memcpy(r->l2r, m->l2r, sizeof(r->l2r));
+    memcpy(r->r2l, m->r2l, sizeof(r->r2l));
+  }
+  if (p) {
+    if (p->status != 0) r->status = p->status;
+    memcpy(r->path, p->path, sizeof(r->path));
+    r->path_fallback = p->fallback;
+    r->n_dense = p->n_dense;
+  }
+}
+
+extern "C" {
+
+const char* fsdp_version(void) { return "fsdp-hip 0.1 (gfx950)"; }
+int fsdp_result_size(void) { return (int)sizeof(fsdp_frame_result); }
+
+int fsdp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* fsdp_last_error(const fsdp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int fsdp_create(int device, int mission, fsdp_ctx** out) {
+  *out = nullptr;
+  int n = fsdp_device_count();
+  if (n <= 0) {
+    g_create_error = "no HIP device visible (libfsdp_hip.so has no CPU fallback)";
+    return 1;
+  }
+  if (device < 0 || device >= n) {
+    g_create_error = "device index out of range";
+    return 1;
+  }
+  // utils/mission_types.py:11-25: acceleration=1, skidpad=2, ebs_test=5 use a relocalizer (full_pipeline.py:46-50)
+  if (mission == 1 || mission == 2 || mission == 5) {
+    g_create_error = "missions with a relocalizer (acceleration / skidpad / ebs_test) are not on this path yet";
+    return 1;
+  }
+  fsdp_ctx* c = new fsdp_ctx();
+  c->device = device;
+  c->mission = mission;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+  if (e == hipSuccess) e = hipMalloc(&c->d_default_path, sizeof(double) * PATH_POINTS * 4);
+  if (e != hipSuccess) {
+    g_create_error = std::string("fsdp_create: ") + hipGetErrorString(e);
+    delete c;
+    return 2;
+  }
+  // constant initial previous path: almost-straight chord (path_calculator_helpers.py:26-68) fitted and
+  // parameterized on the device (core_calculate_path.py:103-121)
+  {
+    double chord[PATH_POINTS][2];
+    default_chord_points(chord);
+    double* d_chord = nullptr;
+    e = hipMalloc(&d_chord, sizeof(chord));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_chord, chord, sizeof(chord), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(default_path_kernel, dim3(1), dim3(WAVE), 0, c->stream, d_chord, c->d_default_path);
+      e = hipStreamSynchronize(c->stream);
+    }
+    if (d_chord) hipFree(d_chord);
+    if (e != hipSuccess) {
+      g_create_error = std::string("fsdp_create(default path): ") + hipGetErrorString(e);
+      delete c;
+      return 2;
+    }
+  }
+  *out = c;
+  return 0;
+}
+
+void fsdp_destroy(fsdp_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  hipFree(c->d_off);
+  hipFree(c->d_cones);
+  hipFree(c->d_poses);
+  hipFree(c->d_sort);
+  hipFree(c->d_match);
+  hipFree(c->d_path);
+  hipFree(c->d_default_path);
+  for (int i = 0; i < 8; i++)
+    if (c->ev[i]) hipEventDestroy(c->ev[i]);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int fsdp_upload(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses) {
+  if (!c || n_frames < 0 || (n_frames > 0 && (!off || !poses))) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t total = n_frames > 0 ? (size_t)off[n_frames] : 0;
+  if (n_frames > 0 && off[0] != 0) {
+    c->err = "cone_offsets[0] must be 0";
+    return 1;
+  }
+  int rc = ensure_capacity(c, n_frames > 0 ? n_frames : 1, total);
+  if (rc) return rc;
+  c->n_frames = n_frames;
+  if (n_frames == 0) return 0;
+  HIP_TRY(c, hipMemcpyAsync(c->d_off, off, sizeof(int32_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, c->stream));
+  if (total) HIP_TRY(c, hipMemcpyAsync(c->d_cones, cones, sizeof(double) * 3 * total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int fsdp_run(fsdp_ctx* c) {
+  if (!c) return 1;
+  if (c->n_frames == 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  launch_sort(c);
+  launch_match(c);
+  launch_path(c);
+  HIP_TRY(c, hipGetLastError());
+  return 0;
+}
+
+int fsdp_sync(fsdp_ctx* c) {
+  if (!c) return 1;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int fsdp_download(fsdp_ctx* c, fsdp_frame_result* results) {
+  if (!c || (c->n_frames > 0 && !results)) return 1;
+  const int n = c->n_frames;
+  if (n == 0) return 0;
+  c->h_sort.resize(n);
+  c->h_match.resize(n);
+  c->h_path.resize(n);
+  HIP_TRY(c, hipMemcpyAsync(c->h_sort.data(), c->d_sort, sizeof(SortOut) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_match.data(), c->d_match, sizeof(MatchOut) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), c->d_path, sizeof(PathOut) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) {
+    memset(&results[i], 0, sizeof(fsdp_frame_result));
+    assemble(&c->h_sort[i], &c->h_match[i], &c->h_path[i], &results[i]);
+  }
+  return 0;
+}
+
+int fsdp_plan_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses,
+                    fsdp_frame_result* results) {
+  int rc = fsdp_upload(c, n_frames, off, cones, poses);
+  if (rc) return rc;
+  rc = fsdp_run(c);
+  if (rc) return rc;
+  return fsdp_download(c, results);
+}
+
+int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
+  if (!c || iters <= 0) return 1;
+  if (c->n_frames == 0) {
+    if (ms_total) *ms_total = 0;
+    if (ms_stage) ms_stage[0] = ms_stage[1] = ms_stage[2] = 0;
+    return 0;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  float acc[3] = {0, 0, 0};
+  float total = 0;
+  for (int it = 0; it < iters; it++) {
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    launch_sort(c);
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    launch_match(c);
+    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    launch_path(c);
+    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev[3]));
+    float t;
+    for (int s = 0; s < 3; s++) {
+      HIP_TRY(c, hipEventElapsedTime(&t, c->ev[s], c->ev[s + 1]));
+      acc[s] += t;
+    }
+    HIP_TRY(c, hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
+    total += t;
+  }
+  HIP_TRY(c, hipGetLastError());
+  if (ms_total) *ms_total = total;
+  if (ms_stage) {
+    ms_stage[0] = acc[0];
+    ms_stage[1] = acc[1];
+    ms_stage[2] = acc[2];
+  }
+  return 0;
+}
+
+int fsdp_sort_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses,
+                    fsdp_frame_result* results) {
+  int rc = fsdp_upload(c, n_frames, off, cones, poses);
+  if (rc) return rc;
+  if (n_frames == 0) return 0;
+  launch_sort(c);
+  c->h_sort.resize(n_frames);
+  HIP_TRY(c, hipMemcpyAsync(c->h_sort.data(), c->d_sort, sizeof(SortOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n_frames; i++) {
+    memset(&results[i], 0, sizeof(fsdp_frame_result));
+    assemble(&c->h_sort[i], nullptr, nullptr, &results[i]);
+  }
+  return 0;
+}
+
+int fsdp_match_batch(fsdp_ctx* c, int n_frames, const double* sorted_left, const int32_t* n_left, const double* sorted_right,
+                     const int32_t* n_right, const double* poses, fsdp_frame_result* results) {
+  if (!c || n_frames < 0) return 1;
+  if (n_frames == 0) return 0;
+  // express the already sorted cones as a tiny frame each: cones = [left..., right...], indices 0..nl-1 / nl..nl+nr-1
+  std::vector<int32_t> off(n_frames + 1, 0);
+  std::vector<double> cones;
+  std::vector<SortOut> so(n_frames);
+  for (int f = 0; f < n_frames; f++) {
+    int nl = n_left[f], nr = n_right[f];
+    if (nl < 0 || nl > MAX_LEN || nr < 0 || nr > MAX_LEN) {
+      c->err = "fsdp_match_batch: side length out of range";
+      return 1;
+    }
+    memset(&so[f], 0, sizeof(SortOut));
+    for (int i = 0; i < MAX_LEN; i++) so[f].left_idx[i] = so[f].right_idx[i] = -1;
+    so[f].n_left = nl;
+    so[f].n_right = nr;
+    for (int i = 0; i < nl; i++) {
+      so[f].left_idx[i] = i;
+      cones.push_back(sorted_left[((size_t)f * MAX_LEN + i) * 2]);
+      cones.push_back(sorted_left[((size_t)f * MAX_LEN + i) * 2 + 1]);
+      cones.push_back((double)T_LEFT);
+    }
+    for (int i = 0; i < nr; i++) {
+      so[f].right_idx[i] = nl + i;
+      cones.push_back(sorted_right[((size_t)f * MAX_LEN + i) * 2]);
+      cones.push_back(sorted_right[((size_t)f * MAX_LEN + i) * 2 + 1]);
+      cones.push_back((double)T_RIGHT);
+    }
+    off[f + 1] = off[f] + nl + nr;
+  }
+  int rc = fsdp_upload(c, n_frames, off.data(), cones.data(), poses);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_sort, so.data(), sizeof(SortOut) * n_frames, hipMemcpyHostToDevice, c->stream));
+  launch_match(c);
+  c->h_match.resize(n_frames);
+  HIP_TRY(c, hipMemcpyAsync(c->h_match.data(), c->d_match, sizeof(MatchOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n_frames; i++) {
+    memset(&results[i], 0, sizeof(fsdp_frame_result));
+    assemble(nullptr, &c->h_match[i], nullptr, &results[i]);
+  }
+  return 0;
+}
+
+int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, fsdp_frame_result* results) {
+  if (!c || n_frames < 0) return 1;
+  if (n_frames == 0) return 0;
+  int rc = ensure_capacity(c, n_frames, 1);
+  if (rc) return rc;
+  c->n_frames = n_frames;
+  std::vector<MatchOut> mo(n_frames);
+  for (int f = 0; f < n_frames; f++) {
+    memset(&mo[f], 0, sizeof(MatchOut));
+    const fsdp_frame_result& r = results[f];
+    if (r.n_left_v < 0 || r.n_left_v > MAX_MATCH || r.n_right_v < 0 || r.n_right_v > MAX_MATCH) {
+      c->err = "fsdp_path_batch: cone count out of range";
+      return 1;
+    }
+    mo[f].n_left_v = r.n_left_v;
+    mo[f].n_right_v = r.n_right_v;
+    memcpy(mo[f].left_v, r.left_v, sizeof(r.left_v));
+    memcpy(mo[f].right_v, r.right_v, sizeof(r.right_v));
+    memcpy(mo[f].l2r, r.l2r, sizeof(r.l2r));
+    memcpy(mo[f].r2l, r.r2l, sizeof(r.r2l));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_match, mo.data(), sizeof(MatchOut) * n_frames, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, c->stream));
+  launch_path(c);
+  c->h_path.resize(n_frames);
+  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), c->d_path, sizeof(PathOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n_frames; i++) {
+    results[i].status = 0;
+    assemble(nullptr, nullptr, &c->h_path[i], &results[i]);
+  }
+  return 0;
+}
+
+int fsdp_default_path(fsdp_ctx* c, double* out) {
+  if (!c || !out) return 1;
+  HIP_TRY(c, hipMemcpy(out, c->d_default_path, sizeof(double) * PATH_POINTS * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+}

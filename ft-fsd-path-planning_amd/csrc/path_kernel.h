@@ -1,0 +1,722 @@
+// calculate_path step as a wave-per-frame HIP kernel (gfx950).
+//
+// Replaces CalculatePath.run_path_calculation for independent frames (fresh-planner semantics: the
+// "previous path" is the constant initial path), reference calculate_path/core_calculate_path.py:514-575:
+//   centre points of the matches (:151-205)                      lane = cone
+//   fit #1 + dense evaluation every 0.1 m (:207-223)              spline_device.h
+//   too-far check, connect to car, circular/linear extension, trim behind the car (:225-334,:430-465)
+//   fit #2 + 300-sample evaluation, cut at 20 m (:239-259,:467-499)
+//   PathParameterizer.parameterize_path (path_parameterization.py:297-328): fit #3 (s = 0.01), dense
+//   evaluation, circle-fit curvature over sliding windows (lane = window), uniform filter, 40-index resample.
+// Every float that feeds the sample-count decision ceil(max_u / predict_every) is produced in the
+// reference's rounding order (see DESIGN.md "arithmetic contract").
+//
+// LDS per frame: polyline arena 3 x 768 doubles (18 KB) reused by the three fits and the dense output,
+// spline workspace ~9 KB, small vectors < 2 KB  => ~30 KB, 5 frames resident per CU.
+#pragma once
+#include "fsdp_device.h"
+#include "spline_device.h"
+
+namespace fsdp {
+
+constexpr int PATH_CAP = 768;   // points of the working polyline (dense fit-#1 output + extension)
+constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121 in practice)
+
+struct PathShared {
+  double ax[PATH_CAP];  // polyline arena: x
+  double ay[PATH_CAP];  //                 y
+  double au[PATH_CAP];  //                 parameter / scratch
+  double cxp[PATH_POINTS], cyp[PATH_POINTS], cup[PATH_POINTS];  // centre points (<= 24) or previous path (40)
+  double prevx[PATH_POINTS], prevy[PATH_POINTS];                // previous path xy
+  double curv[DENSE_CAP], filt[DENSE_CAP];
+  SplineWS ws;
+};
+
+// np.sum of a contiguous run (NumPy pairwise summation, any n) — wave-uniform
+__device__ inline double np_sum_run(const double* a, int n) {
+  if (n <= 128) return np_sum_small(a, n);
+  // explicit recursion tree: split n -> n2 = n/2 - (n/2)%8, n - n2
+  int st_off[12], st_n[12], st_state[12];
+  double st_acc[12];
+  int sp = 0;
+  st_off[0] = 0;
+  st_n[0] = n;
+  st_state[0] = 0;
+  st_acc[0] = 0.0;
+  double ret = 0.0;
+  while (sp >= 0) {
+    int nn = st_n[sp];
+    if (nn <= 128) {
+      double r = 0.0;
+      // leaf without the "0.0 +" of np_sum_small's reduce identity
+      if (nn < 8) {
+        for (int i = 0; i < nn; i++) r += a[st_off[sp] + i];
+      } else {
+        const double* b = a + st_off[sp];
+        double r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3], r4 = b[4], r5 = b[5], r6 = b[6], r7 = b[7];
+        int i = 8;
+        for (; i < nn - (nn % 8); i += 8) {
+          r0 += b[i];
+          r1 += b[i + 1];
+          r2 += b[i + 2];
+          r3 += b[i + 3];
+          r4 += b[i + 4];
+          r5 += b[i + 5];
+          r6 += b[i + 6];
+          r7 += b[i + 7];
+        }
+        r = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < nn; i++) r += b[i];
+      }
+      ret = r;
+      sp--;
+      continue;
+    }
+    int n2 = nn / 2;
+    n2 -= n2 % 8;
+    if (st_state[sp] == 0) {
+      st_state[sp] = 1;
+      st_off[sp + 1] = st_off[sp];
+      st_n[sp + 1] = n2;
+      st_state[sp + 1] = 0;
+      sp++;
+    } else if (st_state[sp] == 1) {
+      st_acc[sp] = ret;
+      st_state[sp] = 2;
+      st_off[sp + 1] = st_off[sp] + n2;
+      st_n[sp + 1] = nn - n2;
+      st_state[sp + 1] = 0;
+      sp++;
+    } else {
+      ret = st_acc[sp] + ret;
+      sp--;
+    }
+  }
+  return 0.0 + ret;
+}
+
+// NumPy pairwise sum of f(0..n-1) for n <= 128 without materialising the operands
+template <class F>
+__device__ __forceinline__ double np_sum_fn(int n, F f) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; i++) r += f(i);
+    return 0.0 + r;
+  }
+  double r0 = f(0), r1 = f(1), r2 = f(2), r3 = f(3), r4 = f(4), r5 = f(5), r6 = f(6), r7 = f(7);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+    r0 += f(i);
+    r1 += f(i + 1);
+    r2 += f(i + 2);
+    r3 += f(i + 3);
+    r4 += f(i + 4);
+    r5 += f(i + 5);
+    r6 += f(i + 6);
+    r7 += f(i + 7);
+  }
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < n; i++) res += f(i);
+  return 0.0 + res;
+}
+
+// utils/math_utils.py:579-646 circle_fit of points (px[idx0 + i], py[idx0 + i]), i < n (n <= 128)
+__device__ inline void circle_fit(const double* px, const double* py, int idx0, int n, double& ocx, double& ocy,
+                                  double& orad) {
+  const double* X = px + idx0;
+  const double* Y = py + idx0;
+  const double dn = (double)n;
+  double xm = np_sum_fn(n, [&](int i) { return X[i]; }) / dn;
+  double ym = np_sum_fn(n, [&](int i) { return Y[i]; }) / dn;
+  auto Xi = [&](int i) { return X[i] - xm; };
+  auto Yi = [&](int i) { return Y[i] - ym; };
+  auto Zi = [&](int i) {
+    double a = X[i] - xm, b = Y[i] - ym;
+    return a * a + b * b;
+  };
+  double Mxy = np_sum_fn(n, [&](int i) { return Xi(i) * Yi(i); }) / dn;
+  double Mxx = np_sum_fn(n, [&](int i) { return Xi(i) * Xi(i); }) / dn;
+  double Myy = np_sum_fn(n, [&](int i) { return Yi(i) * Yi(i); }) / dn;
+  double Mxz = np_sum_fn(n, [&](int i) { return Xi(i) * Zi(i); }) / dn;
+  double Myz = np_sum_fn(n, [&](int i) { return Yi(i) * Zi(i); }) / dn;
+  double Mzz = np_sum_fn(n, [&](int i) { return Zi(i) * Zi(i); }) / dn;
+  double Mz = Mxx + Myy;
+  double Cov_xy = Mxx * Myy - Mxy * Mxy;
+  double Var_z = Mzz - Mz * Mz;
+  double A2 = 4 * Cov_xy - 3 * Mz * Mz - Mzz;
+  double A1 = Var_z * Mz + 4.0 * Cov_xy * Mz - Mxz * Mxz - Myz * Myz;
+  double A0 = Mxz * (Mxz * Myy - Myz * Mxy) + Myz * (Myz * Mxx - Mxz * Mxy) - Var_z * Cov_xy;
+  double A22 = A2 + A2;
+  double y = A0, x = 0.0;
+  for (int it = 0; it < 99; it++) {
+    double Dy = A1 + x * (A22 + 16.0 * x * x);
+    double x_new = x - y / Dy;
+    if (x_new == x || !isfinite(x_new)) break;
+    double y_new = A0 + x_new * (A1 + x_new * (A2 + 4.0 * x_new * x_new));
+    if (fabs(y_new) >= fabs(y)) break;
+    x = x_new;
+    y = y_new;
+  }
+  double det = x * x - x * Mz + Cov_xy;
+  double Xc = (Mxz * (Myy - x) - Myz * Mxy) / det / 2.0;
+  double Yc = (Myz * (Mxx - x) - Mxz * Mxy) / det / 2.0;
+  ocx = Xc + xm;
+  ocy = Yc + ym;
+  orad = sqrt(fabs(Xc * Xc + Yc * Yc + Mz));
+}
+
+// det([[1,x0,y0],[1,x1,y1],[1,x2,y2]]) via LU with partial pivoting (what numpy.linalg.det does)
+__device__ inline double det3_lu(double x0, double y0, double x1, double y1, double x2, double y2) {
+  double a[3][3] = {{1.0, x0, y0}, {1.0, x1, y1}, {1.0, x2, y2}};
+  int sign = 1;
+  for (int k = 0; k < 3; k++) {
+    int p = k;
+    double best = fabs(a[k][k]);
+    for (int i = k + 1; i < 3; i++)
+      if (fabs(a[i][k]) > best) {
+        best = fabs(a[i][k]);
+        p = i;
+      }
+    if (a[p][k] == 0.0) return 0.0;
+    if (p != k) {
+      for (int j = 0; j < 3; j++) {
+        double t = a[p][j];
+        a[p][j] = a[k][j];
+        a[k][j] = t;
+      }
+      sign = -sign;
+    }
+    double inv = 1.0 / a[k][k];
+    for (int i = k + 1; i < 3; i++) a[i][k] *= inv;
+    for (int j = k + 1; j < 3; j++)
+      for (int i = k + 1; i < 3; i++) a[i][j] -= a[i][k] * a[k][j];
+  }
+  double det = 1.0;
+  for (int k = 0; k < 3; k++) det *= a[k][k];
+  return sign * det;
+}
+
+__device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
+__device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
+
+// chord lengths -> parameter values: au[off + i] = cumulative length (np.cumsum, sequential); returns max_u.
+__device__ inline double build_parameter(PathShared& S, int off, int m) {
+  const int lane = lane_id();
+  double acc = 0.0;
+  if (lane == 0) S.au[off] = 0.0;
+  for (int base = 0; base < m - 1; base += WAVE) {
+    int i = base + lane;
+    if (i < m - 1) {
+      double dx = S.ax[off + i + 1] - S.ax[off + i], dy = S.ay[off + i + 1] - S.ay[off + i];
+      S.ws.term[lane] = sqrt(dx * dx + dy * dy);
+    }
+    __syncthreads();
+    int cnt = (m - 1 - base) < WAVE ? (m - 1 - base) : WAVE;
+    for (int r = 0; r < cnt; r++) {
+      acc += S.ws.term[r];
+      if (lane == 0) S.au[off + base + r + 1] = acc;
+    }
+    __syncthreads();
+  }
+  return acc;
+}
+
+// utils/spline_fit.py:95-128 on the arena polyline [off, off+m).  rc: 0 ok, 1 ValueError, >=200 overflow
+__device__ inline int fit_polyline(PathShared& S, int off, int m, double smoothing, SplineFit& f, double& max_u) {
+  int k = m - 1;
+  k = k < 1 ? 1 : (k > 3 ? 3 : k);
+  max_u = build_parameter(S, off, m);
+  f = spline_fit(S.ws, S.au + off, S.ax + off, S.ay + off, m, k, smoothing);
+  return f.status;
+}
+
+__device__ __forceinline__ int arange_len(double stop, double step) {
+  double q = stop / step;
+  if (!(q > 0)) return 0;
+  return (int)ceil(q);
+}
+
+// calculate_path/path_parameterization.py:297-328 on the arena polyline [off, off+n).
+// rc: 0 ok (out filled), 1 ValueError, ST_* otherwise.
+__device__ inline int parameterize_path(PathShared& S, int off, int n, double (*out)[4], int* n_dense) {
+  const int lane = lane_id();
+  if (n < 2) return ST_REF_UNDEFINED_PATH;
+  // _refit_spline :125-161
+  for (int i = lane; i < n - 1; i += WAVE) {
+    double dx = S.ax[off + i + 1] - S.ax[off + i], dy = S.ay[off + i + 1] - S.ay[off + i];
+    S.au[off + i] = sqrt(dx * dx + dy * dy);
+  }
+  __syncthreads();
+  double path_length = np_sum_run(S.au + off, n - 1);
+  int n10 = (n - 1) < 10 ? (n - 1) : 10;
+  double mean_pd = np_sum_small(S.au + off, n10) / (double)n10;
+  double predict_every = path_length / PATH_POINTS / 3;
+  int skip;
+  {
+    double q = predict_every / mean_pd;
+    if (isnan(q))
+      skip = 1;
+    else if (isinf(q))
+      return ST_REF_UNDEFINED_PATH;
+    else {
+      skip = (int)q;
+      if (skip < 1) skip = 1;
+    }
+  }
+  __syncthreads();
+  int ns = n;
+  if (skip > 1) {
+    ns = (n + skip - 1) / skip;
+    for (int base = 0; base < ns; base += WAVE) {
+      int i = base + lane;
+      double vx = 0, vy = 0;
+      if (i < ns) {
+        vx = S.ax[off + i * skip];
+        vy = S.ay[off + i * skip];
+      }
+      __syncthreads();
+      if (i < ns) {
+        S.ax[off + i] = vx;
+        S.ay[off + i] = vy;
+      }
+      __syncthreads();
+    }
+  }
+  SplineFit f;
+  double max_u;
+  int rc = fit_polyline(S, off, ns, 0.01, f, max_u);
+  if (rc) return rc;
+  // _calculate_path_curvature :163-193 — dense samples into the arena start
+  int L = arange_len(max_u, predict_every);
+  if (L > DENSE_CAP) return ST_OVERFLOW_PATH;
+  if (L == 0) return ST_REF_UNDEFINED_PATH;
+  spline_eval(S.ws, f, predict_every, L, S.ax, S.ay, S.au);
+  int window = (L / 5) < 30 ? (L / 5) : 30;
+  if (window % 2 == 0) window += 1;
+  const int half = window / 2;
+  for (int i = lane; i < L; i += WAVE) {
+    // cyclic window cut at the wrap-around for an open path (path_parameterization.py:64-77)
+    int lo = i - half, hi = i + half;
+    int w0, wn;
+    if (lo >= 0 && hi < L) {
+      w0 = lo;
+      wn = window;
+    } else if (lo < 0) {  // wraps at the start (then i < window always): keep the part after the wrap
+      w0 = 0;
+      wn = hi + 1;
+    } else if (i < window) {  // wraps at the end while i < window (only for very short paths): keeps the wrapped tail
+      w0 = 0;
+      wn = hi - L + 1;
+    } else {  // wraps at the end: keep the part before the wrap
+      w0 = lo;
+      wn = L - lo;
+    }
+    double cx, cy, r;
+    circle_fit(S.ax, S.ay, w0, wn, cx, cy, r);
+    r = py_min(py_max(r, 1.0), 3000.0);
+    double c = 1 / r;
+    int i1 = wn / 2;
+    double sg = det3_lu(S.ax[w0], S.ay[w0], S.ax[w0 + i1], S.ay[w0 + i1], S.ax[w0 + wn - 1], S.ay[w0 + wn - 1]);
+    S.curv[i] = c * sign_of(sg);
+    if (isnan(sg)) S.curv[i] = sg;
+  }
+  __syncthreads();
+  // scipy.ndimage.uniform_filter1d(size = max(2, window // 2), mode = "nearest"): running sum, wave-uniform
+  {
+    int size = (window / 2) > 2 ? (window / 2) : 2;
+    int s1 = size / 2, s2 = size - s1 - 1;
+    double tmp = 0.0;
+    for (int j = -s1; j <= s2; j++) {
+      int q = j < 0 ? 0 : (j > L - 1 ? L - 1 : j);
+      tmp += S.curv[q];
+    }
+    if (lane == 0) S.filt[0] = tmp / size;
+    for (int i = 1; i < L; i++) {
+      int qa = i + s2, qb = i - 1 - s1;
+      qa = qa < 0 ? 0 : (qa > L - 1 ? L - 1 : qa);
+      qb = qb < 0 ? 0 : (qb > L - 1 ? L - 1 : qb);
+      tmp += S.curv[qa] - S.curv[qb];
+      if (lane == 0) S.filt[i] = tmp / size;
+    }
+  }
+  __syncthreads();
+  // _sample_path_parameters_for_prediction_horizon :252-295: np.linspace(0, L-1, 40, dtype=int)
+  {
+    double step = ((double)(L - 1) - 0.0) / (double)(PATH_POINTS - 1);
+    int idx = 0, prev = -1;
+    bool dup = false;
+    if (lane < PATH_POINTS) {
+      double v = (double)lane * step + 0.0;
+      if (lane == PATH_POINTS - 1) v = (double)(L - 1);
+      idx = (int)floor(v);
+      if (lane > 0) {
+        double vp = (double)(lane - 1) * step + 0.0;
+        prev = (int)floor(vp);
+        dup = (prev == idx);
+      }
+    }
+    if (__ballot(dup) != 0ull) return 1;  // "Indices of resampled path appear twice" (ValueError)
+    if (lane < PATH_POINTS) {
+      out[lane][0] = S.au[idx];
+      out[lane][1] = S.ax[idx];
+      out[lane][2] = S.ay[idx];
+      out[lane][3] = S.filt[idx];
+    }
+  }
+  *n_dense = L;
+  __syncthreads();
+  return 0;
+}
+
+// core_calculate_path.py:380-417 do_all_mpc_parameter_calculations on the polyline [1, 1+n) of the arena
+// (slot 0 is reserved for the point connect_path_to_car may prepend).  rc as parameterize_path.
+__device__ inline int do_all_mpc(PathShared& S, int n, double px, double py, double dx, double dy, double (*out)[4],
+                                 int* fallback, int* n_dense) {
+  const int lane = lane_id();
+  if (n <= 0) return ST_REF_UNDEFINED_PATH;
+  int off = 1;
+  // connect_path_to_car :430-457
+  {
+    double fx = S.ax[1], fy = S.ay[1];
+    double d = norm_blas(px - fx, py - fy);
+    double cx = fx - px, cy = fy - py;
+    double ang = angle_between(cx, cy, dx, dy);
+    if (!(d < 0.5 || ang > FSDP_PI / 2)) {
+      double nrm = norm_blas(cx, cy);
+      __syncthreads();
+      if (lane == 0) {
+        S.ax[0] = px + (cx / nrm) * 0.2;
+        S.ay[0] = py + (cy / nrm) * 0.2;
+      }
+      off = 0;
+      n += 1;
+    }
+  }
+  __syncthreads();
+  // extend_path :261-334
+  {
+    // first index in front of the car (np.dot(car_to_path, direction) > 0), all later points count as in front
+    int first = n;
+    for (int base = 0; base < n; base += WAVE) {
+      int i = base + lane;
+      bool fr = i < n && blas_dot2(S.ax[off + i] - px, dx, S.ay[off + i] - py, dy) > 0;
+      unsigned long long m = __ballot(fr);
+      if (m) {
+        first = base + (__ffsll(m) - 1);
+        break;
+      }
+    }
+    int tail = n - 20 < 0 ? 0 : n - 20;
+    int f0 = first < tail ? first : tail;  // mask[first:] = True, mask[-20:] = True  -> contiguous [f0, n)
+    int nin = n - f0;
+    if (nin >= 1) {
+      if (nin < 2) return ST_REF_UNDEFINED_PATH;  // cumsum([])[-1] -> IndexError
+      // path length in front of the car: np.cumsum of the segment lengths (sequential)
+      for (int i = lane; i < nin - 1; i += WAVE) {
+        double ddx = S.ax[off + f0 + i + 1] - S.ax[off + f0 + i], ddy = S.ay[off + f0 + i + 1] - S.ay[off + f0 + i];
+        S.au[i] = sqrt(ddx * ddx + ddy * ddy);
+      }
+      __syncthreads();
+      double plen = 0.0;
+      for (int i = 0; i < nin - 1; i++) plen += S.au[i];
+      __syncthreads();
+      if (!(plen > 20.0)) {
+        int nrel = nin < 20 ? nin : 20;
+        int r0 = off + n - nrel;
+        double ccx, ccy, radius;
+        circle_fit(S.ax, S.ay, r0, nrel, ccx, ccy, radius);
+        double r_use = py_min(py_max(radius, 10), 100);
+        const double lastx = S.ax[off + n - 1], lasty = S.ay[off + n - 1];
+        int n_new;
+        if (r_use < 80) {
+          *fallback |= 16;
+          int i1 = nrel / 2;
+          double t0x = S.ax[r0] - ccx, t0y = S.ay[r0] - ccy;
+          double t1x = S.ax[r0 + i1] - ccx, t1y = S.ay[r0 + i1] - ccy;
+          double t2x = S.ax[r0 + nrel - 1] - ccx, t2y = S.ay[r0 + nrel - 1] - ccy;
+          double sg = sign_of(det3_lu(t0x, t0y, t1x, t1y, t2x, t2y));
+          double start = atan2(t0y, t0x);
+          double end = start + sg * FSDP_PI;
+          const int NP = 50;
+          double step = (end - start) / (double)(NP - 1);
+          double raw0x = cos(start) * r_use, raw0y = sin(start) * r_use;  // i = 0: 0*step + start
+          n_new = NP - 1;
+          if (off + n + n_new > PATH_CAP) return ST_OVERFLOW_PATH;
+          __syncthreads();
+          if (lane >= 1 && lane < NP) {
+            double a = (double)lane * step + start;
+            if (lane == NP - 1) a = end;
+            double rx = cos(a) * r_use, ry = sin(a) * r_use;
+            S.ax[off + n + lane - 1] = rx - raw0x + lastx;
+            S.ay[off + n + lane - 1] = ry - raw0y + lasty;
+          }
+        } else {
+          *fallback |= 32;
+          double ddx = lastx - S.ax[off + n - 2], ddy = lasty - S.ay[off + n - 2];
+          double nrm = norm_blas(ddx, ddy);
+          ddx /= nrm;
+          ddy /= nrm;
+          n_new = 29;
+          if (off + n + n_new > PATH_CAP) return ST_OVERFLOW_PATH;
+          __syncthreads();
+          if (lane >= 1 && lane < 30) {
+            S.ax[off + n + lane - 1] = lastx + ddx * (double)lane;
+            S.ay[off + n + lane - 1] = lasty + ddy * (double)lane;
+          }
+        }
+        n += n_new;
+        __syncthreads();
+      }
+    }
+  }
+  // remove_path_behind_car :459-465
+  {
+    double bv = 0.0;
+    int bi = -1;
+    for (int i = lane; i < n; i += WAVE) {
+      double d = norm_axis(px - S.ax[off + i], py - S.ay[off + i]);
+      if (bi < 0 || d < bv) {
+        bv = d;
+        bi = i;
+      }
+    }
+    wave_argmin(bv, bi);
+    off += bi;
+    n -= bi;
+  }
+  __syncthreads();
+  // refit_path_for_mpc_with_safety_factor :239-259 (predict to 1.5 * 20 m), then cut at 20 m :467-499
+  int n5;
+  {
+    int n4 = 0;
+    SplineFit f;
+    if (n >= 2) {
+      double max_u;
+      int rc = fit_polyline(S, off, n, 0.2, f, max_u);
+      if (rc) return rc;
+      n4 = arange_len(20.0 * 1.5, 0.1);
+      spline_eval(S.ws, f, 0.1, n4, S.ax, S.ay, nullptr);
+    }
+    int nseg = n4 - 1;
+    if (nseg <= 1) return 1;  // previous (40,4) array handed on -> LinAlgError (a ValueError) downstream
+    for (int i = lane; i < nseg; i += WAVE) {
+      double ddx = S.ax[i + 1] - S.ax[i], ddy = S.ay[i + 1] - S.ay[i];
+      S.au[i] = sqrt(ddx * ddx + ddy * ddy);
+    }
+    __syncthreads();
+    double cum = 0.0;
+    int first = nseg;
+    for (int i = 0; i < nseg; i++) {
+      cum += S.au[i];
+      if (cum > 20.0) {
+        first = i;
+        break;
+      }
+    }
+    n5 = first;
+    __syncthreads();
+  }
+  return parameterize_path(S, 0, n5, out, n_dense);
+}
+
+// path_calculator_helpers.py:26-68 calculate_almost_straight_path (host side, libm = what NumPy uses)
+inline void default_chord_points(double (*chord)[2]) {
+  const int NP = PATH_POINTS;
+  const double max_angle = FSDP_PI / 50;
+  const double step = (fabs(max_angle) - 0.0) / (double)(NP - 1);
+  const double c = cos(-(FSDP_PI / 2)), s = sin(-(FSDP_PI / 2));
+  for (int i = 0; i < NP; i++) {
+    double a = (double)i * step + 0.0;
+    if (i == NP - 1) a = fabs(max_angle);
+    double px = (cos(a) - 1.0) * 1000.0, py = (sin(a) - 0.0) * 1000.0;
+    double qx = fma(py, -s, px * c), qy = fma(py, c, px * s);
+    chord[i][0] = qx;
+    chord[i][1] = qy * 1.0;
+  }
+}
+
+// core_calculate_path.py:103-121: previous_paths[0] = parameterize_path(fit(chord).predict())
+__global__ void __launch_bounds__(64) default_path_kernel(const double* __restrict__ chord, double* __restrict__ out) {
+  __shared__ PathShared S;
+  const int lane = lane_id();
+  if (lane < PATH_POINTS) {
+    S.ax[lane] = chord[2 * lane];
+    S.ay[lane] = chord[2 * lane + 1];
+  }
+  __syncthreads();
+  SplineFit f;
+  double max_u;
+  int rc = fit_polyline(S, 0, PATH_POINTS, 0.2, f, max_u);
+  int n1 = arange_len(max_u, 0.1);
+  if (rc == 0 && n1 <= PATH_CAP) {
+    spline_eval(S.ws, f, 0.1, n1, S.ax, S.ay, nullptr);
+    int nd = 0;
+    double(*o)[4] = (double(*)[4])out;
+    rc = parameterize_path(S, 0, n1, o, &nd);
+  }
+  if (rc != 0 && lane < PATH_POINTS)
+    for (int q = 0; q < 4; q++) out[4 * lane + q] = NAN;
+}
+
+__global__ void __launch_bounds__(64) path_kernel(int n_frames, const double* __restrict__ poses,
+                                                  const MatchOut* __restrict__ matched,
+                                                  const double* __restrict__ default_path, PathOut* __restrict__ out) {
+  __shared__ PathShared S;
+  const int frame = blockIdx.x;
+  if (frame >= n_frames) return;
+  const int lane = lane_id();
+  const MatchOut* mo = &matched[frame];
+  PathOut* o = &out[frame];
+  const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
+  int status = mo->status;
+  int fallback = 0, n_dense = 0;
+  if (lane < PATH_POINTS) {
+    S.prevx[lane] = default_path[4 * lane + 1];
+    S.prevy[lane] = default_path[4 * lane + 2];
+  }
+  __syncthreads();
+  const int nl = mo->n_left_v, nr = mo->n_right_v;
+  int nc = 0;  // centre points in S.cxp/cyp
+  if (status == ST_OK) {
+    bool use_prev = false;
+    if (nl < 3 && nr < 3) {
+      use_prev = true;
+    } else {
+      // select_side_to_use :151-183
+      int ml = (lane < nl) ? mo->l2r[lane] : -1;
+      int mr = (lane < nr) ? mo->r2l[lane] : -1;
+      unsigned long long bl = __ballot(ml != -1), br = __ballot(mr != -1);
+      int cntl = __popcll(bl), cntr = __popcll(br);
+      int sl = 0, sr = 0;
+      for (int i = 0; i < nl; i++) {
+        int v = mo->l2r[i];
+        if (v != -1) sl += v;
+      }
+      for (int i = 0; i < nr; i++) {
+        int v = mo->r2l[i];
+        if (v != -1) sr += v;
+      }
+      bool use_left = !((cntr > cntl) || (cntr == cntl && sr > sl));
+      const int ns = use_left ? nl : nr, no = use_left ? nr : nl;
+      const int mine = use_left ? ml : mr;
+      const unsigned long long bm = use_left ? bl : br;
+      if (ns > 0 && no == 0) {
+        status = ST_REF_UNDEFINED_MATCH_IDX;
+      } else {
+        bool bad = false;
+        if (lane < ns) {
+          int j = mine < 0 ? no + mine : mine;
+          if (j < 0 || j >= no) bad = true;
+          if (!bad && mine != -1) {
+            const double(*sv)[2] = use_left ? mo->left_v : mo->right_v;
+            const double(*ov)[2] = use_left ? mo->right_v : mo->left_v;
+            int p = __popcll(bm & ((1ull << lane) - 1ull));
+            S.cxp[p] = (sv[lane][0] + ov[j][0]) / 2;
+            S.cyp[p] = (sv[lane][1] + ov[j][1]) / 2;
+          }
+        }
+        if (__ballot(bad) != 0ull) status = ST_REF_UNDEFINED_MATCH_IDX;
+        nc = __popcll(bm);
+        if (nc < 2) use_prev = true;
+      }
+    }
+    __syncthreads();
+    if (use_prev) {
+      fallback |= 1;
+      if (lane < PATH_POINTS) {
+        S.cxp[lane] = S.prevx[lane];
+        S.cyp[lane] = S.prevy[lane];
+      }
+      nc = PATH_POINTS;
+    }
+    __syncthreads();
+  }
+  // fit_matches_as_spline :207-223 -> dense path update in arena [1, 1+n1)
+  int n1 = 0;
+  if (status == ST_OK) {
+    for (int attempt = 0; attempt < 2; attempt++) {
+      if (lane < nc) {
+        S.ax[lane] = S.cxp[lane];
+        S.ay[lane] = S.cyp[lane];
+      }
+      __syncthreads();
+      SplineFit f;
+      double max_u;
+      int rc = fit_polyline(S, 0, nc, 0.2, f, max_u);
+      if (rc == 0) {
+        n1 = arange_len(max_u, 0.1);
+        if (n1 + 1 + 50 > PATH_CAP) {
+          status = ST_OVERFLOW_PATH;
+        } else {
+          spline_eval(S.ws, f, 0.1, n1, S.ax + 1, S.ay + 1, nullptr);
+        }
+        break;
+      }
+      if (rc != 1) {
+        status = rc;
+        break;
+      }
+      if (attempt == 1) {
+        status = ST_REF_UNDEFINED_PATH;  // the fallback fit raised as well
+        break;
+      }
+      fallback |= 2;
+      if (lane < PATH_POINTS) {
+        S.cxp[lane] = S.prevx[lane];
+        S.cyp[lane] = S.prevy[lane];
+      }
+      nc = PATH_POINTS;
+      __syncthreads();
+    }
+  }
+  if (status == ST_OK && n1 == 0) status = ST_REF_UNDEFINED_PATH;  // min() of an empty array
+  // overwrite_path_if_it_is_too_far_away :225-237
+  if (status == ST_OK) {
+    double bv = 0.0;
+    int bi = -1;
+    for (int i = lane; i < n1; i += WAVE) {
+      double d = norm_axis(px - S.ax[1 + i], py - S.ay[1 + i]);
+      if (bi < 0 || d < bv) {
+        bv = d;
+        bi = i;
+      }
+    }
+    wave_argmin(bv, bi);
+    if (bv > 5.0) {
+      fallback |= 4;
+      __syncthreads();
+      if (lane < PATH_POINTS) {
+        S.ax[1 + lane] = S.prevx[lane];
+        S.ay[1 + lane] = S.prevy[lane];
+      }
+      n1 = PATH_POINTS;
+      __syncthreads();
+    }
+  }
+  if (status == ST_OK) {
+    int rc = do_all_mpc(S, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
+    if (rc == 1) {  // ValueError -> redo with the previous path (:564-570)
+      fallback |= 8;
+      __syncthreads();
+      if (lane < PATH_POINTS) {
+        S.ax[1 + lane] = S.prevx[lane];
+        S.ay[1 + lane] = S.prevy[lane];
+      }
+      __syncthreads();
+      rc = do_all_mpc(S, PATH_POINTS, px, py, dx, dy, o->path, &fallback, &n_dense);
+      if (rc == 1) rc = ST_REF_UNDEFINED_PATH;
+    }
+    if (rc != 0) status = rc;
+  }
+  __syncthreads();
+  if (status != ST_OK && lane < PATH_POINTS)
+    for (int q = 0; q < 4; q++) o->path[lane][q] = NAN;
+  if (lane == 0) {
+    o->status = status;
+    o->fallback = fallback;
+    o->n_dense = n_dense;
+    o->pad = 0;
+  }
+}
+
+}  // namespace fsdp

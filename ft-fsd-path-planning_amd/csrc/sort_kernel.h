@@ -1,0 +1,865 @@
+// sorting_cones step as a hand-written wave-per-frame HIP kernel (gfx950).
+//
+// Replaces, for a batch of independent frames, the reference call chain
+//   TraceSorter.sort_left_right                     sorting_cones/trace_sorter/core_trace_sorter.py:148-216
+//     select_first_k_starting_cones                 :409-465   (lanes = cones, wave arg-min)
+//     create_adjacency_matrix                       adjacency_matrix.py:60-128 (lane = row, register top-5,
+//                                                   mutual-kNN through LDS, ballot-frontier BFS)
+//     _impl_find_all_end_configurations             end_configurations.py:320-431 (explicit LDS stack, lanes =
+//                                                   candidate neighbours, ballot + popcount prefix for pushes)
+//     find_all_end_configurations post-filters      :434-520   (lane = raw configuration)
+//     cost_configurations                           cost_function.py:213-304 (lane = configuration; side counting
+//                                                   nearby_cone_search.py:213-297 with lanes = cones + ballots)
+//     calc_final_configs_for_left_and_right         combine_traces.py:21-257 (wave-uniform)
+//
+// LDS per frame (one wavefront): cone x/y 4 KB, type 256 B, per-cone start-cone scalars 2.3 KB, neighbour lists
+// 1.5 KB, end configurations 1.5 KB, misc < 1 KB  => ~11 KB, 14 frames resident per CU.
+#pragma once
+#include "fsdp_device.h"
+
+namespace fsdp {
+
+struct SortShared {
+  double x[MAX_CONES];
+  double y[MAX_CONES];
+  double dist[MAX_CONES];          // distance car->cone (start-cone selection)
+  uint8_t type[MAX_CONES];
+  uint8_t flags[MAX_CONES];        // bit0 in ellipse, bit1 angle>0, bit2 angle<0, bit3 angle window, bit4 "in front" (skip for 2nd cone)
+  uint8_t knn[MAX_CONES][KNN];     // k nearest (index), 255 = none
+  uint8_t knn_ok[MAX_CONES];       // bit q: knn[q] within max_dist
+  uint8_t nbr[MAX_CONES][KNN];     // mutual neighbours, ascending
+  uint8_t nbr_cnt[MAX_CONES];
+  uint8_t vis[MAX_CONES];
+  int16_t ends[MAX_ENDS][MAX_LEN]; // raw / filtered end configurations, -1 padded
+  uint8_t keep[MAX_ENDS];
+  double cost[MAX_ENDS];
+  int32_t good[MAX_ENDS];
+  int32_t bad[MAX_ENDS];
+  int16_t stack[MAX_STACK][2];
+  int16_t attempt[MAX_LEN];
+  int16_t all_list[MAX_ENDS * MAX_LEN > MAX_CONES ? MAX_CONES : MAX_ENDS * MAX_LEN];
+  unsigned long long all_mask[MAX_CONES / 64];
+  unsigned long long near_mask[MAX_CONES / 64];
+  unsigned long long close_mask[MAX_CONES / 64];
+  int16_t best[2][MAX_LEN];        // best configuration per side (0 = left, 1 = right)
+  int32_t best_len[2];
+  int32_t n_configs[2];
+  double best_cost[2];
+  int32_t first_k[2][2];
+};
+
+// ---- trace_sorter/line_segment_intersection.py:136-200 (epsilon 1e-6) ----
+__device__ inline bool segments_intersect(double a0x, double a0y, double a1x, double a1y, double b0x, double b0y, double b1x,
+                                          double b1y) {
+  const double eps = 1e-6;
+  // homogeneous lines: cross(h0,h1), cross(h2,h3), then their cross (numpy.cross component order)
+  double la0 = a0y * 1.0 - 1.0 * a1y, la1 = 1.0 * a1x - a0x * 1.0, la2 = a0x * a1y - a0y * a1x;
+  double lb0 = b0y * 1.0 - 1.0 * b1y, lb1 = 1.0 * b1x - b0x * 1.0, lb2 = b0x * b1y - b0y * b1x;
+  double ix = la1 * lb2 - la2 * lb1;
+  double iy = la2 * lb0 - la0 * lb2;
+  double iz = la0 * lb1 - la1 * lb0;
+  if (fabs(iz) < eps) {
+    // _handle_line_segment_intersection_parallel_case :34-72
+    double dx = a1x - a0x, dy = a1y - a0y;
+    bool maybe;
+    double slope;
+    if (dx < eps) {
+      maybe = fabs(a0x - b0x) < eps;
+      slope = INFINITY;
+    } else {
+      slope = dy / dx;
+      double ia = a0y - slope * a0x;
+      double ib = b0y - slope * b0x;
+      maybe = fabs(ia - ib) < eps;
+    }
+    if (!maybe) return false;
+    bool use_y = slope > 1;
+    double as = use_y ? a0y : a0x, ae = use_y ? a1y : a1x, bs = use_y ? b0y : b0x, be = use_y ? b1y : b1x;
+    double left_end, right_start;
+    if (as < bs) {
+      left_end = ae;
+      right_start = fmin(bs, be);
+    } else {
+      left_end = be;
+      right_start = fmin(as, ae);
+    }
+    return left_end >= right_start;
+  }
+  double px = ix / iz, py = iy / iz;
+  double al = fmin(a0x, a1x), ar = fmax(a0x, a1x), bl = fmin(b0x, b1x), br = fmax(b0x, b1x);
+  double ab = fmin(a0y, a1y), at = fmax(a0y, a1y), bb = fmin(b0y, b1y), bt = fmax(b0y, b1y);
+  return (al - eps <= px && px <= ar + eps) && (bl - eps <= px && px <= br + eps) && (ab - eps <= py && py <= at + eps) &&
+         (bb - eps <= py && py <= bt + eps);
+}
+
+__device__ inline bool inside_ellipse(double px, double py, double cx, double cy, double dirx, double diry, double major,
+                                      double minor) {
+  // utils/math_utils.py:493-530
+  double ang = atan2(diry, dirx);
+  Rot2 r = make_rot(-ang);
+  double qx, qy;
+  rot_apply(r, px - cx, py - cy, qx, qy);
+  double crit = (qx * qx) / (major * major) + (qy * qy) / (minor * minor);
+  return crit < 1;
+}
+
+// end_configurations.py:108-223 for ONE candidate neighbour `cand` of the popped node.
+__device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type, int pos, int node, int cand, int n_nb,
+                                              double px, double py, double dx, double dy, double dnx, double dny) {
+  for (int q = 0; q <= pos; q++)
+    if (S.attempt[q] == cand) return false;
+  const double lx = S.x[node], ly = S.y[node];
+  const double cx = S.x[cand], cy = S.y[cand];
+  int sl = (pos >= 1) ? S.attempt[pos - 1] : 0;
+  if (pos >= 1) {
+    if (!inside_ellipse(cx, cy, lx, ly, lx - S.x[sl], ly - S.y[sl], 6, 3)) return false;
+  }
+  if (pos == 0) {
+    double a_car = atan2(dny, dnx);
+    double a_n = atan2(cy - py, cx - px);
+    double diff = angle_difference(a_n, a_car);
+    double want = (cone_type == T_LEFT) ? 1.0 : -1.0;
+    if (!((sign_of(diff) == want) || (fabs(diff) < 5 * FSDP_DEG))) return false;
+  }
+  // check_if_neighbor_lies_between_last_in_attempt_and_candidate :226-257
+  for (int q = 0; q < n_nb; q++) {
+    int nb = S.nbr[node][q];
+    if (nb == cand) continue;
+    double vlx = lx - S.x[nb], vly = ly - S.y[nb];
+    double vcx = cx - S.x[nb], vcy = cy - S.y[nb];
+    double dc = norm_blas(vcx, vcy), dl = norm_blas(vlx, vly);
+    if (dc < 6.0 && dl < 6.0 && angle_between(vlx, vly, vcx, vcy) > 150 * FSDP_DEG) return false;
+  }
+  bool can = true;
+  if (pos >= 1) {
+    double s2lx = lx - S.x[sl], s2ly = ly - S.y[sl];
+    double l2cx = cx - lx, l2cy = cy - ly;
+    double angle_1 = atan2(s2ly, s2lx);
+    double angle_2 = atan2(l2cy, l2cx);
+    double difference = angle_difference(angle_2, angle_1);
+    double len = norm_blas(l2cx, l2cy);
+    if (fabs(difference) > 65 * FSDP_DEG)
+      can = false;
+    else if (cone_type == T_LEFT)
+      can = (difference < 40 * FSDP_DEG) || (len < 4.0);
+    else
+      can = (difference > -(40 * FSDP_DEG)) || (len < 4.0);
+    if (pos >= 2) {
+      int tl = S.attempt[pos - 2];
+      double angle_3 = atan2(S.y[sl] - S.y[tl], S.x[sl] - S.x[tl]);
+      double difference_2 = angle_difference(angle_1, angle_3);
+      if (sign_of(difference) != sign_of(difference_2) && fabs(difference - difference_2) > 1.3) can = false;
+    }
+  }
+  if (can && pos == 1) {
+    int st = S.attempt[0];
+    double off = angle_between(dx, dy, cx - S.x[st], cy - S.y[st]);
+    can = off < FSDP_PI / 2;
+  }
+  if (can) {
+    const double car_size = 2.1;
+    double csx = px - dnx * car_size / 2, csy = py - dny * car_size / 2;
+    double cex = px + dnx * car_size, cey = py + dny * car_size;
+    can = !segments_intersect(lx, ly, cx, cy, csx, csy, cex, cey);
+  }
+  return can;
+}
+
+// one side (cone_type LEFT or RIGHT); side = 0 (left) / 1 (right).  All lanes call.
+// Returns status (wave-uniform).
+__device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int side, double px, double py, double dx,
+                                    double dy) {
+  const int lane = lane_id();
+  const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
+  if (lane == 0) {
+    S.n_configs[side] = 0;
+    S.best_len[side] = 0;
+    S.first_k[side][0] = -1;
+    S.first_k[side][1] = -1;
+    S.best_cost[side] = 0.0;
+  }
+  __syncthreads();
+  if (n < 3) return ST_OK;  // core_trace_sorter.py:272-273
+
+  // ---------------- S4: start cones (core_trace_sorter.py:344-465) ----------------
+  const int want_bit = (cone_type == T_LEFT) ? 2 : 4;  // flags bit1 (angle>0) / bit2 (angle<0)
+  double bv = 0.0;
+  int bi = -1;
+  for (int i = lane; i < n; i += WAVE) {
+    int f = S.flags[i];
+    int t = S.type[i];
+    bool mask_side = ((f & want_bit) && (f & 8)) || (t == cone_type);
+    bool valid = (f & 1) && mask_side && (t != other_type);
+    if (valid && (bi < 0 || S.dist[i] < bv)) {
+      bv = S.dist[i];
+      bi = i;
+    }
+  }
+  wave_argmin(bv, bi);
+  int index_1 = bi;
+  if (index_1 >= 0 && bv > 6.0) index_1 = -1;
+  if (index_1 < 0) return ST_OK;  // no start cone -> side has no result
+  bv = 0.0;
+  bi = -1;
+  for (int i = lane; i < n; i += WAVE) {
+    int f = S.flags[i];
+    int t = S.type[i];
+    bool mask_side = ((f & want_bit) && (f & 8)) || (t == cone_type);
+    bool valid = (f & 1) && mask_side && (t != other_type) && !(f & 16) && (i != index_1);
+    if (valid && (bi < 0 || S.dist[i] < bv)) {
+      bv = S.dist[i];
+      bi = i;
+    }
+  }
+  wave_argmin(bv, bi);
+  int index_2 = bi;
+  if (index_2 >= 0 && bv > 6.0) index_2 = -1;
+  int fk0, fk1 = -1, n_first = 1;
+  if (index_2 < 0) {
+    fk0 = index_1;
+  } else {
+    double d1x = S.x[index_1] - S.x[index_2], d1y = S.y[index_1] - S.y[index_2];
+    double angle_1 = angle_between(d1x, d1y, dx, dy);
+    double angle_2 = angle_between(-d1x, -d1y, dx, dy);
+    // cone_dir_2 = cones[index_2] - cones[index_1]: computed, not negated, in the reference
+    angle_2 = angle_between(S.x[index_2] - S.x[index_1], S.y[index_2] - S.y[index_1], dx, dy);
+    if (angle_1 > angle_2) {
+      int t = index_1;
+      index_1 = index_2;
+      index_2 = t;
+    }
+    double dist = norm_blas(d1x, d1y);
+    if (dist > 6.5 * 1.1 || dist < 1.4) {
+      fk0 = index_1;
+    } else {
+      fk0 = index_2;
+      fk1 = index_1;
+      n_first = 2;
+    }
+  }
+  if (lane == 0) {
+    S.first_k[side][0] = fk0;
+    S.first_k[side][1] = fk1;
+  }
+  const int start_idx = fk0;
+
+  // ---------------- S5: mutual-kNN adjacency (adjacency_matrix.py:60-128) ----------------
+  const int k_nn = (n - 1 < KNN) ? (n - 1) : KNN;
+  for (int i = lane; i < n; i += WAVE) {
+    double bd[KNN];
+    int bj[KNN];
+#pragma unroll
+    for (int q = 0; q < KNN; q++) {
+      bd[q] = INFINITY;
+      bj[q] = 255;
+    }
+    const double xi = S.x[i], yi = S.y[i];
+    const bool row_inf = (S.type[i] == other_type);
+    if (!row_inf) {
+      for (int j = 0; j < n; j++) {
+        if (j == i || S.type[j] == other_type) continue;
+        double d = cdist_sq(xi, yi, S.x[j], S.y[j]);
+        if (d < bd[KNN - 1]) {
+          // insert keeping ascending order; strict '<' keeps the earlier index first on ties
+          int q = KNN - 1;
+          while (q > 0 && d < bd[q - 1]) {
+            bd[q] = bd[q - 1];
+            bj[q] = bj[q - 1];
+            q--;
+          }
+          bd[q] = d;
+          bj[q] = j;
+        }
+      }
+    }
+    int okm = 0;
+#pragma unroll
+    for (int q = 0; q < KNN; q++) {
+      bool in_k = (q < k_nn) && (bj[q] != 255);
+      S.knn[i][q] = in_k ? (uint8_t)bj[q] : (uint8_t)255;
+      if (in_k && !(bd[q] > 6.5 * 6.5)) okm |= (1 << q);
+    }
+    S.knn_ok[i] = (uint8_t)okm;
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += WAVE) {
+    int cnt = 0;
+    uint8_t lst[KNN];
+    int okm = S.knn_ok[i];
+    for (int q = 0; q < KNN; q++) {
+      int j = S.knn[i][q];
+      if (j == 255 || !(okm & (1 << q))) continue;
+      int okj = S.knn_ok[j];
+      bool mutual = false;
+      for (int r = 0; r < KNN; r++)
+        if (S.knn[j][r] == i && (okj & (1 << r))) mutual = true;
+      if (mutual) {
+        // insert ascending by index
+        int p = cnt;
+        while (p > 0 && lst[p - 1] > j) {
+          lst[p] = lst[p - 1];
+          p--;
+        }
+        lst[p] = (uint8_t)j;
+        cnt++;
+      }
+    }
+    for (int q = 0; q < KNN; q++) S.nbr[i][q] = (q < cnt) ? lst[q] : (uint8_t)255;
+    S.nbr_cnt[i] = (uint8_t)cnt;
+    S.vis[i] = (i == start_idx) ? 1 : 0;
+  }
+  __syncthreads();
+  // BFS reachability from start_idx (common.py:36-67); only min(len, 12) is consumed
+  int reach = 1;
+  for (int it = 0; it < MAX_CONES && reach < MAX_LEN; it++) {
+    int add = 0;
+    unsigned long long newbits[MAX_CONES / WAVE];
+    for (int w = 0; w * WAVE < n; w++) {
+      int i = w * WAVE + lane;
+      bool nv = false;
+      if (i < n && !S.vis[i]) {
+        int c = S.nbr_cnt[i];
+        for (int q = 0; q < c; q++)
+          if (S.vis[S.nbr[i][q]]) nv = true;
+      }
+      newbits[w] = __ballot(nv);
+      add += __popcll(newbits[w]);
+    }
+    if (add == 0) break;
+    __syncthreads();
+    for (int w = 0; w * WAVE < n; w++) {
+      int i = w * WAVE + lane;
+      if (i < n && ((newbits[w] >> lane) & 1ull)) S.vis[i] = 1;
+    }
+    __syncthreads();
+    reach += add;
+  }
+  const int target_length = reach < MAX_LEN ? reach : MAX_LEN;
+
+  // ---------------- S8: DFS over the cost tree (end_configurations.py:320-431) ----------------
+  const double nrm = norm_blas(dx, dy);
+  const double dnx = dx / nrm, dny = dy / nrm;
+  int sp = 0, n_ends = 0;
+  int status = ST_OK;
+  if (lane < MAX_LEN) S.attempt[lane] = -1;
+  __syncthreads();
+  if (n_first == 2) {
+    if (target_length < 1) status = ST_REF_UNDEFINED_DFS_OOB;
+    if (lane == 0) {
+      S.attempt[0] = (int16_t)fk0;
+      S.stack[0][0] = (int16_t)fk1;
+      S.stack[0][1] = 1;
+    }
+  } else {
+    if (lane == 0) {
+      S.stack[0][0] = (int16_t)start_idx;
+      S.stack[0][1] = 0;
+    }
+  }
+  sp = 1;
+  __syncthreads();
+  while (sp > 0 && status == ST_OK) {
+    sp--;
+    const int node = S.stack[sp][0];
+    const int pos = S.stack[sp][1];
+    if (pos >= target_length) {  // numpy IndexError at current_attempt[position_in_stack]
+      status = ST_REF_UNDEFINED_DFS_OOB;
+      break;
+    }
+    __syncthreads();
+    if (lane < MAX_LEN) {
+      if (lane == pos) S.attempt[lane] = (int16_t)node;
+      if (lane > pos) S.attempt[lane] = -1;
+    }
+    __syncthreads();
+    const int n_nb = S.nbr_cnt[node];
+    bool can = false;
+    if (lane < n_nb) can = candidate_can_be_added(S, cone_type, pos, node, S.nbr[node][lane], n_nb, px, py, dx, dy, dnx, dny);
+    unsigned long long m = __ballot(can);
+    bool has_valid = (pos < target_length - 1) && (m != 0ull);
+    if (has_valid) {
+      if (can) {
+        int slot = sp + __popcll(m & ((1ull << lane) - 1ull));
+        S.stack[slot][0] = (int16_t)S.nbr[node][lane];
+        S.stack[slot][1] = (int16_t)(pos + 1);
+      }
+      sp += __popcll(m);
+    } else {
+      if (n_ends >= MAX_ENDS) {
+        status = ST_OVERFLOW_ENDS;
+        break;
+      }
+      if (lane < MAX_LEN) S.ends[n_ends][lane] = (lane < target_length) ? S.attempt[lane] : (int16_t)-1;
+      n_ends++;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (status != ST_OK) return status;
+
+  // ---------------- S10: post filters (end_configurations.py:420-515), lane = raw configuration ----------------
+  const int L = target_length;
+  bool keep = false;
+  int16_t cfg[MAX_LEN];
+  int len = 0;
+  if (lane < n_ends) {
+    for (int l = 0; l < MAX_LEN; l++) {
+      cfg[l] = S.ends[lane][l];
+      len += (cfg[l] != -1);
+    }
+    keep = len > 2;
+    if (keep && n_first == 2) keep = (cfg[0] == fk0) && (L > 1) && (cfg[1] == fk1);
+    if (keep) {
+      // drop the last cone if it is not of the side's colour (:491-500)
+      int am = 0;
+      bool found = false;
+      for (int l = 0; l < L; l++)
+        if (cfg[l] == -1) {
+          am = l;
+          found = true;
+          break;
+        }
+      if (!found) am = 0;
+      int last_idx = ((am - 1) % L + L) % L;
+      int last_cone = cfg[last_idx];
+      if (S.type[last_cone] != cone_type) {
+        cfg[last_idx] = -1;
+        len--;
+      }
+      keep = len >= 3;
+    }
+    for (int l = 0; l < MAX_LEN; l++) S.ends[lane][l] = cfg[l];
+  }
+  if (lane < MAX_ENDS) S.keep[lane] = keep ? 1 : 0;
+  __syncthreads();
+  // np.unique(axis=0) + prefix removal (:507-515)
+  if (lane < n_ends && keep) {
+    bool drop = false;
+    for (int o = 0; o < n_ends && !drop; o++) {
+      if (o == lane || !S.keep[o]) continue;
+      bool same = true, prefix = true;
+      for (int l = 0; l < MAX_LEN; l++) {
+        int a = S.ends[o][l], b = cfg[l];
+        if (a != b) same = false;
+        if (!(a == b || b == -1)) prefix = false;
+      }
+      if (same && o < lane) drop = true;       // duplicate of an earlier row
+      if (!same && prefix) drop = true;        // strict prefix of another row
+    }
+    keep = !drop;
+  }
+  __syncthreads();
+  if (lane < MAX_ENDS) S.keep[lane] = keep ? 1 : 0;
+  __syncthreads();
+  unsigned long long keepm = __ballot(keep);
+  const int C = __popcll(keepm);
+  if (lane == 0) S.n_configs[side] = C;
+  if (C == 0) return ST_OK;  // NoPathError -> side has no result
+
+  // ---------------- S12: cones on either side (nearby_cone_search.py:213-297) ----------------
+  const int n_words = (n + WAVE - 1) / WAVE;
+  if (lane < MAX_CONES / WAVE) {
+    S.all_mask[lane] = 0ull;
+  }
+  __syncthreads();
+  if (keep) {
+    for (int l = 0; l < MAX_LEN; l++)
+      if (cfg[l] != -1) atomicOr(&S.all_mask[cfg[l] >> 6], 1ull << (cfg[l] & 63));
+  }
+  __syncthreads();
+  // all_list: ascending indices of all_mask (wave-uniform build)
+  int n_all = 0;
+  for (int w = 0; w < n_words; w++) {
+    unsigned long long mw = S.all_mask[w];
+    if ((mw >> lane) & 1ull) S.all_list[n_all + __popcll(mw & ((1ull << lane) - 1ull))] = (int16_t)(w * WAVE + lane);
+    n_all += __popcll(mw);
+  }
+  __syncthreads();
+  // near_mask[j]: any i in all with D[i][j] < 36 (diag 1e7)
+  for (int w = 0; w < n_words; w++) {
+    int j = w * WAVE + lane;
+    bool nr = false;
+    if (j < n) {
+      double xj = S.x[j], yj = S.y[j];
+      for (int a = 0; a < n_all && !nr; a++) {
+        int i = S.all_list[a];
+        if (i == j) continue;
+        if (cdist_sq(S.x[i], S.y[i], xj, yj) < 36.0) nr = true;
+      }
+    }
+    unsigned long long mw = __ballot(nr);
+    if (lane == 0) {
+      S.near_mask[w] = mw;
+      S.close_mask[w] = mw;
+    }
+  }
+  __syncthreads();
+  // sorted_set_diff(near_all, all) with the searchsorted quirk (:88-94) — wave-uniform
+  {
+    bool undefined = false;
+    if (lane == 0) {
+      for (int a = 0; a < n_all; a++) {
+        int b = S.all_list[a];
+        // position = first element of near_all >= b
+        int pos = -1;
+        for (int w = b >> 6; w < n_words && pos < 0; w++) {
+          unsigned long long mw = S.near_mask[w];
+          if (w == (b >> 6)) mw &= ~((1ull << (b & 63)) - 1ull);
+          if (mw) pos = w * WAVE + (__ffsll(mw) - 1);
+        }
+        if (pos < 0)
+          undefined = true;
+        else
+          S.close_mask[pos >> 6] &= ~(1ull << (pos & 63));
+      }
+    }
+    undefined = __ballot(undefined) != 0ull;
+    __syncthreads();
+    if (undefined) return ST_REF_UNDEFINED_SET_DIFF;
+  }
+  // per kept configuration (wave-uniform loop), per cone of it, lanes scan the candidate cones
+  for (int c = 0; c < n_ends; c++) {
+    if (!((keepm >> c) & 1ull)) continue;
+    int clen = 0;
+    for (int l = 0; l < MAX_LEN; l++) clen += (S.ends[c][l] != -1);
+    int good = 0, bad = 0;
+    for (int j = 0; j < clen; j++) {
+      int a, b;
+      if (j == 0) {
+        a = S.ends[c][0];
+        b = S.ends[c][1];
+      } else if (j == clen - 1) {
+        a = S.ends[c][j - 1];
+        b = S.ends[c][j];
+      } else {
+        a = S.ends[c][j - 1];
+        b = S.ends[c][j + 1];
+      }
+      double sdx, sdy;
+      search_direction(S.x[a], S.y[a], S.x[b], S.y[b], cone_type, sdx, sdy);
+      const int cj = S.ends[c][j];
+      const double xc = S.x[cj], yc = S.y[cj];
+      for (int w = 0; w < n_words; w++) {
+        // other = close ∪ (all \ config)
+        unsigned long long cm = 0ull;
+        for (int l = 0; l < clen; l++) {
+          int v = S.ends[c][l];
+          if ((v >> 6) == w) cm |= (1ull << (v & 63));
+        }
+        unsigned long long om = S.close_mask[w] | (S.all_mask[w] & ~cm);
+        int idx = w * WAVE + lane;
+        bool g = false, bd = false;
+        if (((om >> lane) & 1ull) && idx < n && idx != cj) {
+          if (cdist_sq(xc, yc, S.x[idx], S.y[idx]) < 36.0) {
+            double vx = S.x[idx] - xc, vy = S.y[idx] - yc;
+            g = angle_between(vx, vy, sdx, sdy) < (FSDP_PI / 1.5) / 2;
+            bd = angle_between(vx, vy, -sdx, -sdy) < (FSDP_PI / 1.5) / 2;
+          }
+        }
+        good += __popcll(__ballot(g));
+        bad += __popcll(__ballot(bd));
+      }
+    }
+    if (lane == 0) {
+      S.good[c] = good;
+      S.bad[c] = bad;
+    }
+  }
+  __syncthreads();
+  int mval = 0x7fffffff;
+  for (int c = 0; c < n_ends; c++)
+    if ((keepm >> c) & 1ull) {
+      int d = S.good[c] - S.bad[c];
+      mval = d < mval ? d : mval;
+    }
+
+  // ---------------- S11: cost per configuration (cost_function.py:213-304), lane = configuration ----------------
+  double my_cost = 0.0;
+  if (keep) {
+    auto PX = [&](int l) -> double {
+      int idx = cfg[l];
+      if (idx < 0) idx = n + idx;  // NumPy wrap-around of -1
+      return S.x[idx];
+    };
+    auto PY = [&](int l) -> double {
+      int idx = cfg[l];
+      if (idx < 0) idx = n + idx;
+      return S.y[idx];
+    };
+    int clen = 0;
+    for (int l = 0; l < L; l++) clen += (cfg[l] != -1);
+    double tmp[MAX_LEN];
+    // angle cost :41-79
+    double angle_cost;
+    {
+      int na = L - 2;
+      double cnt = 0.0;
+      int under = 0;
+      for (int a = 0; a < na; a++) {
+        double n0x = PX(a) - PX(a + 1), n0y = PY(a) - PY(a + 1);
+        if (cfg[a + 1] == -1) n0x = n0y = 100.0;
+        double n1x = PX(a + 1) - PX(a + 2), n1y = PY(a + 1) - PY(a + 2);
+        if (cfg[a + 2] == -1) n1x = n1y = 100.0;
+        double ang = angle_between(n1x, n1y, -n0x, -n0y);
+        bool is_part = cfg[a + 2] != -1;
+        double as_cost = (FSDP_PI - ang) / FSDP_PI;
+        tmp[a] = as_cost * (is_part ? 1.0 : 0.0);
+        cnt += is_part ? 1.0 : 0.0;
+        if (ang < 40 * FSDP_DEG && is_part) under++;
+      }
+      angle_cost = np_sum_small(tmp, na) / cnt * (double)(under + 1);
+    }
+    // residual distance cost (cone_distance_cost.py:15-32)
+    double dist_cost;
+    {
+      for (int l = 0; l < L - 1; l++) {
+        double ddx = PX(l + 1) - PX(l), ddy = PY(l + 1) - PY(l);
+        double d = sqrt(ddx * ddx + ddy * ddy);
+        d = d * ((cfg[l + 1] != -1) ? 1.0 : 0.0);
+        tmp[l] = fmax(0.0, d - 3.0);
+      }
+      dist_cost = np_sum_small(tmp, L - 1);
+    }
+    double ncones_cost = 1.0 / (double)clen;
+    double init_cost = angle_between(PX(1) - PX(0), PY(1) - PY(0), dx, dy);
+    double either_cost;
+    {
+      int d = S.good[lane] - S.bad[lane];
+      d += (mval < 0 ? -mval : mval) + 1;
+      either_cost = 1.0 / (double)d;
+    }
+    double wrong_cost = 0.0;
+    if (clen != 3) {
+      double unwanted = (cone_type == T_LEFT) ? 1.0 : -1.0;
+      int ns = 0;
+      double prev_ang = atan2(PY(1) - PY(0), PX(1) - PX(0));
+      for (int l = 1; l < clen - 1; l++) {
+        double a2 = atan2(PY(l + 1) - PY(l), PX(l + 1) - PX(l));
+        double diff = angle_difference(prev_ang, a2);
+        if (sign_of(diff) == unwanted && fabs(diff) > 40 * FSDP_DEG) tmp[ns++] = diff;
+        prev_ang = a2;
+      }
+      wrong_cost = fabs(np_sum_small(tmp, ns));
+    }
+    const double fsum = ((1000.0 + 200.0) + (5000.0 + 1000.0)) + ((0.0 + 1000.0) + 1000.0);  // np.sum of 7: sequential
+    double f0 = 1000.0 / 9200.0, f1 = 200.0 / 9200.0, f2 = 5000.0 / 9200.0, f3 = 1000.0 / 9200.0, f4 = 0.0 / 9200.0;
+    (void)fsum;
+    double cols[7] = {angle_cost * f0, dist_cost * f1, ncones_cost * f2, init_cost * f3, 0.0 * f4, either_cost * f3, wrong_cost * f3};
+    my_cost = np_sum_small(cols, 7);
+  }
+  // argmin with np.unique's lexicographic row order as tie-break (argsort is stable for the short arrays here)
+  {
+    int best = -1;
+    double bc = 0.0;
+    if (lane < MAX_ENDS) S.cost[lane] = my_cost;
+    __syncthreads();
+    for (int c = 0; c < n_ends; c++) {
+      if (!((keepm >> c) & 1ull)) continue;
+      double cc = S.cost[c];
+      bool take = best < 0 || cc < bc;
+      if (!take && cc == bc) {
+        // lexicographic comparison of rows (ints, -1 padded)
+        bool less = false;
+        for (int l = 0; l < MAX_LEN; l++) {
+          int a = S.ends[c][l], b = S.ends[best][l];
+          if (a != b) {
+            less = a < b;
+            break;
+          }
+        }
+        take = less;
+      }
+      if (take) {
+        best = c;
+        bc = cc;
+      }
+    }
+    int blen = 0;
+    for (int l = 0; l < MAX_LEN; l++) blen += (S.ends[best][l] != -1);
+    if (lane < MAX_LEN) S.best[side][lane] = S.ends[best][lane];
+    if (lane == 0) {
+      S.best_len[side] = blen;
+      S.best_cost[side] = bc;
+    }
+  }
+  __syncthreads();
+  return ST_OK;
+}
+
+// combine_traces.py:115-275 (wave-uniform; every lane computes the same scalars)
+__device__ inline void combine_sides(SortShared& S, int& nl, int& nr) {
+  nl = S.best_len[0];
+  nr = S.best_len[1];
+  if (nl == 0 || nr == 0) return;
+  int li = -1, ri = -1;
+  for (int i = 0; i < nl && li < 0; i++)
+    for (int j = 0; j < nr; j++)
+      if (S.best[1][j] == S.best[0][i]) {
+        li = i;
+        break;
+      }
+  if (li < 0) return;
+  for (int i = 0; i < nr && ri < 0; i++)
+    for (int j = 0; j < nl; j++)
+      if (S.best[0][j] == S.best[1][i]) {
+        ri = i;
+        break;
+      }
+  int ls = -1, rs = -1;
+  bool have = false;
+  auto X = [&](int idx) { return S.x[idx]; };
+  auto Y = [&](int idx) { return S.y[idx]; };
+  if (li > 0 && ri > 0) {
+    int pl = S.best[0][li - 1], pr = S.best[1][ri - 1], ic = S.best[0][li];
+    double dl = norm_blas(X(ic) - X(pl), Y(ic) - Y(pl));
+    double dr = norm_blas(X(ic) - X(pr), Y(ic) - Y(pr));
+    bool lv = dl < 3.0, rv = dr < 3.0;
+    if ((lv || rv) && !(lv && rv)) {
+      have = true;
+      if (lv) {
+        ls = nl;
+        rs = ri;
+      } else {
+        ls = li;
+        rs = nr;
+      }
+    }
+  }
+  auto angle_change = [&](int side, int pos) {
+    int p = S.best[side][pos - 1], c = S.best[side][pos], nx = S.best[side][pos + 1];
+    double a_next = atan2(Y(nx) - Y(c), X(nx) - X(c));
+    double a_prev = atan2(Y(p) - Y(c), X(p) - X(c));
+    return angle_difference(a_next, a_prev);
+  };
+  if (!have && S.best[0][li] == S.best[1][ri] && (li >= 1 && li < nl - 1) && (ri >= 1 && ri < nr - 1)) {
+    double al = angle_change(0, li), ar = angle_change(1, ri);
+    double sl = sign_of(al), sr = sign_of(ar);
+    double absdiff = fabs(fabs(al) - fabs(ar));
+    int ndiff = nl > nr ? nl - nr : nr - nl;
+    if (sl == sr) {
+      if (sl == 1) {
+        ls = nl;
+        rs = ri;
+      } else {
+        ls = li;
+        rs = nr;
+      }
+    } else if (ndiff > 2) {
+      if (nl > nr) {
+        ls = nl;
+        rs = ri;
+      } else {
+        ls = li;
+        rs = nr;
+      }
+    } else if (absdiff > 5 * FSDP_DEG) {
+      if (fabs(al) > fabs(ar)) {
+        ls = nl;
+        rs = ri;
+      } else {
+        ls = li;
+        rs = nr;
+      }
+    } else {
+      ls = li;
+      rs = ri;
+    }
+  } else if (!have) {
+    bool le = (li == nl - 1), re = (ri == nr - 1);
+    if (le && re) {
+      ls = nl - 1;
+      rs = nr - 1;
+    } else if (le) {
+      rs = nr;
+      ls = li;
+    } else if (re) {
+      ls = nl;
+      rs = ri;
+    } else {
+      ls = li;
+      rs = ri;
+    }
+  }
+  nl = ls;
+  nr = rs;
+}
+
+// One workgroup (= one wavefront) per frame.
+__global__ void __launch_bounds__(64) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
+                                                  const double* __restrict__ cones_xyt, const double* __restrict__ poses,
+                                                  SortOut* __restrict__ out) {
+  __shared__ SortShared S;
+  const int frame = blockIdx.x;
+  if (frame >= n_frames) return;
+  const int lane = lane_id();
+  const int off = cone_offsets[frame];
+  int n = cone_offsets[frame + 1] - off;
+  const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
+  SortOut* o = &out[frame];
+  int status = ST_OK;
+  if (n > MAX_CONES) {
+    status = ST_OVERFLOW_CONES;
+    n = 0;
+  }
+  // stage the frame's cones in LDS: coalesced loads of the (n,3) row-major block (lane = consecutive doubles)
+  {
+    const double* src = cones_xyt + 3 * (size_t)off;
+    for (int e = lane; e < 3 * n; e += WAVE) {
+      double v = src[e];
+      int i = e / 3, c = e - 3 * i;
+      if (c == 0)
+        S.x[i] = v;
+      else if (c == 1)
+        S.y[i] = v;
+      else
+        S.type[i] = (uint8_t)(int)v;
+    }
+  }
+  __syncthreads();
+  // per-cone scalars of mask_cone_can_be_first_in_config (core_trace_sorter.py:379-407)
+  {
+    double car_ang = atan2(dy, dx);
+    Rot2 r = make_rot(-car_ang);
+    for (int i = lane; i < n; i += WAVE) {
+      double rx, ry;
+      rot_apply(r, S.x[i] - px, S.y[i] - py, rx, ry);
+      double ang = atan2(ry, rx);
+      S.dist[i] = sqrt(rx * rx + ry * ry);
+      double crit = (rx * rx) / (9.0 * 9.0) + (ry * ry) / (4.0 * 4.0);
+      int f = 0;
+      if (crit < 1) f |= 1;
+      if (ang > 0) f |= 2;
+      if (ang < 0) f |= 4;
+      if (fabs(ang) < FSDP_PI - FSDP_PI / 5 && fabs(ang) > FSDP_PI / 10) f |= 8;
+      double a2c = angle_between(S.x[i] - px, S.y[i] - py, dx, dy);
+      if (fabs(a2c) < FSDP_PI / 2) f |= 16;
+      S.flags[i] = (uint8_t)f;
+    }
+  }
+  __syncthreads();
+  if (status == ST_OK) status = sort_one_side(S, n, T_LEFT, 0, px, py, dx, dy);
+  __syncthreads();
+  if (status == ST_OK) status = sort_one_side(S, n, T_RIGHT, 1, px, py, dx, dy);
+  __syncthreads();
+  int nl = 0, nr = 0;
+  if (status == ST_OK) combine_sides(S, nl, nr);
+  if (lane == 0) {
+    o->status = status;
+    o->n_left = nl;
+    o->n_right = nr;
+    o->n_configs_left = S.n_configs[0];
+    o->n_configs_right = S.n_configs[1];
+    o->first_k_left[0] = S.first_k[0][0];
+    o->first_k_left[1] = S.first_k[0][1];
+    o->first_k_right[0] = S.first_k[1][0];
+    o->first_k_right[1] = S.first_k[1][1];
+    o->best_cost_left = S.best_cost[0];
+    o->best_cost_right = S.best_cost[1];
+  }
+  if (lane < MAX_LEN) {
+    o->left_idx[lane] = (status == ST_OK && lane < nl) ? (int32_t)S.best[0][lane] : -1;
+    o->right_idx[lane] = (status == ST_OK && lane < nr) ? (int32_t)S.best[1][lane] : -1;
+  }
+}
+
+}  // namespace fsdp

@@ -1,0 +1,590 @@
+// Smoothing B-spline fit + evaluation on one wavefront (gfx950).
+//
+// What the reference reaches through SciPy (utils/spline_fit.py:117 splprep, :61 splev) is
+// Dierckx's FITPACK parcur/fppara: adaptive knot placement, Givens-QR least squares on a banded
+// observation matrix, and a rational iteration on the smoothing parameter p.  The path stage's
+// discrete decisions (how many dense samples the output is drawn from) hang on the last bit of
+// these results, so this implementation keeps FITPACK's operation ORDER wherever a rounding
+// could differ, and uses the 64 lanes only where the result is order-independent:
+//   * per-data-point work (knot-interval search, de Boor basis values, residual terms, curve
+//     evaluation) runs one point per lane, 64 points per step, staged through LDS;
+//   * the row-by-row Givens rotations, back-substitution, knot bookkeeping and all running sums
+//     are wave-uniform (every lane carries the same scalars; LDS reads broadcast).
+// Arrays are 1-based like the published algorithm.  idim = 2, unit weights, iopt = 0.
+#pragma once
+#include "fsdp_device.h"
+
+namespace fsdp {
+
+constexpr int NK = 48;  // max number of knots kept in LDS (FITPACK's nest is m+2k; OVERFLOW_KNOTS beyond)
+
+struct SplineWS {
+  double t[NK + 2];
+  double c[2 * (NK + 2)];
+  double z[2 * (NK + 2)];
+  double fpint[NK + 2];
+  double a[NK + 2][5];
+  double b[NK + 2][6];
+  double g[NK + 2][6];
+  int32_t nrdata[NK + 2];
+  double hq[WAVE][4];   // per-chunk basis values
+  double term[WAVE];    // per-chunk residual terms
+  int32_t lq[WAVE];     // per-chunk knot interval / "new knot" flags
+  double scal[4];       // lane-0 -> wave broadcast of serial-section scalars
+};
+
+struct SplineFit {
+  int k, n, ier;
+  double fp;
+  int status;  // 0 ok, 1 = scipy would raise ValueError, ST_OVERFLOW_KNOTS
+};
+
+// fpbspl: (k+1) non-zero B-splines at t(l) <= x < t(l+1); h is 1-based [1..k+1]
+__device__ __forceinline__ void fpbspl(const double* t, int k, double x, int l, double* h) {
+  double hh[6];
+  h[1] = 1.0;
+  for (int j = 1; j <= k; j++) {
+    for (int i = 1; i <= j; i++) hh[i] = h[i];
+    h[1] = 0.0;
+    for (int i = 1; i <= j; i++) {
+      int li = l + i;
+      int lj = li - j;
+      if (t[li] == t[lj]) {
+        h[i + 1] = 0.0;
+        continue;
+      }
+      double f = hh[i] / (t[li] - t[lj]);
+      h[i] = h[i] + f * (t[li] - x);
+      h[i + 1] = f * (x - t[lj]);
+    }
+  }
+}
+
+__device__ __forceinline__ void fpgivs(double piv, double& ww, double& cs, double& sn) {
+  double store = fabs(piv);
+  double dd;
+  if (store >= ww) {
+    double r = ww / piv;
+    dd = store * sqrt(1.0 + r * r);
+  } else {
+    double r = piv / ww;
+    dd = ww * sqrt(1.0 + r * r);
+  }
+  cs = ww / dd;
+  sn = piv / dd;
+  ww = dd;
+}
+
+__device__ __forceinline__ void fprota(double cs, double sn, double& a, double& b) {
+  double stor1 = a, stor2 = b;
+  b = cs * stor2 + sn * stor1;
+  a = cs * stor1 - sn * stor2;
+}
+
+// knot interval of x: largest l in [k1, nk1] with t(l) <= x (FITPACK's forward search)
+__device__ __forceinline__ int find_interval(const double* t, int k1, int nk1, double x) {
+  int l = k1;
+  while (!(x < t[l + 1] || l == nk1)) l++;
+  return l;
+}
+
+// back-substitution, band width k (fpback); a is either ws.a (5 cols) or ws.g (6 cols)
+template <int COLS>
+__device__ inline void fpback(double (*a)[COLS], const double* z, int n, int k, double* c) {
+  int k1 = k - 1;
+  c[n] = z[n] / a[n][1];
+  int i = n - 1;
+  if (i == 0) return;
+  for (int j = 2; j <= n; j++) {
+    double store = z[i];
+    int i1 = k1;
+    if (j <= k1) i1 = j - 1;
+    int m = i;
+    for (int l = 1; l <= i1; l++) {
+      m = m + 1;
+      store = store - c[m] * a[i][l + 1];
+    }
+    c[i] = store / a[i][1];
+    i = i - 1;
+  }
+}
+
+// parcur/fppara for idim=2, w=1, iopt=0.  Data in LDS: U (parameter), X, Y, m points (0-based arrays).
+// All lanes call; result (t, c) left in ws; returns wave-uniform SplineFit.
+__device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const double* X, const double* Y, int m, int k,
+                                       double s) {
+  const int lane = lane_id();
+  SplineFit R;
+  R.k = k;
+  R.n = 0;
+  R.ier = 0;
+  R.fp = 0.0;
+  R.status = 0;
+  const int k1 = k + 1, k2 = k1 + 1;
+  const int nmin = 2 * k1;
+  int nest = m + 2 * k;
+  if (nest > NK) nest = NK;
+  if (m < k1 || nest < nmin) {
+    R.status = 1;
+    return R;
+  }
+  // parcur: u must be strictly increasing (ier = 10 -> ValueError in SciPy)
+  {
+    bool badl = false;
+    for (int i = 1 + lane; i < m; i += WAVE)
+      if (!(U[i - 1] < U[i])) badl = true;
+    if (__ballot(badl) != 0ull) {
+      R.status = 1;
+      return R;
+    }
+  }
+  const double ub = U[0], ue = U[m - 1];
+  const double tol = 0.001;
+  const int maxit = 20;
+  // fppara.f sets these from single-precision literals (0.1e0, 0.9e0, 0.4e-01) stored in real*8
+  const double one = 1.0, con1 = (double)0.1f, con9 = (double)0.9f, con4 = (double)0.04f, half = 0.5;
+  const double acc = tol * s;
+  const int nmax = m + k1;
+  int n = nmin, ier = 0, nplus = 0, nrint = 0, nk1 = 0;
+  double fp = 0, fpold = 0, fp0 = 0, fpms = 0;
+  if (lane == 0) ws.nrdata[1] = m - 2;
+  __syncthreads();
+
+  bool done = false, to_part2 = false, interp_knots = false;
+  while (!done && !to_part2) {
+    if (interp_knots) {
+      // knots for interpolation (fppara label 10); k odd: t(i) = u(j), k even: midpoints
+      interp_knots = false;
+      int mk1 = m - k1;
+      if (mk1 != 0 && lane == 0) {
+        int k3 = k / 2;
+        int i = k2;
+        int j = k3 + 2;
+        for (int l = 1; l <= mk1; l++) {
+          ws.t[i] = (k3 * 2 == k) ? (U[j - 1] + U[j - 2]) * half : U[j - 1];
+          i++;
+          j++;
+        }
+      }
+      __syncthreads();
+    }
+    bool restart = false;
+    for (int iter = 1; iter <= m && !restart; iter++) {
+      if (n == nmin) ier = -2;
+      nrint = n - nmin + 1;
+      nk1 = n - k1;
+      if (lane < k1) {
+        ws.t[1 + lane] = ub;
+        ws.t[n - lane] = ue;
+      }
+      for (int i = 1 + lane; i <= 2 * (NK + 1); i += WAVE) ws.z[i] = 0.0;
+      for (int i = 1 + lane; i <= nk1; i += WAVE)
+        for (int j = 1; j <= k1; j++) ws.a[i][j] = 0.0;
+      __syncthreads();
+      fp = 0.0;
+      // ---- observation rows: basis values per lane, Givens rotations wave-uniform in data order ----
+      for (int base = 0; base < m; base += WAVE) {
+        int it = base + lane;
+        if (it < m) {
+          double ui = U[it];
+          int l = find_interval(ws.t, k1, nk1, ui);
+          double h[6];
+          fpbspl(ws.t, k, ui, l, h);
+          for (int q = 0; q < 4; q++) ws.hq[lane][q] = (q < k1) ? h[q + 1] : 0.0;
+          ws.lq[lane] = l;
+        }
+        __syncthreads();
+        int cnt = m - base < WAVE ? m - base : WAVE;
+        if (lane == 0) {  // serial section: rows enter the triangle in data order (single writer of a / z)
+          for (int r = 0; r < cnt; r++) {
+            double h[6];
+            for (int q = 0; q < 4; q++) h[q + 1] = ws.hq[r][q];
+            int l = ws.lq[r];
+            double xi1 = X[base + r], xi2 = Y[base + r];
+            int j = l - k1;
+            for (int i = 1; i <= k1; i++) {
+              j++;
+              double piv = h[i];
+              if (piv == 0.0) continue;
+              double cs, sn;
+              double ww = ws.a[j][1];
+              fpgivs(piv, ww, cs, sn);
+              ws.a[j][1] = ww;
+              double z1 = ws.z[j], z2 = ws.z[j + n];
+              fprota(cs, sn, xi1, z1);
+              fprota(cs, sn, xi2, z2);
+              ws.z[j] = z1;
+              ws.z[j + n] = z2;
+              if (i == k1) break;
+              int i2 = 1;
+              for (int i1 = i + 1; i1 <= k1; i1++) {
+                i2++;
+                double av = ws.a[j][i2];
+                fprota(cs, sn, h[i1], av);
+                ws.a[j][i2] = av;
+              }
+            }
+            fp = fp + xi1 * xi1;
+            fp = fp + xi2 * xi2;
+          }
+        }
+        __syncthreads();
+      }
+      if (lane == 0) {
+        ws.scal[0] = fp;
+        // back substitution (both coordinates)
+        fpback<5>(ws.a, &ws.z[0], nk1, k1, &ws.c[0]);
+        fpback<5>(ws.a, &ws.z[n], nk1, k1, &ws.c[n]);
+      }
+      __syncthreads();
+      fp = ws.scal[0];
+      if (ier == -2) fp0 = fp;
+      if (lane == 0) {
+        ws.fpint[n] = fp0;
+        ws.fpint[n - 1] = fpold;
+        ws.nrdata[n] = nplus;
+      }
+      __syncthreads();
+      fpms = fp - s;
+      if (fabs(fpms) < acc) {
+        done = true;
+        break;
+      }
+      if (fpms < 0.) {
+        to_part2 = true;
+        break;
+      }
+      if (n == nmax) {
+        ier = -1;
+        done = true;
+        break;
+      }
+      if (n == nest) {
+        ier = 1;
+        if (nest == NK && m + 2 * k > NK) R.status = ST_OVERFLOW_KNOTS;
+        done = true;
+        break;
+      }
+      if (ier == 0) {
+        int npl1 = nplus * 2;
+        double rn = nplus;
+        if (fpold - fp > acc) npl1 = (int)(rn * fpms / (fpold - fp));
+        int mx = npl1 > nplus / 2 ? npl1 : nplus / 2;
+        mx = mx > 1 ? mx : 1;
+        nplus = (nplus * 2 < mx) ? nplus * 2 : mx;
+      } else {
+        nplus = 1;
+        ier = 0;
+      }
+      fpold = fp;
+      // ---- residual sums per knot interval (terms per lane, accumulation in data order) ----
+      {
+        double fpart = 0.0;
+        int ii = 1;
+        for (int base = 0; base < m; base += WAVE) {
+          int it = base + lane;
+          if (it < m) {
+            double ui = U[it];
+            // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
+            // l = k2 + #{interior knots <= u(it)}, "new" when the count grew at this point
+            int l = k2;
+            while (l <= nk1 && ui >= ws.t[l]) l++;
+            int lprev = k2;
+            if (it > 0) {
+              double up = U[it - 1];
+              while (lprev <= nk1 && up >= ws.t[lprev]) lprev++;
+            }
+            int lfit = find_interval(ws.t, k1, nk1, ui);
+            double h[6];
+            fpbspl(ws.t, k, ui, lfit, h);
+            int l0 = l - k2;
+            double term = 0.0;
+            for (int d = 0; d < 2; d++) {
+              double fac = 0.0;
+              int j1 = l0 + d * n;
+              for (int j = 1; j <= k1; j++) {
+                j1++;
+                fac = fac + ws.c[j1] * h[j];
+              }
+              double dv = 1.0 * (fac - (d == 0 ? X[it] : Y[it]));
+              term = term + dv * dv;
+            }
+            ws.term[lane] = term;
+            ws.lq[lane] = (l > lprev) ? 1 : 0;
+          }
+          __syncthreads();
+          int cnt = m - base < WAVE ? m - base : WAVE;
+          for (int r = 0; r < cnt; r++) {
+            double term = ws.term[r];
+            if (ws.lq[r]) {
+              double store = term * half;
+              if (lane == 0) ws.fpint[ii] = fpart + store;
+              ii++;
+              fpart = store;
+            } else {
+              fpart = fpart + term;
+            }
+          }
+          __syncthreads();
+        }
+        if (lane == 0) ws.fpint[nrint] = fpart;
+        __syncthreads();
+      }
+      // ---- add nplus knots (fpknot), wave-uniform ----
+      for (int lq = 1; lq <= nplus; lq++) {
+        {
+          int kk = (n - nrint - 1) / 2;
+          double fpmax = 0.;
+          int jbegin = 1;
+          int number = 0, maxpt = 0, maxbeg = 0;
+          for (int j = 1; j <= nrint; j++) {
+            int jpoint = ws.nrdata[j];
+            if (!(fpmax >= ws.fpint[j] || jpoint == 0)) {
+              fpmax = ws.fpint[j];
+              number = j;
+              maxpt = jpoint;
+              maxbeg = jbegin;
+            }
+            jbegin = jbegin + jpoint + 1;
+          }
+          int ihalf = maxpt / 2 + 1;
+          int nrx = maxbeg + ihalf;
+          int next = number + 1;
+          __syncthreads();
+          if (lane == 0) {
+            if (next <= nrint) {
+              for (int j = next; j <= nrint; j++) {
+                int jj = next + nrint - j;
+                ws.fpint[jj + 1] = ws.fpint[jj];
+                ws.nrdata[jj + 1] = ws.nrdata[jj];
+                int jk = jj + kk;
+                ws.t[jk + 1] = ws.t[jk];
+              }
+            }
+            ws.nrdata[number] = ihalf - 1;
+            ws.nrdata[next] = maxpt - ihalf;
+            double am = maxpt;
+            double an = ws.nrdata[number];
+            ws.fpint[number] = fpmax * an / am;
+            an = ws.nrdata[next];
+            ws.fpint[next] = fpmax * an / am;
+            int jk = next + kk;
+            ws.t[jk] = U[nrx - 1];
+          }
+          n = n + 1;
+          nrint = nrint + 1;
+          __syncthreads();
+        }
+        if (n == nmax) {
+          interp_knots = true;
+          restart = true;
+          break;
+        }
+        if (n == nest) break;
+      }
+    }
+    if (!restart && !done && !to_part2) to_part2 = true;
+  }
+
+  if (to_part2 && ier != -2) {
+    // ---- part 2: smoothing spline, root of f(p) = s ----
+    // fpdisc: discontinuity jumps of the k-th derivative at the interior knots (lane = knot)
+    {
+      int nrint2 = nk1 - k;
+      double an = nrint2;
+      double fac = an / (ws.t[nk1 + 1] - ws.t[k1]);
+      for (int l = k2 + lane; l <= nk1; l += WAVE) {
+        double h[13];
+        int lmk = l - k1;
+        for (int j = 1; j <= k1; j++) {
+          int ik = j + k1;
+          int lj = l + j;
+          int lk = lj - k2;
+          h[j] = ws.t[l] - ws.t[lk];
+          h[ik] = ws.t[l] - ws.t[lj];
+        }
+        int lp = lmk;
+        for (int j = 1; j <= k2; j++) {
+          int jk = j;
+          double prod = h[j];
+          for (int i = 1; i <= k; i++) {
+            jk = jk + 1;
+            prod = prod * h[jk] * fac;
+          }
+          int lk = lp + k1;
+          ws.b[lmk][j] = (ws.t[lk] - ws.t[lp]) / prod;
+          lp = lp + 1;
+        }
+      }
+      __syncthreads();
+    }
+    double p1 = 0., f1 = fp0 - s, p3 = -one, f3 = fpms, p = 0.;
+    for (int i = 1; i <= nk1; i++) p = p + ws.a[i][1];
+    double rn = nk1;
+    p = rn / p;
+    int ich1 = 0, ich3 = 0;
+    const int n8 = n - nmin;
+    for (int iter = 1; iter <= maxit; iter++) {
+      double pinv = one / p;
+      __syncthreads();
+      for (int i = 1 + lane; i <= 2 * n; i += WAVE) ws.c[i] = ws.z[i];
+      for (int i = 1 + lane; i <= nk1; i += WAVE) {
+        ws.g[i][k2] = 0.;
+        for (int j = 1; j <= k1; j++) ws.g[i][j] = ws.a[i][j];
+      }
+      __syncthreads();
+      if (lane == 0) {  // serial section (single writer of g / c)
+        for (int it = 1; it <= n8; it++) {
+          double h[8];
+          for (int i = 1; i <= k2; i++) h[i] = ws.b[it][i] * pinv;
+          double xi1 = 0., xi2 = 0.;
+          for (int j = it; j <= nk1; j++) {
+            double piv = h[1];
+            double cs, sn;
+            double ww = ws.g[j][1];
+            fpgivs(piv, ww, cs, sn);
+            ws.g[j][1] = ww;
+            double c1 = ws.c[j], c2 = ws.c[j + n];
+            fprota(cs, sn, xi1, c1);
+            fprota(cs, sn, xi2, c2);
+            ws.c[j] = c1;
+            ws.c[j + n] = c2;
+            if (j == nk1) break;
+            int i2 = k1;
+            if (j > n8) i2 = nk1 - j;
+            for (int i = 1; i <= i2; i++) {
+              int i1 = i + 1;
+              double gv = ws.g[j][i1];
+              fprota(cs, sn, h[i1], gv);
+              ws.g[j][i1] = gv;
+              h[i] = h[i1];
+            }
+            h[i2 + 1] = 0.;
+          }
+        }
+        fpback<6>(ws.g, &ws.c[0], nk1, k2, &ws.c[0]);
+        fpback<6>(ws.g, &ws.c[n], nk1, k2, &ws.c[n]);
+      }
+      __syncthreads();
+      // f(p): terms per lane, accumulation in data order
+      fp = 0.;
+      for (int base = 0; base < m; base += WAVE) {
+        int it = base + lane;
+        if (it < m) {
+          double ui = U[it];
+          int l = k2;
+          while (l <= nk1 && ui >= ws.t[l]) l++;
+          int lfit = find_interval(ws.t, k1, nk1, ui);
+          double h[6];
+          fpbspl(ws.t, k, ui, lfit, h);
+          int l0 = l - k2;
+          double term = 0.;
+          for (int d = 0; d < 2; d++) {
+            double fac = 0.;
+            int j1 = l0 + d * n;
+            for (int j = 1; j <= k1; j++) {
+              j1++;
+              fac = fac + ws.c[j1] * h[j];
+            }
+            double dv = fac - (d == 0 ? X[it] : Y[it]);
+            term = term + dv * dv;
+          }
+          ws.term[lane] = term;
+        }
+        __syncthreads();
+        int cnt = m - base < WAVE ? m - base : WAVE;
+        for (int r = 0; r < cnt; r++) fp = fp + ws.term[r] * (1.0 * 1.0);
+        __syncthreads();
+      }
+      fpms = fp - s;
+      if (fabs(fpms) < acc) break;
+      if (iter == maxit) {
+        ier = 3;
+        break;
+      }
+      double p2 = p, f2 = fpms;
+      bool do_rati = true;
+      if (ich3 == 0) {
+        if ((f2 - f3) > acc) {
+          if (f2 < 0.) ich3 = 1;
+        } else {
+          p3 = p2;
+          f3 = f2;
+          p = p * con4;
+          if (p <= p1) p = p1 * con9 + p2 * con1;
+          do_rati = false;
+        }
+      }
+      if (do_rati && ich1 == 0) {
+        if ((f1 - f2) > acc) {
+          if (f2 > 0.) ich1 = 1;
+        } else {
+          p1 = p2;
+          f1 = f2;
+          p = p / con4;
+          if (!(p3 < 0.)) {
+            if (p >= p3) p = p2 * con1 + p3 * con9;
+          }
+          do_rati = false;
+        }
+      }
+      if (do_rati) {
+        if (f2 >= f1 || f2 <= f3) {
+          ier = 2;
+          break;
+        }
+        // fprati
+        double pn;
+        if (p3 > 0.) {
+          double h1 = f1 * (f2 - f3);
+          double h2 = f2 * (f3 - f1);
+          double h3 = f3 * (f1 - f2);
+          pn = -(p1 * p2 * h3 + p2 * p3 * h1 + p3 * p1 * h2) / (p1 * h1 + p2 * h2 + p3 * h3);
+        } else {
+          pn = (p1 * (f1 - f3) * f2 - p2 * (f2 - f3) * f1) / ((f1 - f2) * f3);
+        }
+        if (f2 < 0.) {
+          p3 = p2;
+          f3 = f2;
+        } else {
+          p1 = p2;
+          f1 = f2;
+        }
+        p = pn;
+      }
+    }
+  }
+  __syncthreads();
+  R.n = n;
+  R.ier = ier;
+  R.fp = fp;
+  return R;
+}
+
+// splev (der = 0, ext = 0) at arg = i * step for i in [0, count): one evaluation point per lane.
+// Outputs to OX/OY (LDS or global), optional parameter values to OU.
+__device__ inline void spline_eval(const SplineWS& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+                                   double* OU) {
+  const int lane = lane_id();
+  const int k = f.k, n = f.n;
+  const int k1 = k + 1, nk1 = n - k1;
+  for (int i = lane; i < count; i += WAVE) {
+    double arg = (double)i * step;
+    int l = find_interval(ws.t, k1, nk1, arg);
+    double h[6];
+    fpbspl(ws.t, k, arg, l, h);
+    double sx = 0., sy = 0.;
+    int ll = l - k1;
+    for (int j = 1; j <= k1; j++) {
+      ll++;
+      sx = sx + ws.c[ll] * h[j];
+      sy = sy + ws.c[ll + n] * h[j];
+    }
+    OX[i] = sx;
+    OY[i] = sy;
+    if (OU) OU[i] = arg;
+  }
+  __syncthreads();
+}
+
+}  // namespace fsdp

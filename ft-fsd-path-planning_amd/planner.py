@@ -1,0 +1,148 @@
+"""Python host mirroring the reference's public interface for the hot path.
+
+Same names, argument meaning and return shapes as
+  fsd_path_planning.PathPlanner / ConeTypes / MissionTypes   (reference fsd_path_planning/__init__.py:8-13,
+  full_pipeline/full_pipeline.py:53-217, utils/cone_types.py, utils/mission_types.py)
+backed by the HIP library through _capi (ctypes, include/fsdp.h).  Semantics for batches:
+independent frames, "fresh PathPlanner per frame" (SURVEY.md §8a quirk 12).
+"""
+from __future__ import annotations
+
+from enum import IntEnum
+from typing import Any, List, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _capi
+
+
+class ConeTypes(IntEnum):
+    """reference utils/cone_types.py:10-19"""
+
+    UNKNOWN = 0
+    RIGHT = YELLOW = 1
+    LEFT = BLUE = 2
+    START_FINISH_AREA = ORANGE_SMALL = 3
+    START_FINISH_LINE = ORANGE_BIG = 4
+
+
+class MissionTypes(IntEnum):
+    """reference utils/mission_types.py:11-25"""
+
+    none = 0
+    acceleration = 1
+    skidpad = 2
+    autocross = 3
+    trackdrive = 4
+    ebs_test = 5
+    inspection = 6
+    manual_driving = 7
+
+
+class ReferenceUndefinedError(RuntimeError):
+    """The reference raises on this input (status 101-104); which exception is reported in .status"""
+
+    def __init__(self, status: int):
+        super().__init__(f"the reference implementation raises on this frame (status {status}, see include/fsdp.h)")
+        self.status = status
+
+
+def flatten_cones_by_type_array(cones_by_type) -> np.ndarray:
+    """reference sorting_cones/trace_sorter/core_trace_sorter.py:37-54 (own restatement)."""
+    if isinstance(cones_by_type, np.ndarray) and cones_by_type.ndim == 2 and cones_by_type.shape[1] == 3:
+        return np.ascontiguousarray(cones_by_type, dtype=np.float64)
+    parts = []
+    for t in ConeTypes.__members__.values():
+        pass
+    for t in (0, 1, 2, 3, 4):
+        c = np.asarray(cones_by_type[t], dtype=np.float64).reshape(-1, 2)
+        parts.append(np.column_stack([c, np.full(len(c), float(t))]))
+    return np.ascontiguousarray(np.concatenate(parts, axis=0)) if parts else np.zeros((0, 3))
+
+
+def _direction_to_array(direction: Any) -> np.ndarray:
+    """reference full_pipeline.py:71-79"""
+    direction = np.squeeze(np.array(direction, dtype=np.float64))
+    if direction.shape == (2,):
+        return direction
+    if direction.shape in [(1,), ()]:
+        a = float(direction)
+        return np.array([np.cos(a), np.sin(a)])
+    raise ValueError("direction must be a float or a 2 element array")
+
+
+def pack_frames(frames: Sequence[Tuple[Any, Any, Any]]):
+    """[(cones_by_type | (N,3), position, direction), ...] -> (offsets, cones_xyt, poses)"""
+    flat = [flatten_cones_by_type_array(f[0]) for f in frames]
+    offsets = np.zeros(len(frames) + 1, dtype=np.int32)
+    offsets[1:] = np.cumsum([len(c) for c in flat])
+    cones = np.concatenate(flat, axis=0) if flat else np.zeros((0, 3))
+    poses = np.array([np.concatenate([np.asarray(f[1], float).reshape(2), _direction_to_array(f[2])]) for f in frames]).reshape(-1, 4)
+    return offsets, cones, poses
+
+
+class PathPlanner:
+    """Drop-in for fsd_path_planning.PathPlanner on the relocalizer-free missions.
+
+    ``calculate_path_in_global_frame`` keeps the reference signature and return values
+    (full_pipeline.py:84-207); ``plan_batch`` is the batched form of the same call.
+    """
+
+    def __init__(self, mission: MissionTypes, experimental_performance_improvements: bool = False, device: int | None = None):
+        if experimental_performance_improvements:
+            # reference README.md:24-27: off by default, changes results, meaningless for independent frames
+            raise NotImplementedError("the experimental sorting cache is out of scope (SURVEY.md §2 row 15)")
+        self.mission = MissionTypes(mission)
+        if self.mission in (MissionTypes.acceleration, MissionTypes.skidpad, MissionTypes.ebs_test):
+            raise NotImplementedError("missions with a relocalizer are not on the MI355X path yet (SURVEY.md §8f)")
+        self._ctx = _capi.Context(device=device, mission=int(self.mission))
+        self.global_path = None
+
+    @property
+    def relocalization_info(self):
+        """reference full_pipeline.py:209-217: None for missions without a relocalizer."""
+        return None
+
+    def set_global_path(self, global_path):  # reference full_pipeline.py:81-82
+        if global_path is not None:
+            raise NotImplementedError("global_path (skidpad) is not on the MI355X path yet")
+        self.global_path = None
+
+    # ---- batched form -------------------------------------------------------------------
+    def plan_batch(self, cone_offsets, cones_xyt, poses) -> np.ndarray:
+        """Structured array (one row per frame, dtype _capi.RESULT_DTYPE)."""
+        return self._ctx.plan_batch(cone_offsets, cones_xyt, poses)
+
+    # ---- reference-shaped single-frame call ---------------------------------------------
+    def calculate_path_in_global_frame(
+        self,
+        cones: List[np.ndarray],
+        vehicle_position: np.ndarray,
+        vehicle_direction: Union[np.ndarray, float],
+        return_intermediate_results: bool = False,
+    ):
+        vehicle_direction = _direction_to_array(vehicle_direction)
+        xyt = flatten_cones_by_type_array(cones)
+        pose = np.concatenate([np.asarray(vehicle_position, dtype=np.float64).reshape(2), vehicle_direction])
+        r = self._ctx.plan_batch(np.array([0, len(xyt)], np.int32), xyt, pose[None])[0]
+        st = int(r["status"])
+        if 100 <= st < 200:
+            raise ReferenceUndefinedError(st)
+        if st != 0:
+            raise _capi.FsdpError(f"device capacity exceeded (status {st}, see include/fsdp.h)")
+        path = np.array(r["path"])
+        if not return_intermediate_results:
+            return path
+        nl, nr = int(r["n_left"]), int(r["n_right"])
+        ml, mr = int(r["n_left_v"]), int(r["n_right_v"])
+        sorted_left = xyt[r["left_idx"][:nl], :2]
+        sorted_right = xyt[r["right_idx"][:nr], :2]
+        return (
+            path,
+            sorted_left,
+            sorted_right,
+            np.array(r["left_v"][:ml]),
+            np.array(r["right_v"][:mr]),
+            np.array(r["l2r"][:ml], dtype=np.int64),
+            np.array(r["r2l"][:mr], dtype=np.int64),
+        )

@@ -1,0 +1,134 @@
+/* fsdp.h — C ABI of the MI355X-native batched PathPlanner hot path (libfsdp_hip.so).
+ *
+ * Drop-in boundary.  The reference (papalotis/ft-fsd-path-planning) is pure Python and has no
+ * FFI layer; the boundary a replacement can sit behind is the method
+ *   PathPlanner.calculate_path_in_global_frame(cones, vehicle_position, vehicle_direction,
+ *                                              return_intermediate_results)
+ *   fsd_path_planning/full_pipeline/full_pipeline.py:84-207
+ * and the three public stage classes it wires together
+ *   ConeSorting.run_cone_sorting      sorting_cones/core_cone_sorting.py:117-136
+ *   ConeMatching.run_cone_matching    cone_matching/core_cone_matching.py:87-124
+ *   CalculatePath.run_path_calculation calculate_path/core_calculate_path.py:514-575
+ * Each entry point below names the reference interface it replaces.  The Python host
+ * (ft-fsd-path-planning_amd/) binds these with ctypes and re-creates the reference's class
+ * API on top; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions: plain C types, caller-allocated buffers, no exceptions across the ABI.
+ * Return value 0 = success; non-zero = API misuse or HIP error (fsdp_last_error()).  Per-frame
+ * conditions are reported in fsdp_frame_result.status, never through the return code.
+ * A context is bound to one GPU and one HIP stream; contexts are independent (one per GPU /
+ * per host thread).  All floating point is IEEE float64.
+ */
+#ifndef FSDP_H
+#define FSDP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSDP_MAX_LEN 12      /* config.py:36 max_length                         */
+#define FSDP_MAX_MATCH 24    /* cones incl. virtual per side after matching     */
+#define FSDP_PATH_POINTS 40  /* config.py:58 mpc_prediction_horizon             */
+#define FSDP_MAX_CONES 256   /* cones per frame the kernels stage in LDS        */
+
+/* ConeTypes — utils/cone_types.py:10-19 (values are part of the input format) */
+enum { FSDP_CONE_UNKNOWN = 0, FSDP_CONE_RIGHT = 1, FSDP_CONE_LEFT = 2, FSDP_CONE_ORANGE_SMALL = 3, FSDP_CONE_ORANGE_BIG = 4 };
+
+/* per-frame status */
+enum {
+  FSDP_OK = 0,
+  /* the reference raises out of calculate_path_in_global_frame on this input */
+  FSDP_REF_UNDEFINED_SET_DIFF = 101,  /* nearby_cone_search.py:88-94                         */
+  FSDP_REF_UNDEFINED_DFS_OOB = 102,   /* end_configurations.py:369                           */
+  FSDP_REF_UNDEFINED_PATH = 103,      /* core_calculate_path.py:482-483 / second fallback    */
+  FSDP_REF_UNDEFINED_MATCH_IDX = 104, /* core_calculate_path.py:544 index into empty array   */
+  /* fixed device capacities exceeded (the reference's buffers grow without bound) */
+  FSDP_OVERFLOW_CONES = 201,
+  FSDP_OVERFLOW_ENDS = 202,
+  FSDP_OVERFLOW_PATH = 203,
+  FSDP_OVERFLOW_KNOTS = 204
+};
+
+/* path_fallback bits */
+enum {
+  FSDP_FB_PREVIOUS_CENTER = 1, /* < 2 centre points / < 3 cones both sides: previous path (core_calculate_path.py:202-203,531-536) */
+  FSDP_FB_SPLINE_ERROR = 2,    /* :218-221 */
+  FSDP_FB_TOO_FAR = 4,         /* :235-236 */
+  FSDP_FB_MPC_RETRY = 8,       /* :564-570 */
+  FSDP_FB_ARC_EXTENSION = 16,  /* :301-324 */
+  FSDP_FB_LINE_EXTENSION = 32  /* :326-331 */
+};
+
+/* What calculate_path_in_global_frame(..., return_intermediate_results=True) returns
+ * (full_pipeline.py:196-205) plus the index form of the sorted cones. */
+typedef struct {
+  int32_t status;
+  int32_t n_left, n_right;
+  int32_t left_idx[FSDP_MAX_LEN];  /* left_config: indices into the frame's flattened cones, -1 padded  */
+  int32_t right_idx[FSDP_MAX_LEN]; /* (trace_sorter/core_trace_sorter.py:197-214)                       */
+  int32_t n_left_v, n_right_v;
+  double left_v[FSDP_MAX_MATCH][2];  /* left_cones_with_virtual  */
+  double right_v[FSDP_MAX_MATCH][2]; /* right_cones_with_virtual */
+  int32_t l2r[FSDP_MAX_MATCH];       /* left_to_right_match, -1 = none */
+  int32_t r2l[FSDP_MAX_MATCH];
+  double path[FSDP_PATH_POINTS][4];  /* [spline parameter, x, y, curvature] */
+  int32_t n_configs_left, n_configs_right;
+  int32_t first_k_left[2], first_k_right[2];
+  double best_cost_left, best_cost_right;
+  int32_t path_fallback;
+  int32_t n_dense; /* number of dense spline samples the 40 outputs were drawn from */
+} fsdp_frame_result;
+
+typedef struct fsdp_ctx fsdp_ctx;
+
+const char* fsdp_version(void);
+int fsdp_result_size(void);                 /* sizeof(fsdp_frame_result), for binding sanity checks */
+int fsdp_device_count(void);                /* number of visible HIP devices (0 if none)            */
+
+/* PathPlanner(mission) — full_pipeline.py:54-69.  Creates the per-GPU context (device buffers,
+ * stream, the constant initial previous path of core_calculate_path.py:103-107 computed on device).
+ * Only relocalizer-free missions (trackdrive / autocross, mission >= 3 of utils/mission_types.py) are
+ * on this path; others return an error. */
+int fsdp_create(int device, int mission, fsdp_ctx** out);
+void fsdp_destroy(fsdp_ctx* ctx);
+const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creation error */
+
+/* calculate_path_in_global_frame for a batch of independent frames (fresh-planner semantics).
+ * cone_offsets: (n_frames+1) CSR offsets; cones_xyt: (total,3) rows [x,y,ConeTypes] — the reference's own
+ * flattened layout (core_trace_sorter.py:37-54); poses: (n_frames,4) rows [px,py,dir_x,dir_y].
+ * Host buffers; does H2D, the three kernels and D2H on the context's stream, then synchronises. */
+int fsdp_plan_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
+                    const double* poses, fsdp_frame_result* results);
+
+/* The same in three steps so a caller (bench, pipelined replay) can keep inputs resident in HBM. */
+int fsdp_upload(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses);
+int fsdp_run(fsdp_ctx* ctx);      /* enqueue sorting, matching, path kernels on the context stream (async) */
+int fsdp_sync(fsdp_ctx* ctx);     /* wait for the stream */
+int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
+
+/* Enqueue `iters` back-to-back passes over the resident batch and time them with HIP events recorded on the
+ * context's stream.  ms_total: whole region; ms_stage[3]: summed time of the sorting / matching / path kernels
+ * (events around each launch).  Either pointer may be NULL. */
+int fsdp_time_runs(fsdp_ctx* ctx, int iters, float* ms_total, float* ms_stage);
+
+/* Stage-level entry points (README "parts of the pipeline are also available as individual classes"). */
+/* ConeSorting.run_cone_sorting — fills status, n_left/right, left/right_idx and the sorting diagnostics. */
+int fsdp_sort_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
+                    const double* poses, fsdp_frame_result* results);
+/* ConeMatching.run_cone_matching — sorted_left/right: (n_frames,12,2) padded, counts (n_frames,). */
+int fsdp_match_batch(fsdp_ctx* ctx, int n_frames, const double* sorted_left, const int32_t* n_left,
+                     const double* sorted_right, const int32_t* n_right, const double* poses,
+                     fsdp_frame_result* results);
+/* CalculatePath.run_path_calculation — inputs: the matching fields of `results` (left_v, right_v, l2r, r2l,
+ * counts) and poses; fills path, path_fallback, n_dense, status. */
+int fsdp_path_batch(fsdp_ctx* ctx, int n_frames, const double* poses, fsdp_frame_result* results);
+
+/* The constant initial previous path (core_calculate_path.py:103-107), (40,4), as computed on the device. */
+int fsdp_default_path(fsdp_ctx* ctx, double* out40x4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSDP_H */

@@ -1,0 +1,71 @@
+// TEST INFRASTRUCTURE — builds the product's kernel *sources* for the host SIMT emulator
+// (tests/emu/hip_emu.h).  Never loaded by the package.
+#include "hip_emu.h"
+
+#include "../../ft-fsd-path-planning_amd/csrc/sort_kernel.h"
+#include "../../ft-fsd-path-planning_amd/csrc/match_kernel.h"
+#include "../../ft-fsd-path-planning_amd/csrc/path_kernel.h"
+
+#include <mutex>
+
+static double g_default_path[fsdp::PATH_POINTS * 4];
+static std::once_flag g_once;
+static void build_default() {
+  double chord[fsdp::PATH_POINTS][2];
+  fsdp::default_chord_points(chord);
+  emu::launch(1, 64, [&]() { fsdp::default_path_kernel(&chord[0][0], g_default_path); });
+}
+
+namespace fsdp {
+// test kernel: fit one polyline (m <= PATH_CAP) and dump knots / coefficients
+__global__ void fit_test_kernel(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
+  __shared__ PathShared S;
+  const int lane = lane_id();
+  for (int i = lane; i < m; i += WAVE) {
+    S.ax[i] = xy[2 * i];
+    S.ay[i] = xy[2 * i + 1];
+  }
+  __syncthreads();
+  SplineFit f;
+  double max_u;
+  int rc = fit_polyline(S, 0, m, smoothing, f, max_u);
+  if (lane == 0) {
+    info[0] = rc;
+    info[1] = f.n;
+    info[2] = f.ier;
+    info[3] = f.k;
+    fp_out[0] = f.fp;
+    fp_out[1] = max_u;
+    for (int i = 1; i <= f.n && i <= NK; i++) {
+      t_out[i - 1] = S.ws.t[i];
+      c_out[i - 1] = S.ws.c[i];
+      c_out[NK + i - 1] = S.ws.c[i + f.n];
+    }
+  }
+}
+}  // namespace fsdp
+
+extern "C" {
+void emu_fit(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
+  emu::launch(1, 64, [&]() { fsdp::fit_test_kernel(xy, m, smoothing, t_out, c_out, info, fp_out); });
+}
+int emu_sizeof_sort_out() { return (int)sizeof(fsdp::SortOut); }
+int emu_sizeof_match_out() { return (int)sizeof(fsdp::MatchOut); }
+int emu_sizeof_path_out() { return (int)sizeof(fsdp::PathOut); }
+
+void emu_sort(int n_frames, const int32_t* offsets, const double* cones, const double* poses, fsdp::SortOut* out) {
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel(n_frames, offsets, cones, poses, out); });
+}
+void emu_match(int n_frames, const int32_t* offsets, const double* cones, const double* poses, const fsdp::SortOut* sorted,
+               fsdp::MatchOut* out) {
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::match_kernel(n_frames, offsets, cones, poses, sorted, out); });
+}
+void emu_default_path(double* out) {
+  std::call_once(g_once, build_default);
+  for (int i = 0; i < fsdp::PATH_POINTS * 4; i++) out[i] = g_default_path[i];
+}
+void emu_path(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
+  std::call_once(g_once, build_default);
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, out); });
+}
+}

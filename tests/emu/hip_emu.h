@@ -1,0 +1,240 @@
+// TEST INFRASTRUCTURE — a minimal host-side SIMT emulator for the HIP kernels in
+// ft-fsd-path-planning_amd/csrc/.  It lets the CPU test-suite execute the *kernel source*
+// (one fiber per lane, 64 lanes per block, cooperative scheduling, cross-lane ops realised
+// as rendezvous) so kernel logic can be checked against the oracle where no GPU exists.
+// It is NOT a product fallback: nothing in the package loads the library built from this,
+// and the product fails loudly when the HIP library is missing.
+//
+// Supported subset (what the kernels use): __global__/__device__/__shared__, threadIdx /
+// blockIdx / blockDim / gridDim (.x), __syncthreads, __ballot, __shfl/__shfl_xor/__shfl_down/
+// __shfl_up (int, unsigned, long long, double), __popcll, __ffsll, __clzll, atomicOr/atomicAdd
+// on shared ints.  Cross-lane operations must be reached by all 64 lanes (wave-uniform
+// control flow) — the same discipline the kernels follow on hardware.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define FSDP_EMU 1
+
+namespace emu {
+
+struct Dim3 {
+  unsigned x = 1, y = 1, z = 1;
+};
+
+constexpr int WAVE = 64;
+constexpr size_t STACK_BYTES = 512 * 1024;
+
+struct Lane {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  Dim3 tid;
+};
+
+struct Block {
+  ucontext_t main_ctx;
+  Lane lanes[WAVE];
+  int n_lanes = WAVE;
+  int cur = 0;
+  int live = 0;
+  int arrived = 0;
+  unsigned gen = 0;
+  Dim3 bid, bdim, gdim;
+  uint64_t slots[WAVE];
+  std::function<void()> body;
+};
+
+inline thread_local Block* B = nullptr;
+
+inline void yield_lane() {
+  Block* b = B;
+  int from = b->cur;
+  int nxt = from;
+  for (int step = 0; step < b->n_lanes; step++) {
+    nxt = (nxt + 1) % b->n_lanes;
+    if (!b->lanes[nxt].done) break;
+  }
+  if (nxt == from) return;
+  b->cur = nxt;
+  swapcontext(&b->lanes[from].ctx, &b->lanes[nxt].ctx);
+}
+
+inline void barrier() {
+  Block* b = B;
+  unsigned g = b->gen;
+  if (++b->arrived == b->live) {
+    b->arrived = 0;
+    b->gen++;
+    return;
+  }
+  while (b->gen == g) yield_lane();
+}
+
+inline void lane_entry() {
+  Block* b = B;
+  b->body();
+  b->lanes[b->cur].done = true;
+  b->live--;
+  // a lane that leaves while others wait at a rendezvous would dead-lock them: the kernels
+  // never do that (all lanes reach the end together), so just hand over.
+  if (b->live > 0) {
+    if (b->arrived == b->live && b->arrived > 0) {  // release waiters if we were the last expected
+      b->arrived = 0;
+      b->gen++;
+    }
+    yield_lane();
+  }
+  swapcontext(&b->lanes[b->cur].ctx, &b->main_ctx);
+}
+
+template <class F>
+void launch(unsigned grid, unsigned block, F&& f) {
+  static thread_local Block* blk = nullptr;
+  if (!blk) {
+    blk = new Block();
+    for (int i = 0; i < WAVE; i++) blk->lanes[i].stack = (char*)malloc(STACK_BYTES);
+  }
+  if (block > (unsigned)WAVE) {
+    fprintf(stderr, "emu: block size %u > 64 unsupported\n", block);
+    abort();
+  }
+  for (unsigned bx = 0; bx < grid; bx++) {
+    Block* b = blk;
+    B = b;
+    b->n_lanes = (int)block;
+    b->live = (int)block;
+    b->arrived = 0;
+    b->gen = 0;
+    b->bid.x = bx;
+    b->bdim.x = block;
+    b->gdim.x = grid;
+    b->body = f;
+    for (unsigned l = 0; l < block; l++) {
+      Lane& L = b->lanes[l];
+      L.done = false;
+      L.tid.x = l;
+      getcontext(&L.ctx);
+      L.ctx.uc_stack.ss_sp = L.stack;
+      L.ctx.uc_stack.ss_size = STACK_BYTES;
+      L.ctx.uc_link = nullptr;
+      makecontext(&L.ctx, (void (*)())lane_entry, 0);
+    }
+    b->cur = 0;
+    swapcontext(&b->main_ctx, &b->lanes[0].ctx);
+    // returns here when a lane finished and found no live lane... make sure all are done
+    while (b->live > 0) {
+      int nxt = -1;
+      for (int l = 0; l < b->n_lanes; l++)
+        if (!b->lanes[l].done) {
+          nxt = l;
+          break;
+        }
+      if (nxt < 0) break;
+      b->cur = nxt;
+      swapcontext(&b->main_ctx, &b->lanes[nxt].ctx);
+    }
+  }
+}
+
+template <class T>
+inline uint64_t to_bits(T v) {
+  uint64_t u = 0;
+  static_assert(sizeof(T) <= 8, "shfl payload too large");
+  memcpy(&u, &v, sizeof(T));
+  return u;
+}
+template <class T>
+inline T from_bits(uint64_t u) {
+  T v;
+  memcpy(&v, &u, sizeof(T));
+  return v;
+}
+
+template <class T>
+inline T exchange(T v, int src) {
+  Block* b = B;
+  int me = b->cur;
+  b->slots[me] = to_bits(v);
+  barrier();
+  T r = (src >= 0 && src < b->n_lanes) ? from_bits<T>(b->slots[src]) : v;
+  barrier();
+  return r;
+}
+
+inline unsigned long long ballot(int pred) {
+  Block* b = B;
+  int me = b->cur;
+  b->slots[me] = pred ? 1 : 0;
+  barrier();
+  unsigned long long m = 0;
+  for (int l = 0; l < b->n_lanes; l++)
+    if (b->slots[l]) m |= (1ull << l);
+  barrier();
+  return m;
+}
+
+}  // namespace emu
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __noinline__
+#define __restrict__
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define threadIdx (emu::B->lanes[emu::B->cur].tid)
+#define blockIdx (emu::B->bid)
+#define blockDim (emu::B->bdim)
+#define gridDim (emu::B->gdim)
+
+using std::isfinite;
+using std::isinf;
+using std::isnan;
+
+inline void __syncthreads() { emu::barrier(); }
+inline unsigned long long __ballot(int p) { return emu::ballot(p); }
+template <class T>
+inline T __shfl(T v, int src, int width = 64) {
+  (void)width;
+  return emu::exchange(v, src);
+}
+template <class T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  (void)width;
+  return emu::exchange(v, emu::B->cur ^ mask);
+}
+template <class T>
+inline T __shfl_down(T v, unsigned d, int width = 64) {
+  (void)width;
+  int s = emu::B->cur + (int)d;
+  return emu::exchange(v, s < emu::WAVE ? s : emu::B->cur);
+}
+template <class T>
+inline T __shfl_up(T v, unsigned d, int width = 64) {
+  (void)width;
+  int s = emu::B->cur - (int)d;
+  return emu::exchange(v, s >= 0 ? s : emu::B->cur);
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+template <class T>
+inline T atomicOr(T* p, T v) {
+  T o = *p;
+  *p = o | v;
+  return o;
+}
+template <class T>
+inline T atomicAdd(T* p, T v) {
+  T o = *p;
+  *p = o + v;
+  return o;
+}

@@ -1,0 +1,113 @@
+"""ctypes binding of the host-SIMT-emulated kernels (tests/emu/libfsdp_emu.so).
+TEST INFRASTRUCTURE: executes the kernel sources of ft-fsd-path-planning_amd/csrc on the CPU
+(one fiber per lane) so their logic can be compared with the oracle without a GPU."""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+EMU_DIR = ROOT / "tests" / "emu"
+LIB = EMU_DIR / "libfsdp_emu.so"
+
+MAX_LEN, MAX_MATCH, PATH_POINTS = 12, 24, 40
+
+SORT_DTYPE = np.dtype(
+    [
+        ("status", "<i4"), ("n_left", "<i4"), ("n_right", "<i4"),
+        ("left_idx", "<i4", (MAX_LEN,)), ("right_idx", "<i4", (MAX_LEN,)),
+        ("n_configs_left", "<i4"), ("n_configs_right", "<i4"),
+        ("first_k_left", "<i4", (2,)), ("first_k_right", "<i4", (2,)),
+        ("best_cost_left", "<f8"), ("best_cost_right", "<f8"),
+    ],
+    align=True,
+)
+MATCH_DTYPE = np.dtype(
+    [
+        ("status", "<i4"), ("n_left_v", "<i4"), ("n_right_v", "<i4"), ("pad", "<i4"),
+        ("left_v", "<f8", (MAX_MATCH, 2)), ("right_v", "<f8", (MAX_MATCH, 2)),
+        ("l2r", "<i4", (MAX_MATCH,)), ("r2l", "<i4", (MAX_MATCH,)),
+    ],
+    align=True,
+)
+PATH_DTYPE = np.dtype(
+    [("path", "<f8", (PATH_POINTS, 4)), ("status", "<i4"), ("fallback", "<i4"), ("n_dense", "<i4"), ("pad", "<i4")],
+    align=True,
+)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-s", "-C", str(EMU_DIR)], check=True)
+        _lib = ctypes.CDLL(str(LIB))
+        assert _lib.emu_sizeof_sort_out() == SORT_DTYPE.itemsize
+    return _lib
+
+
+def _p(a, t=ctypes.c_double):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def sort(offsets, cones, poses):
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    cones = np.ascontiguousarray(cones, np.float64)
+    poses = np.ascontiguousarray(poses, np.float64)
+    n = len(offsets) - 1
+    out = np.zeros(n, SORT_DTYPE)
+    lib().emu_sort(ctypes.c_int(n), _p(offsets, ctypes.c_int32), _p(cones), _p(poses), ctypes.c_void_p(out.ctypes.data))
+    return out
+
+
+def match(offsets, cones, poses, sorted_out):
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    cones = np.ascontiguousarray(cones, np.float64)
+    poses = np.ascontiguousarray(poses, np.float64)
+    n = len(offsets) - 1
+    assert lib().emu_sizeof_match_out() == MATCH_DTYPE.itemsize
+    out = np.zeros(n, MATCH_DTYPE)
+    lib().emu_match(ctypes.c_int(n), _p(offsets, ctypes.c_int32), _p(cones), _p(poses),
+                    ctypes.c_void_p(sorted_out.ctypes.data), ctypes.c_void_p(out.ctypes.data))
+    return out
+
+
+def path(poses, matched):
+    poses = np.ascontiguousarray(poses, np.float64)
+    n = len(poses)
+    assert lib().emu_sizeof_path_out() == PATH_DTYPE.itemsize
+    out = np.zeros(n, PATH_DTYPE)
+    lib().emu_path(ctypes.c_int(n), _p(poses), ctypes.c_void_p(matched.ctypes.data), ctypes.c_void_p(out.ctypes.data))
+    return out
+
+
+def default_path():
+    out = np.zeros((PATH_POINTS, 4))
+    lib().emu_default_path(_p(out))
+    return out
+
+
+def plan(offsets, cones, poses):
+    """Full emulated pipeline; returns a structured array shaped like oracle_lib.RESULT_DTYPE."""
+    import oracle_lib
+
+    s = sort(offsets, cones, poses)
+    m = match(offsets, cones, poses, s)
+    p = path(poses, m)
+    res = np.zeros(len(s), oracle_lib.RESULT_DTYPE)
+    for k in ("n_left", "n_right", "left_idx", "right_idx", "n_configs_left", "n_configs_right", "first_k_left",
+              "first_k_right", "best_cost_left", "best_cost_right"):
+        res[k] = s[k]
+    for k in ("n_left_v", "n_right_v", "left_v", "right_v", "l2r", "r2l"):
+        res[k] = m[k]
+    res["path"] = p["path"]
+    res["path_fallback"] = p["fallback"]
+    st = s["status"].copy()
+    st = np.where(m["status"] != 0, m["status"], st)
+    st = np.where(p["status"] != 0, p["status"], st)
+    res["status"] = st
+    return res, p["n_dense"]

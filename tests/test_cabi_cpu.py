@@ -1,0 +1,59 @@
+"""CPU-side checks of the product boundary: the C-ABI library loads and exports every symbol
+include/fsdp.h declares, the result struct layout matches the Python mirror, and — without a GPU —
+the product fails loudly instead of falling back to anything."""
+import ctypes
+import importlib
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+
+    ge.build_hip()
+    return importlib.import_module("ft-fsd-path-planning_amd")
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = (ROOT / "include" / "fsdp.h").read_text()
+    declared = set(re.findall(r"\b(fsdp_[a-z_]+)\s*\(", header))
+    declared -= {"fsdp_ctx"}
+    lib = ctypes.CDLL(str(pkg._capi.LIB_PATH))
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), sym
+    assert declared == set(pkg._capi.EXPORTED_SYMBOLS)
+    assert lib.fsdp_result_size() == pkg._capi.RESULT_DTYPE.itemsize
+
+
+def test_no_cpu_fallback(pkg):
+    lib = pkg._capi.load()
+    if lib.fsdp_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(pkg.FsdpError, match="no HIP device"):
+        pkg.PathPlanner(pkg.MissionTypes.trackdrive)
+
+
+def test_product_does_not_import_oracle():
+    """The product never imports, links or executes anything under oracle/ (or the emulator)."""
+    pat = re.compile(r"import\s+oracle_lib|from\s+oracle|liboracle|#include\s*[<\"].*oracle|libfsdp_emu|hip_emu\.h|import\s+emu_lib")
+    for p in (ROOT / "ft-fsd-path-planning_amd").rglob("*"):
+        if p.suffix in (".py", ".h", ".hip", ".cpp") and p.is_file():
+            assert not pat.search(p.read_text()), p
+
+
+def test_host_side_packing(pkg):
+    frames = [([np.zeros((0, 2)), np.array([[1.0, -1.5]]), np.array([[1.0, 1.5], [4.0, 1.5]]), [], []], [0.0, 0.0], 0.0),
+              (np.array([[0.0, 1.0, 2.0]]), np.array([1.0, 2.0]), np.array([0.0, 1.0]))]
+    off, cones, poses = pkg.pack_frames(frames)
+    assert off.tolist() == [0, 3, 4]
+    assert cones[:3, 2].tolist() == [1.0, 2.0, 2.0]  # reference flatten order: UNKNOWN, RIGHT, LEFT, ...
+    assert np.allclose(poses[0], [0, 0, 1, 0]) and np.allclose(poses[1], [1, 2, 0, 1])
+    with pytest.raises(ValueError):
+        pkg.planner._direction_to_array([1.0, 2.0, 3.0])
+    assert int(pkg.ConeTypes.LEFT) == 2 and int(pkg.ConeTypes.YELLOW) == 1 and int(pkg.MissionTypes.trackdrive) == 4

@@ -1,0 +1,32 @@
+"""The kernel SOURCES of ft-fsd-path-planning_amd/csrc executed on the CPU by the host SIMT emulator
+(tests/emu/: one fiber per lane, rendezvous for ballot/shuffle/barrier) and compared with the oracle.
+This is how kernel logic is checked where no GPU exists; the -m gpu tests repeat the comparison on
+hardware through the real library."""
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle_lib
+
+
+@pytest.mark.parametrize("name,stride", [("scenarios", 1), ("cfg2_color", 4), ("cfg3_nocolor", 8), ("cfg4_200cones", 8),
+                                          ("cfg4_noisy_nocolor", 6), ("fuzz", 5)])
+def test_emulated_kernels_equal_oracle(golden_dir, name, stride):
+    g = np.load(golden_dir / f"{name}.npz")
+    idx = np.arange(0, len(g["ok"]), stride)
+    off = np.concatenate([[0], np.cumsum([g["offsets"][i + 1] - g["offsets"][i] for i in idx])]).astype(np.int32)
+    cones = np.concatenate([g["cones"][g["offsets"][i] : g["offsets"][i + 1]] for i in idx])
+    poses = g["poses"][idx]
+    res, n_dense = emu_lib.plan(off, cones, poses)
+    ref = oracle_lib.plan_batch(off, cones, poses)
+    assert np.array_equal(res["status"], ref["status"])
+    ok = ref["status"] == 0
+    for f in ("left_idx", "right_idx", "n_left_v", "n_right_v", "l2r", "r2l", "left_v", "right_v", "path_fallback"):
+        assert np.array_equal(res[f][ok], ref[f][ok]), f
+    # same libm on both sides here -> the whole float chain is bit-identical
+    assert np.array_equal(res["path"][ok], ref["path"][ok])
+
+
+def test_emulated_default_path_equals_reference(golden_dir):
+    ref = np.load(golden_dir / "default_path.npz")["path"]
+    assert np.abs(emu_lib.default_path() - ref).max() < 1e-12
