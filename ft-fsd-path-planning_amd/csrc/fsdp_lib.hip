@@ -41,6 +41,7 @@ struct fsdp_ctx {
   MatchOut* d_match = nullptr;
   PathOut* d_path = nullptr;
   double* d_default_path = nullptr;  // (40,4)
+  double* d_arena = nullptr;         // per-frame working polyline (3 x PATH_CAP doubles), HBM/L2 scratch
   // pinned host staging for results
   std::vector<SortOut> h_sort;
   std::vector<MatchOut> h_match;
@@ -58,11 +59,13 @@ struct fsdp_ctx {
 
 static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
   if (n_frames > c->cap_frames) {
-    if (c->d_off) hipFree(c->d_off);
-    if (c->d_poses) hipFree(c->d_poses);
-    if (c->d_sort) hipFree(c->d_sort);
-    if (c->d_match) hipFree(c->d_match);
-    if (c->d_path) hipFree(c->d_path);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->d_poses) (void)hipFree(c->d_poses);
+    if (c->d_sort) (void)hipFree(c->d_sort);
+    if (c->d_match) (void)hipFree(c->d_match);
+    if (c->d_path) (void)hipFree(c->d_path);
+    if (c->d_arena) (void)hipFree(c->d_arena);
+    c->d_arena = nullptr;
     c->d_off = nullptr;
     c->d_poses = nullptr;
     c->d_sort = nullptr;
@@ -74,10 +77,11 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
     HIP_TRY(c, hipMalloc(&c->d_sort, sizeof(SortOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_match, sizeof(MatchOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_path, sizeof(PathOut) * (size_t)n_frames));
+    HIP_TRY(c, hipMalloc(&c->d_arena, sizeof(double) * 3 * PATH_CAP * (size_t)n_frames));
     c->cap_frames = n_frames;
   }
   if (n_cones > c->cap_cones) {
-    if (c->d_cones) hipFree(c->d_cones);
+    if (c->d_cones) (void)hipFree(c->d_cones);
     c->d_cones = nullptr;
     c->cap_cones = 0;
     size_t want = n_cones ? n_cones : 1;
@@ -97,7 +101,7 @@ static void launch_match(fsdp_ctx* c) {
 }
 static void launch_path(fsdp_ctx* c) {
   hipLaunchKernelGGL(path_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_poses, c->d_match,
-                     c->d_default_path, c->d_path);
+                     c->d_default_path, c->d_arena, c->d_path);
 }
 
 static void assemble(const SortOut* s, const MatchOut* m, const PathOut* p, fsdp_frame_result* r) {
@@ -179,13 +183,16 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
     double chord[PATH_POINTS][2];
     default_chord_points(chord);
     double* d_chord = nullptr;
+    double* d_arena0 = nullptr;
     e = hipMalloc(&d_chord, sizeof(chord));
+    if (e == hipSuccess) e = hipMalloc(&d_arena0, sizeof(double) * 3 * PATH_CAP);
     if (e == hipSuccess) e = hipMemcpyAsync(d_chord, chord, sizeof(chord), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(default_path_kernel, dim3(1), dim3(WAVE), 0, c->stream, d_chord, c->d_default_path);
+      hipLaunchKernelGGL(default_path_kernel, dim3(1), dim3(WAVE), 0, c->stream, d_chord, d_arena0, c->d_default_path);
       e = hipStreamSynchronize(c->stream);
     }
-    if (d_chord) hipFree(d_chord);
+    if (d_chord) (void)hipFree(d_chord);
+    if (d_arena0) (void)hipFree(d_arena0);
     if (e != hipSuccess) {
       g_create_error = std::string("fsdp_create(default path): ") + hipGetErrorString(e);
       delete c;
@@ -198,18 +205,19 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
 
 void fsdp_destroy(fsdp_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
-  hipFree(c->d_off);
-  hipFree(c->d_cones);
-  hipFree(c->d_poses);
-  hipFree(c->d_sort);
-  hipFree(c->d_match);
-  hipFree(c->d_path);
-  hipFree(c->d_default_path);
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(c->d_off);
+  (void)hipFree(c->d_cones);
+  (void)hipFree(c->d_poses);
+  (void)hipFree(c->d_sort);
+  (void)hipFree(c->d_match);
+  (void)hipFree(c->d_path);
+  (void)hipFree(c->d_arena);
+  (void)hipFree(c->d_default_path);
   for (int i = 0; i < 8; i++)
-    if (c->ev[i]) hipEventDestroy(c->ev[i]);
-  if (c->stream) hipStreamDestroy(c->stream);
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 

@@ -11,89 +11,69 @@
 // Every float that feeds the sample-count decision ceil(max_u / predict_every) is produced in the
 // reference's rounding order (see DESIGN.md "arithmetic contract").
 //
-// LDS per frame: polyline arena 3 x 768 doubles (18 KB) reused by the three fits and the dense output,
-// spline workspace ~9 KB, small vectors < 2 KB  => ~30 KB, 5 frames resident per CU.
+// Memory: the working polyline (up to PATH_CAP points: x, y, parameter) lives in a per-frame HBM/L2
+// scratch arena (3 x PATH_CAP doubles, lane-coalesced access, L2/MALL resident); the serial sections
+// consume it through 64-point LDS chunk buffers.  LDS per frame: spline workspace ~9 KB, dense output +
+// curvature 5 KB, segment scratch 2.5 KB, small vectors 1.6 KB => ~18 KB.
 #pragma once
 #include "fsdp_device.h"
 #include "spline_device.h"
 
 namespace fsdp {
 
-constexpr int PATH_CAP = 768;   // points of the working polyline (dense fit-#1 output + extension)
+constexpr int PATH_CAP = 1024;  // points of the working polyline (dense fit-#1 output + extension)
 constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121 in practice)
+constexpr int SEG_CAP = WAVE * 7;  // segment-length scratch in LDS (aliases the spline chunk buffers; 300-sample MPC path)
+
+struct Arena {
+  double* x;
+  double* y;
+  double* u;
+};
 
 struct PathShared {
-  double ax[PATH_CAP];  // polyline arena: x
-  double ay[PATH_CAP];  //                 y
-  double au[PATH_CAP];  //                 parameter / scratch
-  double cxp[PATH_POINTS], cyp[PATH_POINTS], cup[PATH_POINTS];  // centre points (<= 24) or previous path (40)
-  double prevx[PATH_POINTS], prevy[PATH_POINTS];                // previous path xy
-  double curv[DENSE_CAP], filt[DENSE_CAP];
+  double cxp[PATH_POINTS], cyp[PATH_POINTS];      // centre points (<= 24) or previous path (40)
+  double prevx[PATH_POINTS], prevy[PATH_POINTS];  // previous path xy
+  double dx[DENSE_CAP], dy[DENSE_CAP], du[DENSE_CAP];  // dense samples of the final spline
   SplineWS ws;
 };
 
-// np.sum of a contiguous run (NumPy pairwise summation, any n) — wave-uniform
-__device__ inline double np_sum_run(const double* a, int n) {
-  if (n <= 128) return np_sum_small(a, n);
-  // explicit recursion tree: split n -> n2 = n/2 - (n/2)%8, n - n2
-  int st_off[12], st_n[12], st_state[12];
-  double st_acc[12];
-  int sp = 0;
-  st_off[0] = 0;
-  st_n[0] = n;
-  st_state[0] = 0;
-  st_acc[0] = 0.0;
-  double ret = 0.0;
-  while (sp >= 0) {
-    int nn = st_n[sp];
-    if (nn <= 128) {
-      double r = 0.0;
-      // leaf without the "0.0 +" of np_sum_small's reduce identity
-      if (nn < 8) {
-        for (int i = 0; i < nn; i++) r += a[st_off[sp] + i];
-      } else {
-        const double* b = a + st_off[sp];
-        double r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3], r4 = b[4], r5 = b[5], r6 = b[6], r7 = b[7];
-        int i = 8;
-        for (; i < nn - (nn % 8); i += 8) {
-          r0 += b[i];
-          r1 += b[i + 1];
-          r2 += b[i + 2];
-          r3 += b[i + 3];
-          r4 += b[i + 4];
-          r5 += b[i + 5];
-          r6 += b[i + 6];
-          r7 += b[i + 7];
-        }
-        r = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-        for (; i < nn; i++) r += b[i];
-      }
-      ret = r;
-      sp--;
-      continue;
-    }
-    int n2 = nn / 2;
-    n2 -= n2 % 8;
-    if (st_state[sp] == 0) {
-      st_state[sp] = 1;
-      st_off[sp + 1] = st_off[sp];
-      st_n[sp + 1] = n2;
-      st_state[sp + 1] = 0;
-      sp++;
-    } else if (st_state[sp] == 1) {
-      st_acc[sp] = ret;
-      st_state[sp] = 2;
-      st_off[sp + 1] = st_off[sp] + n2;
-      st_n[sp + 1] = nn - n2;
-      st_state[sp + 1] = 0;
-      sp++;
-    } else {
-      ret = st_acc[sp] + ret;
-      sp--;
-    }
+// np.sum of a contiguous run (NumPy pairwise summation) — wave-uniform.  The recursion of
+// DOUBLE_pairwise_sum (split n -> n/2 rounded down to a multiple of 8) is bounded at compile time.
+__device__ __forceinline__ double pw_leaf(const double* b, int nn) {
+  if (nn < 8) {
+    double r = 0.0;
+    for (int i = 0; i < nn; i++) r += b[i];
+    return r;
   }
-  return 0.0 + ret;
+  double r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3], r4 = b[4], r5 = b[5], r6 = b[6], r7 = b[7];
+  int i = 8;
+  for (; i < nn - (nn % 8); i += 8) {
+    r0 += b[i];
+    r1 += b[i + 1];
+    r2 += b[i + 2];
+    r3 += b[i + 3];
+    r4 += b[i + 4];
+    r5 += b[i + 5];
+    r6 += b[i + 6];
+    r7 += b[i + 7];
+  }
+  double r = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < nn; i++) r += b[i];
+  return r;
 }
+template <int DEPTH>
+__device__ inline double pw_rec(const double* a, int n) {
+  if (n <= 128) return pw_leaf(a, n);
+  if constexpr (DEPTH == 0) {
+    return pw_leaf(a, n);  // unreachable for n <= 128 * 2^DEPTH
+  } else {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_rec<DEPTH - 1>(a, n2) + pw_rec<DEPTH - 1>(a + n2, n - n2);
+  }
+}
+__device__ inline double np_sum_run(const double* a, int n) { return 0.0 + pw_rec<4>(a, n); }
 
 // NumPy pairwise sum of f(0..n-1) for n <= 128 without materialising the operands
 template <class F>
@@ -199,34 +179,37 @@ __device__ inline double det3_lu(double x0, double y0, double x1, double y1, dou
 __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
 __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
 
-// chord lengths -> parameter values: au[off + i] = cumulative length (np.cumsum, sequential); returns max_u.
-__device__ inline double build_parameter(PathShared& S, int off, int m) {
+// chord lengths -> parameter values: A.u[off + i] = cumulative length (np.cumsum: sequential order); returns max_u.
+__device__ inline double build_parameter(PathShared& S, const Arena& A, int off, int m) {
   const int lane = lane_id();
   double acc = 0.0;
-  if (lane == 0) S.au[off] = 0.0;
+  if (lane == 0) A.u[off] = 0.0;
   for (int base = 0; base < m - 1; base += WAVE) {
     int i = base + lane;
     if (i < m - 1) {
-      double dx = S.ax[off + i + 1] - S.ax[off + i], dy = S.ay[off + i + 1] - S.ay[off + i];
+      double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
       S.ws.term[lane] = sqrt(dx * dx + dy * dy);
     }
     __syncthreads();
     int cnt = (m - 1 - base) < WAVE ? (m - 1 - base) : WAVE;
+    double mine = 0.0;
     for (int r = 0; r < cnt; r++) {
       acc += S.ws.term[r];
-      if (lane == 0) S.au[off + base + r + 1] = acc;
+      if (lane == r) mine = acc;  // lane r keeps element r
     }
+    if (lane < cnt) A.u[off + base + lane + 1] = mine;  // one coalesced store per chunk
     __syncthreads();
   }
   return acc;
 }
 
 // utils/spline_fit.py:95-128 on the arena polyline [off, off+m).  rc: 0 ok, 1 ValueError, >=200 overflow
-__device__ inline int fit_polyline(PathShared& S, int off, int m, double smoothing, SplineFit& f, double& max_u) {
+__device__ inline int fit_polyline(PathShared& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
+                                   double& max_u) {
   int k = m - 1;
   k = k < 1 ? 1 : (k > 3 ? 3 : k);
-  max_u = build_parameter(S, off, m);
-  f = spline_fit(S.ws, S.au + off, S.ax + off, S.ay + off, m, k, smoothing);
+  max_u = build_parameter(S, A, off, m);
+  f = spline_fit(S.ws, A.u + off, A.x + off, A.y + off, m, k, smoothing);
   return f.status;
 }
 
@@ -238,18 +221,19 @@ __device__ __forceinline__ int arange_len(double stop, double step) {
 
 // calculate_path/path_parameterization.py:297-328 on the arena polyline [off, off+n).
 // rc: 0 ok (out filled), 1 ValueError, ST_* otherwise.
-__device__ inline int parameterize_path(PathShared& S, int off, int n, double (*out)[4], int* n_dense) {
+__device__ inline int parameterize_path(PathShared& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
   const int lane = lane_id();
   if (n < 2) return ST_REF_UNDEFINED_PATH;
-  // _refit_spline :125-161
+  // _refit_spline :125-161 — segment lengths (LDS when they fit, else the arena's parameter array)
+  double* seg = (n - 1 <= SEG_CAP) ? S.ws.seg : (A.u + off);
   for (int i = lane; i < n - 1; i += WAVE) {
-    double dx = S.ax[off + i + 1] - S.ax[off + i], dy = S.ay[off + i + 1] - S.ay[off + i];
-    S.au[off + i] = sqrt(dx * dx + dy * dy);
+    double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
+    seg[i] = sqrt(dx * dx + dy * dy);
   }
   __syncthreads();
-  double path_length = np_sum_run(S.au + off, n - 1);
+  double path_length = np_sum_run(seg, n - 1);
   int n10 = (n - 1) < 10 ? (n - 1) : 10;
-  double mean_pd = np_sum_small(S.au + off, n10) / (double)n10;
+  double mean_pd = np_sum_small(seg, n10) / (double)n10;
   double predict_every = path_length / PATH_POINTS / 3;
   int skip;
   {
@@ -271,26 +255,28 @@ __device__ inline int parameterize_path(PathShared& S, int off, int n, double (*
       int i = base + lane;
       double vx = 0, vy = 0;
       if (i < ns) {
-        vx = S.ax[off + i * skip];
-        vy = S.ay[off + i * skip];
+        vx = A.x[off + i * skip];
+        vy = A.y[off + i * skip];
       }
       __syncthreads();
       if (i < ns) {
-        S.ax[off + i] = vx;
-        S.ay[off + i] = vy;
+        A.x[off + i] = vx;
+        A.y[off + i] = vy;
       }
       __syncthreads();
     }
   }
   SplineFit f;
   double max_u;
-  int rc = fit_polyline(S, off, ns, 0.01, f, max_u);
+  int rc = fit_polyline(S, A, off, ns, 0.01, f, max_u);
   if (rc) return rc;
-  // _calculate_path_curvature :163-193 — dense samples into the arena start
+  // _calculate_path_curvature :163-193 — dense samples into LDS
   int L = arange_len(max_u, predict_every);
   if (L > DENSE_CAP) return ST_OVERFLOW_PATH;
   if (L == 0) return ST_REF_UNDEFINED_PATH;
-  spline_eval(S.ws, f, predict_every, L, S.ax, S.ay, S.au);
+  spline_eval(S.ws, f, predict_every, L, S.dx, S.dy, S.du);
+  double* curv = S.ws.seg;  // the spline chunk buffers are dead from here on
+  double* filt = S.ws.seg + DENSE_CAP;
   int window = (L / 5) < 30 ? (L / 5) : 30;
   if (window % 2 == 0) window += 1;
   const int half = window / 2;
@@ -312,31 +298,32 @@ __device__ inline int parameterize_path(PathShared& S, int off, int n, double (*
       wn = L - lo;
     }
     double cx, cy, r;
-    circle_fit(S.ax, S.ay, w0, wn, cx, cy, r);
+    circle_fit(S.dx, S.dy, w0, wn, cx, cy, r);
     r = py_min(py_max(r, 1.0), 3000.0);
     double c = 1 / r;
     int i1 = wn / 2;
-    double sg = det3_lu(S.ax[w0], S.ay[w0], S.ax[w0 + i1], S.ay[w0 + i1], S.ax[w0 + wn - 1], S.ay[w0 + wn - 1]);
-    S.curv[i] = c * sign_of(sg);
-    if (isnan(sg)) S.curv[i] = sg;
+    double sg = det3_lu(S.dx[w0], S.dy[w0], S.dx[w0 + i1], S.dy[w0 + i1], S.dx[w0 + wn - 1], S.dy[w0 + wn - 1]);
+    double cv = c * sign_of(sg);
+    if (isnan(sg)) cv = sg;
+    curv[i] = cv;
   }
   __syncthreads();
-  // scipy.ndimage.uniform_filter1d(size = max(2, window // 2), mode = "nearest"): running sum, wave-uniform
-  {
+  // scipy.ndimage.uniform_filter1d(size = max(2, window // 2), mode = "nearest"): running sum in index order
+  if (lane == 0) {
     int size = (window / 2) > 2 ? (window / 2) : 2;
     int s1 = size / 2, s2 = size - s1 - 1;
     double tmp = 0.0;
     for (int j = -s1; j <= s2; j++) {
       int q = j < 0 ? 0 : (j > L - 1 ? L - 1 : j);
-      tmp += S.curv[q];
+      tmp += curv[q];
     }
-    if (lane == 0) S.filt[0] = tmp / size;
+    filt[0] = tmp / size;
     for (int i = 1; i < L; i++) {
       int qa = i + s2, qb = i - 1 - s1;
       qa = qa < 0 ? 0 : (qa > L - 1 ? L - 1 : qa);
       qb = qb < 0 ? 0 : (qb > L - 1 ? L - 1 : qb);
-      tmp += S.curv[qa] - S.curv[qb];
-      if (lane == 0) S.filt[i] = tmp / size;
+      tmp += curv[qa] - curv[qb];
+      filt[i] = tmp / size;
     }
   }
   __syncthreads();
@@ -357,10 +344,10 @@ __device__ inline int parameterize_path(PathShared& S, int off, int n, double (*
     }
     if (__ballot(dup) != 0ull) return 1;  // "Indices of resampled path appear twice" (ValueError)
     if (lane < PATH_POINTS) {
-      out[lane][0] = S.au[idx];
-      out[lane][1] = S.ax[idx];
-      out[lane][2] = S.ay[idx];
-      out[lane][3] = S.filt[idx];
+      out[lane][0] = S.du[idx];
+      out[lane][1] = S.dx[idx];
+      out[lane][2] = S.dy[idx];
+      out[lane][3] = filt[idx];
     }
   }
   *n_dense = L;
@@ -368,16 +355,46 @@ __device__ inline int parameterize_path(PathShared& S, int off, int n, double (*
   return 0;
 }
 
+// sequential sum of segment lengths of the arena polyline [off, off+n) with optional early stop:
+// returns the running total; *first_over = index of the first segment whose cumulative length exceeds
+// `limit` (or n-1 if none).  Chunks of 64 segments are staged in LDS; the additions keep np.cumsum's order.
+__device__ inline double cumulative_length(PathShared& S, const Arena& A, int off, int n, double limit, int* first_over) {
+  const int lane = lane_id();
+  double acc = 0.0;
+  int first = n - 1;
+  bool stop = false;
+  for (int base = 0; base < n - 1 && !stop; base += WAVE) {
+    int i = base + lane;
+    if (i < n - 1) {
+      double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
+      S.ws.term[lane] = sqrt(dx * dx + dy * dy);
+    }
+    __syncthreads();
+    int cnt = (n - 1 - base) < WAVE ? (n - 1 - base) : WAVE;
+    for (int r = 0; r < cnt; r++) {
+      acc += S.ws.term[r];
+      if (acc > limit) {
+        first = base + r;
+        stop = true;
+        break;
+      }
+    }
+    __syncthreads();
+  }
+  if (first_over) *first_over = first;
+  return acc;
+}
+
 // core_calculate_path.py:380-417 do_all_mpc_parameter_calculations on the polyline [1, 1+n) of the arena
 // (slot 0 is reserved for the point connect_path_to_car may prepend).  rc as parameterize_path.
-__device__ inline int do_all_mpc(PathShared& S, int n, double px, double py, double dx, double dy, double (*out)[4],
-                                 int* fallback, int* n_dense) {
+__device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px, double py, double dx, double dy,
+                                 double (*out)[4], int* fallback, int* n_dense) {
   const int lane = lane_id();
   if (n <= 0) return ST_REF_UNDEFINED_PATH;
   int off = 1;
   // connect_path_to_car :430-457
   {
-    double fx = S.ax[1], fy = S.ay[1];
+    double fx = A.x[1], fy = A.y[1];
     double d = norm_blas(px - fx, py - fy);
     double cx = fx - px, cy = fy - py;
     double ang = angle_between(cx, cy, dx, dy);
@@ -385,8 +402,8 @@ __device__ inline int do_all_mpc(PathShared& S, int n, double px, double py, dou
       double nrm = norm_blas(cx, cy);
       __syncthreads();
       if (lane == 0) {
-        S.ax[0] = px + (cx / nrm) * 0.2;
-        S.ay[0] = py + (cy / nrm) * 0.2;
+        A.x[0] = px + (cx / nrm) * 0.2;
+        A.y[0] = py + (cy / nrm) * 0.2;
       }
       off = 0;
       n += 1;
@@ -399,7 +416,7 @@ __device__ inline int do_all_mpc(PathShared& S, int n, double px, double py, dou
     int first = n;
     for (int base = 0; base < n; base += WAVE) {
       int i = base + lane;
-      bool fr = i < n && blas_dot2(S.ax[off + i] - px, dx, S.ay[off + i] - py, dy) > 0;
+      bool fr = i < n && blas_dot2(A.x[off + i] - px, dx, A.y[off + i] - py, dy) > 0;
       unsigned long long m = __ballot(fr);
       if (m) {
         first = base + (__ffsll(m) - 1);
@@ -412,28 +429,27 @@ __device__ inline int do_all_mpc(PathShared& S, int n, double px, double py, dou
     if (nin >= 1) {
       if (nin < 2) return ST_REF_UNDEFINED_PATH;  // cumsum([])[-1] -> IndexError
       // path length in front of the car: np.cumsum of the segment lengths (sequential)
-      for (int i = lane; i < nin - 1; i += WAVE) {
-        double ddx = S.ax[off + f0 + i + 1] - S.ax[off + f0 + i], ddy = S.ay[off + f0 + i + 1] - S.ay[off + f0 + i];
-        S.au[i] = sqrt(ddx * ddx + ddy * ddy);
-      }
-      __syncthreads();
-      double plen = 0.0;
-      for (int i = 0; i < nin - 1; i++) plen += S.au[i];
-      __syncthreads();
+      double plen = cumulative_length(S, A, off + f0, nin, INFINITY, nullptr);
       if (!(plen > 20.0)) {
         int nrel = nin < 20 ? nin : 20;
         int r0 = off + n - nrel;
+        // the last <= 20 points through LDS for the circle fit
+        if (lane < nrel) {
+          S.dx[lane] = A.x[r0 + lane];
+          S.dy[lane] = A.y[r0 + lane];
+        }
+        __syncthreads();
         double ccx, ccy, radius;
-        circle_fit(S.ax, S.ay, r0, nrel, ccx, ccy, radius);
+        circle_fit(S.dx, S.dy, 0, nrel, ccx, ccy, radius);
         double r_use = py_min(py_max(radius, 10), 100);
-        const double lastx = S.ax[off + n - 1], lasty = S.ay[off + n - 1];
+        const double lastx = S.dx[nrel - 1], lasty = S.dy[nrel - 1];
         int n_new;
         if (r_use < 80) {
           *fallback |= 16;
           int i1 = nrel / 2;
-          double t0x = S.ax[r0] - ccx, t0y = S.ay[r0] - ccy;
-          double t1x = S.ax[r0 + i1] - ccx, t1y = S.ay[r0 + i1] - ccy;
-          double t2x = S.ax[r0 + nrel - 1] - ccx, t2y = S.ay[r0 + nrel - 1] - ccy;
+          double t0x = S.dx[0] - ccx, t0y = S.dy[0] - ccy;
+          double t1x = S.dx[i1] - ccx, t1y = S.dy[i1] - ccy;
+          double t2x = S.dx[nrel - 1] - ccx, t2y = S.dy[nrel - 1] - ccy;
           double sg = sign_of(det3_lu(t0x, t0y, t1x, t1y, t2x, t2y));
           double start = atan2(t0y, t0x);
           double end = start + sg * FSDP_PI;
@@ -442,26 +458,24 @@ __device__ inline int do_all_mpc(PathShared& S, int n, double px, double py, dou
           double raw0x = cos(start) * r_use, raw0y = sin(start) * r_use;  // i = 0: 0*step + start
           n_new = NP - 1;
           if (off + n + n_new > PATH_CAP) return ST_OVERFLOW_PATH;
-          __syncthreads();
           if (lane >= 1 && lane < NP) {
             double a = (double)lane * step + start;
             if (lane == NP - 1) a = end;
             double rx = cos(a) * r_use, ry = sin(a) * r_use;
-            S.ax[off + n + lane - 1] = rx - raw0x + lastx;
-            S.ay[off + n + lane - 1] = ry - raw0y + lasty;
+            A.x[off + n + lane - 1] = rx - raw0x + lastx;
+            A.y[off + n + lane - 1] = ry - raw0y + lasty;
           }
         } else {
           *fallback |= 32;
-          double ddx = lastx - S.ax[off + n - 2], ddy = lasty - S.ay[off + n - 2];
+          double ddx = lastx - S.dx[nrel - 2], ddy = lasty - S.dy[nrel - 2];
           double nrm = norm_blas(ddx, ddy);
           ddx /= nrm;
           ddy /= nrm;
           n_new = 29;
           if (off + n + n_new > PATH_CAP) return ST_OVERFLOW_PATH;
-          __syncthreads();
           if (lane >= 1 && lane < 30) {
-            S.ax[off + n + lane - 1] = lastx + ddx * (double)lane;
-            S.ay[off + n + lane - 1] = lasty + ddy * (double)lane;
+            A.x[off + n + lane - 1] = lastx + ddx * (double)lane;
+            A.y[off + n + lane - 1] = lasty + ddy * (double)lane;
           }
         }
         n += n_new;
@@ -474,7 +488,7 @@ __device__ inline int do_all_mpc(PathShared& S, int n, double px, double py, dou
     double bv = 0.0;
     int bi = -1;
     for (int i = lane; i < n; i += WAVE) {
-      double d = norm_axis(px - S.ax[off + i], py - S.ay[off + i]);
+      double d = norm_axis(px - A.x[off + i], py - A.y[off + i]);
       if (bi < 0 || d < bv) {
         bv = d;
         bi = i;
@@ -492,31 +506,18 @@ __device__ inline int do_all_mpc(PathShared& S, int n, double px, double py, dou
     SplineFit f;
     if (n >= 2) {
       double max_u;
-      int rc = fit_polyline(S, off, n, 0.2, f, max_u);
+      int rc = fit_polyline(S, A, off, n, 0.2, f, max_u);
       if (rc) return rc;
       n4 = arange_len(20.0 * 1.5, 0.1);
-      spline_eval(S.ws, f, 0.1, n4, S.ax, S.ay, nullptr);
+      spline_eval(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
     }
     int nseg = n4 - 1;
     if (nseg <= 1) return 1;  // previous (40,4) array handed on -> LinAlgError (a ValueError) downstream
-    for (int i = lane; i < nseg; i += WAVE) {
-      double ddx = S.ax[i + 1] - S.ax[i], ddy = S.ay[i + 1] - S.ay[i];
-      S.au[i] = sqrt(ddx * ddx + ddy * ddy);
-    }
-    __syncthreads();
-    double cum = 0.0;
     int first = nseg;
-    for (int i = 0; i < nseg; i++) {
-      cum += S.au[i];
-      if (cum > 20.0) {
-        first = i;
-        break;
-      }
-    }
+    cumulative_length(S, A, 0, n4, 20.0, &first);
     n5 = first;
-    __syncthreads();
   }
-  return parameterize_path(S, 0, n5, out, n_dense);
+  return parameterize_path(S, A, 0, n5, out, n_dense);
 }
 
 // path_calculator_helpers.py:26-68 calculate_almost_straight_path (host side, libm = what NumPy uses)
@@ -535,36 +536,45 @@ inline void default_chord_points(double (*chord)[2]) {
   }
 }
 
+__device__ __forceinline__ Arena frame_arena(double* arena, int frame) {
+  double* b = arena + (size_t)frame * (3 * PATH_CAP);
+  return Arena{b, b + PATH_CAP, b + 2 * PATH_CAP};
+}
+
 // core_calculate_path.py:103-121: previous_paths[0] = parameterize_path(fit(chord).predict())
-__global__ void __launch_bounds__(64) default_path_kernel(const double* __restrict__ chord, double* __restrict__ out) {
+__global__ void __launch_bounds__(64) default_path_kernel(const double* __restrict__ chord, double* __restrict__ arena,
+                                                          double* __restrict__ out) {
   __shared__ PathShared S;
   const int lane = lane_id();
+  const Arena A = frame_arena(arena, 0);
   if (lane < PATH_POINTS) {
-    S.ax[lane] = chord[2 * lane];
-    S.ay[lane] = chord[2 * lane + 1];
+    A.x[lane] = chord[2 * lane];
+    A.y[lane] = chord[2 * lane + 1];
   }
   __syncthreads();
   SplineFit f;
   double max_u;
-  int rc = fit_polyline(S, 0, PATH_POINTS, 0.2, f, max_u);
+  int rc = fit_polyline(S, A, 0, PATH_POINTS, 0.2, f, max_u);
   int n1 = arange_len(max_u, 0.1);
   if (rc == 0 && n1 <= PATH_CAP) {
-    spline_eval(S.ws, f, 0.1, n1, S.ax, S.ay, nullptr);
+    spline_eval(S.ws, f, 0.1, n1, A.x, A.y, nullptr);
     int nd = 0;
     double(*o)[4] = (double(*)[4])out;
-    rc = parameterize_path(S, 0, n1, o, &nd);
+    rc = parameterize_path(S, A, 0, n1, o, &nd);
   }
   if (rc != 0 && lane < PATH_POINTS)
     for (int q = 0; q < 4; q++) out[4 * lane + q] = NAN;
 }
 
-__global__ void __launch_bounds__(64) path_kernel(int n_frames, const double* __restrict__ poses,
+__global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double* __restrict__ poses,
                                                   const MatchOut* __restrict__ matched,
-                                                  const double* __restrict__ default_path, PathOut* __restrict__ out) {
+                                                  const double* __restrict__ default_path, double* __restrict__ arena,
+                                                  PathOut* __restrict__ out) {
   __shared__ PathShared S;
   const int frame = blockIdx.x;
   if (frame >= n_frames) return;
   const int lane = lane_id();
+  const Arena A = frame_arena(arena, frame);
   const MatchOut* mo = &matched[frame];
   PathOut* o = &out[frame];
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
@@ -636,19 +646,19 @@ __global__ void __launch_bounds__(64) path_kernel(int n_frames, const double* __
   if (status == ST_OK) {
     for (int attempt = 0; attempt < 2; attempt++) {
       if (lane < nc) {
-        S.ax[lane] = S.cxp[lane];
-        S.ay[lane] = S.cyp[lane];
+        A.x[lane] = S.cxp[lane];
+        A.y[lane] = S.cyp[lane];
       }
       __syncthreads();
       SplineFit f;
       double max_u;
-      int rc = fit_polyline(S, 0, nc, 0.2, f, max_u);
+      int rc = fit_polyline(S, A, 0, nc, 0.2, f, max_u);
       if (rc == 0) {
         n1 = arange_len(max_u, 0.1);
         if (n1 + 1 + 50 > PATH_CAP) {
           status = ST_OVERFLOW_PATH;
         } else {
-          spline_eval(S.ws, f, 0.1, n1, S.ax + 1, S.ay + 1, nullptr);
+          spline_eval(S.ws, f, 0.1, n1, A.x + 1, A.y + 1, nullptr);
         }
         break;
       }
@@ -675,7 +685,7 @@ __global__ void __launch_bounds__(64) path_kernel(int n_frames, const double* __
     double bv = 0.0;
     int bi = -1;
     for (int i = lane; i < n1; i += WAVE) {
-      double d = norm_axis(px - S.ax[1 + i], py - S.ay[1 + i]);
+      double d = norm_axis(px - A.x[1 + i], py - A.y[1 + i]);
       if (bi < 0 || d < bv) {
         bv = d;
         bi = i;
@@ -686,24 +696,24 @@ __global__ void __launch_bounds__(64) path_kernel(int n_frames, const double* __
       fallback |= 4;
       __syncthreads();
       if (lane < PATH_POINTS) {
-        S.ax[1 + lane] = S.prevx[lane];
-        S.ay[1 + lane] = S.prevy[lane];
+        A.x[1 + lane] = S.prevx[lane];
+        A.y[1 + lane] = S.prevy[lane];
       }
       n1 = PATH_POINTS;
       __syncthreads();
     }
   }
   if (status == ST_OK) {
-    int rc = do_all_mpc(S, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
+    int rc = do_all_mpc(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
     if (rc == 1) {  // ValueError -> redo with the previous path (:564-570)
       fallback |= 8;
       __syncthreads();
       if (lane < PATH_POINTS) {
-        S.ax[1 + lane] = S.prevx[lane];
-        S.ay[1 + lane] = S.prevy[lane];
+        A.x[1 + lane] = S.prevx[lane];
+        A.y[1 + lane] = S.prevy[lane];
       }
       __syncthreads();
-      rc = do_all_mpc(S, PATH_POINTS, px, py, dx, dy, o->path, &fallback, &n_dense);
+      rc = do_all_mpc(S, A, PATH_POINTS, px, py, dx, dy, o->path, &fallback, &n_dense);
       if (rc == 1) rc = ST_REF_UNDEFINED_PATH;
     }
     if (rc != 0) status = rc;

@@ -16,7 +16,7 @@
 
 namespace fsdp {
 
-constexpr int NK = 48;  // max number of knots kept in LDS (FITPACK's nest is m+2k; OVERFLOW_KNOTS beyond)
+constexpr int NK = 32;  // max number of knots kept in LDS (FITPACK's nest is m+2k; OVERFLOW_KNOTS beyond)
 
 struct SplineWS {
   double t[NK + 2];
@@ -27,8 +27,14 @@ struct SplineWS {
   double b[NK + 2][6];
   double g[NK + 2][6];
   int32_t nrdata[NK + 2];
-  double hq[WAVE][4];   // per-chunk basis values
-  double term[WAVE];    // per-chunk residual terms
+  union {
+    struct {
+      double hq[WAVE][4];         // per-chunk basis values
+      double xq[WAVE], yq[WAVE];  // per-chunk data points (the polyline itself lives in HBM/L2)
+      double term[WAVE];          // per-chunk residual terms / segment lengths
+    };
+    double seg[WAVE * 7];         // between fits: segment lengths, later raw | filtered curvature (path stage)
+  };
   int32_t lq[WAVE];     // per-chunk knot interval / "new knot" flags
   double scal[4];       // lane-0 -> wave broadcast of serial-section scalars
 };
@@ -40,12 +46,16 @@ struct SplineFit {
 };
 
 // fpbspl: (k+1) non-zero B-splines at t(l) <= x < t(l+1); h is 1-based [1..k+1]
-__device__ __forceinline__ void fpbspl(const double* t, int k, double x, int l, double* h) {
-  double hh[6];
+template <int K>
+__device__ __forceinline__ void fpbspl(const double* t, double x, int l, double* h) {
+  double hh[K + 2];
   h[1] = 1.0;
-  for (int j = 1; j <= k; j++) {
+#pragma unroll
+  for (int j = 1; j <= K; j++) {
+#pragma unroll
     for (int i = 1; i <= j; i++) hh[i] = h[i];
     h[1] = 0.0;
+#pragma unroll
     for (int i = 1; i <= j; i++) {
       int li = l + i;
       int lj = li - j;
@@ -111,8 +121,9 @@ __device__ inline void fpback(double (*a)[COLS], const double* z, int n, int k, 
 
 // parcur/fppara for idim=2, w=1, iopt=0.  Data in LDS: U (parameter), X, Y, m points (0-based arrays).
 // All lanes call; result (t, c) left in ws; returns wave-uniform SplineFit.
-__device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const double* X, const double* Y, int m, int k,
-                                       double s) {
+template <int K>
+__device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const double* X, const double* Y, int m, double s) {
+  constexpr int k = K;
   const int lane = lane_id();
   SplineFit R;
   R.k = k;
@@ -120,8 +131,8 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
   R.ier = 0;
   R.fp = 0.0;
   R.status = 0;
-  const int k1 = k + 1, k2 = k1 + 1;
-  const int nmin = 2 * k1;
+  constexpr int k1 = K + 1, k2 = K + 2;
+  constexpr int nmin = 2 * k1;
   int nest = m + 2 * k;
   if (nest > NK) nest = NK;
   if (m < k1 || nest < nmin) {
@@ -188,20 +199,25 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
         if (it < m) {
           double ui = U[it];
           int l = find_interval(ws.t, k1, nk1, ui);
-          double h[6];
-          fpbspl(ws.t, k, ui, l, h);
-          for (int q = 0; q < 4; q++) ws.hq[lane][q] = (q < k1) ? h[q + 1] : 0.0;
+          double h[K + 2];
+          fpbspl<K>(ws.t, ui, l, h);
+#pragma unroll
+          for (int q = 0; q < k1; q++) ws.hq[lane][q] = h[q + 1];
           ws.lq[lane] = l;
+          ws.xq[lane] = X[it];
+          ws.yq[lane] = Y[it];
         }
         __syncthreads();
         int cnt = m - base < WAVE ? m - base : WAVE;
         if (lane == 0) {  // serial section: rows enter the triangle in data order (single writer of a / z)
           for (int r = 0; r < cnt; r++) {
-            double h[6];
-            for (int q = 0; q < 4; q++) h[q + 1] = ws.hq[r][q];
+            double h[K + 2];
+#pragma unroll
+            for (int q = 0; q < k1; q++) h[q + 1] = ws.hq[r][q];
             int l = ws.lq[r];
-            double xi1 = X[base + r], xi2 = Y[base + r];
+            double xi1 = ws.xq[r], xi2 = ws.yq[r];
             int j = l - k1;
+#pragma unroll
             for (int i = 1; i <= k1; i++) {
               j++;
               double piv = h[i];
@@ -217,6 +233,7 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
               ws.z[j + n] = z2;
               if (i == k1) break;
               int i2 = 1;
+#pragma unroll
               for (int i1 = i + 1; i1 <= k1; i1++) {
                 i2++;
                 double av = ws.a[j][i2];
@@ -295,13 +312,14 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
               while (lprev <= nk1 && up >= ws.t[lprev]) lprev++;
             }
             int lfit = find_interval(ws.t, k1, nk1, ui);
-            double h[6];
-            fpbspl(ws.t, k, ui, lfit, h);
+            double h[K + 2];
+            fpbspl<K>(ws.t, ui, lfit, h);
             int l0 = l - k2;
             double term = 0.0;
             for (int d = 0; d < 2; d++) {
               double fac = 0.0;
               int j1 = l0 + d * n;
+#pragma unroll
               for (int j = 1; j <= k1; j++) {
                 j1++;
                 fac = fac + ws.c[j1] * h[j];
@@ -394,8 +412,9 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
       double an = nrint2;
       double fac = an / (ws.t[nk1 + 1] - ws.t[k1]);
       for (int l = k2 + lane; l <= nk1; l += WAVE) {
-        double h[13];
+        double h[2 * K + 3];
         int lmk = l - k1;
+#pragma unroll
         for (int j = 1; j <= k1; j++) {
           int ik = j + k1;
           int lj = l + j;
@@ -404,9 +423,11 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
           h[ik] = ws.t[l] - ws.t[lj];
         }
         int lp = lmk;
+#pragma unroll
         for (int j = 1; j <= k2; j++) {
           int jk = j;
           double prod = h[j];
+#pragma unroll
           for (int i = 1; i <= k; i++) {
             jk = jk + 1;
             prod = prod * h[jk] * fac;
@@ -435,7 +456,8 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
       __syncthreads();
       if (lane == 0) {  // serial section (single writer of g / c)
         for (int it = 1; it <= n8; it++) {
-          double h[8];
+          double h[K + 4];
+#pragma unroll
           for (int i = 1; i <= k2; i++) h[i] = ws.b[it][i] * pinv;
           double xi1 = 0., xi2 = 0.;
           for (int j = it; j <= nk1; j++) {
@@ -452,14 +474,19 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
             if (j == nk1) break;
             int i2 = k1;
             if (j > n8) i2 = nk1 - j;
-            for (int i = 1; i <= i2; i++) {
-              int i1 = i + 1;
-              double gv = ws.g[j][i1];
-              fprota(cs, sn, h[i1], gv);
-              ws.g[j][i1] = gv;
-              h[i] = h[i1];
+#pragma unroll
+            for (int i = 1; i <= k1; i++) {
+              if (i <= i2) {
+                int i1 = i + 1;
+                double gv = ws.g[j][i1];
+                fprota(cs, sn, h[i1], gv);
+                ws.g[j][i1] = gv;
+                h[i] = h[i1];
+              }
             }
-            h[i2 + 1] = 0.;
+#pragma unroll
+            for (int i = 1; i <= k2; i++)
+              if (i == i2 + 1) h[i] = 0.;
           }
         }
         fpback<6>(ws.g, &ws.c[0], nk1, k2, &ws.c[0]);
@@ -475,13 +502,14 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
           int l = k2;
           while (l <= nk1 && ui >= ws.t[l]) l++;
           int lfit = find_interval(ws.t, k1, nk1, ui);
-          double h[6];
-          fpbspl(ws.t, k, ui, lfit, h);
+          double h[K + 2];
+          fpbspl<K>(ws.t, ui, lfit, h);
           int l0 = l - k2;
           double term = 0.;
           for (int d = 0; d < 2; d++) {
             double fac = 0.;
             int j1 = l0 + d * n;
+#pragma unroll
             for (int j = 1; j <= k1; j++) {
               j1++;
               fac = fac + ws.c[j1] * h[j];
@@ -561,20 +589,30 @@ __device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const doub
   return R;
 }
 
+__device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const double* X, const double* Y, int m, int k,
+                                       double s) {
+  if (k == 3) return spline_fit_k<3>(ws, U, X, Y, m, s);
+  if (k == 2) return spline_fit_k<2>(ws, U, X, Y, m, s);
+  return spline_fit_k<1>(ws, U, X, Y, m, s);
+}
+
 // splev (der = 0, ext = 0) at arg = i * step for i in [0, count): one evaluation point per lane.
 // Outputs to OX/OY (LDS or global), optional parameter values to OU.
-__device__ inline void spline_eval(const SplineWS& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
-                                   double* OU) {
+template <int K>
+__device__ inline void spline_eval_k(const SplineWS& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+                                     double* OU) {
   const int lane = lane_id();
-  const int k = f.k, n = f.n;
-  const int k1 = k + 1, nk1 = n - k1;
+  const int n = f.n;
+  constexpr int k1 = K + 1;
+  const int nk1 = n - k1;
   for (int i = lane; i < count; i += WAVE) {
     double arg = (double)i * step;
     int l = find_interval(ws.t, k1, nk1, arg);
-    double h[6];
-    fpbspl(ws.t, k, arg, l, h);
+    double h[K + 2];
+    fpbspl<K>(ws.t, arg, l, h);
     double sx = 0., sy = 0.;
     int ll = l - k1;
+#pragma unroll
     for (int j = 1; j <= k1; j++) {
       ll++;
       sx = sx + ws.c[ll] * h[j];
@@ -585,6 +623,16 @@ __device__ inline void spline_eval(const SplineWS& ws, const SplineFit& f, doubl
     if (OU) OU[i] = arg;
   }
   __syncthreads();
+}
+
+__device__ inline void spline_eval(const SplineWS& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+                                   double* OU) {
+  if (f.k == 3)
+    spline_eval_k<3>(ws, f, step, count, OX, OY, OU);
+  else if (f.k == 2)
+    spline_eval_k<2>(ws, f, step, count, OX, OY, OU);
+  else
+    spline_eval_k<1>(ws, f, step, count, OX, OY, OU);
 }
 
 }  // namespace fsdp

@@ -7,28 +7,31 @@
 #include "../../ft-fsd-path-planning_amd/csrc/path_kernel.h"
 
 #include <mutex>
+#include <vector>
 
 static double g_default_path[fsdp::PATH_POINTS * 4];
 static std::once_flag g_once;
 static void build_default() {
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
-  emu::launch(1, 64, [&]() { fsdp::default_path_kernel(&chord[0][0], g_default_path); });
+  std::vector<double> arena(3 * fsdp::PATH_CAP);
+  emu::launch(1, 64, [&]() { fsdp::default_path_kernel(&chord[0][0], arena.data(), g_default_path); });
 }
 
 namespace fsdp {
 // test kernel: fit one polyline (m <= PATH_CAP) and dump knots / coefficients
-__global__ void fit_test_kernel(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
+__global__ void fit_test_kernel(const double* xy, int m, double smoothing, double* arena, double* t_out, double* c_out, int* info, double* fp_out) {
   __shared__ PathShared S;
   const int lane = lane_id();
+  const Arena A = frame_arena(arena, 0);
   for (int i = lane; i < m; i += WAVE) {
-    S.ax[i] = xy[2 * i];
-    S.ay[i] = xy[2 * i + 1];
+    A.x[i] = xy[2 * i];
+    A.y[i] = xy[2 * i + 1];
   }
   __syncthreads();
   SplineFit f;
   double max_u;
-  int rc = fit_polyline(S, 0, m, smoothing, f, max_u);
+  int rc = fit_polyline(S, A, 0, m, smoothing, f, max_u);
   if (lane == 0) {
     info[0] = rc;
     info[1] = f.n;
@@ -47,7 +50,8 @@ __global__ void fit_test_kernel(const double* xy, int m, double smoothing, doubl
 
 extern "C" {
 void emu_fit(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
-  emu::launch(1, 64, [&]() { fsdp::fit_test_kernel(xy, m, smoothing, t_out, c_out, info, fp_out); });
+  std::vector<double> arena(3 * fsdp::PATH_CAP);
+  emu::launch(1, 64, [&]() { fsdp::fit_test_kernel(xy, m, smoothing, arena.data(), t_out, c_out, info, fp_out); });
 }
 int emu_sizeof_sort_out() { return (int)sizeof(fsdp::SortOut); }
 int emu_sizeof_match_out() { return (int)sizeof(fsdp::MatchOut); }
@@ -66,6 +70,7 @@ void emu_default_path(double* out) {
 }
 void emu_path(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
   std::call_once(g_once, build_default);
-  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, out); });
+  std::vector<double> arena((size_t)3 * fsdp::PATH_CAP * n_frames);
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, arena.data(), out); });
 }
 }
