@@ -75,60 +75,30 @@ def main():
     ap.add_argument("--latency", action="store_true", help="also measure p50 single-frame latency (batch = 1)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
-
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl")
-        dist = dist_mod
+    d = pkg.dist.Dist()  # nccl (= RCCL over xGMI) when WORLD_SIZE > 1
+    rank, local_rank, world = d.rank, d.local_rank, d.world
 
     ctx = pkg.Context(device=local_rank, mission=int(pkg.MissionTypes.trackdrive))
 
-    if dist is not None:
-        import torch
-
-        # the only collective on this path: rank 0 broadcasts the constant previous-path table (RCCL over xGMI);
-        # every rank checks it against the table its own GPU computed at context creation.
-        mine = torch.from_numpy(ctx.default_path()).cuda()
-        ref = mine.clone()
-        dist.broadcast(ref, src=0)
-        assert torch.equal(ref, mine), "previous-path table differs across ranks"
+    # the only collective on this path: rank 0 broadcasts the constant previous-path table (RCCL over xGMI);
+    # every rank checks it against the table its own GPU computed at context creation.
+    assert d.broadcast_check_table(ctx.default_path()), "previous-path table differs across ranks"
 
     # this rank's shard: an independent 4096-frame replay (different track per rank)
-    off, cones, poses = pkg.synth.make_replay_batch(FRAMES_PER_GPU, CONES_PER_SIDE, 0.15, seed=1 + rank, color=True)
+    off, cones, poses = pkg.synth.make_replay_batch(FRAMES_PER_GPU, CONES_PER_SIDE, 0.15, seed=d.shard_seed(1), color=True)
     ctx.upload(off, cones, poses)
-
-    def barrier():
-        if dist is not None:
-            import torch
-
-            torch.cuda.synchronize()
-            dist.barrier()
 
     for _ in range(args.warmup):
         ctx.run()
     ctx.sync()
-    barrier()
+    d.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.run()
     ctx.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    d.barrier()
+    elapsed = d.max_over_ranks(time.perf_counter() - t0)
 
     # per-kernel durations with HIP events on the library's own stream (roofline of the dominant kernel)
     ev_total_ms, ev_stage_ms = ctx.time_runs(max(3, min(args.steps, 10)))
@@ -187,8 +157,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(off, cones, poses)
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    d.close()
 
 
 if __name__ == "__main__":

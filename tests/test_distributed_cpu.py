@@ -1,0 +1,57 @@
+"""The N > 1 plumbing (ft-fsd-path-planning_amd/dist.py, used by bench.py) on CPU: two gloo processes.
+Checks sharding, the previous-path-table broadcast check, barrier and max/sum reductions."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, table, tamper, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    d = pkg.dist.Dist(backend="gloo")
+    mine = table.copy()
+    if tamper and rank == 1:
+        mine[3, 2] += 1e-12
+    same = d.broadcast_check_table(mine)
+    lo, hi = d.frame_range(10)
+    d.barrier()
+    mx = d.max_over_ranks(float(rank + 1))
+    sm = d.sum_over_ranks(float(hi - lo))
+    # each rank plans its own shard: different seeds -> different synthetic tracks, same shapes
+    off, cones, poses = pkg.synth.make_replay_batch(8, 16, 0.1, seed=d.shard_seed(5))
+    q.put((rank, same, (lo, hi), mx, sm, float(cones[:, :2].sum()), cones.shape))
+    d.close()
+
+
+@pytest.mark.parametrize("tamper", [False, True])
+def test_two_rank_gloo(golden_dir, tamper):
+    table = np.load(golden_dir / "default_path.npz")["path"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, table, tamper, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, same0, fr0, mx0, sm0, cs0, sh0), (r1, same1, fr1, mx1, sm1, cs1, sh1) = res
+    assert same0 == same1 == (not tamper)
+    assert fr0 == (0, 5) and fr1 == (5, 10)
+    assert mx0 == mx1 == 2.0 and sm0 == sm1 == 10.0
+    assert sh0 == sh1 and cs0 != cs1
