@@ -18,6 +18,7 @@
 #pragma once
 #include "fsdp_device.h"
 #include "spline_device.h"
+#include "det_math.h"
 
 namespace fsdp {
 
@@ -451,17 +452,22 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
           double t1x = S.dx[i1] - ccx, t1y = S.dy[i1] - ccy;
           double t2x = S.dx[nrel - 1] - ccx, t2y = S.dy[nrel - 1] - ccy;
           double sg = sign_of(det3_lu(t0x, t0y, t1x, t1y, t2x, t2y));
-          double start = atan2(t0y, t0x);
+          // the only libm values that enter the float chain: deterministic correctly-rounded versions (det_math.h)
+          double start = detm::det_atan2(t0y, t0x);
           double end = start + sg * FSDP_PI;
           const int NP = 50;
           double step = (end - start) / (double)(NP - 1);
-          double raw0x = cos(start) * r_use, raw0y = sin(start) * r_use;  // i = 0: 0*step + start
+          double s0, c0;
+          detm::det_sincos(start, s0, c0);
+          double raw0x = c0 * r_use, raw0y = s0 * r_use;  // i = 0: 0*step + start
           n_new = NP - 1;
           if (off + n + n_new > PATH_CAP) return ST_OVERFLOW_PATH;
           if (lane >= 1 && lane < NP) {
             double a = (double)lane * step + start;
             if (lane == NP - 1) a = end;
-            double rx = cos(a) * r_use, ry = sin(a) * r_use;
+            double sa, ca;
+            detm::det_sincos(a, sa, ca);
+            double rx = ca * r_use, ry = sa * r_use;
             A.x[off + n + lane - 1] = rx - raw0x + lastx;
             A.y[off + n + lane - 1] = ry - raw0y + lasty;
           }

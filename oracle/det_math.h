@@ -1,0 +1,187 @@
+// TEST INFRASTRUCTURE (oracle) copy of ft-fsd-path-planning_amd/csrc/det_math.h — deterministic, (practically) correctly rounded sin / cos / atan2 built only from IEEE-754
+// binary64 + - * / and fma.  Purpose: the circular-arc extension of the path stage
+// (reference calculate_path/core_calculate_path.py:316-321) is the one place where libm values enter the
+// float chain that decides the output sample count; device libm, glibc and NumPy's SIMD atan2 differ
+// in the last bit for a few % of arguments.  These routines give the SAME bits on the GPU and on the
+// host, and equal the correctly rounded result except with probability ~1e-14 per call (double-double
+// evaluation, ~1e-30 relative error) — so they agree with glibc wherever glibc is correctly rounded
+// (99.85 % of arguments, measured).
+//
+// The same text is kept in oracle/det_math.h (test infrastructure; tests/test_det_math.py checks the two
+// copies are identical and checks the results against mpmath).
+#pragma once
+#include <math.h>
+
+#ifndef DETM_FN
+#if defined(__HIPCC__) && !defined(FSDP_EMU)
+#define DETM_FN __host__ __device__ inline
+#else
+#define DETM_FN inline
+#endif
+#endif
+
+namespace detm {
+
+struct dd {
+  double hi, lo;
+};
+
+DETM_FN dd two_sum(double a, double b) {
+  double s = a + b;
+  double bb = s - a;
+  double e = (a - (s - bb)) + (b - bb);
+  return dd{s, e};
+}
+DETM_FN dd quick_two_sum(double a, double b) {  // |a| >= |b|
+  double s = a + b;
+  double e = b - (s - a);
+  return dd{s, e};
+}
+DETM_FN dd two_prod(double a, double b) {
+  double p = a * b;
+  double e = fma(a, b, -p);
+  return dd{p, e};
+}
+DETM_FN dd dd_add(dd a, dd b) {
+  dd s = two_sum(a.hi, b.hi);
+  dd t = two_sum(a.lo, b.lo);
+  s.lo += t.hi;
+  s = quick_two_sum(s.hi, s.lo);
+  s.lo += t.lo;
+  return quick_two_sum(s.hi, s.lo);
+}
+DETM_FN dd dd_add_d(dd a, double b) {
+  dd s = two_sum(a.hi, b);
+  s.lo += a.lo;
+  return quick_two_sum(s.hi, s.lo);
+}
+DETM_FN dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
+DETM_FN dd dd_mul(dd a, dd b) {
+  dd p = two_prod(a.hi, b.hi);
+  p.lo = fma(a.hi, b.lo, p.lo);
+  p.lo = fma(a.lo, b.hi, p.lo);
+  return quick_two_sum(p.hi, p.lo);
+}
+DETM_FN dd dd_mul_d(dd a, double b) {
+  dd p = two_prod(a.hi, b);
+  p.lo = fma(a.lo, b, p.lo);
+  return quick_two_sum(p.hi, p.lo);
+}
+DETM_FN dd dd_div(dd a, dd b) {
+  double q1 = a.hi / b.hi;
+  dd r = dd_add(a, dd_neg(dd_mul_d(b, q1)));
+  double q2 = r.hi / b.hi;
+  r = dd_add(r, dd_neg(dd_mul_d(b, q2)));
+  double q3 = r.hi / b.hi;
+  dd q = quick_two_sum(q1, q2);
+  return dd_add_d(q, q3);
+}
+
+// sin and cos of a double-double argument |r| <= ~0.8 (Taylor series in double-double)
+DETM_FN void sincos_kernel(dd r, dd& s, dd& c) {
+  // 1/n! as double-double, n = 2 .. 29
+  const double FH[30] = {0, 0, 0x1.0000000000000p-1, 0x1.5555555555555p-3, 0x1.5555555555555p-5, 0x1.1111111111111p-7,
+                         0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-16, 0x1.71de3a556c734p-19,
+                         0x1.27e4fb7789f5cp-22, 0x1.ae64567f544e4p-26, 0x1.1eed8eff8d898p-29, 0x1.6124613a86d09p-33,
+                         0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-41, 0x1.ae7f3e733b81fp-45, 0x1.952c77030ad4ap-49,
+                         0x1.6827863b97d97p-53, 0x1.2f49b46814157p-57, 0x1.e542ba4020225p-62, 0x1.71b8ef6dcf572p-66,
+                         0x1.0ce396db7f853p-70, 0x1.761b41316381ap-75, 0x1.f2cf01972f578p-80, 0x1.3f3ccdd165fa9p-84,
+                         0x1.88e85fc6a4e5ap-89, 0x1.d1ab1c2dccea3p-94, 0x1.0a18a2635085dp-98, 0x1.259f98b4358adp-103};
+  const double FL[30] = {0, 0, 0x0.0p+0, 0x1.5555555555555p-57, 0x1.5555555555555p-59, 0x1.1111111111111p-63,
+                         -0x1.f49f49f49f49fp-65, 0x1.a01a01a01a01ap-73, 0x1.a01a01a01a01ap-76, -0x1.c154f8ddc6c00p-73,
+                         0x1.cbbc05b4fa99ap-76, -0x1.c062e06d1f209p-80, -0x1.2aec959e14c06p-83, 0x1.f28e0cc748ebep-87,
+                         0x1.05d6f8a2efd1fp-92, 0x1.1d8656b0ee8cbp-97, 0x1.1d8656b0ee8cbp-101, 0x1.ac981465ddc6cp-103,
+                         0x1.eec01221a8b0bp-107, 0x1.2650f61dbdcb4p-112, 0x1.ea72b4afe3c2fp-120, -0x1.d043ae40c4647p-120,
+                         -0x1.aebcdbd20331cp-124, -0x1.3423c7d91404fp-130, -0x1.9ada5fcc1ab14p-135, -0x1.58ddadf344487p-139,
+                         -0x1.71c37ebd16540p-143, 0x1.054d0c78aea14p-149, 0x1.b9e2e28e1aa54p-153, 0x1.eaf8c39dd9bc5p-157};
+  dd r2 = dd_mul(r, r);
+  // sin r = r * (1 - r2/3! + r2^2/5! - ... ), Horner from n = 29
+  dd ps = dd{FH[29], FL[29]};
+  for (int n = 27; n >= 3; n -= 2) {
+    ps = dd_mul(ps, r2);
+    ps = dd_add(dd{FH[n], FL[n]}, dd_neg(ps));
+  }
+  // now ps = 1/3! - r2/5! + ...
+  ps = dd_mul(ps, r2);
+  ps = dd_add(dd{1.0, 0.0}, dd_neg(ps));
+  s = dd_mul(ps, r);
+  // cos r = 1 - r2/2! + r2^2/4! - ..., Horner from n = 28
+  dd pc = dd{FH[28], FL[28]};
+  for (int n = 26; n >= 2; n -= 2) {
+    pc = dd_mul(pc, r2);
+    pc = dd_add(dd{FH[n], FL[n]}, dd_neg(pc));
+  }
+  pc = dd_mul(pc, r2);
+  c = dd_add(dd{1.0, 0.0}, dd_neg(pc));
+}
+
+// double-double sin/cos of a double-double angle (|x| < ~1e3)
+DETM_FN void sincos_dd(dd x, dd& s, dd& c) {
+  const double PIO2_1 = 0x1.921fb54442d18p+0, PIO2_2 = 0x1.1a62633145c07p-54, PIO2_3 = -0x1.f1976b7ed8fbcp-110;
+  const double TWO_OVER_PI = 0x1.45f306dc9c883p-1;
+  double k = nearbyint(x.hi * TWO_OVER_PI);
+  // r = x - k*pi/2 in double-double (three-term pi/2)
+  dd r = dd_add(x, dd_neg(two_prod(k, PIO2_1)));
+  r = dd_add(r, dd_neg(two_prod(k, PIO2_2)));
+  r = dd_add_d(r, -(k * PIO2_3));
+  dd sr, cr;
+  sincos_kernel(r, sr, cr);
+  long long q = (long long)k;
+  int m = (int)(((q % 4) + 4) % 4);
+  if (m == 0) {
+    s = sr;
+    c = cr;
+  } else if (m == 1) {
+    s = cr;
+    c = dd_neg(sr);
+  } else if (m == 2) {
+    s = dd_neg(sr);
+    c = dd_neg(cr);
+  } else {
+    s = dd_neg(cr);
+    c = sr;
+  }
+}
+
+DETM_FN void det_sincos(double x, double& sn, double& cs) {
+  dd s, c;
+  sincos_dd(dd{x, 0.0}, s, c);
+  sn = s.hi + s.lo;
+  cs = c.hi + c.lo;
+}
+DETM_FN double det_sin(double x) {
+  dd s, c;
+  sincos_dd(dd{x, 0.0}, s, c);
+  return s.hi + s.lo;
+}
+DETM_FN double det_cos(double x) {
+  dd s, c;
+  sincos_dd(dd{x, 0.0}, s, c);
+  return c.hi + c.lo;
+}
+
+// atan2 for finite arguments (not both zero): crude polynomial start, two Newton steps on
+// f(a) = x sin a - y cos a in double-double (a <- a - f(a) / (x cos a + y sin a)).
+DETM_FN double det_atan2(double y, double x) {
+  if (x == 0.0 && y == 0.0) return 0.0;
+  const double PI_HI = 0x1.921fb54442d18p+1;
+  double ax = fabs(x), ay = fabs(y);
+  double mn = ax < ay ? ax : ay, mx = ax < ay ? ay : ax;
+  double t = mn / mx;
+  double t2 = t * t;
+  double a0 = t * (0.99535435 + t2 * (-0.28867900 + t2 * 0.07933100));  // |err| < 1e-3
+  if (ay > ax) a0 = PI_HI * 0.5 - a0;
+  if (x < 0) a0 = PI_HI - a0;
+  if (y < 0) a0 = -a0;
+  dd a = dd{a0, 0.0};
+  for (int it = 0; it < 3; it++) {
+    dd s, c;
+    sincos_dd(a, s, c);
+    dd f = dd_add(dd_mul_d(s, x), dd_neg(dd_mul_d(c, y)));
+    dd g = dd_add(dd_mul_d(c, x), dd_mul_d(s, y));
+    a = dd_add(a, dd_neg(dd_div(f, g)));
+  }
+  return a.hi + a.lo;
+}
+
+}  // namespace detm

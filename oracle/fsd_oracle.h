@@ -69,6 +69,10 @@ void fsdo_default_path(double* out40x4);
 int fsdo_side_configs(const double* cones_xyt, int n, const double* pose, int cone_type, int32_t* configs_out,
                       double* costs_out, int max_configs, int32_t* first_k_out /*2*/);
 
+// math mode for the arc extension: 0 = libm (default; reference pinning), 1 = det_math.h (exact parity with the HIP kernels)
+void fsdo_set_math_mode(int mode);
+int fsdo_get_math_mode(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,9 @@
 #include "oracle_internal.h"
 
 using namespace fsdo;
+namespace fsdo {
+extern int g_math_mode;
+}
 
 static Frame make_frame(const double* xyt, int n, const double* pose) {
   Frame f;
@@ -185,4 +188,7 @@ int fsdo_side_configs(const double* xyt, int n, const double* pose, int cone_typ
 }
 
 int fsdo_result_size(void) { return (int)sizeof(fsdo_frame_result); }
+
+void fsdo_set_math_mode(int mode) { fsdo::g_math_mode = mode; }
+int fsdo_get_math_mode(void) { return fsdo::g_math_mode; }
 }

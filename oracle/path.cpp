@@ -11,8 +11,16 @@
 #include <cstdlib>
 
 #include "oracle_internal.h"
+#include "det_math.h"
 
 namespace fsdo {
+
+// 0: libm (what NumPy calls; pins the oracle to the reference's golden vectors)
+// 1: deterministic correctly-rounded sin/cos/atan2 (det_math.h) — what the HIP kernels use, for exact GPU parity
+int g_math_mode = 0;
+static inline double m_atan2(double y, double x) { return g_math_mode ? detm::det_atan2(y, x) : std::atan2(y, x); }
+static inline double m_cos(double a) { return g_math_mode ? detm::det_cos(a) : std::cos(a); }
+static inline double m_sin(double a) { return g_math_mode ? detm::det_sin(a) : std::sin(a); }
 
 static const double SMOOTHING = 0.2, PREDICT_EVERY = 0.1;  // config.py:48
 static const int MAX_DEG = 3;
@@ -273,7 +281,7 @@ static Pts extend_path(const Pts& path, Vec2 pos, Vec2 dir, int* flags) {
     Vec2 t0{rel[i0].x - cx, rel[i0].y - cy}, t1{rel[i1].x - cx, rel[i1].y - cy}, t2{rel[i2].x - cx, rel[i2].y - cy};
     double hm[3][3] = {{1.0, t0.x, t0.y}, {1.0, t1.x, t1.y}, {1.0, t2.x, t2.y}};
     double sg = np_sign(det3_lu(hm));
-    double start = std::atan2(t0.y, t0.x);
+    double start = m_atan2(t0.y, t0.x);
     double end = start + sg * PI;
     // np.linspace(start, end) -> 50 points
     const int NP = 50;
@@ -282,7 +290,7 @@ static Pts extend_path(const Pts& path, Vec2 pos, Vec2 dir, int* flags) {
     for (int i = 0; i < NP; i++) {
       double a = (double)i * step + start;
       if (i == NP - 1) a = end;
-      raw[i] = Vec2{std::cos(a) * r_use, std::sin(a) * r_use};
+      raw[i] = Vec2{m_cos(a) * r_use, m_sin(a) * r_use};
     }
     Vec2 last = path[n - 1];
     for (int i = 0; i < NP; i++) newp.push_back(Vec2{raw[i].x - raw[0].x + last.x, raw[i].y - raw[0].y + last.y});

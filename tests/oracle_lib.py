@@ -89,6 +89,23 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def set_math_mode(mode: int) -> None:
+    """0 = libm (reference pinning, default); 1 = deterministic sin/cos/atan2 (exact parity with the HIP kernels)."""
+    lib().fsdo_set_math_mode(ctypes.c_int(mode))
+
+
+class math_mode:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = lib().fsdo_get_math_mode()
+        set_math_mode(self.mode)
+
+    def __exit__(self, *a):
+        set_math_mode(self.prev)
+
+
 def _p(a, t=ctypes.c_double):
     return a.ctypes.data_as(ctypes.POINTER(t))
 

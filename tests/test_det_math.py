@@ -1,0 +1,64 @@
+"""det_math.h: the deterministic sin/cos/atan2 used by the arc extension.  The product copy
+(ft-fsd-path-planning_amd/csrc/det_math.h) and the oracle copy (oracle/det_math.h) must be the same text;
+results are checked for correct rounding against mpmath (when present) and against glibc."""
+import ctypes
+import math
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _body(p):
+    lines = p.read_text().splitlines()
+    return "\n".join(lines[1:])  # first line is the per-copy banner
+
+
+def test_two_copies_identical():
+    assert _body(ROOT / "oracle" / "det_math.h") == _body(ROOT / "ft-fsd-path-planning_amd" / "csrc" / "det_math.h")
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("detm")
+    src = d / "t.cpp"
+    src.write_text(
+        f'#include "{ROOT / "ft-fsd-path-planning_amd" / "csrc" / "det_math.h"}"\n'
+        'extern "C" { double t_sin(double x){return detm::det_sin(x);} double t_cos(double x){return detm::det_cos(x);}'
+        " double t_atan2(double y,double x){return detm::det_atan2(y,x);} }\n"
+    )
+    so = d / "libdetm.so"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", str(src), "-o", str(so)], check=True)
+    L = ctypes.CDLL(str(so))
+    for f in (L.t_sin, L.t_cos):
+        f.restype = ctypes.c_double
+        f.argtypes = [ctypes.c_double]
+    L.t_atan2.restype = ctypes.c_double
+    L.t_atan2.argtypes = [ctypes.c_double, ctypes.c_double]
+    return L
+
+
+def test_agrees_with_glibc_almost_everywhere(lib):
+    rng = np.random.default_rng(0)
+    xs = rng.uniform(-7, 7, 20000)
+    diff = sum(lib.t_sin(x) != math.sin(x) for x in xs) + sum(lib.t_cos(x) != math.cos(x) for x in xs)
+    assert diff < 0.005 * 2 * len(xs)  # glibc is not correctly rounded in ~0.15 % of arguments
+    worst = max(abs(lib.t_sin(x) - math.sin(x)) for x in xs)
+    assert worst < 3e-16
+    ys, x2 = rng.uniform(-60, 60, 5000), rng.uniform(-60, 60, 5000)
+    assert sum(lib.t_atan2(a, b) != math.atan2(a, b) for a, b in zip(ys, x2)) < 25
+    assert lib.t_atan2(0.0, 1.0) == 0.0 and lib.t_atan2(1.0, 0.0) == math.pi / 2 and lib.t_atan2(0.0, -1.0) == math.pi
+
+
+def test_correctly_rounded_against_mpmath(lib):
+    mpmath = pytest.importorskip("mpmath")
+    mpmath.mp.prec = 300
+    rng = np.random.default_rng(1)
+    for x in np.concatenate([rng.uniform(-7, 7, 3000), rng.uniform(-1e-3, 1e-3, 300), [0.0, math.pi, -math.pi / 2]]):
+        assert lib.t_sin(x) == float(mpmath.sin(mpmath.mpf(float(x))))
+        assert lib.t_cos(x) == float(mpmath.cos(mpmath.mpf(float(x))))
+    for a, b in zip(rng.uniform(-60, 60, 3000), rng.uniform(-60, 60, 3000)):
+        assert lib.t_atan2(a, b) == float(mpmath.atan2(mpmath.mpf(float(a)), mpmath.mpf(float(b))))

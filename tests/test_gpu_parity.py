@@ -55,18 +55,21 @@ def test_hip_matches_reference_golden(ctx, golden_dir, name):
         if cat in ("IDX", "MATCH", "PATH", "STATUS"):
             bad.append((k, cat, detail))
     assert not bad, bad[:5]
-    assert cats["flip"] <= max(1, int(0.60 * n_arc)), (cats, n_arc)
+    assert cats["flip"] <= max(1, int(0.10 * n_arc)), (cats, n_arc)
 
 
 @pytest.mark.parametrize("name", SETS)
 def test_hip_matches_oracle_on_golden_inputs(ctx, golden_dir, name):
     g = np.load(golden_dir / f"{name}.npz")
     res = ctx.plan_batch(g["offsets"], g["cones"], g["poses"])
-    ref = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=os.cpu_count() or 1)
+    with oracle_lib.math_mode(1):
+        ref = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=os.cpu_count() or 1)
     _assert_equal_to_oracle(res, ref)
 
 
-def _assert_equal_to_oracle(res, ref, allow_arc_flips=True):
+def _assert_equal_to_oracle(res, ref):
+    """Against the oracle in det-math mode (the kernels use det_math.h for the arc extension): every
+    discrete output equal, and the path bit-identical — the float chain holds no libm value."""
     assert np.array_equal(res["status"], ref["status"])
     ok = ref["status"] == 0
     for f in ("n_left", "n_right", "left_idx", "right_idx", "n_left_v", "n_right_v", "l2r", "r2l"):
@@ -75,15 +78,7 @@ def _assert_equal_to_oracle(res, ref, allow_arc_flips=True):
     assert np.array_equal(res["right_v"][ok], ref["right_v"][ok])
     assert np.array_equal(res["path_fallback"][ok], ref["path_fallback"][ok])
     err = np.abs(res["path"][ok] - ref["path"][ok]).reshape(ok.sum(), -1).max(axis=1) if ok.any() else np.zeros(0)
-    arc = (ref["path_fallback"][ok] & parity.ARC_FLAG) != 0
-    # outside the arc branch the float chain has no libm call: expect exact agreement (tolerance 1e-9);
-    # inside it device sin/cos/atan2 may differ from glibc in the last bit -> sample-count flip possible
-    assert (err[~arc] <= 1e-9).all(), float(err[~arc].max())
-    if allow_arc_flips:
-        n_bad = int((err[arc] > 1e-5).sum())
-        assert n_bad <= max(1, int(0.60 * arc.sum())), (n_bad, int(arc.sum()))
-    else:
-        assert (err <= 1e-5).all()
+    assert (err <= 1e-9).all(), (float(err.max()), int((err > 1e-9).sum()))
 
 
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
@@ -97,7 +92,8 @@ def test_full_size_batches_against_oracle(pkg, ctx, cfg):
     else:
         off, cones, poses = pkg.synth.make_replay_batch(2048, 100, 0.0, seed=7, frame_noise=0.1, random_pose=True)
     res = ctx.plan_batch(off, cones, poses)
-    ref = oracle_lib.plan_batch(off, cones, poses, n_threads=os.cpu_count() or 1)
+    with oracle_lib.math_mode(1):
+        ref = oracle_lib.plan_batch(off, cones, poses, n_threads=os.cpu_count() or 1)
     _assert_equal_to_oracle(res, ref)
     assert (res["status"] == 0).mean() > 0.95
 

@@ -11,10 +11,13 @@ import parity
 SETS = ["scenarios", "cfg2_color", "cfg3_nocolor", "cfg4_200cones", "cfg4_noisy_nocolor", "fuzz"]
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["libm", "detmath"])
 @pytest.mark.parametrize("name", SETS)
-def test_oracle_matches_reference_golden(golden_dir, name):
+def test_oracle_matches_reference_golden(golden_dir, name, mode):
+    """mode 0: libm sin/cos/atan2 (what NumPy calls); mode 1: det_math.h (what the HIP kernels use)."""
     g = np.load(golden_dir / f"{name}.npz")
-    res = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=4)
+    with oracle_lib.math_mode(mode):
+        res = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=4)
     cats = collections.Counter()
     bad = []
     n_arc = 0
