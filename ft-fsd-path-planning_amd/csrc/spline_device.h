@@ -119,6 +119,131 @@ __device__ inline void fpback(double (*a)[COLS], const double* z, int n, int k, 
   }
 }
 
+// ---- 4-stage systolic Givens pipeline (degree 3) ------------------------------------------------------
+// A data row touches the 4 consecutive band rows l-3..l, one rotation each, in that order; consecutive data
+// rows touch (almost always) the same band rows.  Lane p of the first quad owns band row j with j mod 4 = p and
+// keeps it in registers; a data row travels lane -> lane (quad rotate, DPP) one stage per step, so up to 4
+// data rows are in flight.  Every band row still sees the data rows in data order and every data row still
+// visits its band rows in order: the arithmetic (fpgivs / fprota) and its sequence per element are exactly
+// FITPACK's, only independent rotations overlap in time.
+struct GivItem {
+  double piv, r0, r1, r2, x1, x2;
+  int j;      // band row this stage rotates against
+  int info;   // stage (1..4, 0 = empty) | data-row slot << 8
+};
+
+__device__ __forceinline__ GivItem quad_rot_prev(const GivItem& v) {
+#ifdef FSDP_EMU
+  int l = lane_id();
+  return emu::exchange_struct(v, (l & ~3) | ((l + 3) & 3));
+#else
+  GivItem o;
+  auto rot = [](double d) {
+    int lo = __double2loint(d), hi = __double2hiint(d);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x93, 0xf, 0xf, true);  // quad_perm:[3,0,1,2] -> lane p reads lane p-1
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x93, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  o.piv = rot(v.piv);
+  o.r0 = rot(v.r0);
+  o.r1 = rot(v.r1);
+  o.r2 = rot(v.r2);
+  o.x1 = rot(v.x1);
+  o.x2 = rot(v.x2);
+  o.j = __builtin_amdgcn_mov_dpp(v.j, 0x93, 0xf, 0xf, true);
+  o.info = __builtin_amdgcn_mov_dpp(v.info, 0x93, 0xf, 0xf, true);
+  return o;
+#endif
+}
+
+struct GivRow {  // the band row a lane currently owns
+  int j;
+  double a1, a2, a3, a4, z1, z2;
+};
+
+__device__ __forceinline__ void giv_flush(SplineWS& ws, const GivRow& r, int n) {
+  if (r.j > 0) {
+    ws.a[r.j][1] = r.a1;
+    ws.a[r.j][2] = r.a2;
+    ws.a[r.j][3] = r.a3;
+    ws.a[r.j][4] = r.a4;
+    ws.z[r.j] = r.z1;
+    ws.z[r.j + n] = r.z2;
+  }
+}
+
+// one chunk of `cnt` data rows (basis values / interval / data in ws.hq, ws.lq, ws.xq, ws.yq) through the pipeline;
+// leaves each row's rotated-out right-hand side in ws.xq/yq (for the residual sum).  All lanes call.
+__device__ inline void givens_chunk_pipelined(SplineWS& ws, int cnt, int n, GivRow& row) {
+  const int lane = lane_id();
+  constexpr int k1 = 4;
+  GivItem out;
+  out.piv = out.r0 = out.r1 = out.r2 = out.x1 = out.x2 = 0.0;
+  out.j = 0;
+  out.info = 0;
+  int next_r = 0, t_next = 0, last_finish = -1;
+  for (int tau = 0; next_r < cnt || tau <= last_finish; tau++) {
+    GivItem in = quad_rot_prev(out);
+    if (next_r < cnt && tau >= t_next) {
+      const int l = ws.lq[next_r];
+      const int j0 = l - k1 + 1;
+      if (lane == (j0 & 3)) {
+        in.piv = ws.hq[next_r][0];
+        in.r0 = ws.hq[next_r][1];
+        in.r1 = ws.hq[next_r][2];
+        in.r2 = ws.hq[next_r][3];
+        in.x1 = ws.xq[next_r];
+        in.x2 = ws.yq[next_r];
+        in.j = j0;
+        in.info = 1 | (next_r << 8);
+      }
+      last_finish = tau + k1 - 1;
+      int l_next = (next_r + 1 < cnt) ? ws.lq[next_r + 1] : l;
+      t_next = tau + 1 + (l_next - l);
+      next_r++;
+    }
+    const int stage = in.info & 0xff;
+    out = in;
+    out.info = 0;
+    if (stage > 0 && lane < 4) {
+      if (row.j != in.j) {
+        giv_flush(ws, row, n);
+        row.j = in.j;
+        row.a1 = ws.a[in.j][1];
+        row.a2 = ws.a[in.j][2];
+        row.a3 = ws.a[in.j][3];
+        row.a4 = ws.a[in.j][4];
+        row.z1 = ws.z[in.j];
+        row.z2 = ws.z[in.j + n];
+      }
+      double piv = in.piv, r0 = in.r0, r1 = in.r1, r2 = in.r2, x1 = in.x1, x2 = in.x2;
+      if (piv != 0.0) {
+        double cs, sn;
+        fpgivs(piv, row.a1, cs, sn);
+        fprota(cs, sn, x1, row.z1);
+        fprota(cs, sn, x2, row.z2);
+        if (stage <= 3) fprota(cs, sn, r0, row.a2);
+        if (stage <= 2) fprota(cs, sn, r1, row.a3);
+        if (stage <= 1) fprota(cs, sn, r2, row.a4);
+      }
+      if (stage == k1) {
+        int slot = in.info >> 8;
+        ws.xq[slot] = x1;
+        ws.yq[slot] = x2;
+      } else {
+        out.piv = r0;
+        out.r0 = r1;
+        out.r1 = r2;
+        out.r2 = 0.0;
+        out.x1 = x1;
+        out.x2 = x2;
+        out.j = in.j + 1;
+        out.info = (stage + 1) | (in.info & ~0xff);
+      }
+    }
+  }
+}
+
 // parcur/fppara for idim=2, w=1, iopt=0.  Data in LDS: U (parameter), X, Y, m points (0-based arrays).
 // All lanes call; result (t, c) left in ws; returns wave-uniform SplineFit.
 template <int K>
@@ -193,6 +318,9 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
         for (int j = 1; j <= k1; j++) ws.a[i][j] = 0.0;
       __syncthreads();
       fp = 0.0;
+      GivRow grow;
+      grow.j = 0;
+      grow.a1 = grow.a2 = grow.a3 = grow.a4 = grow.z1 = grow.z2 = 0.0;
       // ---- observation rows: basis values per lane, Givens rotations wave-uniform in data order ----
       for (int base = 0; base < m; base += WAVE) {
         int it = base + lane;
@@ -209,52 +337,72 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
         }
         __syncthreads();
         int cnt = m - base < WAVE ? m - base : WAVE;
-        if (lane == 0) {  // serial section: rows enter the triangle in data order (single writer of a / z)
+        if constexpr (K == 3) {
+          givens_chunk_pipelined(ws, cnt, n, grow);
+          __syncthreads();
+          // sum of squared rotated-out right-hand sides, in data order
           for (int r = 0; r < cnt; r++) {
-            double h[K + 2];
-#pragma unroll
-            for (int q = 0; q < k1; q++) h[q + 1] = ws.hq[r][q];
-            int l = ws.lq[r];
             double xi1 = ws.xq[r], xi2 = ws.yq[r];
-            int j = l - k1;
+            fp = fp + xi1 * xi1;
+            fp = fp + xi2 * xi2;
+          }
+        } else {
+          if (lane == 0) {  // serial section: rows enter the triangle in data order (single writer of a / z)
+            for (int r = 0; r < cnt; r++) {
+              double h[K + 2];
 #pragma unroll
-            for (int i = 1; i <= k1; i++) {
-              j++;
-              double piv = h[i];
-              if (piv == 0.0) continue;
-              double cs, sn;
-              double ww = ws.a[j][1];
-              fpgivs(piv, ww, cs, sn);
-              ws.a[j][1] = ww;
-              double z1 = ws.z[j], z2 = ws.z[j + n];
-              fprota(cs, sn, xi1, z1);
-              fprota(cs, sn, xi2, z2);
-              ws.z[j] = z1;
-              ws.z[j + n] = z2;
-              if (i == k1) break;
-              int i2 = 1;
+              for (int q = 0; q < k1; q++) h[q + 1] = ws.hq[r][q];
+              int l = ws.lq[r];
+              double xi1 = ws.xq[r], xi2 = ws.yq[r];
+              int j = l - k1;
 #pragma unroll
-              for (int i1 = i + 1; i1 <= k1; i1++) {
-                i2++;
-                double av = ws.a[j][i2];
-                fprota(cs, sn, h[i1], av);
-                ws.a[j][i2] = av;
+              for (int i = 1; i <= k1; i++) {
+                j++;
+                double piv = h[i];
+                if (piv == 0.0) continue;
+                double cs, sn;
+                double ww = ws.a[j][1];
+                fpgivs(piv, ww, cs, sn);
+                ws.a[j][1] = ww;
+                double z1 = ws.z[j], z2 = ws.z[j + n];
+                fprota(cs, sn, xi1, z1);
+                fprota(cs, sn, xi2, z2);
+                ws.z[j] = z1;
+                ws.z[j + n] = z2;
+                if (i == k1) break;
+                int i2 = 1;
+#pragma unroll
+                for (int i1 = i + 1; i1 <= k1; i1++) {
+                  i2++;
+                  double av = ws.a[j][i2];
+                  fprota(cs, sn, h[i1], av);
+                  ws.a[j][i2] = av;
+                }
               }
+              ws.xq[r] = xi1;
+              ws.yq[r] = xi2;
             }
+          }
+          __syncthreads();
+          for (int r = 0; r < cnt; r++) {
+            double xi1 = ws.xq[r], xi2 = ws.yq[r];
             fp = fp + xi1 * xi1;
             fp = fp + xi2 * xi2;
           }
         }
         __syncthreads();
       }
+      if constexpr (K == 3) {
+        if (lane < 4) giv_flush(ws, grow, n);
+        grow.j = 0;
+        __syncthreads();
+      }
       if (lane == 0) {
-        ws.scal[0] = fp;
         // back substitution (both coordinates)
         fpback<5>(ws.a, &ws.z[0], nk1, k1, &ws.c[0]);
         fpback<5>(ws.a, &ws.z[n], nk1, k1, &ws.c[n]);
       }
       __syncthreads();
-      fp = ws.scal[0];
       if (ier == -2) fp0 = fp;
       if (lane == 0) {
         ws.fpint[n] = fp0;

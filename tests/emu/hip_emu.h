@@ -168,6 +168,24 @@ inline T exchange(T v, int src) {
   return r;
 }
 
+// exchange of an arbitrary POD (<= 64 bytes) in one rendezvous
+struct BigSlots {
+  unsigned char b[WAVE][64];
+};
+inline thread_local BigSlots g_big;
+template <class T>
+inline T exchange_struct(const T& v, int src) {
+  static_assert(sizeof(T) <= 64, "struct too large");
+  Block* b = B;
+  int me = b->cur;
+  memcpy(g_big.b[me], &v, sizeof(T));
+  barrier();
+  T r = v;
+  if (src >= 0 && src < b->n_lanes) memcpy(&r, g_big.b[src], sizeof(T));
+  barrier();
+  return r;
+}
+
 inline unsigned long long ballot(int pred) {
   Block* b = B;
   int me = b->cur;
