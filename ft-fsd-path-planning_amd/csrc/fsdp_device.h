@@ -165,6 +165,25 @@ __device__ __forceinline__ double np_sum_small(const double* a, int n) {
 }
 
 // ------------------------------------------------------------------------------------------
+// optional per-section cycle accounting (tools/section_profile.py builds with -DFSDP_PROFILE)
+// ------------------------------------------------------------------------------------------
+#if defined(FSDP_PROFILE) && !defined(FSDP_EMU)
+__device__ long long* g_prof = nullptr;  // [n_frames][32] cycle sums
+struct ProfScope {
+  long long t0;
+  int slot;
+  __device__ ProfScope(int s) : t0(clock64()), slot(s) {}
+  __device__ ~ProfScope() {
+    long long t1 = clock64();
+    if (g_prof && (threadIdx.x & 63) == 0) g_prof[(size_t)blockIdx.x * 32 + slot] += (t1 - t0);
+  }
+};
+#define PROF(slot) ProfScope prof_scope_##slot(slot)
+#else
+#define PROF(slot)
+#endif
+
+// ------------------------------------------------------------------------------------------
 // wave primitives
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

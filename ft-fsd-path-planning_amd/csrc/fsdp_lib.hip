@@ -416,6 +416,25 @@ int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, fsdp_frame_r
   return 0;
 }
 
+#ifdef FSDP_PROFILE
+// profiling build only (tools/section_profile.py): per-frame per-section cycle sums of the path kernel
+int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
+  if (!c || c->n_frames == 0) return 1;
+  long long* d = nullptr;
+  size_t bytes = sizeof(long long) * 32 * (size_t)c->n_frames;
+  HIP_TRY(c, hipMalloc(&d, bytes));
+  HIP_TRY(c, hipMemset(d, 0, bytes));
+  HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(fsdp::g_prof), &d, sizeof(d)));
+  launch_path(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out32_per_frame, d, bytes, hipMemcpyDeviceToHost));
+  long long* z = nullptr;
+  HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(fsdp::g_prof), &z, sizeof(z)));
+  (void)hipFree(d);
+  return 0;
+}
+#endif
+
 int fsdp_default_path(fsdp_ctx* c, double* out) {
   if (!c || !out) return 1;
   HIP_TRY(c, hipMemcpy(out, c->d_default_path, sizeof(double) * PATH_POINTS * 4, hipMemcpyDeviceToHost));

@@ -182,6 +182,7 @@ __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? 
 
 // chord lengths -> parameter values: A.u[off + i] = cumulative length (np.cumsum: sequential order); returns max_u.
 __device__ inline double build_parameter(PathShared& S, const Arena& A, int off, int m) {
+  PROF(19);
   const int lane = lane_id();
   double acc = 0.0;
   if (lane == 0) A.u[off] = 0.0;
@@ -269,18 +270,27 @@ __device__ inline int parameterize_path(PathShared& S, const Arena& A, int off, 
   }
   SplineFit f;
   double max_u;
-  int rc = fit_polyline(S, A, off, ns, 0.01, f, max_u);
+  int rc;
+  {
+    PROF(7);
+    rc = fit_polyline(S, A, off, ns, 0.01, f, max_u);
+  }
   if (rc) return rc;
   // _calculate_path_curvature :163-193 — dense samples into LDS
   int L = arange_len(max_u, predict_every);
   if (L > DENSE_CAP) return ST_OVERFLOW_PATH;
   if (L == 0) return ST_REF_UNDEFINED_PATH;
-  spline_eval(S.ws, f, predict_every, L, S.dx, S.dy, S.du);
+  {
+    PROF(8);
+    spline_eval(S.ws, f, predict_every, L, S.dx, S.dy, S.du);
+  }
   double* curv = S.ws.seg;  // the spline chunk buffers are dead from here on
   double* filt = S.ws.seg + DENSE_CAP;
   int window = (L / 5) < 30 ? (L / 5) : 30;
   if (window % 2 == 0) window += 1;
   const int half = window / 2;
+  {
+  PROF(9);
   for (int i = lane; i < L; i += WAVE) {
     // cyclic window cut at the wrap-around for an open path (path_parameterization.py:64-77)
     int lo = i - half, hi = i + half;
@@ -309,6 +319,8 @@ __device__ inline int parameterize_path(PathShared& S, const Arena& A, int off, 
     curv[i] = cv;
   }
   __syncthreads();
+  }
+  PROF(18);
   // scipy.ndimage.uniform_filter1d(size = max(2, window // 2), mode = "nearest"): running sum in index order
   if (lane == 0) {
     int size = (window / 2) > 2 ? (window / 2) : 2;
@@ -512,8 +524,13 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
     SplineFit f;
     if (n >= 2) {
       double max_u;
-      int rc = fit_polyline(S, A, off, n, 0.2, f, max_u);
+      int rc;
+      {
+        PROF(4);
+        rc = fit_polyline(S, A, off, n, 0.2, f, max_u);
+      }
       if (rc) return rc;
+      PROF(5);
       n4 = arange_len(20.0 * 1.5, 0.1);
       spline_eval(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
     }
@@ -579,6 +596,7 @@ __global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double*
   __shared__ PathShared S;
   const int frame = blockIdx.x;
   if (frame >= n_frames) return;
+  PROF(0);
   const int lane = lane_id();
   const Arena A = frame_arena(arena, frame);
   const MatchOut* mo = &matched[frame];
@@ -658,6 +676,7 @@ __global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double*
       __syncthreads();
       SplineFit f;
       double max_u;
+      PROF(1);
       int rc = fit_polyline(S, A, 0, nc, 0.2, f, max_u);
       if (rc == 0) {
         n1 = arange_len(max_u, 0.1);

@@ -324,6 +324,8 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
       // ---- observation rows: basis values per lane, Givens rotations wave-uniform in data order ----
       for (int base = 0; base < m; base += WAVE) {
         int it = base + lane;
+        {
+        PROF(10);
         if (it < m) {
           double ui = U[it];
           int l = find_interval(ws.t, k1, nk1, ui);
@@ -336,10 +338,15 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
           ws.yq[lane] = Y[it];
         }
         __syncthreads();
+        }
         int cnt = m - base < WAVE ? m - base : WAVE;
         if constexpr (K == 3) {
-          givens_chunk_pipelined(ws, cnt, n, grow);
-          __syncthreads();
+          {
+            PROF(11);
+            givens_chunk_pipelined(ws, cnt, n, grow);
+            __syncthreads();
+          }
+          PROF(12);
           // sum of squared rotated-out right-hand sides, in data order
           for (int r = 0; r < cnt; r++) {
             double xi1 = ws.xq[r], xi2 = ws.yq[r];
@@ -398,6 +405,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
         __syncthreads();
       }
       if (lane == 0) {
+        PROF(13);
         // back substitution (both coordinates)
         fpback<5>(ws.a, &ws.z[0], nk1, k1, &ws.c[0]);
         fpback<5>(ws.a, &ws.z[n], nk1, k1, &ws.c[n]);
@@ -444,6 +452,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
       fpold = fp;
       // ---- residual sums per knot interval (terms per lane, accumulation in data order) ----
       {
+        PROF(14);
         double fpart = 0.0;
         int ii = 1;
         for (int base = 0; base < m; base += WAVE) {
@@ -499,6 +508,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
       // ---- add nplus knots (fpknot), wave-uniform ----
       for (int lq = 1; lq <= nplus; lq++) {
         {
+          PROF(15);
           int kk = (n - nrint - 1) / 2;
           double fpmax = 0.;
           int jbegin = 1;
@@ -603,6 +613,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
       }
       __syncthreads();
       if (lane == 0) {  // serial section (single writer of g / c)
+        PROF(16);
         for (int it = 1; it <= n8; it++) {
           double h[K + 4];
 #pragma unroll
@@ -642,6 +653,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
       }
       __syncthreads();
       // f(p): terms per lane, accumulation in data order
+      PROF(17);
       fp = 0.;
       for (int base = 0; base < m; base += WAVE) {
         int it = base + lane;
