@@ -66,6 +66,16 @@ def cpu_baseline(off, cones, poses, budget_s: float = 12.0):
     }
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    produced by tools/profile_gpu.sh; FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); None if absent."""
+    try:
+        d = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
+        return d[kernel]["hbm_bytes_per_launch"] / 1e9 if kernel in d else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,10 +149,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": _pmc_traffic(names[dom]),
                 "kernel_ms": {n: m for n, m in zip(names, stage_ms)},
+                "traffic_unit": "GB per launch (PMC, profiles/pmc_traffic.json)",
                 "note": "algorithmic bytes/frame = 4488 (SURVEY 8d) x 4096 frames / dominant-kernel duration (HIP events on the "
-                        "library stream); the path is latency/FP64-issue bound, not HBM bound",
+                        "library stream); the path is FP64-issue bound (serial spline QR), not HBM bound",
             },
             "status_histogram": status_hist,
         }
