@@ -78,6 +78,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
     "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
+    "fsdp_skidpad_set_tables", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
 ]
 
 

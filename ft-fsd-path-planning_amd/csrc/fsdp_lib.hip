@@ -14,6 +14,7 @@
 #include "sort_kernel.h"
 #include "match_kernel.h"
 #include "path_kernel.h"
+#include "skidpad_kernel.h"
 
 using namespace fsdp;
 
@@ -42,6 +43,18 @@ struct fsdp_ctx {
   PathOut* d_path = nullptr;
   double* d_default_path = nullptr;  // (40,4)
   double* d_arena = nullptr;         // per-frame working polyline (3 x PATH_CAP doubles), HBM/L2 scratch
+  double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
+  // skidpad mission
+  double* d_table = nullptr;
+  double* d_noise = nullptr;
+  SkidTables tables = {};
+  bool have_tables = false;
+  SkidState* d_skid = nullptr;
+  SkidState* d_skid_backup = nullptr;
+  SkidInfo* d_skid_info = nullptr;
+  int32_t* d_skid_status = nullptr;
+  int n_instances = 0;
+  std::vector<SkidInfo> h_skid_info;
   // pinned host staging for results
   std::vector<SortOut> h_sort;
   std::vector<MatchOut> h_match;
@@ -161,8 +174,8 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
     return 1;
   }
   // utils/mission_types.py:11-25: acceleration=1, skidpad=2, ebs_test=5 use a relocalizer (full_pipeline.py:46-50)
-  if (mission == 1 || mission == 2 || mission == 5) {
-    g_create_error = "missions with a relocalizer (acceleration / skidpad / ebs_test) are not on this path yet";
+  if (mission == 1 || mission == 5) {
+    g_create_error = "acceleration / ebs_test use the unseeded AccelerationRelocalizer (SURVEY.md 2 row 6b): out of scope";
     return 1;
   }
   fsdp_ctx* c = new fsdp_ctx();
@@ -182,7 +195,7 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
   {
     double chord[PATH_POINTS][2];
     default_chord_points(chord);
-    double* d_chord = nullptr;
+    double*& d_chord = c->d_chord;
     double* d_arena0 = nullptr;
     e = hipMalloc(&d_chord, sizeof(chord));
     if (e == hipSuccess) e = hipMalloc(&d_arena0, sizeof(double) * 3 * PATH_CAP);
@@ -191,7 +204,6 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
       hipLaunchKernelGGL(default_path_kernel, dim3(1), dim3(WAVE), 0, c->stream, d_chord, d_arena0, c->d_default_path);
       e = hipStreamSynchronize(c->stream);
     }
-    if (d_chord) (void)hipFree(d_chord);
     if (d_arena0) (void)hipFree(d_arena0);
     if (e != hipSuccess) {
       g_create_error = std::string("fsdp_create(default path): ") + hipGetErrorString(e);
@@ -214,6 +226,13 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_match);
   (void)hipFree(c->d_path);
   (void)hipFree(c->d_arena);
+  (void)hipFree(c->d_chord);
+  (void)hipFree(c->d_table);
+  (void)hipFree(c->d_noise);
+  (void)hipFree(c->d_skid);
+  (void)hipFree(c->d_skid_backup);
+  (void)hipFree(c->d_skid_info);
+  (void)hipFree(c->d_skid_status);
   (void)hipFree(c->d_default_path);
   for (int i = 0; i < 8; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -434,6 +453,120 @@ int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
   return 0;
 }
 #endif
+
+int fsdp_skidpad_set_tables(fsdp_ctx* c, const double* table_xy, int n_table, const double* noise, int n_noise,
+                            const double* ref4, double mean_distance) {
+  if (!c || !table_xy || n_table < 20 || !noise || n_noise < 6 || !ref4) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  // known global path = table[::2] (skidpad_relocalizer.py:242-243)
+  std::vector<double> half;
+  for (int i = 0; i < n_table; i += 2) {
+    half.push_back(table_xy[2 * i]);
+    half.push_back(table_xy[2 * i + 1]);
+  }
+  if (c->d_table) (void)hipFree(c->d_table);
+  if (c->d_noise) (void)hipFree(c->d_noise);
+  HIP_TRY(c, hipMalloc(&c->d_table, sizeof(double) * half.size()));
+  HIP_TRY(c, hipMalloc(&c->d_noise, sizeof(double) * (size_t)n_noise));
+  HIP_TRY(c, hipMemcpy(c->d_table, half.data(), sizeof(double) * half.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_noise, noise, sizeof(double) * (size_t)n_noise, hipMemcpyHostToDevice));
+  c->tables.path = c->d_table;
+  c->tables.n_path = (int)(half.size() / 2);
+  c->tables.noise = c->d_noise;
+  c->tables.n_noise = n_noise;
+  c->tables.ref_right[0] = ref4[0];
+  c->tables.ref_right[1] = ref4[1];
+  c->tables.ref_left[0] = ref4[2];
+  c->tables.ref_left[1] = ref4[3];
+  c->tables.mean_distance = mean_distance;
+  c->have_tables = true;
+  return 0;
+}
+
+int fsdp_skidpad_reset(fsdp_ctx* c, int n_instances) {
+  if (!c || n_instances <= 0) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_instances != c->n_instances) {
+    if (c->d_skid) (void)hipFree(c->d_skid);
+    if (c->d_skid_backup) (void)hipFree(c->d_skid_backup);
+    if (c->d_skid_info) (void)hipFree(c->d_skid_info);
+    if (c->d_skid_status) (void)hipFree(c->d_skid_status);
+    c->d_skid = nullptr;
+    HIP_TRY(c, hipMalloc(&c->d_skid, sizeof(SkidState) * (size_t)n_instances));
+    HIP_TRY(c, hipMalloc(&c->d_skid_backup, sizeof(SkidState) * (size_t)n_instances));
+    HIP_TRY(c, hipMalloc(&c->d_skid_info, sizeof(SkidInfo) * (size_t)n_instances));
+    HIP_TRY(c, hipMalloc(&c->d_skid_status, sizeof(int32_t) * (size_t)n_instances));
+    c->n_instances = n_instances;
+  }
+  // fresh planners: nothing latched, previous path = the constant initial path
+  std::vector<SkidState> init(n_instances);
+  double def[PATH_POINTS][4];
+  HIP_TRY(c, hipMemcpy(def, c->d_default_path, sizeof(def), hipMemcpyDeviceToHost));
+  for (auto& s : init) {
+    memset(&s, 0, sizeof(s));
+    memcpy(s.prev, def, sizeof(def));
+  }
+  HIP_TRY(c, hipMemcpy(c->d_skid, init.data(), sizeof(SkidState) * (size_t)n_instances, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static void launch_skid(fsdp_ctx* c, bool reloc) {
+  if (reloc)
+    hipLaunchKernelGGL(skid_reloc_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_off, c->d_cones,
+                       c->d_poses, c->d_skid, c->tables, c->d_arena, c->d_skid_status);
+  hipLaunchKernelGGL(skid_path_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_poses, c->d_skid, c->tables,
+                     c->d_chord, c->d_arena, c->d_skid_status, c->d_path, c->d_skid_info);
+}
+
+int fsdp_skidpad_step(fsdp_ctx* c, int n_instances, const int32_t* off, const double* cones, const double* poses,
+                      fsdp_frame_result* results, fsdp_skidpad_info* info) {
+  if (!c || !c->have_tables || n_instances != c->n_instances || !c->d_skid) {
+    if (c) c->err = "fsdp_skidpad_step: call fsdp_skidpad_set_tables and fsdp_skidpad_reset(n_instances) first";
+    return 1;
+  }
+  int rc = fsdp_upload(c, n_instances, off, cones, poses);
+  if (rc) return rc;
+  launch_skid(c, true);
+  HIP_TRY(c, hipGetLastError());
+  c->h_path.resize(n_instances);
+  c->h_skid_info.resize(n_instances);
+  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), c->d_path, sizeof(PathOut) * n_instances, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_skid_info.data(), c->d_skid_info, sizeof(SkidInfo) * n_instances, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n_instances; i++) {
+    if (results) {
+      memset(&results[i], 0, sizeof(fsdp_frame_result));
+      for (int q = 0; q < MAX_LEN; q++) results[i].left_idx[q] = results[i].right_idx[q] = -1;
+      for (int q = 0; q < MAX_MATCH; q++) results[i].l2r[q] = results[i].r2l[q] = -1;
+      assemble(nullptr, nullptr, &c->h_path[i], &results[i]);
+    }
+    if (info) {
+      info[i].relocalized = c->h_skid_info[i].relocalized;
+      info[i].index_along_path = c->h_skid_info[i].index_along_path;
+      info[i].translation[0] = c->h_skid_info[i].translation[0];
+      info[i].translation[1] = c->h_skid_info[i].translation[1];
+      info[i].rotation = c->h_skid_info[i].rotation;
+    }
+  }
+  return 0;
+}
+
+int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
+  if (!c || !c->d_skid || c->n_frames != c->n_instances || iters <= 0) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t bytes = sizeof(SkidState) * (size_t)c->n_instances;
+  HIP_TRY(c, hipMemcpyAsync(c->d_skid_backup, c->d_skid, bytes, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+  for (int i = 0; i < iters; i++) launch_skid(c, false);
+  HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
+  HIP_TRY(c, hipEventSynchronize(c->ev[5]));
+  float t = 0;
+  HIP_TRY(c, hipEventElapsedTime(&t, c->ev[4], c->ev[5]));
+  HIP_TRY(c, hipMemcpyAsync(c->d_skid, c->d_skid_backup, bytes, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (ms_total) *ms_total = t;
+  return 0;
+}
 
 int fsdp_default_path(fsdp_ctx* c, double* out) {
   if (!c || !out) return 1;

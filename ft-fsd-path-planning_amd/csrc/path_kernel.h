@@ -22,7 +22,7 @@
 
 namespace fsdp {
 
-constexpr int PATH_CAP = 1024;  // points of the working polyline (dense fit-#1 output + extension)
+constexpr int PATH_CAP = 1152;  // points of the working polyline (dense fit-#1 output + extension)
 constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121 in practice)
 constexpr int SEG_CAP = WAVE * 7;  // segment-length scratch in LDS (aliases the spline chunk buffers; 300-sample MPC path)
 
@@ -543,6 +543,50 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
   return parameterize_path(S, A, 0, n5, out, n_dense);
 }
 
+// core_calculate_path.py:555-575: too-far check + MPC step with its ValueError retry, on the dense path update stored
+// in the arena at [1, 1+n1); previous path xy in S.prevx/prevy.  Returns the frame status.
+__device__ inline int finish_path(PathShared& S, const Arena& A, int n1, double px, double py, double dx, double dy,
+                                  double (*out)[4], int* fallback, int* n_dense) {
+  const int lane = lane_id();
+  if (n1 == 0) return ST_REF_UNDEFINED_PATH;  // min() of an empty array
+  // overwrite_path_if_it_is_too_far_away :225-237
+  {
+    double bv = 0.0;
+    int bi = -1;
+    for (int i = lane; i < n1; i += WAVE) {
+      double d = norm_axis(px - A.x[1 + i], py - A.y[1 + i]);
+      if (bi < 0 || d < bv) {
+        bv = d;
+        bi = i;
+      }
+    }
+    wave_argmin(bv, bi);
+    if (bv > 5.0) {
+      *fallback |= 4;
+      __syncthreads();
+      if (lane < PATH_POINTS) {
+        A.x[1 + lane] = S.prevx[lane];
+        A.y[1 + lane] = S.prevy[lane];
+      }
+      n1 = PATH_POINTS;
+      __syncthreads();
+    }
+  }
+  int rc = do_all_mpc(S, A, n1, px, py, dx, dy, out, fallback, n_dense);
+  if (rc == 1) {  // ValueError -> redo with the previous path (:564-570)
+    *fallback |= 8;
+    __syncthreads();
+    if (lane < PATH_POINTS) {
+      A.x[1 + lane] = S.prevx[lane];
+      A.y[1 + lane] = S.prevy[lane];
+    }
+    __syncthreads();
+    rc = do_all_mpc(S, A, PATH_POINTS, px, py, dx, dy, out, fallback, n_dense);
+    if (rc == 1) rc = ST_REF_UNDEFINED_PATH;
+  }
+  return rc;
+}
+
 // path_calculator_helpers.py:26-68 calculate_almost_straight_path (host side, libm = what NumPy uses)
 inline void default_chord_points(double (*chord)[2]) {
   const int NP = PATH_POINTS;
@@ -704,45 +748,7 @@ __global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double*
       __syncthreads();
     }
   }
-  if (status == ST_OK && n1 == 0) status = ST_REF_UNDEFINED_PATH;  // min() of an empty array
-  // overwrite_path_if_it_is_too_far_away :225-237
-  if (status == ST_OK) {
-    double bv = 0.0;
-    int bi = -1;
-    for (int i = lane; i < n1; i += WAVE) {
-      double d = norm_axis(px - A.x[1 + i], py - A.y[1 + i]);
-      if (bi < 0 || d < bv) {
-        bv = d;
-        bi = i;
-      }
-    }
-    wave_argmin(bv, bi);
-    if (bv > 5.0) {
-      fallback |= 4;
-      __syncthreads();
-      if (lane < PATH_POINTS) {
-        A.x[1 + lane] = S.prevx[lane];
-        A.y[1 + lane] = S.prevy[lane];
-      }
-      n1 = PATH_POINTS;
-      __syncthreads();
-    }
-  }
-  if (status == ST_OK) {
-    int rc = do_all_mpc(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
-    if (rc == 1) {  // ValueError -> redo with the previous path (:564-570)
-      fallback |= 8;
-      __syncthreads();
-      if (lane < PATH_POINTS) {
-        A.x[1 + lane] = S.prevx[lane];
-        A.y[1 + lane] = S.prevy[lane];
-      }
-      __syncthreads();
-      rc = do_all_mpc(S, A, PATH_POINTS, px, py, dx, dy, o->path, &fallback, &n_dense);
-      if (rc == 1) rc = ST_REF_UNDEFINED_PATH;
-    }
-    if (rc != 0) status = rc;
-  }
+  if (status == ST_OK) status = finish_path(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
   __syncthreads();
   if (status != ST_OK && lane < PATH_POINTS)
     for (int q = 0; q < 4; q++) o->path[lane][q] = NAN;

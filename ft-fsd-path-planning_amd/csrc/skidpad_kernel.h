@@ -1,0 +1,472 @@
+// Skidpad mission (BASELINE config 5) as wave-per-planner-instance HIP kernels (gfx950).
+//
+// Replaces, per planner instance and per frame, the relocalizer branch of
+// PathPlanner.calculate_path_in_global_frame (reference full_pipeline/full_pipeline.py:118-194):
+//   skid_reloc_kernel : Relocalizer.attempt_relocalization_calculation (relocalization_base_class.py:50-75) ->
+//                       SkidpadRelocalizer.do_relocalization_once (skidpad_relocalizer.py:198-240):
+//                       20 nearest cones (wave arg-min), all C(20,3) = 1140 circle fits one per lane,
+//                       DBSCAN(eps=3, min_samples=1) as min-label propagation over the <= 3 m graph,
+//                       per-cluster medians by rank counting, best centre pair, rigid transform.
+//   skid_path_kernel  : pose into the map frame, SkidpadCalculatePath.fit_matches_as_spline
+//                       (skidpad_calculate_path.py:49-71: stateful window arg-min on the known path) or the trivial
+//                       path before relocalization (core_calculate_path.py:127-134), then the common MPC step
+//                       (finish_path) with the instance's previous path, path back to the original frame
+//                       (full_pipeline.py:178-194), state update.
+// State lives in HBM per instance (SkidState); the known path table, the fixed-seed noise table and the
+// reference centres are constant inputs uploaded once (fsdp_skidpad_set_tables).
+#pragma once
+#include "path_kernel.h"
+
+namespace fsdp {
+
+constexpr int SKID_MAX_CLUSTERS = 64;
+constexpr int SKID_NEAR = 20;
+constexpr int ST_OVERFLOW_CLUSTERS = 205;
+
+struct SkidState {
+  int32_t has_original, relocalized, index_along_path, pad;
+  double orig[4];          // pose latched at the first relocalization attempt
+  double translation[2];
+  double right_calc[2];
+  double rotation;
+  double prev[PATH_POINTS][4];  // previous_paths[-1] (map frame once relocalized)
+};
+
+struct SkidTables {
+  const double* path;    // known global path = BASE_SKIDPAD_PATH[::2], (n_path, 2)
+  int n_path;
+  const double* noise;   // RandomState(42).randn(n_noise / 6, 3, 2)
+  int n_noise;
+  double ref_right[2], ref_left[2];  // calculate_reference_centers_for_skidpad_path
+  double mean_distance;              // mean of the first 9 segment lengths of the known path (NumPy mean)
+};
+
+struct SkidInfo {  // what RelocalizationInformation / the planner state expose (relocalization_information.py:12-35)
+  int32_t relocalized, index_along_path;
+  double translation[2];
+  double rotation;
+};
+
+struct SkidShared {
+  double nx[SKID_NEAR], ny[SKID_NEAR];
+  double medx[SKID_MAX_CLUSTERS], medy[SKID_MAX_CLUSTERS];
+  int32_t root[SKID_MAX_CLUSTERS];
+  int32_t n_roots;
+};
+
+// unrank the s-th 3-subset of {0..m-1} in itertools.combinations order
+__device__ inline void unrank3(int s, int m, int& a, int& b, int& c) {
+  a = 0;
+  for (;;) {
+    int rest = m - 1 - a;
+    int cnt = rest * (rest - 1) / 2;
+    if (s < cnt) break;
+    s -= cnt;
+    a++;
+  }
+  b = a + 1;
+  for (;;) {
+    int cnt = m - 1 - b;
+    if (s < cnt) break;
+    s -= cnt;
+    b++;
+  }
+  c = b + 1 + s;
+}
+
+__global__ void __launch_bounds__(64) skid_reloc_kernel(int n_inst, const int32_t* __restrict__ cone_offsets,
+                                                        const double* __restrict__ cones_xyt, const double* __restrict__ poses,
+                                                        SkidState* __restrict__ states, SkidTables T, double* __restrict__ arena,
+                                                        int32_t* __restrict__ status_out) {
+  __shared__ SkidShared S;
+  const int inst = blockIdx.x;
+  if (inst >= n_inst) return;
+  const int lane = lane_id();
+  SkidState* st = &states[inst];
+  if (lane == 0) status_out[inst] = ST_OK;
+  const int already = st->relocalized;
+  if (already) return;
+  const double px = poses[4 * inst + 0], py = poses[4 * inst + 1], dx = poses[4 * inst + 2], dy = poses[4 * inst + 3];
+  // latch the pose of the first attempt (relocalization_base_class.py:66-68)
+  const int had_original = st->has_original;
+  const double opx = had_original ? st->orig[0] : px, opy = had_original ? st->orig[1] : py;
+  const double odx = had_original ? st->orig[2] : dx, ody = had_original ? st->orig[3] : dy;
+  __syncthreads();
+  if (!had_original && lane == 0) {
+    st->has_original = 1;
+    st->orig[0] = px;
+    st->orig[1] = py;
+    st->orig[2] = dx;
+    st->orig[3] = dy;
+  }
+  const int off = cone_offsets[inst];
+  const int n = cone_offsets[inst + 1] - off;
+  const double* cones = cones_xyt + 3 * (size_t)off;
+  const Arena A = frame_arena(arena, inst);
+  // ---- 20 closest cones, in argsort order (stable) ----
+  const int m = n < SKID_NEAR ? n : SKID_NEAR;
+  {
+    // distances into the arena (n may exceed 64); repeated wave arg-min with the taken ones masked by +inf
+    for (int i = lane; i < n; i += WAVE) A.u[i] = norm_axis(cones[3 * i] - px, cones[3 * i + 1] - py);
+    __syncthreads();
+    for (int k = 0; k < m; k++) {
+      double bv = 0.0;
+      int bi = -1;
+      for (int i = lane; i < n; i += WAVE) {
+        double d = A.u[i];
+        if (d >= 0 && (bi < 0 || d < bv)) {  // taken entries are marked negative
+          bv = d;
+          bi = i;
+        }
+      }
+      wave_argmin(bv, bi);
+      __syncthreads();
+      if (lane == 0) {
+        S.nx[k] = cones[3 * bi];
+        S.ny[k] = cones[3 * bi + 1];
+        A.u[bi] = -1.0;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- circle_fit_powerset: every 3-subset, one per lane, accepted centres compacted in subset order ----
+  const int n_sub = (m >= 3) ? m * (m - 1) * (m - 2) / 6 : 0;
+  int n_centers = 0;
+  bool noise_short = false;
+  for (int base = 0; base < n_sub; base += WAVE) {
+    int s = base + lane;
+    bool acc = false;
+    double cx = 0, cy = 0;
+    if (s < n_sub) {
+      if ((s + 1) * 6 > T.n_noise) {
+        noise_short = true;
+      } else {
+        int ia, ib, ic;
+        unrank3(s, m, ia, ib, ic);
+        int id[3] = {ia, ib, ic};
+        double qx[3], qy[3];
+        double mind[3];
+#pragma unroll
+        for (int col = 0; col < 3; col++) {
+          double best = 0.0;
+          bool first = true;
+#pragma unroll
+          for (int row = 0; row < 3; row++) {
+            double d = (row == col) ? INFINITY : sqrt(cdist_sq(S.nx[id[row]], S.ny[id[row]], S.nx[id[col]], S.ny[id[col]]));
+            if (first) {
+              best = d;
+              first = false;
+            } else if (isnan(d) || isnan(best)) {
+              best = NAN;
+            } else if (d < best) {
+              best = d;
+            }
+          }
+          mind[col] = best;
+        }
+        double mean_distance = (0.0 + ((mind[0] + mind[1]) + mind[2])) / 3.0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          qx[r] = S.nx[id[r]] + T.noise[(size_t)s * 6 + 2 * r] * 1e-3;
+          qy[r] = S.ny[id[r]] + T.noise[(size_t)s * 6 + 2 * r + 1] * 1e-3;
+        }
+        double rad;
+        circle_fit(qx, qy, 0, 3, cx, cy, rad);
+        double res[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) res[r] = fabs(norm_axis(cx - qx[r], cy - qy[r]) - rad);
+        double residual = (0.0 + ((res[0] + res[1]) + res[2])) / 3.0;
+        acc = fabs(rad - 7.625) < 1.0 && fabs(mean_distance - 2.4) < 1.5 && residual < 0.4;
+      }
+    }
+    unsigned long long am = __ballot(acc);
+    if (acc) {
+      int p = n_centers + __popcll(am & ((1ull << lane) - 1ull));
+      A.x[p] = cx;
+      A.y[p] = cy;
+    }
+    n_centers += __popcll(am);
+  }
+  if (__ballot(noise_short) != 0ull) {
+    if (lane == 0) status_out[inst] = ST_REF_UNDEFINED_PATH;
+    return;
+  }
+  __syncthreads();
+  if (n_centers < 3) return;
+  // ---- DBSCAN(eps = 3, min_samples = 1): connected components by min-label propagation; label = smallest member index ----
+  const int C = n_centers;
+  int32_t* label = (int32_t*)A.u;  // the distance scratch is dead
+  for (int i = lane; i < C; i += WAVE) label[i] = i;
+  __syncthreads();
+  for (int iter = 0; iter < C; iter++) {
+    bool changed = false;
+    for (int base = 0; base < C; base += WAVE) {
+      int i = base + lane;
+      int nl = 0;
+      if (i < C) {
+        nl = label[i];
+        double xi = A.x[i], yi = A.y[i];
+        for (int j = 0; j < C; j++) {
+          double ddx = xi - A.x[j], ddy = yi - A.y[j];
+          if (sqrt(ddx * ddx + ddy * ddy) <= 3.0) {
+            int lj = label[j];
+            nl = lj < nl ? lj : nl;
+          }
+        }
+      }
+      __syncthreads();
+      if (i < C && nl != label[i]) {
+        label[i] = nl;
+        changed = true;
+      }
+      __syncthreads();
+    }
+    if (__ballot(changed) == 0ull) break;
+  }
+  // roots in ascending order = np.unique(labels)
+  int n_roots = 0;
+  bool too_many = false;
+  for (int base = 0; base < C; base += WAVE) {
+    int i = base + lane;
+    bool is_root = i < C && label[i] == i;
+    unsigned long long rm = __ballot(is_root);
+    if (is_root) {
+      int p = n_roots + __popcll(rm & ((1ull << lane) - 1ull));
+      if (p < SKID_MAX_CLUSTERS) S.root[p] = i;
+    }
+    n_roots += __popcll(rm);
+  }
+  if (n_roots > SKID_MAX_CLUSTERS) too_many = true;
+  __syncthreads();
+  if (too_many) {
+    if (lane == 0) status_out[inst] = ST_OVERFLOW_CLUSTERS;
+    return;
+  }
+  if (!(n_roots > 1)) return;  // AssertionError in the reference -> attempt fails
+  // per-cluster medians (np.median per axis): rank counting, lanes = members
+  for (int r = 0; r < n_roots; r++) {
+    const int root = S.root[r];
+    int k = 0;
+    for (int base = 0; base < C; base += WAVE) {
+      int i = base + lane;
+      k += __popcll(__ballot(i < C && label[i] == root));
+    }
+    const int lo_rank = (k % 2 == 1) ? k / 2 : k / 2 - 1, hi_rank = k / 2;
+    double lox = 0, hix = 0, loy = 0, hiy = 0;
+    for (int base = 0; base < C; base += WAVE) {
+      int i = base + lane;
+      bool mem = i < C && label[i] == root;
+      int rx = 0, ry = 0;
+      double xi = 0, yi = 0;
+      if (mem) {
+        xi = A.x[i];
+        yi = A.y[i];
+        for (int j = 0; j < C; j++) {
+          if (label[j] != root) continue;
+          double xj = A.x[j], yj = A.y[j];
+          rx += (xj < xi) || (xj == xi && j < i);
+          ry += (yj < yi) || (yj == yi && j < i);
+        }
+      }
+      // exactly one member holds each rank: broadcast through ballots
+      unsigned long long b;
+      b = __ballot(mem && rx == lo_rank);
+      if (b) lox = __shfl(xi, __ffsll(b) - 1, WAVE);
+      b = __ballot(mem && rx == hi_rank);
+      if (b) hix = __shfl(xi, __ffsll(b) - 1, WAVE);
+      b = __ballot(mem && ry == lo_rank);
+      if (b) loy = __shfl(yi, __ffsll(b) - 1, WAVE);
+      b = __ballot(mem && ry == hi_rank);
+      if (b) hiy = __shfl(yi, __ffsll(b) - 1, WAVE);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      S.medx[r] = (k % 2 == 1) ? hix : (0.0 + (lox + hix)) / 2.0;
+      S.medy[r] = (k % 2 == 1) ? hiy : (0.0 + (loy + hiy)) / 2.0;
+    }
+    __syncthreads();
+  }
+  // best centre pair: |18.25 - distance| minimal, first pair (label order) on ties
+  double best_distance = 1000.0;
+  int best_pair = -1;
+  {
+    const int n_pairs = n_roots * (n_roots - 1) / 2;
+    double bv = 0.0;
+    int bi = -1;
+    for (int pidx = lane; pidx < n_pairs; pidx += WAVE) {
+      // unrank pair in combinations order
+      int a = 0, s = pidx;
+      while (s >= n_roots - 1 - a) {
+        s -= n_roots - 1 - a;
+        a++;
+      }
+      int b = a + 1 + s;
+      double d = fabs(18.25 - norm_blas(S.medx[a] - S.medx[b], S.medy[a] - S.medy[b]));
+      if (bi < 0 || d < bv) {
+        bv = d;
+        bi = pidx;
+      }
+    }
+    wave_argmin(bv, bi);
+    if (bi >= 0 && bv < best_distance) {
+      best_distance = bv;
+      best_pair = bi;
+    }
+  }
+  if (best_pair < 0 || best_distance > 0.5) return;  // ValueError in the reference -> attempt fails
+  int ca = 0, cs = best_pair;
+  while (cs >= n_roots - 1 - ca) {
+    cs -= n_roots - 1 - ca;
+    ca++;
+  }
+  const int cb = ca + 1 + cs;
+  // ---- calculate_transformation (skidpad_relocalizer.py:101-169), wave-uniform scalars; det_math for libm values ----
+  const double c0x = S.medx[ca], c0y = S.medy[ca], c1x = S.medx[cb], c1y = S.medy[cb];
+  const double yaw0 = detm::det_atan2(ody, odx);
+  double sn, cs_;
+  detm::det_sincos(-yaw0, sn, cs_);
+  const double v0y = blas_dot2(c0x - opx, sn, c0y - opy, cs_);
+  const double v1y = blas_dot2(c1x - opx, sn, c1y - opy, cs_);
+  const bool r0 = v0y < 0.0, r1 = v1y < 0.0;
+  if (r0 == r1) return;  // IndexError in the reference -> attempt fails
+  const double rcx = r0 ? c0x : c1x, rcy = r0 ? c0y : c1y;
+  const double lcx = r0 ? c1x : c0x, lcy = r0 ? c1y : c0y;
+  const double reference_angle = detm::det_atan2(T.ref_left[1] - T.ref_right[1], T.ref_left[0] - T.ref_right[0]);
+  const double calculated_angle = detm::det_atan2(lcy - rcy, lcx - rcx);
+  __syncthreads();
+  if (lane == 0) {
+    st->translation[0] = T.ref_right[0] - rcx;
+    st->translation[1] = T.ref_right[1] - rcy;
+    st->rotation = reference_angle - calculated_angle;
+    st->right_calc[0] = rcx;
+    st->right_calc[1] = rcy;
+    st->relocalized = 1;
+  }
+}
+
+__global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, const double* __restrict__ poses,
+                                                          SkidState* __restrict__ states, SkidTables T,
+                                                          const double* __restrict__ chord, double* __restrict__ arena,
+                                                          const int32_t* __restrict__ status_in, PathOut* __restrict__ out,
+                                                          SkidInfo* __restrict__ info) {
+  __shared__ PathShared S;
+  const int inst = blockIdx.x;
+  if (inst >= n_inst) return;
+  const int lane = lane_id();
+  const Arena A = frame_arena(arena, inst);
+  SkidState* st = &states[inst];
+  PathOut* o = &out[inst];
+  double px = poses[4 * inst + 0], py = poses[4 * inst + 1], dx = poses[4 * inst + 2], dy = poses[4 * inst + 3];
+  int status = status_in[inst];
+  int fallback = 0, n_dense = 0;
+  if (lane < PATH_POINTS) {
+    S.prevx[lane] = st->prev[lane][1];
+    S.prevy[lane] = st->prev[lane][2];
+  }
+  __syncthreads();
+  const bool reloc = st->relocalized != 0;
+  const double rotation = st->rotation, tx = st->translation[0], ty = st->translation[1];
+  const double rcx = st->right_calc[0], rcy = st->right_calc[1];
+  int n1 = 0;
+  int new_index = st->index_along_path;
+  if (status == ST_OK) {
+    if (reloc) {
+      // full_pipeline.py:126-134: pose into the known map frame
+      double yaw = detm::det_atan2(dy, dx);
+      double sn, cs;
+      detm::det_sincos(rotation, sn, cs);
+      double qx = px + tx - T.ref_right[0], qy = py + ty - T.ref_right[1];
+      double rx = blas_dot2(qx, cs, qy, -sn), ry = blas_dot2(qx, sn, qy, cs);
+      px = rx + T.ref_right[0];
+      py = ry + T.ref_right[1];
+      yaw = yaw + rotation;
+      detm::det_sincos(yaw, dy, dx);
+      // SkidpadCalculatePath.fit_matches_as_spline (skidpad_calculate_path.py:49-71)
+      const int max_change = (int)(20 / T.mean_distance);
+      int lo = st->index_along_path - max_change;
+      lo = lo < 0 ? 0 : lo;
+      int hi = st->index_along_path + max_change;
+      hi = hi > T.n_path ? T.n_path : hi;
+      if (hi <= lo) {
+        status = ST_REF_UNDEFINED_PATH;
+      } else {
+        double bv = 0.0;
+        int bi = -1;
+        for (int i = lo + lane; i < hi; i += WAVE) {
+          double d = norm_axis(px - T.path[2 * i], py - T.path[2 * i + 1]);
+          if (bi < 0 || d < bv) {
+            bv = d;
+            bi = i;
+          }
+        }
+        wave_argmin(bv, bi);
+        new_index = bi;
+        int fin = bi + (int)(25 / T.mean_distance);
+        fin = fin > T.n_path ? T.n_path : fin;
+        n1 = fin - bi;
+        for (int i = lane; i < n1; i += WAVE) {
+          A.x[1 + i] = T.path[2 * (bi + i)];
+          A.y[1 + i] = T.path[2 * (bi + i) + 1];
+        }
+      }
+    } else {
+      // calculate_trivial_path (core_calculate_path.py:127-134): chord[1:] rotated by the car yaw, + position
+      double yaw = detm::det_atan2(dy, dx);
+      double sn, cs;
+      detm::det_sincos(yaw, sn, cs);
+      n1 = PATH_POINTS - 1;
+      if (lane < n1) {
+        double cxp = chord[2 * (lane + 1)], cyp = chord[2 * (lane + 1) + 1];
+        A.x[1 + lane] = blas_dot2(cxp, cs, cyp, -sn) + px;
+        A.y[1 + lane] = blas_dot2(cxp, sn, cyp, cs) + py;
+      }
+    }
+    __syncthreads();
+  }
+  if (status == ST_OK) status = finish_path(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
+  __syncthreads();
+  if (status == ST_OK) {
+    // previous_paths[-1] <- this result (map frame); then path xy back to the original frame (full_pipeline.py:178-194)
+    if (lane < PATH_POINTS) {
+      double u = o->path[lane][0], x = o->path[lane][1], y = o->path[lane][2], k = o->path[lane][3];
+      st->prev[lane][0] = u;
+      st->prev[lane][1] = x;
+      st->prev[lane][2] = y;
+      st->prev[lane][3] = k;
+      if (reloc) {
+        double sn, cs;
+        detm::det_sincos(-rotation, sn, cs);
+        double qx = x - tx - rcx, qy = y - ty - rcy;
+        o->path[lane][1] = blas_dot2(qx, cs, qy, -sn) + rcx;
+        o->path[lane][2] = blas_dot2(qx, sn, qy, cs) + rcy;
+      }
+    }
+    if (lane == 0) st->index_along_path = new_index;
+  } else if (lane < PATH_POINTS) {
+    for (int q = 0; q < 4; q++) o->path[lane][q] = NAN;
+  }
+  if (lane == 0) {
+    o->status = status;
+    o->fallback = fallback;
+    o->n_dense = n_dense;
+    o->pad = 0;
+    SkidInfo* fi = &info[inst];
+    fi->relocalized = reloc ? 1 : 0;
+    fi->index_along_path = (status == ST_OK) ? new_index : st->index_along_path;
+    fi->translation[0] = fi->translation[1] = fi->rotation = NAN;
+    if (reloc) {
+      // RelocalizationInformation.from_transform_function: images of (0,0) and (1,0)
+      double sn, cs;
+      detm::det_sincos(rotation, sn, cs);
+      double ax0 = 0.0 + tx - T.ref_right[0], ay0 = 0.0 + ty - T.ref_right[1];
+      double ax1 = 1.0 + tx - T.ref_right[0];
+      double o0x = blas_dot2(ax0, cs, ay0, -sn) + T.ref_right[0], o0y = blas_dot2(ax0, sn, ay0, cs) + T.ref_right[1];
+      double o1x = blas_dot2(ax1, cs, ay0, -sn) + T.ref_right[0], o1y = blas_dot2(ax1, sn, ay0, cs) + T.ref_right[1];
+      fi->translation[0] = o0x;
+      fi->translation[1] = o0y;
+      fi->rotation = atan2(o1y - o0y, o1x - o0x);
+    }
+  }
+}
+
+}  // namespace fsdp

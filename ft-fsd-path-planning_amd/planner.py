@@ -93,15 +93,28 @@ class PathPlanner:
             # reference README.md:24-27: off by default, changes results, meaningless for independent frames
             raise NotImplementedError("the experimental sorting cache is out of scope (SURVEY.md §2 row 15)")
         self.mission = MissionTypes(mission)
-        if self.mission in (MissionTypes.acceleration, MissionTypes.skidpad, MissionTypes.ebs_test):
-            raise NotImplementedError("missions with a relocalizer are not on the MI355X path yet (SURVEY.md §8f)")
-        self._ctx = _capi.Context(device=device, mission=int(self.mission))
+        if self.mission in (MissionTypes.acceleration, MissionTypes.ebs_test):
+            # AccelerationRelocalizer draws from an unseeded RNG (acceleration_relocalization.py:32): parity unpinnable
+            raise NotImplementedError("acceleration / ebs_test missions are out of scope (SURVEY.md §2 row 6b)")
         self.global_path = None
+        self._skid = None
+        self._skid_info = None
+        if self.mission == MissionTypes.skidpad:
+            from .skidpad import SkidpadBatch
+
+            self._skid = SkidpadBatch(1, device=device)  # stateful, like the reference's skidpad planner
+            self._ctx = self._skid._ctx
+        else:
+            self._ctx = _capi.Context(device=device, mission=int(self.mission))
 
     @property
     def relocalization_info(self):
-        """reference full_pipeline.py:209-217: None for missions without a relocalizer."""
-        return None
+        """reference full_pipeline.py:209-217: None without a relocalizer or before relocalization."""
+        if self._skid is None or self._skid_info is None or not int(self._skid_info["relocalized"]):
+            return None
+        from .skidpad import RelocalizationInformation
+
+        return RelocalizationInformation(np.array(self._skid_info["translation"]), float(self._skid_info["rotation"]))
 
     def set_global_path(self, global_path):  # reference full_pipeline.py:81-82
         if global_path is not None:
@@ -111,6 +124,8 @@ class PathPlanner:
     # ---- batched form -------------------------------------------------------------------
     def plan_batch(self, cone_offsets, cones_xyt, poses) -> np.ndarray:
         """Structured array (one row per frame, dtype _capi.RESULT_DTYPE)."""
+        if self._skid is not None:
+            raise RuntimeError("the skidpad mission is stateful: use skidpad.SkidpadBatch.step for batches of planner instances")
         return self._ctx.plan_batch(cone_offsets, cones_xyt, poses)
 
     # ---- reference-shaped single-frame call ---------------------------------------------
@@ -124,6 +139,20 @@ class PathPlanner:
         vehicle_direction = _direction_to_array(vehicle_direction)
         xyt = flatten_cones_by_type_array(cones)
         pose = np.concatenate([np.asarray(vehicle_position, dtype=np.float64).reshape(2), vehicle_direction])
+        if self._skid is not None:
+            # skidpad: stateful call; sorting and matching are skipped (full_pipeline.py:138-140)
+            res, info = self._skid.step(np.array([0, len(xyt)], np.int32), xyt, pose[None])
+            self._skid_info = info[0]
+            st = int(res[0]["status"])
+            if 100 <= st < 200:
+                raise ReferenceUndefinedError(st)
+            if st != 0:
+                raise _capi.FsdpError(f"device capacity exceeded (status {st}, see include/fsdp.h)")
+            path = np.array(res[0]["path"])
+            if not return_intermediate_results:
+                return path
+            e2, ei = np.zeros((0, 2)), np.zeros(0, dtype=int)
+            return (path, e2, e2.copy(), e2.copy(), e2.copy(), ei, ei.copy())
         r = self._ctx.plan_batch(np.array([0, len(xyt)], np.int32), xyt, pose[None])[0]
         st = int(r["status"])
         if 100 <= st < 200:

@@ -48,7 +48,8 @@ enum {
   FSDP_OVERFLOW_CONES = 201,
   FSDP_OVERFLOW_ENDS = 202,
   FSDP_OVERFLOW_PATH = 203,
-  FSDP_OVERFLOW_KNOTS = 204
+  FSDP_OVERFLOW_KNOTS = 204,
+  FSDP_OVERFLOW_CLUSTERS = 205 /* skidpad relocalization: more than 64 centre clusters */
 };
 
 /* path_fallback bits */
@@ -124,6 +125,33 @@ int fsdp_match_batch(fsdp_ctx* ctx, int n_frames, const double* sorted_left, con
 /* CalculatePath.run_path_calculation — inputs: the matching fields of `results` (left_v, right_v, l2r, r2l,
  * counts) and poses; fills path, path_fallback, n_dense, status. */
 int fsdp_path_batch(fsdp_ctx* ctx, int n_frames, const double* poses, fsdp_frame_result* results);
+
+/* ---- skidpad mission (BASELINE config 5): stateful planner instances ------------------------------------------------
+ * PathPlanner(MissionTypes.skidpad) keeps state across calls (relocalizer transform, SkidpadCalculatePath.index_along_path,
+ * previous path: full_pipeline.py:118-194, relocalization/*, calculate_path/skidpad_calculate_path.py).  A context created
+ * with mission = 2 holds n_instances independent planners; one fsdp_skidpad_step call = one
+ * calculate_path_in_global_frame call of every instance (instance i gets frame i of the batch). */
+typedef struct {
+  int32_t relocalized;       /* Relocalizer.is_relocalized after this call                                  */
+  int32_t index_along_path;  /* SkidpadCalculatePath.index_along_path                                       */
+  double translation[2];     /* PathPlanner.relocalization_info.translation (relocalization_information.py) */
+  double rotation;           /*                              .rotation                                        */
+} fsdp_skidpad_info;
+
+/* Constant inputs (data, not code): table_xy = the known skidpad path BASE_SKIDPAD_PATH (n_table,2)
+ * (relocalization/skidpad/skidpad_path_data.py); noise_randn = numpy.random.RandomState(42).randn(1140,3,2) flattened
+ * (circle_fit_powerset re-seeds on every call, skidpad_relocalizer.py:38,52); ref_centers = [right xy, left xy] of
+ * calculate_reference_centers_for_skidpad_path (:172-183); mean_distance = np.mean of the first 9 segment lengths of
+ * table_xy[::2] (skidpad_calculate_path.py:58).  The Python host computes the last three with NumPy. */
+int fsdp_skidpad_set_tables(fsdp_ctx* ctx, const double* table_xy, int n_table, const double* noise_randn, int n_noise,
+                            const double* ref_centers4, double mean_distance);
+/* (re)create n_instances fresh planners (PathPlanner.__init__ / "reset = construct a new object", README.md:153-154) */
+int fsdp_skidpad_reset(fsdp_ctx* ctx, int n_instances);
+/* one frame for every instance; results[i].path is in the caller's (original) frame like the reference's return value */
+int fsdp_skidpad_step(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offsets, const double* cones_xyt,
+                      const double* poses, fsdp_frame_result* results, fsdp_skidpad_info* info);
+/* time `iters` repetitions of the path kernel of the last step with HIP events (state is restored afterwards) */
+int fsdp_skidpad_time_path(fsdp_ctx* ctx, int iters, float* ms_total);
 
 /* The constant initial previous path (core_calculate_path.py:103-107), (40,4), as computed on the device. */
 int fsdp_default_path(fsdp_ctx* ctx, double* out40x4);

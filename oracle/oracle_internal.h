@@ -49,4 +49,12 @@ const double (*default_previous_path())[4];
 void calculate_path(const Pts& left_v, const Pts& right_v, const std::vector<int>& l2r, const std::vector<int>& r2l,
                     Vec2 pos, Vec2 dir, PathOut& out);
 
+void finish_path(Pts path_update, const Pts& prev_xy, Vec2 pos, Vec2 dir, PathOut& out);
+Pts almost_straight_path();
+void circle_fit(const Pts& p, double& ocx, double& ocy, double& orad);
+void do_all_mpc(const Pts& path_update, Vec2 pos, Vec2 dir, double out[][4], int* flags);
+double m_atan2(double y, double x);
+double m_cos(double a);
+double m_sin(double a);
+
 }  // namespace fsdo

@@ -18,9 +18,9 @@ namespace fsdo {
 // 0: libm (what NumPy calls; pins the oracle to the reference's golden vectors)
 // 1: deterministic correctly-rounded sin/cos/atan2 (det_math.h) — what the HIP kernels use, for exact GPU parity
 int g_math_mode = 0;
-static inline double m_atan2(double y, double x) { return g_math_mode ? detm::det_atan2(y, x) : std::atan2(y, x); }
-static inline double m_cos(double a) { return g_math_mode ? detm::det_cos(a) : std::cos(a); }
-static inline double m_sin(double a) { return g_math_mode ? detm::det_sin(a) : std::sin(a); }
+double m_atan2(double y, double x) { return g_math_mode ? detm::det_atan2(y, x) : std::atan2(y, x); }
+double m_cos(double a) { return g_math_mode ? detm::det_cos(a) : std::cos(a); }
+double m_sin(double a) { return g_math_mode ? detm::det_sin(a) : std::sin(a); }
 
 static const double SMOOTHING = 0.2, PREDICT_EVERY = 0.1;  // config.py:48
 static const int MAX_DEG = 3;
@@ -28,7 +28,7 @@ static const double MAX_DIST_VALID_PATH = 5.0, MPC_PATH_LENGTH = 20.0;  // confi
 static const int HORIZON = FSDO_PATH_POINTS;
 
 // utils/math_utils.py:579-646 circle_fit (hyper fit); returns (cx, cy, r)
-static void circle_fit(const Pts& p, double& ocx, double& ocy, double& orad) {
+void circle_fit(const Pts& p, double& ocx, double& ocy, double& orad) {
   const int n = (int)p.size();
   std::vector<double> X(n), Y(n), tmp(n);
   for (int i = 0; i < n; i++) {
@@ -325,7 +325,7 @@ static Pts remove_path_behind_car(const Pts& path, Vec2 pos) {
 struct FourColPath {};  // marker: remove_path_not_in_prediction_horizon returned the (40,4) previous path
 
 // core_calculate_path.py:380-417 do_all_mpc_parameter_calculations
-static void do_all_mpc(const Pts& path_update, Vec2 pos, Vec2 dir, double out[][4], int* flags) {
+void do_all_mpc(const Pts& path_update, Vec2 pos, Vec2 dir, double out[][4], int* flags) {
   if (path_update.empty()) throw RefUndefined{FSDO_REF_UNDEFINED_PATH};
   Pts p1 = connect_path_to_car(path_update, pos, dir);
   Pts p2 = extend_path(p1, pos, dir, flags);
@@ -440,6 +440,11 @@ void calculate_path(const Pts& left_v, const Pts& right_v, const std::vector<int
     Fitted f = spline_fit(prev_xy, SMOOTHING, PREDICT_EVERY);
     path_update = spline_predict(f, f.max_u);
   }
+  finish_path(path_update, prev_xy, pos, dir, out);
+}
+
+// core_calculate_path.py:555-575: overwrite-if-too-far, MPC step with its ValueError retry
+void finish_path(Pts path_update, const Pts& prev_xy, Vec2 pos, Vec2 dir, PathOut& out) {
   // overwrite_path_if_it_is_too_far_away :225-237
   if (path_update.empty()) throw RefUndefined{FSDO_REF_UNDEFINED_PATH};  // min() of empty
   {
@@ -463,6 +468,24 @@ void calculate_path(const Pts& left_v, const Pts& right_v, const std::vector<int
       throw RefUndefined{FSDO_REF_UNDEFINED_PATH};
     }
   }
+}
+
+// path_calculator_helpers.py:56-68 calculate_almost_straight_path (40 chord points)
+Pts almost_straight_path() {
+  const int NP = 40;
+  double max_angle = PI / 50;
+  double step = (std::fabs(max_angle) - 0.0) / (double)(NP - 1);
+  Rot rot(-(PI / 2));
+  Pts chord(NP);
+  for (int i = 0; i < NP; i++) {
+    double a = (double)i * step + 0.0;
+    if (i == NP - 1) a = std::fabs(max_angle);
+    double px = (std::cos(a) - 1.0) * 1000.0, py = (std::sin(a) - 0.0) * 1000.0;
+    Vec2 q = rot.apply(px, py);
+    q.y *= np_sign(max_angle);
+    chord[i] = q;
+  }
+  return chord;
 }
 
 }  // namespace fsdo

@@ -5,6 +5,7 @@
 #include "../../ft-fsd-path-planning_amd/csrc/sort_kernel.h"
 #include "../../ft-fsd-path-planning_amd/csrc/match_kernel.h"
 #include "../../ft-fsd-path-planning_amd/csrc/path_kernel.h"
+#include "../../ft-fsd-path-planning_amd/csrc/skidpad_kernel.h"
 
 #include <mutex>
 #include <vector>
@@ -64,6 +65,34 @@ void emu_match(int n_frames, const int32_t* offsets, const double* cones, const 
                fsdp::MatchOut* out) {
   emu::launch((unsigned)n_frames, 64, [&]() { fsdp::match_kernel(n_frames, offsets, cones, poses, sorted, out); });
 }
+int emu_sizeof_skid_state() { return (int)sizeof(fsdp::SkidState); }
+int emu_sizeof_skid_info() { return (int)sizeof(fsdp::SkidInfo); }
+
+// one skidpad step for n_inst planner instances (states updated in place)
+void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, const double* poses, fsdp::SkidState* states,
+                      const double* half_table, int n_path, const double* noise, int n_noise, const double* ref4,
+                      double mean_distance, fsdp::PathOut* out, fsdp::SkidInfo* info) {
+  std::call_once(g_once, build_default);
+  fsdp::SkidTables T;
+  T.path = half_table;
+  T.n_path = n_path;
+  T.noise = noise;
+  T.n_noise = n_noise;
+  T.ref_right[0] = ref4[0];
+  T.ref_right[1] = ref4[1];
+  T.ref_left[0] = ref4[2];
+  T.ref_left[1] = ref4[3];
+  T.mean_distance = mean_distance;
+  double chord[fsdp::PATH_POINTS][2];
+  fsdp::default_chord_points(chord);
+  std::vector<double> arena((size_t)3 * fsdp::PATH_CAP * n_inst);
+  std::vector<int32_t> status(n_inst, 0);
+  emu::launch((unsigned)n_inst, 64, [&]() { fsdp::skid_reloc_kernel(n_inst, offsets, cones, poses, states, T, arena.data(), status.data()); });
+  emu::launch((unsigned)n_inst, 64, [&]() {
+    fsdp::skid_path_kernel(n_inst, poses, states, T, &chord[0][0], arena.data(), status.data(), out, info);
+  });
+}
+
 void emu_default_path(double* out) {
   std::call_once(g_once, build_default);
   for (int i = 0; i < fsdp::PATH_POINTS * 4; i++) out[i] = g_default_path[i];

@@ -111,3 +111,37 @@ def plan(offsets, cones, poses):
     st = np.where(p["status"] != 0, p["status"], st)
     res["status"] = st
     return res, p["n_dense"]
+
+
+SKID_STATE_DTYPE = np.dtype(
+    [("has_original", "<i4"), ("relocalized", "<i4"), ("index_along_path", "<i4"), ("pad", "<i4"), ("orig", "<f8", (4,)),
+     ("translation", "<f8", (2,)), ("right_calc", "<f8", (2,)), ("rotation", "<f8"), ("prev", "<f8", (PATH_POINTS, 4))],
+    align=True,
+)
+SKID_INFO_DTYPE = np.dtype([("relocalized", "<i4"), ("index_along_path", "<i4"), ("translation", "<f8", (2,)), ("rotation", "<f8")], align=True)
+
+
+class SkidpadEmu:
+    """The skidpad kernels under the emulator: n planner instances, stateful."""
+
+    def __init__(self, n, table, noise, ref, mean_distance):
+        assert lib().emu_sizeof_skid_state() == SKID_STATE_DTYPE.itemsize and lib().emu_sizeof_skid_info() == SKID_INFO_DTYPE.itemsize
+        self.n = n
+        self.half = np.ascontiguousarray(table[::2], np.float64)
+        self.noise = np.ascontiguousarray(noise, np.float64).ravel()
+        self.ref = np.ascontiguousarray(ref, np.float64).ravel()
+        self.md = float(mean_distance)
+        self.states = np.zeros(n, SKID_STATE_DTYPE)
+        self.states["prev"] = default_path()
+
+    def step(self, offsets, cones, poses):
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        cones = np.ascontiguousarray(cones, np.float64).reshape(-1, 3)
+        poses = np.ascontiguousarray(poses, np.float64)
+        out = np.zeros(self.n, PATH_DTYPE)
+        info = np.zeros(self.n, SKID_INFO_DTYPE)
+        lib().emu_skidpad_step(
+            ctypes.c_int(self.n), _p(offsets, ctypes.c_int32), _p(cones), _p(poses), ctypes.c_void_p(self.states.ctypes.data),
+            _p(self.half), ctypes.c_int(len(self.half)), _p(self.noise), ctypes.c_int(len(self.noise)), _p(self.ref),
+            ctypes.c_double(self.md), ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(info.ctypes.data))
+        return out, info

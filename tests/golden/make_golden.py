@@ -240,7 +240,42 @@ def main():
         cdist=my_cdist_sq_euclidean(v[:40], v[:40]), rot=rotate(v, 0.7), rot_theta=np.array(0.7),
         sums=np.array([v[:k, 0].sum() for k in range(1, 400)]),
     )
+    skidpad_golden()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--skidpad-only" not in sys.argv:
     main()
+
+
+def skidpad_golden():
+    """demo/skidpad.json (341 frames) replayed through ONE reference PathPlanner(MissionTypes.skidpad): the stateful
+    sequence (relocalizes at frame 16).  Stored: inputs as CSR + per-frame path, relocalization info, index_along_path."""
+    import json
+
+    m = refharness.load()
+    d = json.load(open("/root/reference/fsd_path_planning/demo/skidpad.json"))
+    pp = m["PathPlanner"](m["MissionTypes"].skidpad)
+    cones_all, off, poses, paths, reloc, info, idx = [], [0], [], [], [], [], []
+    for f in d:
+        cones = [np.array(c, dtype=float).reshape(-1, 2) for c in f["slam_cones"]]
+        xyt = np.concatenate([np.column_stack([c, np.full(len(c), float(t))]) for t, c in enumerate(cones)])
+        pos, dr = np.array(f["car_position"], float), np.array(f["car_direction"], float)
+        path = pp.calculate_path_in_global_frame(cones, pos, dr)
+        cones_all.append(xyt.reshape(-1, 3))
+        off.append(off[-1] + len(xyt))
+        poses.append(np.concatenate([pos, dr]))
+        paths.append(np.array(path))
+        ri = pp.relocalization_info
+        reloc.append(ri is not None)
+        info.append([np.nan] * 3 if ri is None else [ri.translation[0], ri.translation[1], ri.rotation])
+        idx.append(pp.pathing.index_along_path)
+    np.savez_compressed(
+        HERE / "skidpad_sequence.npz", offsets=np.array(off, np.int32), cones=np.concatenate(cones_all), poses=np.array(poses),
+        path=np.array(paths), relocalized=np.array(reloc), info=np.array(info), index_along_path=np.array(idx, np.int32),
+        reference_centers=np.array(pp.relocalizer.reference_centers),
+    )
+    print("skidpad_sequence frames", len(d), "relocalized from frame", int(np.argmax(reloc)))
+
+
+if __name__ == "__main__" and "--skidpad-only" in sys.argv:
+    skidpad_golden()

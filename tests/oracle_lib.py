@@ -177,3 +177,33 @@ def splev(t, cx, cy, k, u_eval):
     oy = np.zeros(len(u_eval))
     lib().fsdo_splev(_p(t), _p(cx), _p(cy), ctypes.c_int(len(t)), ctypes.c_int(k), _p(u_eval), ctypes.c_long(len(u_eval)), _p(ox), _p(oy))
     return np.column_stack([ox, oy])
+
+
+class SkidpadPlanner:
+    """Stateful skidpad-mission oracle (oracle/skidpad.cpp).  table: BASE_SKIDPAD_PATH (n,2); noise: RandomState(42).randn(1140,3,2)."""
+
+    def __init__(self, table, noise):
+        table = np.ascontiguousarray(table, np.float64)
+        noise = np.ascontiguousarray(noise, np.float64).ravel()
+        L = lib()
+        L.fsdo_skidpad_create.restype = ctypes.c_void_p
+        self._h = ctypes.c_void_p(L.fsdo_skidpad_create(_p(table), ctypes.c_int(len(table)), _p(noise), ctypes.c_int(len(noise))))
+
+    def step(self, xyt, pose):
+        xyt = np.ascontiguousarray(xyt, np.float64).reshape(-1, 3)
+        pose = np.ascontiguousarray(pose, np.float64)
+        out = np.zeros(1, RESULT_DTYPE)
+        info = np.zeros(5)
+        lib().fsdo_skidpad_step(self._h, _p(xyt), ctypes.c_int(len(xyt)), _p(pose), ctypes.c_void_p(out.ctypes.data), _p(info))
+        return out[0], info
+
+    def reference_centers(self):
+        out = np.zeros(4)
+        lib().fsdo_skidpad_reference_centers(self._h, _p(out))
+        return out.reshape(2, 2)
+
+    def __del__(self):
+        try:
+            lib().fsdo_skidpad_destroy(self._h)
+        except Exception:
+            pass
