@@ -5,6 +5,7 @@
 lib/libfsdp_hip.so (hand-written HIP kernels, C ABI in include/fsdp.h).
 """
 from .planner import ConeTypes, MissionTypes, PathPlanner, ReferenceUndefinedError, flatten_cones_by_type_array, pack_frames  # noqa: F401
-from . import dist, skidpad, synth  # noqa: F401
+from . import dist, replay, skidpad, stages, synth  # noqa: F401
+from .stages import CalculatePath, ConeMatching, ConeSorting, ConeMatchingInput, ConeSortingInput, PathCalculationInput  # noqa: F401
 from .skidpad import SkidpadBatch  # noqa: F401
 from ._capi import Context, FsdpError, RESULT_DTYPE  # noqa: F401

@@ -56,6 +56,17 @@ class Dist:
         self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN)
         return bool(flag.item() == 1)
 
+    def broadcast_array(self, arr: np.ndarray | None, shape, src: int = 0) -> np.ndarray:
+        """Track-map broadcast: rank `src` owns the constant skidpad tables (known path 5786x2 f64 =
+        92 576 B, noise table, reference centres) and broadcasts them once at start-up; the other ranks pass arr=None."""
+        if self.world == 1:
+            return np.ascontiguousarray(arr, dtype=np.float64)
+        t = self._torch.zeros(tuple(shape), dtype=self._torch.float64, device=self.device)
+        if self.rank == src:
+            t.copy_(self._torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)))
+        self._dist.broadcast(t, src=src)
+        return t.cpu().numpy()
+
     def barrier(self):
         if self.world > 1:
             if self.backend == "nccl":

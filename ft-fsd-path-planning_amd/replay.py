@@ -1,0 +1,102 @@
+"""JSON replay loader + timing CLI — this build's counterpart of the reference's only benchmark harness
+(demo/json_demo.py: load_data_json :255-275, select_mission_by_filename :38-51, warm-up :89-94, timed per-frame
+loop :103-131).  Same file schema: a list of {"car_position":[x,y], "car_direction":[dx,dy], "slam_cones":[5 lists of [x,y]]}.
+
+  python -m fsd_path_planning_amd.replay --data-path fsg_19_2_laps.json [--remove-color-info] [--batched] [--output-path out.npz]
+
+Two replay modes:
+  per-frame : one PathPlanner, one calculate_path_in_global_frame call per frame, wall-clock per call (what the
+              reference's demo measures; for the skidpad mission this is the stateful sequence);
+  --batched : all frames of the recording as ONE batch of independent frames through plan_batch (fresh-planner
+              semantics per frame; trackdrive/autocross recordings only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import time
+from pathlib import Path
+from typing import List, Tuple
+
+import numpy as np
+
+from .planner import ConeTypes, MissionTypes, PathPlanner, pack_frames
+
+
+def select_mission_by_filename(filename: str) -> MissionTypes:
+    """"skidpad" in the name -> skidpad, "accel" -> acceleration, else trackdrive (json_demo.py:38-51)."""
+    if "skidpad" in filename:
+        return MissionTypes.skidpad
+    if "accel" in filename:
+        return MissionTypes.acceleration
+    return MissionTypes.trackdrive
+
+
+def load_data_json(data_path: Path, remove_color_info: bool = False) -> Tuple[np.ndarray, np.ndarray, List[List[np.ndarray]]]:
+    data = json.loads(Path(data_path).read_text())
+    positions = np.array([d["car_position"] for d in data], dtype=float).reshape(-1, 2)
+    directions = np.array([d["car_direction"] for d in data], dtype=float).reshape(-1, 2)
+    observations = [[np.array(c, dtype=float).reshape(-1, 2) for c in d["slam_cones"]] for d in data]
+    if remove_color_info:
+        stripped = []
+        for cones in observations:
+            new = [np.zeros((0, 2)) for _ in range(5)]
+            new[int(ConeTypes.UNKNOWN)] = np.concatenate([c.reshape(-1, 2) for c in cones], axis=0)  # stacked in type order
+            stripped.append(new)
+        observations = stripped
+    return positions, directions, observations
+
+
+def replay_per_frame(mission, positions, directions, observations, device=None):
+    warm = PathPlanner(mission, device=device)  # warm-up on a throw-away planner (json_demo.py:89-94)
+    warm.calculate_path_in_global_frame(observations[0], positions[0], directions[0])
+    planner = PathPlanner(mission, device=device)
+    paths, times, reloc_frame = [], [], None
+    for i, (p, d, c) in enumerate(zip(positions, directions, observations)):
+        if reloc_frame is None and planner.relocalization_info is not None:
+            reloc_frame = i
+        t0 = time.perf_counter()
+        paths.append(planner.calculate_path_in_global_frame(c, p, d))
+        times.append(time.perf_counter() - t0)
+    return np.array(paths), np.array(times), reloc_frame, planner.relocalization_info
+
+
+def replay_batched(mission, positions, directions, observations, device=None, repeats: int = 5):
+    planner = PathPlanner(mission, device=device)
+    off, cones, poses = pack_frames(list(zip(observations, positions, directions)))
+    planner.plan_batch(off, cones, poses)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        res = planner.plan_batch(off, cones, poses)
+    return res, (time.perf_counter() - t0) / repeats
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--data-path", "-i", type=Path, required=True)
+    ap.add_argument("--remove-color-info", action="store_true")
+    ap.add_argument("--batched", action="store_true")
+    ap.add_argument("--output-path", "-o", type=Path, default=None)
+    ap.add_argument("--device", type=int, default=None)
+    a = ap.parse_args(argv)
+    mission = select_mission_by_filename(a.data_path.name)
+    positions, directions, observations = load_data_json(a.data_path, a.remove_color_info)
+    out = {"file": str(a.data_path), "mission": mission.name, "frames": len(positions)}
+    if a.batched:
+        res, sec = replay_batched(mission, positions, directions, observations, a.device)
+        out.update(mode="batched", seconds_per_batch=sec, frames_per_s=len(res) / sec,
+                   status_histogram={int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))})
+        paths = res["path"]
+    else:
+        paths, times, reloc_frame, info = replay_per_frame(mission, positions, directions, observations, a.device)
+        out.update(mode="per-frame", p50_us=float(np.median(times) * 1e6), mean_us=float(times.mean() * 1e6),
+                   max_us=float(times.max() * 1e6), frames_over_100ms=int((times > 0.1).sum()), relocalized_at_frame=reloc_frame)
+        if info is not None:
+            out.update(translation=[float(x) for x in info.translation], rotation_deg=float(np.rad2deg(info.rotation)))
+    if a.output_path:
+        np.savez_compressed(a.output_path, path=paths)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

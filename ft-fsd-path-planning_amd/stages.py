@@ -1,0 +1,155 @@
+"""The three stage classes the reference exposes individually (README.md:78-79), with the same 3-call protocol
+``set_new_input(Input dataclass) -> run_*()`` and the same return tuples, backed by the stage-level C-ABI entry
+points (fsdp_sort_batch / fsdp_match_batch / fsdp_path_batch):
+
+  ConeSorting   sorting_cones/core_cone_sorting.py:21-136
+  ConeMatching  cone_matching/core_cone_matching.py:26-124
+  CalculatePath calculate_path/core_calculate_path.py:36-60,514-575   (fresh-planner semantics)
+
+Only the reference's default parameters (config.py) are compiled into the kernels; other values are rejected.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+
+from . import _capi
+from .planner import ConeTypes, ReferenceUndefinedError, flatten_cones_by_type_array
+
+_shared_ctx = {}
+
+
+def _ctx(device=None):
+    key = device
+    if key not in _shared_ctx:
+        _shared_ctx[key] = _capi.Context(device=device, mission=4)
+    return _shared_ctx[key]
+
+
+def _check(status):
+    status = int(status)
+    if 100 <= status < 200:
+        raise ReferenceUndefinedError(status)
+    if status != 0:
+        raise _capi.FsdpError(f"device capacity exceeded (status {status})")
+
+
+@dataclass
+class ConeSortingInput:
+    slam_cones: List[np.ndarray] = field(default_factory=lambda: [np.zeros((0, 2)) for _ in ConeTypes])
+    slam_position: np.ndarray = field(default_factory=lambda: np.zeros(2))
+    slam_direction: np.ndarray = field(default_factory=lambda: np.zeros(2))
+
+
+class ConeSorting:
+    """Default parameters of config.py:33-41 (max_n_neighbors 5, max_dist 6.5, max_dist_to_first 6.0, max_length 12,
+    thresholds 40/65 deg, use_unknown_cones True)."""
+
+    DEFAULTS = dict(max_n_neighbors=5, max_dist=6.5, max_dist_to_first=6.0, max_length=12,
+                    threshold_directional_angle=np.deg2rad(40), threshold_absolute_angle=np.deg2rad(65), use_unknown_cones=True)
+
+    def __init__(self, device=None, **kwargs):
+        for k, v in kwargs.items():
+            if k == "experimental_performance_improvements" and not v:
+                continue
+            if k not in self.DEFAULTS or self.DEFAULTS[k] != v:
+                raise NotImplementedError(f"only the reference defaults are compiled into the kernel ({k}={v!r})")
+        self.input = ConeSortingInput()
+        self._device = device
+
+    def set_new_input(self, slam_input: ConeSortingInput) -> None:
+        self.input = slam_input
+
+    def run_cone_sorting(self) -> Tuple[np.ndarray, np.ndarray]:
+        xyt = flatten_cones_by_type_array(self.input.slam_cones)
+        pose = np.concatenate([np.asarray(self.input.slam_position, float).reshape(2), np.asarray(self.input.slam_direction, float).reshape(2)])
+        r = _ctx(self._device).sort_batch(np.array([0, len(xyt)], np.int32), xyt, pose[None])[0]
+        _check(r["status"])
+        self.last_result = r
+        return xyt[r["left_idx"][: r["n_left"]], :2], xyt[r["right_idx"][: r["n_right"]], :2]
+
+
+@dataclass
+class ConeMatchingInput:
+    sorted_cones: List[np.ndarray] = field(default_factory=lambda: [np.zeros((0, 2)) for _ in ConeTypes])
+    slam_position: np.ndarray = field(default_factory=lambda: np.zeros(2))
+    slam_direction: np.ndarray = field(default_factory=lambda: np.zeros(2))
+
+
+class ConeMatching:
+    """Default parameters of config.py:124-129,162 (min_track_width 3, max_search_range 5, max_search_angle 50 deg,
+    matches_should_be_monotonic False — the pipeline's choice, full_pipeline.py:65)."""
+
+    DEFAULTS = dict(min_track_width=3, max_search_range=5, max_search_angle=np.deg2rad(50), matches_should_be_monotonic=False)
+
+    def __init__(self, device=None, **kwargs):
+        for k, v in kwargs.items():
+            if k not in self.DEFAULTS or self.DEFAULTS[k] != v:
+                raise NotImplementedError(f"only the pipeline's defaults are compiled into the kernel ({k}={v!r})")
+        self.input = ConeMatchingInput()
+        self._device = device
+
+    def set_new_input(self, cone_matching_input: ConeMatchingInput) -> None:
+        self.input = cone_matching_input
+
+    def run_cone_matching(self):
+        left = np.asarray(self.input.sorted_cones[int(ConeTypes.LEFT)], float).reshape(-1, 2)
+        right = np.asarray(self.input.sorted_cones[int(ConeTypes.RIGHT)], float).reshape(-1, 2)
+        if len(left) > 12 or len(right) > 12:
+            raise _capi.FsdpError("at most 12 sorted cones per side (config.py:36 max_length)")
+        sl, sr = np.zeros((1, 12, 2)), np.zeros((1, 12, 2))
+        sl[0, : len(left)], sr[0, : len(right)] = left, right
+        pose = np.concatenate([np.asarray(self.input.slam_position, float).reshape(2), np.asarray(self.input.slam_direction, float).reshape(2)])
+        r = _ctx(self._device).match_batch(sl, [len(left)], sr, [len(right)], pose[None])[0]
+        _check(r["status"])
+        self.last_result = r
+        ml, mr = int(r["n_left_v"]), int(r["n_right_v"])
+        return (np.array(r["left_v"][:ml]), np.array(r["right_v"][:mr]), np.array(r["l2r"][:ml], dtype=np.int64), np.array(r["r2l"][:mr], dtype=np.int64))
+
+
+@dataclass
+class PathCalculationInput:
+    left_cones: np.ndarray = field(default_factory=lambda: np.zeros((0, 2)))
+    right_cones: np.ndarray = field(default_factory=lambda: np.zeros((0, 2)))
+    left_to_right_matches: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    right_to_left_matches: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    position_global: np.ndarray = field(default_factory=lambda: np.zeros(2))
+    direction_global: np.ndarray = field(default_factory=lambda: np.array([1.0, 0.0]))
+    global_path: np.ndarray | None = None
+
+
+class CalculatePath:
+    """Defaults of config.py:48,55-59 (smoothing 0.2, predict_every 0.1, max_deg 3, max valid distance 5 m, MPC length
+    20 m, horizon 40).  Each call starts from the constant initial previous path (fresh-planner semantics)."""
+
+    DEFAULTS = dict(smoothing=0.2, predict_every=0.1, max_deg=3, maximal_distance_for_valid_path=5, mpc_path_length=20, mpc_prediction_horizon=40)
+
+    def __init__(self, device=None, **kwargs):
+        for k, v in kwargs.items():
+            if k not in self.DEFAULTS or self.DEFAULTS[k] != v:
+                raise NotImplementedError(f"only the reference defaults are compiled into the kernel ({k}={v!r})")
+        self.input = PathCalculationInput()
+        self._device = device
+
+    def set_new_input(self, new_input: PathCalculationInput) -> None:
+        self.input = new_input
+
+    def run_path_calculation(self):
+        i = self.input
+        if i.global_path is not None:
+            raise NotImplementedError("global_path belongs to the skidpad mission: use PathPlanner(MissionTypes.skidpad)")
+        res = np.zeros(1, dtype=_capi.RESULT_DTYPE)
+        lv, rv = np.asarray(i.left_cones, float).reshape(-1, 2), np.asarray(i.right_cones, float).reshape(-1, 2)
+        if len(lv) > 24 or len(rv) > 24:
+            raise _capi.FsdpError("at most 24 cones per side")
+        res["n_left_v"], res["n_right_v"] = len(lv), len(rv)
+        res["left_v"][0, : len(lv)], res["right_v"][0, : len(rv)] = lv, rv
+        res["l2r"][0, : len(lv)] = np.asarray(i.left_to_right_matches, dtype=np.int32)
+        res["r2l"][0, : len(rv)] = np.asarray(i.right_to_left_matches, dtype=np.int32)
+        pose = np.concatenate([np.asarray(i.position_global, float).reshape(2), np.asarray(i.direction_global, float).reshape(2)])
+        out = _ctx(self._device).path_batch(pose[None], res)[0]
+        _check(out["status"])
+        self.last_result = out
+        return np.array(out["path"]), None

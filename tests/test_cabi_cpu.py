@@ -57,3 +57,27 @@ def test_host_side_packing(pkg):
     with pytest.raises(ValueError):
         pkg.planner._direction_to_array([1.0, 2.0, 3.0])
     assert int(pkg.ConeTypes.LEFT) == 2 and int(pkg.ConeTypes.YELLOW) == 1 and int(pkg.MissionTypes.trackdrive) == 4
+
+
+def test_replay_loader_matches_reference_schema(pkg, golden_dir, tmp_path):
+    """load_data_json / remove_color_info / mission-by-filename mirror demo/json_demo.py:38-51,255-275 (own code)."""
+    import json
+
+    g = np.load(golden_dir / "skidpad_sequence.npz")
+    frames = []
+    for t in range(5, 30):
+        xyt = g["cones"][g["offsets"][t] : g["offsets"][t + 1]]
+        frames.append({"car_position": g["poses"][t, :2].tolist(), "car_direction": g["poses"][t, 2:].tolist(),
+                       "slam_cones": [xyt[xyt[:, 2] == k, :2].tolist() for k in range(5)]})
+    f = tmp_path / "my_skidpad_run.json"
+    f.write_text(json.dumps(frames))
+    pos, dirs, obs = pkg.replay.load_data_json(f)
+    assert pos.shape == (25, 2) and dirs.shape == (25, 2) and len(obs) == 25 and len(obs[0]) == 5
+    assert all(o.shape[1] == 2 for o in obs[3])
+    pos2, dirs2, obs2 = pkg.replay.load_data_json(f, remove_color_info=True)
+    for a, b in zip(obs, obs2):
+        assert sum(len(x) for x in a) == len(b[0]) and all(len(x) == 0 for x in b[1:])
+        assert np.array_equal(np.concatenate(a), b[0])  # stacked in type order
+    assert pkg.replay.select_mission_by_filename(f.name) == pkg.MissionTypes.skidpad
+    assert pkg.replay.select_mission_by_filename("accel_run.json") == pkg.MissionTypes.acceleration
+    assert pkg.replay.select_mission_by_filename("fsg_19_2_laps.json") == pkg.MissionTypes.trackdrive

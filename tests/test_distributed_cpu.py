@@ -27,6 +27,10 @@ def _worker(rank, world, port, table, tamper, q):
     if tamper and rank == 1:
         mine[3, 2] += 1e-12
     same = d.broadcast_check_table(mine)
+    # track-map broadcast: only rank 0 holds the skidpad path table
+    tbl = pkg.skidpad.load_tables()[0] if rank == 0 else None
+    got = d.broadcast_array(tbl, (5786, 2))
+    assert got.shape == (5786, 2) and np.array_equal(got, pkg.skidpad.load_tables()[0])
     lo, hi = d.frame_range(10)
     d.barrier()
     mx = d.max_over_ranks(float(rank + 1))

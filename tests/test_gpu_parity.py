@@ -186,3 +186,48 @@ def test_stage_entry_points(pkg, ctx, golden_dir):
         assert np.array_equal(m[f], full[f]), f
     p = ctx.path_batch(g["poses"], m.copy())
     assert np.array_equal(p["path"], full["path"])
+
+
+def test_stage_classes_mirror_reference_protocol(pkg, golden_dir):
+    """ConeSorting / ConeMatching / CalculatePath with set_new_input -> run_* (README.md:78-79 of the reference)."""
+    g = np.load(golden_dir / "scenarios.npz")
+    for k in (2, 9, 12):
+        xyt = g["cones"][g["offsets"][k] : g["offsets"][k + 1]]
+        pose = g["poses"][k]
+        cs = pkg.ConeSorting(max_n_neighbors=5, max_dist=6.5, max_length=12)
+        cs.set_new_input(pkg.ConeSortingInput(xyt, pose[:2], pose[2:]))
+        sl, sr = cs.run_cone_sorting()
+        nl, nr = g["n_left"][k], g["n_right"][k]
+        assert np.array_equal(sl, xyt[g["left_idx"][k][:nl], :2]) and np.array_equal(sr, xyt[g["right_idx"][k][:nr], :2])
+        cm = pkg.ConeMatching(min_track_width=3, matches_should_be_monotonic=False)
+        sc = [np.zeros((0, 2)) for _ in range(5)]
+        sc[int(pkg.ConeTypes.LEFT)], sc[int(pkg.ConeTypes.RIGHT)] = sl, sr
+        cm.set_new_input(pkg.ConeMatchingInput(sc, pose[:2], pose[2:]))
+        lv, rv, l2r, r2l = cm.run_cone_matching()
+        ml, mr = g["n_left_v"][k], g["n_right_v"][k]
+        assert np.array_equal(lv, g["left_v"][k][:ml]) and np.array_equal(rv, g["right_v"][k][:mr])
+        assert np.array_equal(l2r, g["l2r"][k][:ml]) and np.array_equal(r2l, g["r2l"][k][:mr])
+        cp = pkg.CalculatePath(smoothing=0.2, mpc_path_length=20)
+        cp.set_new_input(pkg.PathCalculationInput(lv, rv, l2r, r2l, pose[:2], pose[2:]))
+        path, _ = cp.run_path_calculation()
+        assert np.abs(path - g["path"][k]).max() < 1e-5 or parity.is_sample_count_flip(path, g["path"][k])
+    with pytest.raises(NotImplementedError):
+        pkg.ConeSorting(max_dist=7.0)
+
+
+def test_replay_cli_roundtrip(pkg, golden_dir, tmp_path):
+    import json
+
+    g = np.load(golden_dir / "cfg2_color.npz")
+    frames = []
+    for t in range(16):
+        xyt = g["cones"][g["offsets"][t] : g["offsets"][t + 1]]
+        frames.append({"car_position": g["poses"][t, :2].tolist(), "car_direction": g["poses"][t, 2:].tolist(),
+                       "slam_cones": [xyt[xyt[:, 2] == k, :2].tolist() for k in range(5)]})
+    f = tmp_path / "replay.json"
+    f.write_text(json.dumps(frames))
+    pos, dirs, obs = pkg.replay.load_data_json(f)
+    paths, times, reloc, info = pkg.replay.replay_per_frame(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0)
+    res, sec = pkg.replay.replay_batched(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0, repeats=1)
+    assert np.array_equal(paths, res["path"]) and reloc is None and info is None
+    assert np.abs(paths - g["path"][:16]).max() < 1e-5
