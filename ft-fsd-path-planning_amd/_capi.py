@@ -78,6 +78,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
     "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
+    "fsdp_plan_batch_sequential", "fsdp_set_previous_paths",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
 ]
 
@@ -132,6 +133,15 @@ class Context:
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
         out = np.zeros(n, dtype=RESULT_DTYPE)
         self._check(self._lib.fsdp_plan_batch(self._h, n, _ip(offsets), _dp(cones), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_plan_batch")
+        self.n_frames = n
+        return out
+
+    def plan_batch_sequential(self, offsets, cones, poses, prev_paths) -> np.ndarray:
+        """plan_batch with a per-frame previous path (n_frames,40,4): the stateful fallbacks of the reference."""
+        offsets, cones, poses, n = self._prep(offsets, cones, poses)
+        prev = np.ascontiguousarray(prev_paths, dtype=np.float64).reshape(n, PATH_POINTS, 4)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        self._check(self._lib.fsdp_plan_batch_sequential(self._h, n, _ip(offsets), _dp(cones), _dp(poses), _dp(prev), ctypes.c_void_p(out.ctypes.data)), "fsdp_plan_batch_sequential")
         self.n_frames = n
         return out
 

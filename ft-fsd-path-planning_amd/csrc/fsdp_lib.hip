@@ -44,6 +44,8 @@ struct fsdp_ctx {
   double* d_default_path = nullptr;  // (40,4)
   double* d_arena = nullptr;         // per-frame working polyline (3 x PATH_CAP doubles), HBM/L2 scratch
   double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
+  double* d_prev = nullptr;          // optional per-frame previous paths (n_frames,40,4) for sequential replays
+  bool use_prev = false;
   // skidpad mission
   double* d_table = nullptr;
   double* d_noise = nullptr;
@@ -78,6 +80,9 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
     if (c->d_match) (void)hipFree(c->d_match);
     if (c->d_path) (void)hipFree(c->d_path);
     if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->d_prev) (void)hipFree(c->d_prev);
+    c->d_prev = nullptr;
+    c->use_prev = false;
     c->d_arena = nullptr;
     c->d_off = nullptr;
     c->d_poses = nullptr;
@@ -91,6 +96,7 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
     HIP_TRY(c, hipMalloc(&c->d_match, sizeof(MatchOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_path, sizeof(PathOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_arena, sizeof(double) * 3 * PATH_CAP * (size_t)n_frames));
+    HIP_TRY(c, hipMalloc(&c->d_prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n_frames));
     c->cap_frames = n_frames;
   }
   if (n_cones > c->cap_cones) {
@@ -114,7 +120,7 @@ static void launch_match(fsdp_ctx* c) {
 }
 static void launch_path(fsdp_ctx* c) {
   hipLaunchKernelGGL(path_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_poses, c->d_match,
-                     c->d_default_path, c->d_arena, c->d_path);
+                     c->d_default_path, c->use_prev ? c->d_prev : nullptr, c->d_arena, c->d_path);
 }
 
 static void assemble(const SortOut* s, const MatchOut* m, const PathOut* p, fsdp_frame_result* r) {
@@ -226,6 +232,7 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_match);
   (void)hipFree(c->d_path);
   (void)hipFree(c->d_arena);
+  (void)hipFree(c->d_prev);
   (void)hipFree(c->d_chord);
   (void)hipFree(c->d_table);
   (void)hipFree(c->d_noise);
@@ -291,6 +298,34 @@ int fsdp_download(fsdp_ctx* c, fsdp_frame_result* results) {
     assemble(&c->h_sort[i], &c->h_match[i], &c->h_path[i], &results[i]);
   }
   return 0;
+}
+
+int fsdp_set_previous_paths(fsdp_ctx* c, const double* prev_paths) {
+  if (!c) return 1;
+  if (!prev_paths) {
+    c->use_prev = false;
+    return 0;
+  }
+  if (c->n_frames <= 0 || !c->d_prev) {
+    c->err = "fsdp_set_previous_paths: upload a batch first";
+    return 1;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_prev, prev_paths, sizeof(double) * PATH_POINTS * 4 * (size_t)c->n_frames, hipMemcpyHostToDevice,
+                            c->stream));
+  c->use_prev = true;
+  return 0;
+}
+
+int fsdp_plan_batch_sequential(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses,
+                               const double* prev_paths, fsdp_frame_result* results) {
+  int rc = fsdp_upload(c, n_frames, off, cones, poses);
+  if (rc) return rc;
+  rc = fsdp_set_previous_paths(c, prev_paths);
+  if (rc) return rc;
+  rc = fsdp_run(c);
+  c->use_prev = false;
+  if (rc) return rc;
+  return fsdp_download(c, results);
 }
 
 int fsdp_plan_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses,

@@ -635,7 +635,8 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
 
 __global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double* __restrict__ poses,
                                                   const MatchOut* __restrict__ matched,
-                                                  const double* __restrict__ default_path, double* __restrict__ arena,
+                                                  const double* __restrict__ default_path,
+                                                  const double* __restrict__ prev_paths, double* __restrict__ arena,
                                                   PathOut* __restrict__ out) {
   __shared__ PathShared S;
   const int frame = blockIdx.x;
@@ -648,9 +649,12 @@ __global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double*
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
   int status = mo->status;
   int fallback = 0, n_dense = 0;
+  // previous_paths[-1]: the constant initial path (fresh planner) or, for sequential replays, the caller-supplied
+  // previous output of this planner (core_calculate_path.py:572-573)
+  const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
   if (lane < PATH_POINTS) {
-    S.prevx[lane] = default_path[4 * lane + 1];
-    S.prevy[lane] = default_path[4 * lane + 2];
+    S.prevx[lane] = prev[4 * lane + 1];
+    S.prevy[lane] = prev[4 * lane + 2];
   }
   __syncthreads();
   const int nl = mo->n_left_v, nr = mo->n_right_v;

@@ -88,7 +88,8 @@ class PathPlanner:
     (full_pipeline.py:84-207); ``plan_batch`` is the batched form of the same call.
     """
 
-    def __init__(self, mission: MissionTypes, experimental_performance_improvements: bool = False, device: int | None = None):
+    def __init__(self, mission: MissionTypes, experimental_performance_improvements: bool = False, device: int | None = None,
+                 stateful: bool = True):
         if experimental_performance_improvements:
             # reference README.md:24-27: off by default, changes results, meaningless for independent frames
             raise NotImplementedError("the experimental sorting cache is out of scope (SURVEY.md §2 row 15)")
@@ -97,6 +98,10 @@ class PathPlanner:
             # AccelerationRelocalizer draws from an unseeded RNG (acceleration_relocalization.py:32): parity unpinnable
             raise NotImplementedError("acceleration / ebs_test missions are out of scope (SURVEY.md §2 row 6b)")
         self.global_path = None
+        # like the reference object, consecutive calls chain the previous path (core_calculate_path.py:572-573);
+        # stateful=False gives every call a fresh planner (what plan_batch does for every frame)
+        self.stateful = stateful
+        self._prev = None
         self._skid = None
         self._skid_info = None
         if self.mission == MissionTypes.skidpad:
@@ -153,13 +158,19 @@ class PathPlanner:
                 return path
             e2, ei = np.zeros((0, 2)), np.zeros(0, dtype=int)
             return (path, e2, e2.copy(), e2.copy(), e2.copy(), ei, ei.copy())
-        r = self._ctx.plan_batch(np.array([0, len(xyt)], np.int32), xyt, pose[None])[0]
+        off1 = np.array([0, len(xyt)], np.int32)
+        if self.stateful and self._prev is not None:
+            r = self._ctx.plan_batch_sequential(off1, xyt, pose[None], self._prev[None])[0]
+        else:
+            r = self._ctx.plan_batch(off1, xyt, pose[None])[0]
         st = int(r["status"])
         if 100 <= st < 200:
             raise ReferenceUndefinedError(st)
         if st != 0:
             raise _capi.FsdpError(f"device capacity exceeded (status {st}, see include/fsdp.h)")
         path = np.array(r["path"])
+        if self.stateful:
+            self._prev = path.copy()
         if not return_intermediate_results:
             return path
         nl, nr = int(r["n_left"]), int(r["n_right"])

@@ -103,6 +103,14 @@ const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creat
 int fsdp_plan_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
                     const double* poses, fsdp_frame_result* results);
 
+/* Sequential-replay form: frame i additionally gets prev_paths[i] (40,4) = the path this planner returned for its previous
+ * frame, i.e. CalculatePath.previous_paths[-1] (core_calculate_path.py:203,219-221,236,531-536,568-573).  prev_paths NULL =
+ * fresh planners (identical to fsdp_plan_batch).  Typical use: n_frames = number of cars advanced in lock-step. */
+int fsdp_plan_batch_sequential(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
+                               const double* poses, const double* prev_paths, fsdp_frame_result* results);
+/* the resident form of the above: applies to the next fsdp_run calls until reset with NULL */
+int fsdp_set_previous_paths(fsdp_ctx* ctx, const double* prev_paths);
+
 /* The same in three steps so a caller (bench, pipelined replay) can keep inputs resident in HBM. */
 int fsdp_upload(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses);
 int fsdp_run(fsdp_ctx* ctx);      /* enqueue sorting, matching, path kernels on the context stream (async) */

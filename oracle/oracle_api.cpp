@@ -121,7 +121,12 @@ void fsdo_path(const double* left_v, int nl, const double* right_v, int nr, cons
   }
 }
 
-void fsdo_plan_frame(const double* xyt, int n, const double* pose, fsdo_frame_result* o) {
+void fsdo_plan_frame_prev(const double* xyt, int n, const double* pose, const double* prev40x4, fsdo_frame_result* o);
+
+void fsdo_plan_frame(const double* xyt, int n, const double* pose, fsdo_frame_result* o) { fsdo_plan_frame_prev(xyt, n, pose, nullptr, o); }
+
+// sequential-replay form: prev40x4 = the previous output of this planner (CalculatePath.previous_paths[-1]) or NULL
+void fsdo_plan_frame_prev(const double* xyt, int n, const double* pose, const double* prev40x4, fsdo_frame_result* o) {
   clear_result(o);
   try {
     Frame f = make_frame(xyt, n, pose);
@@ -136,7 +141,7 @@ void fsdo_plan_frame(const double* xyt, int n, const double* pose, fsdo_frame_re
     match_cones(sl, sr, Vec2{f.px, f.py}, lv, rv, l2r, r2l);
     fill_match(lv, rv, l2r, r2l, o);
     PathOut po;
-    calculate_path(lv, rv, l2r, r2l, Vec2{f.px, f.py}, Vec2{f.dx, f.dy}, po);
+    calculate_path(lv, rv, l2r, r2l, Vec2{f.px, f.py}, Vec2{f.dx, f.dy}, po, (const double(*)[4])prev40x4);
     std::memcpy(o->path, po.p, sizeof(po.p));
     o->path_fallback = po.fallback;
   } catch (RefUndefined& e) {

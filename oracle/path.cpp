@@ -390,8 +390,8 @@ const double (*default_previous_path())[4] {
 
 // core_calculate_path.py:514-575 run_path_calculation (global_path is None)
 void calculate_path(const Pts& left_v, const Pts& right_v, const std::vector<int>& l2r, const std::vector<int>& r2l,
-                    Vec2 pos, Vec2 dir, PathOut& out) {
-  const double(*prev)[4] = default_previous_path();
+                    Vec2 pos, Vec2 dir, PathOut& out, const double (*prev_in)[4]) {
+  const double(*prev)[4] = prev_in ? prev_in : default_previous_path();
   Pts prev_xy(HORIZON);
   for (int i = 0; i < HORIZON; i++) prev_xy[i] = Vec2{prev[i][1], prev[i][2]};
   out.fallback = 0;

@@ -11,6 +11,7 @@
 #include <vector>
 
 static double g_default_path[fsdp::PATH_POINTS * 4];
+static const double* g_prev_paths = nullptr;
 static std::once_flag g_once;
 static void build_default() {
   double chord[fsdp::PATH_POINTS][2];
@@ -93,6 +94,8 @@ void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, c
   });
 }
 
+void emu_set_prev_paths(const double* p) { g_prev_paths = p; }
+
 void emu_default_path(double* out) {
   std::call_once(g_once, build_default);
   for (int i = 0; i < fsdp::PATH_POINTS * 4; i++) out[i] = g_default_path[i];
@@ -100,6 +103,6 @@ void emu_default_path(double* out) {
 void emu_path(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
   std::call_once(g_once, build_default);
   std::vector<double> arena((size_t)3 * fsdp::PATH_CAP * n_frames);
-  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, arena.data(), out); });
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, g_prev_paths, arena.data(), out); });
 }
 }

@@ -243,8 +243,9 @@ def main():
     skidpad_golden()
 
 
-if __name__ == "__main__" and "--skidpad-only" not in sys.argv:
+if __name__ == "__main__" and "--skidpad-only" not in sys.argv and "--sequence-only" not in sys.argv:
     main()
+    trackdrive_sequence_golden()
 
 
 def skidpad_golden():
@@ -279,3 +280,40 @@ def skidpad_golden():
 
 if __name__ == "__main__" and "--skidpad-only" in sys.argv:
     skidpad_golden()
+
+
+def trackdrive_sequence_golden():
+    """ONE reference PathPlanner(trackdrive) driven along a synthetic loop for 90 consecutive frames with cone drop-outs,
+    so that the stateful previous-path fallbacks (core_calculate_path.py:203,531-536,568-573) are exercised."""
+    m = refharness.load()
+    rng = np.random.default_rng(21)
+    left, right, centre_fn = synth.closed_track(40, 21)
+    left = left + rng.normal(0, 0.1, left.shape)
+    right = right + rng.normal(0, 0.1, right.shape)
+    pp = m["PathPlanner"](m["MissionTypes"].trackdrive)
+    cones_all, off, poses, paths, ok = [], [0], [], [], []
+    for t in range(90):
+        pos, tan = centre_fn(0.1 + t * 0.0035)
+        l, r = left, right
+        if t % 9 in (4, 5):  # perception drop-out: nothing but two far cones
+            l, r = left[:1], right[:1]
+        if t % 13 == 7:  # only one side visible
+            l = left[:0]
+        xyt = np.concatenate([np.column_stack([r, np.full(len(r), 1.0)]), np.column_stack([l, np.full(len(l), 2.0)])])
+        try:
+            path = pp.calculate_path_in_global_frame(xyt, np.array(pos), np.array(tan))
+            ok.append(True)
+        except Exception:  # noqa
+            path = np.full((40, 4), np.nan)
+            ok.append(False)
+        cones_all.append(xyt)
+        off.append(off[-1] + len(xyt))
+        poses.append(np.concatenate([pos, tan]))
+        paths.append(np.array(path))
+    np.savez_compressed(HERE / "trackdrive_sequence.npz", offsets=np.array(off, np.int32), cones=np.concatenate(cones_all),
+                        poses=np.array(poses), path=np.array(paths), ok=np.array(ok))
+    print("trackdrive_sequence frames", len(ok), "ok", int(np.sum(ok)))
+
+
+if __name__ == "__main__" and "--sequence-only" in sys.argv:
+    trackdrive_sequence_golden()

@@ -118,6 +118,16 @@ def plan_frame(xyt: np.ndarray, pose: np.ndarray) -> np.ndarray:
     return out[0]
 
 
+def plan_frame_prev(xyt: np.ndarray, pose: np.ndarray, prev: np.ndarray | None) -> np.ndarray:
+    """Sequential-replay form: prev = the previous (40,4) output of the same planner, or None for a fresh one."""
+    xyt = np.ascontiguousarray(xyt, dtype=np.float64).reshape(-1, 3)
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    out = np.zeros(1, dtype=RESULT_DTYPE)
+    pp = None if prev is None else _p(np.ascontiguousarray(prev, dtype=np.float64))
+    lib().fsdo_plan_frame_prev(_p(xyt), ctypes.c_int(len(xyt)), _p(pose), pp, ctypes.c_void_p(out.ctypes.data))
+    return out[0]
+
+
 def plan_batch(offsets, xyt, poses, n_threads: int = 1) -> np.ndarray:
     offsets = np.ascontiguousarray(offsets, dtype=np.int32)
     xyt = np.ascontiguousarray(xyt, dtype=np.float64)
