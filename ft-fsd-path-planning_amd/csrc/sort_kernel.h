@@ -165,6 +165,22 @@ __device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type
   return can;
 }
 
+// NumPy pairwise sum of the first n (<= 11) entries of a register array, static indexing only
+__device__ __forceinline__ double np_sum_reg(const double (&a)[MAX_LEN], int n) {
+  if (n < 8) {
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+      if (i < n) r += a[i];
+    return r;
+  }
+  double res = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+#pragma unroll
+  for (int i = 8; i < MAX_LEN - 1; i++)
+    if (i < n) res += a[i];
+  return 0.0 + res;
+}
+
 // one side (cone_type LEFT or RIGHT); side = 0 (left) / 1 (right).  All lanes call.
 // Returns status (wave-uniform).
 __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int side, double px, double py, double dx,
@@ -260,15 +276,18 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
         if (j == i || S.type[j] == other_type) continue;
         double d = cdist_sq(xi, yi, S.x[j], S.y[j]);
         if (d < bd[KNN - 1]) {
-          // insert keeping ascending order; strict '<' keeps the earlier index first on ties
-          int q = KNN - 1;
-          while (q > 0 && d < bd[q - 1]) {
-            bd[q] = bd[q - 1];
-            bj[q] = bj[q - 1];
-            q--;
+          // sorted insertion through registers; strict '<' keeps the earlier index first on ties
+          int cj = j;
+#pragma unroll
+          for (int q = 0; q < KNN; q++) {
+            bool lt = d < bd[q];
+            double td = lt ? bd[q] : d;
+            int tj = lt ? bj[q] : cj;
+            bd[q] = lt ? d : bd[q];
+            bj[q] = lt ? cj : bj[q];
+            d = td;
+            cj = tj;
           }
-          bd[q] = d;
-          bj[q] = j;
         }
       }
     }
@@ -284,27 +303,34 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   __syncthreads();
   for (int i = lane; i < n; i += WAVE) {
     int cnt = 0;
-    uint8_t lst[KNN];
+    int lst[KNN];
+#pragma unroll
+    for (int q = 0; q < KNN; q++) lst[q] = 255;
     int okm = S.knn_ok[i];
+#pragma unroll
     for (int q = 0; q < KNN; q++) {
       int j = S.knn[i][q];
       if (j == 255 || !(okm & (1 << q))) continue;
       int okj = S.knn_ok[j];
       bool mutual = false;
+#pragma unroll
       for (int r = 0; r < KNN; r++)
         if (S.knn[j][r] == i && (okj & (1 << r))) mutual = true;
       if (mutual) {
-        // insert ascending by index
-        int p = cnt;
-        while (p > 0 && lst[p - 1] > j) {
-          lst[p] = lst[p - 1];
-          p--;
+        // ascending insertion (255 = empty sorts last)
+        int v = j;
+#pragma unroll
+        for (int p = 0; p < KNN; p++) {
+          bool lt = v < lst[p];
+          int tv = lt ? lst[p] : v;
+          lst[p] = lt ? v : lst[p];
+          v = tv;
         }
-        lst[p] = (uint8_t)j;
         cnt++;
       }
     }
-    for (int q = 0; q < KNN; q++) S.nbr[i][q] = (q < cnt) ? lst[q] : (uint8_t)255;
+#pragma unroll
+    for (int q = 0; q < KNN; q++) S.nbr[i][q] = (uint8_t)lst[q];
     S.nbr_cnt[i] = (uint8_t)cnt;
     S.vis[i] = (i == start_idx) ? 1 : 0;
   }
@@ -403,6 +429,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   int16_t cfg[MAX_LEN];
   int len = 0;
   if (lane < n_ends) {
+#pragma unroll
     for (int l = 0; l < MAX_LEN; l++) {
       cfg[l] = S.ends[lane][l];
       len += (cfg[l] != -1);
@@ -421,9 +448,14 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
         }
       if (!found) am = 0;
       int last_idx = ((am - 1) % L + L) % L;
-      int last_cone = cfg[last_idx];
+      int last_cone = 0;
+#pragma unroll
+      for (int l = 0; l < MAX_LEN; l++)
+        if (l == last_idx) last_cone = cfg[l];
       if (S.type[last_cone] != cone_type) {
-        cfg[last_idx] = -1;
+#pragma unroll
+        for (int l = 0; l < MAX_LEN; l++)
+          if (l == last_idx) cfg[l] = -1;
         len--;
       }
       keep = len >= 3;
@@ -576,49 +608,54 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   // ---------------- S11: cost per configuration (cost_function.py:213-304), lane = configuration ----------------
   double my_cost = 0.0;
   if (keep) {
+    const int16_t* ccfg = S.ends[lane];  // this lane's configuration (LDS; dynamic indexing stays out of registers)
     auto PX = [&](int l) -> double {
-      int idx = cfg[l];
+      int idx = ccfg[l];
       if (idx < 0) idx = n + idx;  // NumPy wrap-around of -1
       return S.x[idx];
     };
     auto PY = [&](int l) -> double {
-      int idx = cfg[l];
+      int idx = ccfg[l];
       if (idx < 0) idx = n + idx;
       return S.y[idx];
     };
     int clen = 0;
-    for (int l = 0; l < L; l++) clen += (cfg[l] != -1);
-    double tmp[MAX_LEN];
+    for (int l = 0; l < L; l++) clen += (ccfg[l] != -1);
+    double tmp[MAX_LEN];  // static indexing only (fully unrolled loops) so that it stays in registers
     // angle cost :41-79
     double angle_cost;
     {
       int na = L - 2;
       double cnt = 0.0;
       int under = 0;
-      for (int a = 0; a < na; a++) {
+#pragma unroll
+      for (int a = 0; a < MAX_LEN - 2; a++) {
+        if (a >= na) continue;
         double n0x = PX(a) - PX(a + 1), n0y = PY(a) - PY(a + 1);
-        if (cfg[a + 1] == -1) n0x = n0y = 100.0;
+        if (ccfg[a + 1] == -1) n0x = n0y = 100.0;
         double n1x = PX(a + 1) - PX(a + 2), n1y = PY(a + 1) - PY(a + 2);
-        if (cfg[a + 2] == -1) n1x = n1y = 100.0;
+        if (ccfg[a + 2] == -1) n1x = n1y = 100.0;
         double ang = angle_between(n1x, n1y, -n0x, -n0y);
-        bool is_part = cfg[a + 2] != -1;
+        bool is_part = ccfg[a + 2] != -1;
         double as_cost = (FSDP_PI - ang) / FSDP_PI;
         tmp[a] = as_cost * (is_part ? 1.0 : 0.0);
         cnt += is_part ? 1.0 : 0.0;
         if (ang < 40 * FSDP_DEG && is_part) under++;
       }
-      angle_cost = np_sum_small(tmp, na) / cnt * (double)(under + 1);
+      angle_cost = np_sum_reg(tmp, na) / cnt * (double)(under + 1);
     }
     // residual distance cost (cone_distance_cost.py:15-32)
     double dist_cost;
     {
-      for (int l = 0; l < L - 1; l++) {
+#pragma unroll
+      for (int l = 0; l < MAX_LEN - 1; l++) {
+        if (l >= L - 1) continue;
         double ddx = PX(l + 1) - PX(l), ddy = PY(l + 1) - PY(l);
         double d = sqrt(ddx * ddx + ddy * ddy);
-        d = d * ((cfg[l + 1] != -1) ? 1.0 : 0.0);
+        d = d * ((ccfg[l + 1] != -1) ? 1.0 : 0.0);
         tmp[l] = fmax(0.0, d - 3.0);
       }
-      dist_cost = np_sum_small(tmp, L - 1);
+      dist_cost = np_sum_reg(tmp, L - 1);
     }
     double ncones_cost = 1.0 / (double)clen;
     double init_cost = angle_between(PX(1) - PX(0), PY(1) - PY(0), dx, dy);
@@ -633,19 +670,34 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
       double unwanted = (cone_type == T_LEFT) ? 1.0 : -1.0;
       int ns = 0;
       double prev_ang = atan2(PY(1) - PY(0), PX(1) - PX(0));
-      for (int l = 1; l < clen - 1; l++) {
+#pragma unroll
+      for (int l = 1; l < MAX_LEN - 1; l++) {
+        if (l >= clen - 1) continue;
         double a2 = atan2(PY(l + 1) - PY(l), PX(l + 1) - PX(l));
         double diff = angle_difference(prev_ang, a2);
-        if (sign_of(diff) == unwanted && fabs(diff) > 40 * FSDP_DEG) tmp[ns++] = diff;
+        if (sign_of(diff) == unwanted && fabs(diff) > 40 * FSDP_DEG) {
+          // compacting append with static indexing
+#pragma unroll
+          for (int q = 0; q < MAX_LEN - 2; q++)
+            if (q == ns) tmp[q] = diff;
+          ns++;
+        }
         prev_ang = a2;
       }
-      wrong_cost = fabs(np_sum_small(tmp, ns));
+      wrong_cost = fabs(np_sum_reg(tmp, ns));
     }
     const double fsum = ((1000.0 + 200.0) + (5000.0 + 1000.0)) + ((0.0 + 1000.0) + 1000.0);  // np.sum of 7: sequential
     double f0 = 1000.0 / 9200.0, f1 = 200.0 / 9200.0, f2 = 5000.0 / 9200.0, f3 = 1000.0 / 9200.0, f4 = 0.0 / 9200.0;
     (void)fsum;
-    double cols[7] = {angle_cost * f0, dist_cost * f1, ncones_cost * f2, init_cost * f3, 0.0 * f4, either_cost * f3, wrong_cost * f3};
-    my_cost = np_sum_small(cols, 7);
+    // np.sum over the 7 weighted columns (n < 8: sequential from 0)
+    my_cost = 0.0;
+    my_cost += angle_cost * f0;
+    my_cost += dist_cost * f1;
+    my_cost += ncones_cost * f2;
+    my_cost += init_cost * f3;
+    my_cost += 0.0 * f4;
+    my_cost += either_cost * f3;
+    my_cost += wrong_cost * f3;
   }
   // argmin with np.unique's lexicographic row order as tie-break (argsort is stable for the short arrays here)
   {
@@ -785,7 +837,7 @@ __device__ inline void combine_sides(SortShared& S, int& nl, int& nr) {
 }
 
 // One workgroup (= one wavefront) per frame.
-__global__ void __launch_bounds__(64) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
+__global__ void __launch_bounds__(64, 3) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
                                                   const double* __restrict__ cones_xyt, const double* __restrict__ poses,
                                                   SortOut* __restrict__ out) {
   __shared__ SortShared S;

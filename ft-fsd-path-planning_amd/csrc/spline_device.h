@@ -71,15 +71,13 @@ __device__ __forceinline__ void fpbspl(const double* t, double x, int l, double*
 }
 
 __device__ __forceinline__ void fpgivs(double piv, double& ww, double& cs, double& sn) {
+  // fpgivs.f: dd = |piv| * sqrt(1 + (ww/piv)^2) if |piv| >= ww else ww * sqrt(1 + (piv/ww)^2) — written with selects so
+  // that one division and one square root are issued (same operations, same operands, same bits)
   double store = fabs(piv);
-  double dd;
-  if (store >= ww) {
-    double r = ww / piv;
-    dd = store * sqrt(1.0 + r * r);
-  } else {
-    double r = piv / ww;
-    dd = ww * sqrt(1.0 + r * r);
-  }
+  bool big = store >= ww;
+  double num = big ? ww : piv, den = big ? piv : ww, scale = big ? store : ww;
+  double r = num / den;
+  double dd = scale * sqrt(1.0 + r * r);
   cs = ww / dd;
   sn = piv / dd;
   ww = dd;

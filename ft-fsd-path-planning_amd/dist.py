@@ -18,7 +18,9 @@ class Dist:
         self.backend = None
         self._dist = None
         self._torch = None
-        if self.world > 1:
+        # FSDP_FORCE_DIST=1 initialises the process group even for a single rank (exercises the RCCL plumbing on one GPU)
+        self._active = self.world > 1 or os.environ.get("FSDP_FORCE_DIST") == "1"
+        if self._active:
             import torch
             import torch.distributed as dist
 
@@ -28,7 +30,9 @@ class Dist:
             if self.backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
             if not dist.is_initialized():
-                dist.init_process_group(backend=self.backend)
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29531")
+                dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world)
 
     @property
     def device(self):
@@ -46,7 +50,7 @@ class Dist:
 
     def broadcast_check_table(self, table: np.ndarray) -> bool:
         """Rank 0 broadcasts the constant previous-path table; every rank compares with its own copy."""
-        if self.world == 1:
+        if not self._active:
             return True
         t = self._torch.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(self.device)
         ref = t.clone()
@@ -59,7 +63,7 @@ class Dist:
     def broadcast_array(self, arr: np.ndarray | None, shape, src: int = 0) -> np.ndarray:
         """Track-map broadcast: rank `src` owns the constant skidpad tables (known path 5786x2 f64 =
         92 576 B, noise table, reference centres) and broadcasts them once at start-up; the other ranks pass arr=None."""
-        if self.world == 1:
+        if not self._active:
             return np.ascontiguousarray(arr, dtype=np.float64)
         t = self._torch.zeros(tuple(shape), dtype=self._torch.float64, device=self.device)
         if self.rank == src:
@@ -68,25 +72,25 @@ class Dist:
         return t.cpu().numpy()
 
     def barrier(self):
-        if self.world > 1:
+        if self._active:
             if self.backend == "nccl":
                 self._torch.cuda.synchronize()
             self._dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
-        if self.world == 1:
+        if not self._active:
             return float(value)
         t = self._torch.tensor([value], dtype=self._torch.float64, device=self.device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_over_ranks(self, value: float) -> float:
-        if self.world == 1:
+        if not self._active:
             return float(value)
         t = self._torch.tensor([value], dtype=self._torch.float64, device=self.device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return float(t.item())
 
     def close(self):
-        if self.world > 1 and self._dist.is_initialized():
+        if self._active and self._dist.is_initialized():
             self._dist.destroy_process_group()
