@@ -4,6 +4,7 @@
 #include <thread>
 #include <atomic>
 #include <cmath>
+#include <malloc.h>
 
 #include "oracle_internal.h"
 
@@ -154,6 +155,12 @@ void fsdo_plan_frame_prev(const double* xyt, int n, const double* pose, const do
 void fsdo_plan_batch(int n_frames, const int32_t* off, const double* xyt, const double* poses, fsdo_frame_result* out,
                      int n_threads) {
   default_previous_path();
+  static bool tuned = false;
+  if (!tuned) {  // keep per-frame temporaries off mmap/munmap (many host threads)
+    mallopt(M_MMAP_THRESHOLD, 64 << 20);
+    mallopt(M_TRIM_THRESHOLD, 256 << 20);
+    tuned = true;
+  }
   if (n_threads <= 1) {
     for (int i = 0; i < n_frames; i++) fsdo_plan_frame(xyt + 3 * (size_t)off[i], off[i + 1] - off[i], poses + 4 * (size_t)i, &out[i]);
     return;

@@ -108,7 +108,10 @@ static void create_adjacency(const Frame& f, int n_neighbors, int start_idx, int
   const int n = f.n;
   const double max_dist = 6.5;
   const int other = invert_cone_type(cone_type);
-  std::vector<double> D((size_t)n * n);
+  // thread-local scratch: an N x N double matrix is 128 KB at N = 128 — above glibc's mmap threshold, so a fresh
+  // std::vector per call would mmap/munmap on every frame and serialise many host threads in the kernel
+  static thread_local std::vector<double> D;
+  if (D.size() < (size_t)n * n) D.resize((size_t)n * n);
   for (int i = 0; i < n; i++)
     for (int j = 0; j < n; j++) {
       double d = cdist_sq(f.x[i], f.y[i], f.x[j], f.y[j]);
@@ -116,7 +119,8 @@ static void create_adjacency(const Frame& f, int n_neighbors, int start_idx, int
       if (f.type[i] == other || f.type[j] == other) d = INFINITY;
       D[(size_t)i * n + j] = d;
     }
-  std::vector<char> adj((size_t)n * n, 0);
+  static thread_local std::vector<char> adj;
+  adj.assign((size_t)n * n, 0);
   std::vector<int> order(n);
   for (int i = 0; i < n; i++) {
     for (int j = 0; j < n; j++) order[j] = j;
