@@ -34,13 +34,32 @@ ALGO_BYTES_PER_FRAME = 2 * CONES_PER_SIDE * 24 + 32 + 1280 + 96 + 8  # 4488 at N
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def usable_cores() -> int:
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs but grants a 16-CPU quota; more threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(off, cones, poses, budget_s: float = 12.0):
     """The CPU oracle (oracle/, parity-checked restatement of the reference; kind 'port') timed on this
     host's cores over a bounded sample of the same workload.  Baseline, not target."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib  # test infrastructure, used here only as the measured CPU baseline
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = len(off) - 1
     oracle_lib.plan_batch(off[:65], cones[: off[64]], poses[:64], n_threads=cores)  # warm (default path, page-in)
     # single-thread latency sample
@@ -60,7 +79,8 @@ def cpu_baseline(off, cones, poses, budget_s: float = 12.0):
         "unit": "frames/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{done} frames ({done // n} passes over the {n}-frame batch), std::thread over frames; "
+        "sample": f"{done} frames ({done // n} passes over the {n}-frame batch), std::thread over frames, threads = "
+                  f"usable cores (affinity {os.cpu_count()} capped by the cgroup CPU quota); "
                   f"1-thread latency {t_single * 1e6:.0f} us/frame",
         "single_thread_us_per_frame": t_single * 1e6,
     }

@@ -215,4 +215,86 @@ __device__ __forceinline__ int wave_min_int(int v) {
   return v;
 }
 
+// ------------------------------------------------------------------------------------------
+// lane groups: G lanes per frame, WAVE / G frames per wavefront
+// ------------------------------------------------------------------------------------------
+// The sorting / matching kernels give a frame the whole wavefront (G = 64).  The path stage is dominated by
+// serial FP64 chains (spline QR) that keep 1-4 lanes busy, so it packs WAVE / G frames into one wavefront
+// (G = 16: four frames, one per DPP row): a serial instruction then advances four frames at once.  Groups are
+// aligned; control flow is uniform WITHIN a group and may diverge BETWEEN groups (the hardware runs the union of
+// the paths, masked).  Cross-lane traffic never leaves a group.  sync() orders LDS / scratch hand-offs between the
+// lanes of a group: with one wavefront per workgroup the lanes run in lock-step, so only the compiler and the memory
+// counters need a fence (no s_barrier, which must not sit in divergent code).
+template <int G>
+struct Grp {
+  static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group size");
+  static constexpr int SIZE = G;
+  static constexpr int PER_WAVE = WAVE / G;
+  static __device__ __forceinline__ int lane() { return (int)(threadIdx.x & (G - 1)); }
+  static __device__ __forceinline__ int index() { return (int)((threadIdx.x & 63) / G); }
+  static __device__ __forceinline__ void sync() {
+#ifdef FSDP_EMU
+    emu::gbarrier(G);
+#else
+    if constexpr (G == WAVE) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+#endif
+  }
+  // bit i = lane i of this group
+  static __device__ __forceinline__ unsigned long long ballot(bool p) {
+#ifdef FSDP_EMU
+    return emu::gballot(p, G);
+#else
+    unsigned long long m = __ballot(p);
+    if constexpr (G == WAVE)
+      return m;
+    else
+      return (m >> (index() * G)) & ((1ull << G) - 1ull);
+#endif
+  }
+  // value of group lane `src` (group-uniform src)
+  template <class T>
+  static __device__ __forceinline__ T bcast(T v, int src) {
+#ifdef FSDP_EMU
+    return emu::gexchange(v, (emu::B->cur & ~(G - 1)) | src, G);
+#else
+    return __shfl(v, (int)((threadIdx.x & 63) & ~(G - 1)) | src, WAVE);
+#endif
+  }
+  template <class T>
+  static __device__ __forceinline__ T shfl_xor(T v, int mask) {
+#ifdef FSDP_EMU
+    return emu::gexchange(v, emu::B->cur ^ mask, G);
+#else
+    return __shfl_xor(v, mask, WAVE);
+#endif
+  }
+  // value of the previous lane of the group (lane 0 keeps its own)
+  template <class T>
+  static __device__ __forceinline__ T shfl_up1(T v) {
+#ifdef FSDP_EMU
+    return emu::gexchange(v, lane() > 0 ? emu::B->cur - 1 : emu::B->cur, G);
+#else
+    int me = (int)(threadIdx.x & 63);
+    return __shfl(v, lane() > 0 ? me - 1 : me, WAVE);
+#endif
+  }
+  // argmin over (value, index) pairs with "first smallest" semantics; lanes holding no candidate pass idx = -1
+  static __device__ __forceinline__ void argmin(double& v, int& idx) {
+    for (int off = G / 2; off >= 1; off >>= 1) {
+      double ov = shfl_xor(v, off);
+      int oi = shfl_xor(idx, off);
+      bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && oi < idx));
+      if (take) {
+        v = ov;
+        idx = oi;
+      }
+    }
+  }
+};
+
 }  // namespace fsdp

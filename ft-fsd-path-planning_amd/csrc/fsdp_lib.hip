@@ -119,7 +119,7 @@ static void launch_match(fsdp_ctx* c) {
                      c->d_sort, c->d_match);
 }
 static void launch_path(fsdp_ctx* c) {
-  hipLaunchKernelGGL(path_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_poses, c->d_match,
+  hipLaunchKernelGGL(path_kernel, dim3((c->n_frames + WAVE / PATH_G - 1) / (WAVE / PATH_G)), dim3(WAVE), 0, c->stream, c->n_frames, c->d_poses, c->d_match,
                      c->d_default_path, c->use_prev ? c->d_prev : nullptr, c->d_arena, c->d_path);
 }
 

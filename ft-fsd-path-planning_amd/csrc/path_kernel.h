@@ -11,10 +11,12 @@
 // Every float that feeds the sample-count decision ceil(max_u / predict_every) is produced in the
 // reference's rounding order (see DESIGN.md "arithmetic contract").
 //
+// Lanes: the stage is templated on the group size G (lanes per frame).  The product kernel runs G = 16, four
+// frames per wavefront (fsdp_device.h Grp<G>): the stage is dominated by serial FP64 chains, and a serial
+// instruction then advances four frames.  Results do not depend on G (sums keep the reference's order).
 // Memory: the working polyline (up to PATH_CAP points: x, y, parameter) lives in a per-frame HBM/L2
 // scratch arena (3 x PATH_CAP doubles, lane-coalesced access, L2/MALL resident); the serial sections
-// consume it through 64-point LDS chunk buffers.  LDS per frame: spline workspace ~9 KB, dense output +
-// curvature 5 KB, segment scratch 2.5 KB, small vectors 1.6 KB => ~18 KB.
+// consume it through LDS chunk buffers.  LDS per frame (G = 16): 9.6 KB.
 #pragma once
 #include "fsdp_device.h"
 #include "spline_device.h"
@@ -23,8 +25,7 @@
 namespace fsdp {
 
 constexpr int PATH_CAP = 1152;  // points of the working polyline (dense fit-#1 output + extension)
-constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121 in practice)
-constexpr int SEG_CAP = WAVE * 7;  // segment-length scratch in LDS (aliases the spline chunk buffers; 300-sample MPC path)
+constexpr int SEG_CAP = 5 * DENSE_CAP;  // segment-length scratch in LDS (the "dense" region of the spline workspace)
 
 struct Arena {
   double* x;
@@ -32,11 +33,20 @@ struct Arena {
   double* u;
 };
 
+// Per-frame LDS.  The region ws.dense aliases the fit-only part of the spline workspace (dead whenever no fit is
+// running): segment lengths before fit #3, the <= 20 tail points of the extension, and after fit #3 the dense
+// samples x | y | u | raw curvature | filtered curvature.
+template <int G>
 struct PathShared {
   double cxp[PATH_POINTS], cyp[PATH_POINTS];      // centre points (<= 24) or previous path (40)
   double prevx[PATH_POINTS], prevy[PATH_POINTS];  // previous path xy
-  double dx[DENSE_CAP], dy[DENSE_CAP], du[DENSE_CAP];  // dense samples of the final spline
-  SplineWS ws;
+  SplineWS<G> ws;
+  __device__ __forceinline__ double* seg() { return ws.dense; }
+  __device__ __forceinline__ double* dx() { return ws.dense; }
+  __device__ __forceinline__ double* dy() { return ws.dense + DENSE_CAP; }
+  __device__ __forceinline__ double* du() { return ws.dense + 2 * DENSE_CAP; }
+  __device__ __forceinline__ double* curv() { return ws.dense + 3 * DENSE_CAP; }
+  __device__ __forceinline__ double* filt() { return ws.dense + 4 * DENSE_CAP; }
 };
 
 // np.sum of a contiguous run (NumPy pairwise summation) — wave-uniform.  The recursion of
@@ -181,37 +191,51 @@ __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? 
 __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
 
 // chord lengths -> parameter values: A.u[off + i] = cumulative length (np.cumsum: sequential order); returns max_u.
-__device__ inline double build_parameter(PathShared& S, const Arena& A, int off, int m) {
+template <int G>
+__device__ inline double build_parameter(PathShared<G>& S, const Arena& A, int off, int m) {
   PROF(19);
-  const int lane = lane_id();
+  using GR = Grp<G>;
+  constexpr int CH = SplineWS<G>::CH;
+  constexpr int NR = CH / G;
+  const int lane = GR::lane();
   double acc = 0.0;
   if (lane == 0) A.u[off] = 0.0;
-  for (int base = 0; base < m - 1; base += WAVE) {
-    int i = base + lane;
-    if (i < m - 1) {
+  for (int base = 0; base < m - 1; base += CH) {
+    const int cnt = (m - 1 - base) < CH ? (m - 1 - base) : CH;
+    for (int r = lane; r < cnt; r += G) {
+      int i = base + r;
       double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
-      S.ws.term[lane] = sqrt(dx * dx + dy * dy);
+      S.ws.term[r] = sqrt(dx * dx + dy * dy);
     }
-    __syncthreads();
-    int cnt = (m - 1 - base) < WAVE ? (m - 1 - base) : WAVE;
-    double mine = 0.0;
-    for (int r = 0; r < cnt; r++) {
-      acc += S.ws.term[r];
-      if (lane == r) mine = acc;  // lane r keeps element r
+    GR::sync();
+    double mine[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      mine[q] = 0.0;
+      for (int rr = 0; rr < G; rr++) {
+        int r = q * G + rr;
+        if (r < cnt) {
+          acc += S.ws.term[r];
+          if (lane == rr) mine[q] = acc;  // lane rr keeps element q*G + rr
+        }
+      }
     }
-    if (lane < cnt) A.u[off + base + lane + 1] = mine;  // one coalesced store per chunk
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+      if (q * G + lane < cnt) A.u[off + base + q * G + lane + 1] = mine[q];  // coalesced stores
+    GR::sync();
   }
   return acc;
 }
 
 // utils/spline_fit.py:95-128 on the arena polyline [off, off+m).  rc: 0 ok, 1 ValueError, >=200 overflow
-__device__ inline int fit_polyline(PathShared& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
+template <int G>
+__device__ inline int fit_polyline(PathShared<G>& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
                                    double& max_u) {
   int k = m - 1;
   k = k < 1 ? 1 : (k > 3 ? 3 : k);
-  max_u = build_parameter(S, A, off, m);
-  f = spline_fit(S.ws, A.u + off, A.x + off, A.y + off, m, k, smoothing);
+  max_u = build_parameter<G>(S, A, off, m);
+  f = spline_fit<G>(S.ws, A.u + off, A.x + off, A.y + off, m, k, smoothing);
   return f.status;
 }
 
@@ -223,16 +247,18 @@ __device__ __forceinline__ int arange_len(double stop, double step) {
 
 // calculate_path/path_parameterization.py:297-328 on the arena polyline [off, off+n).
 // rc: 0 ok (out filled), 1 ValueError, ST_* otherwise.
-__device__ inline int parameterize_path(PathShared& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
-  const int lane = lane_id();
+template <int G>
+__device__ inline int parameterize_path(PathShared<G>& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
+  using GR = Grp<G>;
+  const int lane = GR::lane();
   if (n < 2) return ST_REF_UNDEFINED_PATH;
   // _refit_spline :125-161 — segment lengths (LDS when they fit, else the arena's parameter array)
-  double* seg = (n - 1 <= SEG_CAP) ? S.ws.seg : (A.u + off);
-  for (int i = lane; i < n - 1; i += WAVE) {
+  double* seg = (n - 1 <= SEG_CAP) ? S.seg() : (A.u + off);
+  for (int i = lane; i < n - 1; i += G) {
     double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
     seg[i] = sqrt(dx * dx + dy * dy);
   }
-  __syncthreads();
+  GR::sync();
   double path_length = np_sum_run(seg, n - 1);
   int n10 = (n - 1) < 10 ? (n - 1) : 10;
   double mean_pd = np_sum_small(seg, n10) / (double)n10;
@@ -249,23 +275,23 @@ __device__ inline int parameterize_path(PathShared& S, const Arena& A, int off, 
       if (skip < 1) skip = 1;
     }
   }
-  __syncthreads();
+  GR::sync();
   int ns = n;
   if (skip > 1) {
     ns = (n + skip - 1) / skip;
-    for (int base = 0; base < ns; base += WAVE) {
+    for (int base = 0; base < ns; base += G) {
       int i = base + lane;
       double vx = 0, vy = 0;
       if (i < ns) {
         vx = A.x[off + i * skip];
         vy = A.y[off + i * skip];
       }
-      __syncthreads();
+      GR::sync();
       if (i < ns) {
         A.x[off + i] = vx;
         A.y[off + i] = vy;
       }
-      __syncthreads();
+      GR::sync();
     }
   }
   SplineFit f;
@@ -273,25 +299,28 @@ __device__ inline int parameterize_path(PathShared& S, const Arena& A, int off, 
   int rc;
   {
     PROF(7);
-    rc = fit_polyline(S, A, off, ns, 0.01, f, max_u);
+    rc = fit_polyline<G>(S, A, off, ns, 0.01, f, max_u);
   }
   if (rc) return rc;
   // _calculate_path_curvature :163-193 — dense samples into LDS
   int L = arange_len(max_u, predict_every);
   if (L > DENSE_CAP) return ST_OVERFLOW_PATH;
   if (L == 0) return ST_REF_UNDEFINED_PATH;
+  double* const DX = S.dx();
+  double* const DY = S.dy();
+  double* const DU = S.du();
   {
     PROF(8);
-    spline_eval(S.ws, f, predict_every, L, S.dx, S.dy, S.du);
+    spline_eval<G>(S.ws, f, predict_every, L, DX, DY, DU);
   }
-  double* curv = S.ws.seg;  // the spline chunk buffers are dead from here on
-  double* filt = S.ws.seg + DENSE_CAP;
+  double* curv = S.curv();
+  double* filt = S.filt();
   int window = (L / 5) < 30 ? (L / 5) : 30;
   if (window % 2 == 0) window += 1;
   const int half = window / 2;
   {
   PROF(9);
-  for (int i = lane; i < L; i += WAVE) {
+  for (int i = lane; i < L; i += G) {
     // cyclic window cut at the wrap-around for an open path (path_parameterization.py:64-77)
     int lo = i - half, hi = i + half;
     int w0, wn;
@@ -309,16 +338,16 @@ __device__ inline int parameterize_path(PathShared& S, const Arena& A, int off, 
       wn = L - lo;
     }
     double cx, cy, r;
-    circle_fit(S.dx, S.dy, w0, wn, cx, cy, r);
+    circle_fit(DX, DY, w0, wn, cx, cy, r);
     r = py_min(py_max(r, 1.0), 3000.0);
     double c = 1 / r;
     int i1 = wn / 2;
-    double sg = det3_lu(S.dx[w0], S.dy[w0], S.dx[w0 + i1], S.dy[w0 + i1], S.dx[w0 + wn - 1], S.dy[w0 + wn - 1]);
+    double sg = det3_lu(DX[w0], DY[w0], DX[w0 + i1], DY[w0 + i1], DX[w0 + wn - 1], DY[w0 + wn - 1]);
     double cv = c * sign_of(sg);
     if (isnan(sg)) cv = sg;
     curv[i] = cv;
   }
-  __syncthreads();
+  GR::sync();
   }
   PROF(18);
   // scipy.ndimage.uniform_filter1d(size = max(2, window // 2), mode = "nearest"): running sum in index order
@@ -339,51 +368,51 @@ __device__ inline int parameterize_path(PathShared& S, const Arena& A, int off, 
       filt[i] = tmp / size;
     }
   }
-  __syncthreads();
+  GR::sync();
   // _sample_path_parameters_for_prediction_horizon :252-295: np.linspace(0, L-1, 40, dtype=int)
   {
-    double step = ((double)(L - 1) - 0.0) / (double)(PATH_POINTS - 1);
-    int idx = 0, prev = -1;
+    const double step = ((double)(L - 1) - 0.0) / (double)(PATH_POINTS - 1);
+    auto sample_index = [&](int i) {
+      double v = (double)i * step + 0.0;
+      if (i == PATH_POINTS - 1) v = (double)(L - 1);
+      return (int)floor(v);
+    };
     bool dup = false;
-    if (lane < PATH_POINTS) {
-      double v = (double)lane * step + 0.0;
-      if (lane == PATH_POINTS - 1) v = (double)(L - 1);
-      idx = (int)floor(v);
-      if (lane > 0) {
-        double vp = (double)(lane - 1) * step + 0.0;
-        prev = (int)floor(vp);
-        dup = (prev == idx);
-      }
-    }
-    if (__ballot(dup) != 0ull) return 1;  // "Indices of resampled path appear twice" (ValueError)
-    if (lane < PATH_POINTS) {
-      out[lane][0] = S.du[idx];
-      out[lane][1] = S.dx[idx];
-      out[lane][2] = S.dy[idx];
-      out[lane][3] = filt[idx];
+    for (int i = lane; i < PATH_POINTS; i += G)
+      if (i > 0 && sample_index(i - 1) == sample_index(i)) dup = true;
+    if (GR::ballot(dup) != 0ull) return 1;  // "Indices of resampled path appear twice" (ValueError)
+    for (int i = lane; i < PATH_POINTS; i += G) {
+      int idx = sample_index(i);
+      out[i][0] = DU[idx];
+      out[i][1] = DX[idx];
+      out[i][2] = DY[idx];
+      out[i][3] = filt[idx];
     }
   }
   *n_dense = L;
-  __syncthreads();
+  GR::sync();
   return 0;
 }
 
 // sequential sum of segment lengths of the arena polyline [off, off+n) with optional early stop:
 // returns the running total; *first_over = index of the first segment whose cumulative length exceeds
-// `limit` (or n-1 if none).  Chunks of 64 segments are staged in LDS; the additions keep np.cumsum's order.
-__device__ inline double cumulative_length(PathShared& S, const Arena& A, int off, int n, double limit, int* first_over) {
-  const int lane = lane_id();
+// `limit` (or n-1 if none).  Chunks of segments are staged in LDS; the additions keep np.cumsum's order.
+template <int G>
+__device__ inline double cumulative_length(PathShared<G>& S, const Arena& A, int off, int n, double limit, int* first_over) {
+  using GR = Grp<G>;
+  constexpr int CH = SplineWS<G>::CH;
+  const int lane = GR::lane();
   double acc = 0.0;
   int first = n - 1;
   bool stop = false;
-  for (int base = 0; base < n - 1 && !stop; base += WAVE) {
-    int i = base + lane;
-    if (i < n - 1) {
+  for (int base = 0; base < n - 1 && !stop; base += CH) {
+    const int cnt = (n - 1 - base) < CH ? (n - 1 - base) : CH;
+    for (int r = lane; r < cnt; r += G) {
+      int i = base + r;
       double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
-      S.ws.term[lane] = sqrt(dx * dx + dy * dy);
+      S.ws.term[r] = sqrt(dx * dx + dy * dy);
     }
-    __syncthreads();
-    int cnt = (n - 1 - base) < WAVE ? (n - 1 - base) : WAVE;
+    GR::sync();
     for (int r = 0; r < cnt; r++) {
       acc += S.ws.term[r];
       if (acc > limit) {
@@ -392,7 +421,7 @@ __device__ inline double cumulative_length(PathShared& S, const Arena& A, int of
         break;
       }
     }
-    __syncthreads();
+    GR::sync();
   }
   if (first_over) *first_over = first;
   return acc;
@@ -400,9 +429,11 @@ __device__ inline double cumulative_length(PathShared& S, const Arena& A, int of
 
 // core_calculate_path.py:380-417 do_all_mpc_parameter_calculations on the polyline [1, 1+n) of the arena
 // (slot 0 is reserved for the point connect_path_to_car may prepend).  rc as parameterize_path.
-__device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px, double py, double dx, double dy,
+template <int G>
+__device__ inline int do_all_mpc(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
                                  double (*out)[4], int* fallback, int* n_dense) {
-  const int lane = lane_id();
+  using GR = Grp<G>;
+  const int lane = GR::lane();
   if (n <= 0) return ST_REF_UNDEFINED_PATH;
   int off = 1;
   // connect_path_to_car :430-457
@@ -413,7 +444,7 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
     double ang = angle_between(cx, cy, dx, dy);
     if (!(d < 0.5 || ang > FSDP_PI / 2)) {
       double nrm = norm_blas(cx, cy);
-      __syncthreads();
+      GR::sync();
       if (lane == 0) {
         A.x[0] = px + (cx / nrm) * 0.2;
         A.y[0] = py + (cy / nrm) * 0.2;
@@ -422,15 +453,15 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
       n += 1;
     }
   }
-  __syncthreads();
+  GR::sync();
   // extend_path :261-334
   {
     // first index in front of the car (np.dot(car_to_path, direction) > 0), all later points count as in front
     int first = n;
-    for (int base = 0; base < n; base += WAVE) {
+    for (int base = 0; base < n; base += G) {
       int i = base + lane;
       bool fr = i < n && blas_dot2(A.x[off + i] - px, dx, A.y[off + i] - py, dy) > 0;
-      unsigned long long m = __ballot(fr);
+      unsigned long long m = GR::ballot(fr);
       if (m) {
         first = base + (__ffsll(m) - 1);
         break;
@@ -442,27 +473,29 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
     if (nin >= 1) {
       if (nin < 2) return ST_REF_UNDEFINED_PATH;  // cumsum([])[-1] -> IndexError
       // path length in front of the car: np.cumsum of the segment lengths (sequential)
-      double plen = cumulative_length(S, A, off + f0, nin, INFINITY, nullptr);
+      double plen = cumulative_length<G>(S, A, off + f0, nin, INFINITY, nullptr);
       if (!(plen > 20.0)) {
         int nrel = nin < 20 ? nin : 20;
         int r0 = off + n - nrel;
         // the last <= 20 points through LDS for the circle fit
-        if (lane < nrel) {
-          S.dx[lane] = A.x[r0 + lane];
-          S.dy[lane] = A.y[r0 + lane];
+        double* const TX = S.dx();
+        double* const TY = S.dy();
+        for (int i = lane; i < nrel; i += G) {
+          TX[i] = A.x[r0 + i];
+          TY[i] = A.y[r0 + i];
         }
-        __syncthreads();
+        GR::sync();
         double ccx, ccy, radius;
-        circle_fit(S.dx, S.dy, 0, nrel, ccx, ccy, radius);
+        circle_fit(TX, TY, 0, nrel, ccx, ccy, radius);
         double r_use = py_min(py_max(radius, 10), 100);
-        const double lastx = S.dx[nrel - 1], lasty = S.dy[nrel - 1];
+        const double lastx = TX[nrel - 1], lasty = TY[nrel - 1];
         int n_new;
         if (r_use < 80) {
           *fallback |= 16;
           int i1 = nrel / 2;
-          double t0x = S.dx[0] - ccx, t0y = S.dy[0] - ccy;
-          double t1x = S.dx[i1] - ccx, t1y = S.dy[i1] - ccy;
-          double t2x = S.dx[nrel - 1] - ccx, t2y = S.dy[nrel - 1] - ccy;
+          double t0x = TX[0] - ccx, t0y = TY[0] - ccy;
+          double t1x = TX[i1] - ccx, t1y = TY[i1] - ccy;
+          double t2x = TX[nrel - 1] - ccx, t2y = TY[nrel - 1] - ccy;
           double sg = sign_of(det3_lu(t0x, t0y, t1x, t1y, t2x, t2y));
           // the only libm values that enter the float chain: deterministic correctly-rounded versions (det_math.h)
           double start = detm::det_atan2(t0y, t0x);
@@ -474,30 +507,30 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
           double raw0x = c0 * r_use, raw0y = s0 * r_use;  // i = 0: 0*step + start
           n_new = NP - 1;
           if (off + n + n_new > PATH_CAP) return ST_OVERFLOW_PATH;
-          if (lane >= 1 && lane < NP) {
-            double a = (double)lane * step + start;
-            if (lane == NP - 1) a = end;
+          for (int i = 1 + lane; i < NP; i += G) {
+            double a = (double)i * step + start;
+            if (i == NP - 1) a = end;
             double sa, ca;
             detm::det_sincos(a, sa, ca);
             double rx = ca * r_use, ry = sa * r_use;
-            A.x[off + n + lane - 1] = rx - raw0x + lastx;
-            A.y[off + n + lane - 1] = ry - raw0y + lasty;
+            A.x[off + n + i - 1] = rx - raw0x + lastx;
+            A.y[off + n + i - 1] = ry - raw0y + lasty;
           }
         } else {
           *fallback |= 32;
-          double ddx = lastx - S.dx[nrel - 2], ddy = lasty - S.dy[nrel - 2];
+          double ddx = lastx - TX[nrel - 2], ddy = lasty - TY[nrel - 2];
           double nrm = norm_blas(ddx, ddy);
           ddx /= nrm;
           ddy /= nrm;
           n_new = 29;
           if (off + n + n_new > PATH_CAP) return ST_OVERFLOW_PATH;
-          if (lane >= 1 && lane < 30) {
-            A.x[off + n + lane - 1] = lastx + ddx * (double)lane;
-            A.y[off + n + lane - 1] = lasty + ddy * (double)lane;
+          for (int i = 1 + lane; i < 30; i += G) {
+            A.x[off + n + i - 1] = lastx + ddx * (double)i;
+            A.y[off + n + i - 1] = lasty + ddy * (double)i;
           }
         }
         n += n_new;
-        __syncthreads();
+        GR::sync();
       }
     }
   }
@@ -505,18 +538,18 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
   {
     double bv = 0.0;
     int bi = -1;
-    for (int i = lane; i < n; i += WAVE) {
+    for (int i = lane; i < n; i += G) {
       double d = norm_axis(px - A.x[off + i], py - A.y[off + i]);
       if (bi < 0 || d < bv) {
         bv = d;
         bi = i;
       }
     }
-    wave_argmin(bv, bi);
+    GR::argmin(bv, bi);
     off += bi;
     n -= bi;
   }
-  __syncthreads();
+  GR::sync();
   // refit_path_for_mpc_with_safety_factor :239-259 (predict to 1.5 * 20 m), then cut at 20 m :467-499
   int n5;
   {
@@ -527,61 +560,63 @@ __device__ inline int do_all_mpc(PathShared& S, const Arena& A, int n, double px
       int rc;
       {
         PROF(4);
-        rc = fit_polyline(S, A, off, n, 0.2, f, max_u);
+        rc = fit_polyline<G>(S, A, off, n, 0.2, f, max_u);
       }
       if (rc) return rc;
       PROF(5);
       n4 = arange_len(20.0 * 1.5, 0.1);
-      spline_eval(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
+      spline_eval<G>(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
     }
     int nseg = n4 - 1;
     if (nseg <= 1) return 1;  // previous (40,4) array handed on -> LinAlgError (a ValueError) downstream
     int first = nseg;
-    cumulative_length(S, A, 0, n4, 20.0, &first);
+    cumulative_length<G>(S, A, 0, n4, 20.0, &first);
     n5 = first;
   }
-  return parameterize_path(S, A, 0, n5, out, n_dense);
+  return parameterize_path<G>(S, A, 0, n5, out, n_dense);
 }
 
 // core_calculate_path.py:555-575: too-far check + MPC step with its ValueError retry, on the dense path update stored
 // in the arena at [1, 1+n1); previous path xy in S.prevx/prevy.  Returns the frame status.
-__device__ inline int finish_path(PathShared& S, const Arena& A, int n1, double px, double py, double dx, double dy,
+template <int G>
+__device__ inline int finish_path(PathShared<G>& S, const Arena& A, int n1, double px, double py, double dx, double dy,
                                   double (*out)[4], int* fallback, int* n_dense) {
-  const int lane = lane_id();
+  using GR = Grp<G>;
+  const int lane = GR::lane();
   if (n1 == 0) return ST_REF_UNDEFINED_PATH;  // min() of an empty array
   // overwrite_path_if_it_is_too_far_away :225-237
   {
     double bv = 0.0;
     int bi = -1;
-    for (int i = lane; i < n1; i += WAVE) {
+    for (int i = lane; i < n1; i += G) {
       double d = norm_axis(px - A.x[1 + i], py - A.y[1 + i]);
       if (bi < 0 || d < bv) {
         bv = d;
         bi = i;
       }
     }
-    wave_argmin(bv, bi);
+    GR::argmin(bv, bi);
     if (bv > 5.0) {
       *fallback |= 4;
-      __syncthreads();
-      if (lane < PATH_POINTS) {
-        A.x[1 + lane] = S.prevx[lane];
-        A.y[1 + lane] = S.prevy[lane];
+      GR::sync();
+      for (int i = lane; i < PATH_POINTS; i += G) {
+        A.x[1 + i] = S.prevx[i];
+        A.y[1 + i] = S.prevy[i];
       }
       n1 = PATH_POINTS;
-      __syncthreads();
+      GR::sync();
     }
   }
-  int rc = do_all_mpc(S, A, n1, px, py, dx, dy, out, fallback, n_dense);
+  int rc = do_all_mpc<G>(S, A, n1, px, py, dx, dy, out, fallback, n_dense);
   if (rc == 1) {  // ValueError -> redo with the previous path (:564-570)
     *fallback |= 8;
-    __syncthreads();
-    if (lane < PATH_POINTS) {
-      A.x[1 + lane] = S.prevx[lane];
-      A.y[1 + lane] = S.prevy[lane];
+    GR::sync();
+    for (int i = lane; i < PATH_POINTS; i += G) {
+      A.x[1 + i] = S.prevx[i];
+      A.y[1 + i] = S.prevy[i];
     }
-    __syncthreads();
-    rc = do_all_mpc(S, A, PATH_POINTS, px, py, dx, dy, out, fallback, n_dense);
+    GR::sync();
+    rc = do_all_mpc<G>(S, A, PATH_POINTS, px, py, dx, dy, out, fallback, n_dense);
     if (rc == 1) rc = ST_REF_UNDEFINED_PATH;
   }
   return rc;
@@ -611,7 +646,8 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame) {
 // core_calculate_path.py:103-121: previous_paths[0] = parameterize_path(fit(chord).predict())
 __global__ void __launch_bounds__(64) default_path_kernel(const double* __restrict__ chord, double* __restrict__ arena,
                                                           double* __restrict__ out) {
-  __shared__ PathShared S;
+  constexpr int G = WAVE;
+  __shared__ PathShared<G> S;
   const int lane = lane_id();
   const Arena A = frame_arena(arena, 0);
   if (lane < PATH_POINTS) {
@@ -621,28 +657,29 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
   __syncthreads();
   SplineFit f;
   double max_u;
-  int rc = fit_polyline(S, A, 0, PATH_POINTS, 0.2, f, max_u);
+  int rc = fit_polyline<G>(S, A, 0, PATH_POINTS, 0.2, f, max_u);
   int n1 = arange_len(max_u, 0.1);
   if (rc == 0 && n1 <= PATH_CAP) {
-    spline_eval(S.ws, f, 0.1, n1, A.x, A.y, nullptr);
+    spline_eval<G>(S.ws, f, 0.1, n1, A.x, A.y, nullptr);
     int nd = 0;
     double(*o)[4] = (double(*)[4])out;
-    rc = parameterize_path(S, A, 0, n1, o, &nd);
+    rc = parameterize_path<G>(S, A, 0, n1, o, &nd);
   }
   if (rc != 0 && lane < PATH_POINTS)
     for (int q = 0; q < 4; q++) out[4 * lane + q] = NAN;
 }
 
-__global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double* __restrict__ poses,
-                                                  const MatchOut* __restrict__ matched,
-                                                  const double* __restrict__ default_path,
-                                                  const double* __restrict__ prev_paths, double* __restrict__ arena,
-                                                  PathOut* __restrict__ out) {
-  __shared__ PathShared S;
-  const int frame = blockIdx.x;
-  if (frame >= n_frames) return;
+// lanes per frame of the product path kernel: four frames per wavefront (see the header comment)
+constexpr int PATH_G = 16;
+
+template <int G>
+__device__ inline void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
+                                  const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
+                                  const double* __restrict__ prev_paths, double* __restrict__ arena,
+                                  PathOut* __restrict__ out) {
+  using GR = Grp<G>;
   PROF(0);
-  const int lane = lane_id();
+  const int lane = GR::lane();
   const Arena A = frame_arena(arena, frame);
   const MatchOut* mo = &matched[frame];
   PathOut* o = &out[frame];
@@ -652,11 +689,11 @@ __global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double*
   // previous_paths[-1]: the constant initial path (fresh planner) or, for sequential replays, the caller-supplied
   // previous output of this planner (core_calculate_path.py:572-573)
   const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
-  if (lane < PATH_POINTS) {
-    S.prevx[lane] = prev[4 * lane + 1];
-    S.prevy[lane] = prev[4 * lane + 2];
+  for (int i = lane; i < PATH_POINTS; i += G) {
+    S.prevx[i] = prev[4 * i + 1];
+    S.prevy[i] = prev[4 * i + 2];
   }
-  __syncthreads();
+  GR::sync();
   const int nl = mo->n_left_v, nr = mo->n_right_v;
   int nc = 0;  // centre points in S.cxp/cyp
   if (status == ST_OK) {
@@ -664,74 +701,78 @@ __global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double*
     if (nl < 3 && nr < 3) {
       use_prev = true;
     } else {
-      // select_side_to_use :151-183
-      int ml = (lane < nl) ? mo->l2r[lane] : -1;
-      int mr = (lane < nr) ? mo->r2l[lane] : -1;
-      unsigned long long bl = __ballot(ml != -1), br = __ballot(mr != -1);
-      int cntl = __popcll(bl), cntr = __popcll(br);
-      int sl = 0, sr = 0;
+      // select_side_to_use :151-183 (<= 24 entries per side: group-uniform scalar loops)
+      int cntl = 0, cntr = 0, sl = 0, sr = 0;
       for (int i = 0; i < nl; i++) {
         int v = mo->l2r[i];
-        if (v != -1) sl += v;
+        if (v != -1) {
+          cntl++;
+          sl += v;
+        }
       }
       for (int i = 0; i < nr; i++) {
         int v = mo->r2l[i];
-        if (v != -1) sr += v;
+        if (v != -1) {
+          cntr++;
+          sr += v;
+        }
       }
       bool use_left = !((cntr > cntl) || (cntr == cntl && sr > sl));
       const int ns = use_left ? nl : nr, no = use_left ? nr : nl;
-      const int mine = use_left ? ml : mr;
-      const unsigned long long bm = use_left ? bl : br;
       if (ns > 0 && no == 0) {
         status = ST_REF_UNDEFINED_MATCH_IDX;
       } else {
+        const int32_t* mv = use_left ? mo->l2r : mo->r2l;
+        const double(*sv)[2] = use_left ? mo->left_v : mo->right_v;
+        const double(*ov)[2] = use_left ? mo->right_v : mo->left_v;
         bool bad = false;
-        if (lane < ns) {
-          int j = mine < 0 ? no + mine : mine;
-          if (j < 0 || j >= no) bad = true;
-          if (!bad && mine != -1) {
-            const double(*sv)[2] = use_left ? mo->left_v : mo->right_v;
-            const double(*ov)[2] = use_left ? mo->right_v : mo->left_v;
-            int p = __popcll(bm & ((1ull << lane) - 1ull));
-            S.cxp[p] = (sv[lane][0] + ov[j][0]) / 2;
-            S.cyp[p] = (sv[lane][1] + ov[j][1]) / 2;
+        int p = 0;
+        for (int i = 0; i < ns; i++) {
+          const int mine = mv[i];
+          const int j = mine < 0 ? no + mine : mine;
+          if (j < 0 || j >= no) {
+            bad = true;
+          } else if (mine != -1 && !bad && lane == 0) {
+            S.cxp[p] = (sv[i][0] + ov[j][0]) / 2;
+            S.cyp[p] = (sv[i][1] + ov[j][1]) / 2;
           }
+          if (mine != -1) p++;
         }
-        if (__ballot(bad) != 0ull) status = ST_REF_UNDEFINED_MATCH_IDX;
-        nc = __popcll(bm);
+        if (bad) status = ST_REF_UNDEFINED_MATCH_IDX;
+        nc = p;
         if (nc < 2) use_prev = true;
       }
     }
-    __syncthreads();
+    GR::sync();
     if (use_prev) {
       fallback |= 1;
-      if (lane < PATH_POINTS) {
-        S.cxp[lane] = S.prevx[lane];
-        S.cyp[lane] = S.prevy[lane];
+      for (int i = lane; i < PATH_POINTS; i += G) {
+        S.cxp[i] = S.prevx[i];
+        S.cyp[i] = S.prevy[i];
       }
       nc = PATH_POINTS;
     }
-    __syncthreads();
+    GR::sync();
   }
   // fit_matches_as_spline :207-223 -> dense path update in arena [1, 1+n1)
   int n1 = 0;
   if (status == ST_OK) {
     for (int attempt = 0; attempt < 2; attempt++) {
-      if (lane < nc) {
-        A.x[lane] = S.cxp[lane];
-        A.y[lane] = S.cyp[lane];
+      for (int i = lane; i < nc; i += G) {
+        A.x[i] = S.cxp[i];
+        A.y[i] = S.cyp[i];
       }
-      __syncthreads();
+      GR::sync();
       SplineFit f;
       double max_u;
       PROF(1);
-      int rc = fit_polyline(S, A, 0, nc, 0.2, f, max_u);
+      int rc = fit_polyline<G>(S, A, 0, nc, 0.2, f, max_u);
       if (rc == 0) {
         n1 = arange_len(max_u, 0.1);
         if (n1 + 1 + 50 > PATH_CAP) {
           status = ST_OVERFLOW_PATH;
         } else {
-          spline_eval(S.ws, f, 0.1, n1, A.x + 1, A.y + 1, nullptr);
+          spline_eval<G>(S.ws, f, 0.1, n1, A.x + 1, A.y + 1, nullptr);
         }
         break;
       }
@@ -744,24 +785,38 @@ __global__ void __launch_bounds__(64, 3) path_kernel(int n_frames, const double*
         break;
       }
       fallback |= 2;
-      if (lane < PATH_POINTS) {
-        S.cxp[lane] = S.prevx[lane];
-        S.cyp[lane] = S.prevy[lane];
+      for (int i = lane; i < PATH_POINTS; i += G) {
+        S.cxp[i] = S.prevx[i];
+        S.cyp[i] = S.prevy[i];
       }
       nc = PATH_POINTS;
-      __syncthreads();
+      GR::sync();
     }
   }
-  if (status == ST_OK) status = finish_path(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
-  __syncthreads();
-  if (status != ST_OK && lane < PATH_POINTS)
-    for (int q = 0; q < 4; q++) o->path[lane][q] = NAN;
+  if (status == ST_OK) status = finish_path<G>(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
+  GR::sync();
+  if (status != ST_OK)
+    for (int i = lane; i < PATH_POINTS; i += G)
+      for (int q = 0; q < 4; q++) o->path[i][q] = NAN;
   if (lane == 0) {
     o->status = status;
     o->fallback = fallback;
     o->n_dense = n_dense;
     o->pad = 0;
   }
+}
+
+// grid = ceil(n_frames / (64 / PATH_G)) workgroups of one wavefront; group g of block b plans frame b * 4 + g
+__global__ void __launch_bounds__(64, 1) path_kernel(int n_frames, const double* __restrict__ poses,
+                                                     const MatchOut* __restrict__ matched,
+                                                     const double* __restrict__ default_path,
+                                                     const double* __restrict__ prev_paths, double* __restrict__ arena,
+                                                     PathOut* __restrict__ out) {
+  constexpr int G = PATH_G;
+  __shared__ PathShared<G> S_all[WAVE / G];
+  const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
+  if (frame >= n_frames) return;
+  path_frame<G>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, arena, out);
 }
 
 }  // namespace fsdp

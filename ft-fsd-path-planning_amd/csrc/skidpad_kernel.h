@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, const doub
                                                           const double* __restrict__ chord, double* __restrict__ arena,
                                                           const int32_t* __restrict__ status_in, PathOut* __restrict__ out,
                                                           SkidInfo* __restrict__ info) {
-  __shared__ PathShared S;
+  __shared__ PathShared<WAVE> S;
   const int inst = blockIdx.x;
   if (inst >= n_inst) return;
   const int lane = lane_id();
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, const doub
     }
     __syncthreads();
   }
-  if (status == ST_OK) status = finish_path(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
+  if (status == ST_OK) status = finish_path<WAVE>(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
   __syncthreads();
   if (status == ST_OK) {
     // previous_paths[-1] <- this result (map frame); then path xy back to the original frame (full_pipeline.py:178-194)

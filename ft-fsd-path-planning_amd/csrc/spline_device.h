@@ -1,15 +1,17 @@
-// Smoothing B-spline fit + evaluation on one wavefront (gfx950).
+// Smoothing B-spline fit + evaluation on one lane group (G lanes of a wavefront, gfx950).
 //
 // What the reference reaches through SciPy (utils/spline_fit.py:117 splprep, :61 splev) is
 // Dierckx's FITPACK parcur/fppara: adaptive knot placement, Givens-QR least squares on a banded
 // observation matrix, and a rational iteration on the smoothing parameter p.  The path stage's
 // discrete decisions (how many dense samples the output is drawn from) hang on the last bit of
 // these results, so this implementation keeps FITPACK's operation ORDER wherever a rounding
-// could differ, and uses the 64 lanes only where the result is order-independent:
+// could differ, and uses the group's lanes only where the result is order-independent:
 //   * per-data-point work (knot-interval search, de Boor basis values, residual terms, curve
-//     evaluation) runs one point per lane, 64 points per step, staged through LDS;
+//     evaluation) runs one point per lane, staged through LDS in chunks of CH rows;
 //   * the row-by-row Givens rotations, back-substitution, knot bookkeeping and all running sums
-//     are wave-uniform (every lane carries the same scalars; LDS reads broadcast).
+//     are group-uniform (every lane carries the same scalars; LDS reads broadcast).
+// Everything is templated on the group size G (fsdp_device.h Grp<G>): G = 64 is one frame per wavefront,
+// G = 16 packs four frames into a wavefront so that the serial sections advance four fits per instruction.
 // Arrays are 1-based like the published algorithm.  idim = 2, unit weights, iopt = 0.
 #pragma once
 #include "fsdp_device.h"
@@ -18,25 +20,30 @@ namespace fsdp {
 
 constexpr int NK = 32;  // max number of knots kept in LDS (FITPACK's nest is m+2k; OVERFLOW_KNOTS beyond)
 
+constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121 in practice)
+
+template <int G>
 struct SplineWS {
+  static constexpr int CH = (G >= 32) ? G : 32;  // data rows staged per chunk
   double t[NK + 2];
   double c[2 * (NK + 2)];
-  double z[2 * (NK + 2)];
-  double fpint[NK + 2];
-  double a[NK + 2][5];
-  double b[NK + 2][6];
-  double g[NK + 2][6];
-  int32_t nrdata[NK + 2];
   union {
-    struct {
-      double hq[WAVE][4];         // per-chunk basis values
-      double xq[WAVE], yq[WAVE];  // per-chunk data points (the polyline itself lives in HBM/L2)
-      double term[WAVE];          // per-chunk residual terms / segment lengths
+    struct {  // alive during a fit
+      double z[2 * (NK + 2)];
+      double fpint[NK + 2];
+      double a[NK + 2][5];
+      double b[NK + 2][6];
+      double g[NK + 2][6];
+      int32_t nrdata[NK + 2];
+      double hq[CH][4];          // per-chunk basis values
+      double xq[CH], yq[CH];     // per-chunk data points (the polyline itself lives in HBM/L2)
+      double term[CH];           // per-chunk residual terms / segment lengths
+      int32_t lq[CH];            // per-chunk knot interval / "new knot" flags
     };
-    double seg[WAVE * 7];         // between fits: segment lengths, later raw | filtered curvature (path stage)
+    // between / after fits (path stage): segment lengths, later dense samples x | y | u | raw | filtered curvature
+    double dense[5 * DENSE_CAP];
   };
-  int32_t lq[WAVE];     // per-chunk knot interval / "new knot" flags
-  double scal[4];       // lane-0 -> wave broadcast of serial-section scalars
+  double scal[4];  // lane-0 -> group broadcast of serial-section scalars
 };
 
 struct SplineFit {
@@ -96,6 +103,14 @@ __device__ __forceinline__ int find_interval(const double* t, int k1, int nk1, d
   return l;
 }
 
+// the same search started at a known lower bound (t[lstart] <= x): data are processed in increasing order, so a lane
+// resumes at its previous interval instead of rescanning the knot vector
+__device__ __forceinline__ int find_interval_from(const double* t, int lstart, int nk1, double x) {
+  int l = lstart;
+  while (!(x < t[l + 1] || l == nk1)) l++;
+  return l;
+}
+
 // back-substitution, band width k (fpback); a is either ws.a (5 cols) or ws.g (6 cols)
 template <int COLS>
 __device__ inline void fpback(double (*a)[COLS], const double* z, int n, int k, double* c) {
@@ -119,7 +134,7 @@ __device__ inline void fpback(double (*a)[COLS], const double* z, int n, int k, 
 
 // ---- 4-stage systolic Givens pipeline (degree 3) ------------------------------------------------------
 // A data row touches the 4 consecutive band rows l-3..l, one rotation each, in that order; consecutive data
-// rows touch (almost always) the same band rows.  Lane p of the first quad owns band row j with j mod 4 = p and
+// rows touch (almost always) the same band rows.  Lane p of the group's first quad owns band row j with j mod 4 = p and
 // keeps it in registers; a data row travels lane -> lane (quad rotate, DPP) one stage per step, so up to 4
 // data rows are in flight.  Every band row still sees the data rows in data order and every data row still
 // visits its band rows in order: the arithmetic (fpgivs / fprota) and its sequence per element are exactly
@@ -130,10 +145,11 @@ struct GivItem {
   int info;   // stage (1..4, 0 = empty) | data-row slot << 8
 };
 
+template <int G>
 __device__ __forceinline__ GivItem quad_rot_prev(const GivItem& v) {
 #ifdef FSDP_EMU
-  int l = lane_id();
-  return emu::exchange_struct(v, (l & ~3) | ((l + 3) & 3));
+  int l = emu::B->cur;
+  return emu::gexchange_struct(v, (l & ~3) | ((l + 3) & 3), G);
 #else
   GivItem o;
   auto rot = [](double d) {
@@ -159,7 +175,8 @@ struct GivRow {  // the band row a lane currently owns
   double a1, a2, a3, a4, z1, z2;
 };
 
-__device__ __forceinline__ void giv_flush(SplineWS& ws, const GivRow& r, int n) {
+template <int G>
+__device__ __forceinline__ void giv_flush(SplineWS<G>& ws, const GivRow& r, int n) {
   if (r.j > 0) {
     ws.a[r.j][1] = r.a1;
     ws.a[r.j][2] = r.a2;
@@ -171,9 +188,10 @@ __device__ __forceinline__ void giv_flush(SplineWS& ws, const GivRow& r, int n) 
 }
 
 // one chunk of `cnt` data rows (basis values / interval / data in ws.hq, ws.lq, ws.xq, ws.yq) through the pipeline;
-// leaves each row's rotated-out right-hand side in ws.xq/yq (for the residual sum).  All lanes call.
-__device__ inline void givens_chunk_pipelined(SplineWS& ws, int cnt, int n, GivRow& row) {
-  const int lane = lane_id();
+// leaves each row's rotated-out right-hand side in ws.xq/yq (for the residual sum).  All lanes of the group call.
+template <int G>
+__device__ inline void givens_chunk_pipelined(SplineWS<G>& ws, int cnt, int n, GivRow& row) {
+  const int lane = Grp<G>::lane();
   constexpr int k1 = 4;
   GivItem out;
   out.piv = out.r0 = out.r1 = out.r2 = out.x1 = out.x2 = 0.0;
@@ -181,7 +199,7 @@ __device__ inline void givens_chunk_pipelined(SplineWS& ws, int cnt, int n, GivR
   out.info = 0;
   int next_r = 0, t_next = 0, last_finish = -1;
   for (int tau = 0; next_r < cnt || tau <= last_finish; tau++) {
-    GivItem in = quad_rot_prev(out);
+    GivItem in = quad_rot_prev<G>(out);
     if (next_r < cnt && tau >= t_next) {
       const int l = ws.lq[next_r];
       const int j0 = l - k1 + 1;
@@ -242,12 +260,14 @@ __device__ inline void givens_chunk_pipelined(SplineWS& ws, int cnt, int n, GivR
   }
 }
 
-// parcur/fppara for idim=2, w=1, iopt=0.  Data in LDS: U (parameter), X, Y, m points (0-based arrays).
-// All lanes call; result (t, c) left in ws; returns wave-uniform SplineFit.
-template <int K>
-__device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const double* X, const double* Y, int m, double s) {
+// parcur/fppara for idim=2, w=1, iopt=0.  Data (0-based arrays U = parameter, X, Y; m points) in LDS or HBM.
+// All lanes of the group call; result (t, c) left in ws; returns the group-uniform SplineFit.
+template <int K, int G>
+__device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const double* X, const double* Y, int m, double s) {
+  using GR = Grp<G>;
+  constexpr int CH = SplineWS<G>::CH;
   constexpr int k = K;
-  const int lane = lane_id();
+  const int lane = GR::lane();
   SplineFit R;
   R.k = k;
   R.n = 0;
@@ -265,9 +285,9 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
   // parcur: u must be strictly increasing (ier = 10 -> ValueError in SciPy)
   {
     bool badl = false;
-    for (int i = 1 + lane; i < m; i += WAVE)
+    for (int i = 1 + lane; i < m; i += G)
       if (!(U[i - 1] < U[i])) badl = true;
-    if (__ballot(badl) != 0ull) {
+    if (GR::ballot(badl) != 0ull) {
       R.status = 1;
       return R;
     }
@@ -282,7 +302,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
   int n = nmin, ier = 0, nplus = 0, nrint = 0, nk1 = 0;
   double fp = 0, fpold = 0, fp0 = 0, fpms = 0;
   if (lane == 0) ws.nrdata[1] = m - 2;
-  __syncthreads();
+  GR::sync();
 
   bool done = false, to_part2 = false, interp_knots = false;
   while (!done && !to_part2) {
@@ -300,7 +320,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
           j++;
         }
       }
-      __syncthreads();
+      GR::sync();
     }
     bool restart = false;
     for (int iter = 1; iter <= m && !restart; iter++) {
@@ -311,38 +331,40 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
         ws.t[1 + lane] = ub;
         ws.t[n - lane] = ue;
       }
-      for (int i = 1 + lane; i <= 2 * (NK + 1); i += WAVE) ws.z[i] = 0.0;
-      for (int i = 1 + lane; i <= nk1; i += WAVE)
+      for (int i = 1 + lane; i <= 2 * (NK + 1); i += G) ws.z[i] = 0.0;
+      for (int i = 1 + lane; i <= nk1; i += G)
         for (int j = 1; j <= k1; j++) ws.a[i][j] = 0.0;
-      __syncthreads();
+      GR::sync();
       fp = 0.0;
       GivRow grow;
       grow.j = 0;
       grow.a1 = grow.a2 = grow.a3 = grow.a4 = grow.z1 = grow.z2 = 0.0;
-      // ---- observation rows: basis values per lane, Givens rotations wave-uniform in data order ----
-      for (int base = 0; base < m; base += WAVE) {
-        int it = base + lane;
+      int lres = k1;  // this lane's previous knot interval (data are increasing: the search resumes there)
+      // ---- observation rows: basis values per lane, Givens rotations group-uniform in data order ----
+      for (int base = 0; base < m; base += CH) {
+        const int cnt = m - base < CH ? m - base : CH;
         {
-        PROF(10);
-        if (it < m) {
-          double ui = U[it];
-          int l = find_interval(ws.t, k1, nk1, ui);
-          double h[K + 2];
-          fpbspl<K>(ws.t, ui, l, h);
+          PROF(10);
+          for (int r = lane; r < cnt; r += G) {
+            const int it = base + r;
+            double ui = U[it];
+            int l = find_interval_from(ws.t, lres, nk1, ui);
+            lres = l;
+            double h[K + 2];
+            fpbspl<K>(ws.t, ui, l, h);
 #pragma unroll
-          for (int q = 0; q < k1; q++) ws.hq[lane][q] = h[q + 1];
-          ws.lq[lane] = l;
-          ws.xq[lane] = X[it];
-          ws.yq[lane] = Y[it];
+            for (int q = 0; q < k1; q++) ws.hq[r][q] = h[q + 1];
+            ws.lq[r] = l;
+            ws.xq[r] = X[it];
+            ws.yq[r] = Y[it];
+          }
+          GR::sync();
         }
-        __syncthreads();
-        }
-        int cnt = m - base < WAVE ? m - base : WAVE;
         if constexpr (K == 3) {
           {
             PROF(11);
-            givens_chunk_pipelined(ws, cnt, n, grow);
-            __syncthreads();
+            givens_chunk_pipelined<G>(ws, cnt, n, grow);
+            GR::sync();
           }
           PROF(12);
           // sum of squared rotated-out right-hand sides, in data order
@@ -388,19 +410,19 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
               ws.yq[r] = xi2;
             }
           }
-          __syncthreads();
+          GR::sync();
           for (int r = 0; r < cnt; r++) {
             double xi1 = ws.xq[r], xi2 = ws.yq[r];
             fp = fp + xi1 * xi1;
             fp = fp + xi2 * xi2;
           }
         }
-        __syncthreads();
+        GR::sync();
       }
       if constexpr (K == 3) {
-        if (lane < 4) giv_flush(ws, grow, n);
+        if (lane < 4) giv_flush<G>(ws, grow, n);
         grow.j = 0;
-        __syncthreads();
+        GR::sync();
       }
       if (lane == 0) {
         PROF(13);
@@ -408,14 +430,14 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
         fpback<5>(ws.a, &ws.z[0], nk1, k1, &ws.c[0]);
         fpback<5>(ws.a, &ws.z[n], nk1, k1, &ws.c[n]);
       }
-      __syncthreads();
+      GR::sync();
       if (ier == -2) fp0 = fp;
       if (lane == 0) {
         ws.fpint[n] = fp0;
         ws.fpint[n - 1] = fpold;
         ws.nrdata[n] = nplus;
       }
-      __syncthreads();
+      GR::sync();
       fpms = fp - s;
       if (fabs(fpms) < acc) {
         done = true;
@@ -453,40 +475,47 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
         PROF(14);
         double fpart = 0.0;
         int ii = 1;
-        for (int base = 0; base < m; base += WAVE) {
-          int it = base + lane;
-          if (it < m) {
-            double ui = U[it];
+        int lres2 = k1;
+        int lcarry = k2;  // FITPACK's running l after the last point of the previous round
+        for (int base = 0; base < m; base += CH) {
+          const int cnt = m - base < CH ? m - base : CH;
+          for (int r0 = 0; r0 < CH; r0 += G) {  // all lanes take every round (the shuffles below are group-wide)
+            const int r = r0 + lane;
+            const bool act = r < cnt;
+            const int it = base + r;
             // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
-            // l = k2 + #{interior knots <= u(it)}, "new" when the count grew at this point
-            int l = k2;
-            while (l <= nk1 && ui >= ws.t[l]) l++;
-            int lprev = k2;
-            if (it > 0) {
-              double up = U[it - 1];
-              while (lprev <= nk1 && up >= ws.t[lprev]) lprev++;
+            // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point
+            double ui = 0.0;
+            int l = lcarry;
+            if (act) {
+              ui = U[it];
+              lres2 = find_interval_from(ws.t, lres2, nk1, ui);
+              l = lres2 + 1;
             }
-            int lfit = find_interval(ws.t, k1, nk1, ui);
-            double h[K + 2];
-            fpbspl<K>(ws.t, ui, lfit, h);
-            int l0 = l - k2;
-            double term = 0.0;
-            for (int d = 0; d < 2; d++) {
-              double fac = 0.0;
-              int j1 = l0 + d * n;
+            int lprev = GR::shfl_up1(l);
+            if (lane == 0) lprev = lcarry;
+            lcarry = GR::bcast(l, G - 1);
+            if (act) {
+              double h[K + 2];
+              fpbspl<K>(ws.t, ui, l - 1, h);
+              int l0 = l - k2;
+              double term = 0.0;
+              for (int d = 0; d < 2; d++) {
+                double fac = 0.0;
+                int j1 = l0 + d * n;
 #pragma unroll
-              for (int j = 1; j <= k1; j++) {
-                j1++;
-                fac = fac + ws.c[j1] * h[j];
+                for (int j = 1; j <= k1; j++) {
+                  j1++;
+                  fac = fac + ws.c[j1] * h[j];
+                }
+                double dv = 1.0 * (fac - (d == 0 ? X[it] : Y[it]));
+                term = term + dv * dv;
               }
-              double dv = 1.0 * (fac - (d == 0 ? X[it] : Y[it]));
-              term = term + dv * dv;
+              ws.term[r] = term;
+              ws.lq[r] = (l > lprev) ? 1 : 0;
             }
-            ws.term[lane] = term;
-            ws.lq[lane] = (l > lprev) ? 1 : 0;
           }
-          __syncthreads();
-          int cnt = m - base < WAVE ? m - base : WAVE;
+          GR::sync();
           for (int r = 0; r < cnt; r++) {
             double term = ws.term[r];
             if (ws.lq[r]) {
@@ -498,12 +527,12 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
               fpart = fpart + term;
             }
           }
-          __syncthreads();
+          GR::sync();
         }
         if (lane == 0) ws.fpint[nrint] = fpart;
-        __syncthreads();
+        GR::sync();
       }
-      // ---- add nplus knots (fpknot), wave-uniform ----
+      // ---- add nplus knots (fpknot), group-uniform ----
       for (int lq = 1; lq <= nplus; lq++) {
         {
           PROF(15);
@@ -524,7 +553,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
           int ihalf = maxpt / 2 + 1;
           int nrx = maxbeg + ihalf;
           int next = number + 1;
-          __syncthreads();
+          GR::sync();
           if (lane == 0) {
             if (next <= nrint) {
               for (int j = next; j <= nrint; j++) {
@@ -547,7 +576,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
           }
           n = n + 1;
           nrint = nrint + 1;
-          __syncthreads();
+          GR::sync();
         }
         if (n == nmax) {
           interp_knots = true;
@@ -567,7 +596,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
       int nrint2 = nk1 - k;
       double an = nrint2;
       double fac = an / (ws.t[nk1 + 1] - ws.t[k1]);
-      for (int l = k2 + lane; l <= nk1; l += WAVE) {
+      for (int l = k2 + lane; l <= nk1; l += G) {
         double h[2 * K + 3];
         int lmk = l - k1;
 #pragma unroll
@@ -593,7 +622,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
           lp = lp + 1;
         }
       }
-      __syncthreads();
+      GR::sync();
     }
     double p1 = 0., f1 = fp0 - s, p3 = -one, f3 = fpms, p = 0.;
     for (int i = 1; i <= nk1; i++) p = p + ws.a[i][1];
@@ -603,13 +632,13 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
     const int n8 = n - nmin;
     for (int iter = 1; iter <= maxit; iter++) {
       double pinv = one / p;
-      __syncthreads();
-      for (int i = 1 + lane; i <= 2 * n; i += WAVE) ws.c[i] = ws.z[i];
-      for (int i = 1 + lane; i <= nk1; i += WAVE) {
+      GR::sync();
+      for (int i = 1 + lane; i <= 2 * n; i += G) ws.c[i] = ws.z[i];
+      for (int i = 1 + lane; i <= nk1; i += G) {
         ws.g[i][k2] = 0.;
         for (int j = 1; j <= k1; j++) ws.g[i][j] = ws.a[i][j];
       }
-      __syncthreads();
+      GR::sync();
       if (lane == 0) {  // serial section (single writer of g / c)
         PROF(16);
         for (int it = 1; it <= n8; it++) {
@@ -649,19 +678,20 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
         fpback<6>(ws.g, &ws.c[0], nk1, k2, &ws.c[0]);
         fpback<6>(ws.g, &ws.c[n], nk1, k2, &ws.c[n]);
       }
-      __syncthreads();
+      GR::sync();
       // f(p): terms per lane, accumulation in data order
       PROF(17);
       fp = 0.;
-      for (int base = 0; base < m; base += WAVE) {
-        int it = base + lane;
-        if (it < m) {
+      int lres3 = k1;
+      for (int base = 0; base < m; base += CH) {
+        const int cnt = m - base < CH ? m - base : CH;
+        for (int r = lane; r < cnt; r += G) {
+          const int it = base + r;
           double ui = U[it];
-          int l = k2;
-          while (l <= nk1 && ui >= ws.t[l]) l++;
-          int lfit = find_interval(ws.t, k1, nk1, ui);
+          lres3 = find_interval_from(ws.t, lres3, nk1, ui);
+          const int l = lres3 + 1;
           double h[K + 2];
-          fpbspl<K>(ws.t, ui, lfit, h);
+          fpbspl<K>(ws.t, ui, lres3, h);
           int l0 = l - k2;
           double term = 0.;
           for (int d = 0; d < 2; d++) {
@@ -675,12 +705,11 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
             double dv = fac - (d == 0 ? X[it] : Y[it]);
             term = term + dv * dv;
           }
-          ws.term[lane] = term;
+          ws.term[r] = term;
         }
-        __syncthreads();
-        int cnt = m - base < WAVE ? m - base : WAVE;
+        GR::sync();
         for (int r = 0; r < cnt; r++) fp = fp + ws.term[r] * (1.0 * 1.0);
-        __syncthreads();
+        GR::sync();
       }
       fpms = fp - s;
       if (fabs(fpms) < acc) break;
@@ -740,30 +769,32 @@ __device__ inline SplineFit spline_fit_k(SplineWS& ws, const double* U, const do
       }
     }
   }
-  __syncthreads();
+  GR::sync();
   R.n = n;
   R.ier = ier;
   R.fp = fp;
   return R;
 }
 
-__device__ inline SplineFit spline_fit(SplineWS& ws, const double* U, const double* X, const double* Y, int m, int k,
+template <int G>
+__device__ inline SplineFit spline_fit(SplineWS<G>& ws, const double* U, const double* X, const double* Y, int m, int k,
                                        double s) {
-  if (k == 3) return spline_fit_k<3>(ws, U, X, Y, m, s);
-  if (k == 2) return spline_fit_k<2>(ws, U, X, Y, m, s);
-  return spline_fit_k<1>(ws, U, X, Y, m, s);
+  if (k == 3) return spline_fit_k<3, G>(ws, U, X, Y, m, s);
+  if (k == 2) return spline_fit_k<2, G>(ws, U, X, Y, m, s);
+  return spline_fit_k<1, G>(ws, U, X, Y, m, s);
 }
 
 // splev (der = 0, ext = 0) at arg = i * step for i in [0, count): one evaluation point per lane.
-// Outputs to OX/OY (LDS or global), optional parameter values to OU.
-template <int K>
-__device__ inline void spline_eval_k(const SplineWS& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+// Outputs to OX/OY (LDS or global), optional parameter values to OU.  Reads only t / c, so the outputs may alias the
+// rest of the fit workspace (the dense samples of the final spline do).
+template <int K, int G>
+__device__ inline void spline_eval_k(const SplineWS<G>& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
                                      double* OU) {
-  const int lane = lane_id();
+  const int lane = Grp<G>::lane();
   const int n = f.n;
   constexpr int k1 = K + 1;
   const int nk1 = n - k1;
-  for (int i = lane; i < count; i += WAVE) {
+  for (int i = lane; i < count; i += G) {
     double arg = (double)i * step;
     int l = find_interval(ws.t, k1, nk1, arg);
     double h[K + 2];
@@ -780,17 +811,18 @@ __device__ inline void spline_eval_k(const SplineWS& ws, const SplineFit& f, dou
     OY[i] = sy;
     if (OU) OU[i] = arg;
   }
-  __syncthreads();
+  Grp<G>::sync();
 }
 
-__device__ inline void spline_eval(const SplineWS& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+template <int G>
+__device__ inline void spline_eval(const SplineWS<G>& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
                                    double* OU) {
   if (f.k == 3)
-    spline_eval_k<3>(ws, f, step, count, OX, OY, OU);
+    spline_eval_k<3, G>(ws, f, step, count, OX, OY, OU);
   else if (f.k == 2)
-    spline_eval_k<2>(ws, f, step, count, OX, OY, OU);
+    spline_eval_k<2, G>(ws, f, step, count, OX, OY, OU);
   else
-    spline_eval_k<1>(ws, f, step, count, OX, OY, OU);
+    spline_eval_k<1, G>(ws, f, step, count, OX, OY, OU);
 }
 
 }  // namespace fsdp

@@ -23,7 +23,7 @@ static void build_default() {
 namespace fsdp {
 // test kernel: fit one polyline (m <= PATH_CAP) and dump knots / coefficients
 __global__ void fit_test_kernel(const double* xy, int m, double smoothing, double* arena, double* t_out, double* c_out, int* info, double* fp_out) {
-  __shared__ PathShared S;
+  __shared__ PathShared<WAVE> S;
   const int lane = lane_id();
   const Arena A = frame_arena(arena, 0);
   for (int i = lane; i < m; i += WAVE) {
@@ -33,7 +33,7 @@ __global__ void fit_test_kernel(const double* xy, int m, double smoothing, doubl
   __syncthreads();
   SplineFit f;
   double max_u;
-  int rc = fit_polyline(S, A, 0, m, smoothing, f, max_u);
+  int rc = fit_polyline<WAVE>(S, A, 0, m, smoothing, f, max_u);
   if (lane == 0) {
     info[0] = rc;
     info[1] = f.n;
@@ -103,6 +103,8 @@ void emu_default_path(double* out) {
 void emu_path(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
   std::call_once(g_once, build_default);
   std::vector<double> arena((size_t)3 * fsdp::PATH_CAP * n_frames);
-  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, g_prev_paths, arena.data(), out); });
+  const unsigned per = 64 / fsdp::PATH_G;
+  emu::launch(((unsigned)n_frames + per - 1) / per, 64,
+              [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, g_prev_paths, arena.data(), out); });
 }
 }

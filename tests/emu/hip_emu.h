@@ -8,8 +8,9 @@
 // Supported subset (what the kernels use): __global__/__device__/__shared__, threadIdx /
 // blockIdx / blockDim / gridDim (.x), __syncthreads, __ballot, __shfl/__shfl_xor/__shfl_down/
 // __shfl_up (int, unsigned, long long, double), __popcll, __ffsll, __clzll, atomicOr/atomicAdd
-// on shared ints.  Cross-lane operations must be reached by all 64 lanes (wave-uniform
-// control flow) — the same discipline the kernels follow on hardware.
+// on shared ints.  Cross-lane operations are rendezvous of an aligned G-lane group (G = 64
+// by default; the path stage runs several frames per wavefront with G = 16): all lanes of a group must reach them
+// (group-uniform control flow) — the same discipline the kernels follow on hardware; groups may diverge.
 #pragma once
 #include <ucontext.h>
 
@@ -44,8 +45,8 @@ struct Block {
   int n_lanes = WAVE;
   int cur = 0;
   int live = 0;
-  int arrived = 0;
-  unsigned gen = 0;
+  int garrived[WAVE] = {0};
+  unsigned ggen[WAVE] = {0};
   Dim3 bid, bdim, gdim;
   uint64_t slots[WAVE];
   std::function<void()> body;
@@ -66,31 +67,35 @@ inline void yield_lane() {
   swapcontext(&b->lanes[from].ctx, &b->lanes[nxt].ctx);
 }
 
-inline void barrier() {
+// Rendezvous of the G-lane group the current lane belongs to (G = 64: the whole block).  Groups are aligned
+// (first lane = cur & ~(G-1)); a group's lanes follow the same control flow, different groups may diverge.
+inline int group_live(Block* b, int first, int G) {
+  int n = 0;
+  for (int l = first; l < first + G && l < b->n_lanes; l++)
+    if (!b->lanes[l].done) n++;
+  return n;
+}
+inline void gbarrier(int G) {
   Block* b = B;
-  unsigned g = b->gen;
-  if (++b->arrived == b->live) {
-    b->arrived = 0;
-    b->gen++;
+  int first = b->cur & ~(G - 1);
+  unsigned g = b->ggen[first];
+  if (++b->garrived[first] >= group_live(b, first, G)) {
+    b->garrived[first] = 0;
+    b->ggen[first]++;
     return;
   }
-  while (b->gen == g) yield_lane();
+  while (b->ggen[first] == g) yield_lane();
 }
+inline void barrier() { gbarrier(WAVE); }
 
 inline void lane_entry() {
   Block* b = B;
   b->body();
   b->lanes[b->cur].done = true;
   b->live--;
-  // a lane that leaves while others wait at a rendezvous would dead-lock them: the kernels
-  // never do that (all lanes reach the end together), so just hand over.
-  if (b->live > 0) {
-    if (b->arrived == b->live && b->arrived > 0) {  // release waiters if we were the last expected
-      b->arrived = 0;
-      b->gen++;
-    }
-    yield_lane();
-  }
+  // a lane that leaves while others of its group wait at a rendezvous would dead-lock them: the kernels never do
+  // that (all lanes of a group reach the end together), so just hand over.
+  if (b->live > 0) yield_lane();
   swapcontext(&b->lanes[b->cur].ctx, &b->main_ctx);
 }
 
@@ -110,8 +115,10 @@ void launch(unsigned grid, unsigned block, F&& f) {
     B = b;
     b->n_lanes = (int)block;
     b->live = (int)block;
-    b->arrived = 0;
-    b->gen = 0;
+    for (int i = 0; i < WAVE; i++) {
+      b->garrived[i] = 0;
+      b->ggen[i] = 0;
+    }
     b->bid.x = bx;
     b->bdim.x = block;
     b->gdim.x = grid;
@@ -157,15 +164,21 @@ inline T from_bits(uint64_t u) {
   return v;
 }
 
+// src = absolute lane index inside the block (must belong to the caller's group)
 template <class T>
-inline T exchange(T v, int src) {
+inline T gexchange(T v, int src, int G) {
   Block* b = B;
   int me = b->cur;
   b->slots[me] = to_bits(v);
-  barrier();
-  T r = (src >= 0 && src < b->n_lanes) ? from_bits<T>(b->slots[src]) : v;
-  barrier();
+  gbarrier(G);
+  int first = me & ~(G - 1);
+  T r = (src >= first && src < first + G && src < b->n_lanes) ? from_bits<T>(b->slots[src]) : v;
+  gbarrier(G);
   return r;
+}
+template <class T>
+inline T exchange(T v, int src) {
+  return gexchange(v, src, WAVE);
 }
 
 // exchange of an arbitrary POD (<= 64 bytes) in one rendezvous
@@ -174,29 +187,37 @@ struct BigSlots {
 };
 inline thread_local BigSlots g_big;
 template <class T>
-inline T exchange_struct(const T& v, int src) {
+inline T gexchange_struct(const T& v, int src, int G) {
   static_assert(sizeof(T) <= 64, "struct too large");
   Block* b = B;
   int me = b->cur;
   memcpy(g_big.b[me], &v, sizeof(T));
-  barrier();
+  gbarrier(G);
+  int first = me & ~(G - 1);
   T r = v;
-  if (src >= 0 && src < b->n_lanes) memcpy(&r, g_big.b[src], sizeof(T));
-  barrier();
+  if (src >= first && src < first + G && src < b->n_lanes) memcpy(&r, g_big.b[src], sizeof(T));
+  gbarrier(G);
   return r;
 }
+template <class T>
+inline T exchange_struct(const T& v, int src) {
+  return gexchange_struct(v, src, WAVE);
+}
 
-inline unsigned long long ballot(int pred) {
+// ballot over the caller's group; bit i = lane (first + i)
+inline unsigned long long gballot(int pred, int G) {
   Block* b = B;
   int me = b->cur;
   b->slots[me] = pred ? 1 : 0;
-  barrier();
+  gbarrier(G);
+  int first = me & ~(G - 1);
   unsigned long long m = 0;
-  for (int l = 0; l < b->n_lanes; l++)
-    if (b->slots[l]) m |= (1ull << l);
-  barrier();
+  for (int l = first; l < first + G && l < b->n_lanes; l++)
+    if (!b->lanes[l].done && b->slots[l]) m |= (1ull << (l - first));
+  gbarrier(G);
   return m;
 }
+inline unsigned long long ballot(int pred) { return gballot(pred, WAVE); }
 
 }  // namespace emu
 

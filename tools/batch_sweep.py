@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Kernel times vs batch size (resident batches, HIP events): shows the single-wave latency floor and where the
+chip fills up.  One JSON line per batch size."""
+import importlib
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+pkg = importlib.import_module("ft-fsd-path-planning_amd")
+ctx = pkg.Context(device=0)
+sizes = [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192, 16384]
+off, cones, poses = pkg.synth.make_replay_batch(max(sizes), 64, 0.15, seed=1, color=True)
+for n in sizes:
+    ctx.upload(off[: n + 1], cones[: off[n]], poses[:n])
+    ctx.time_runs(2)
+    tot, st = ctx.time_runs(10)
+    print(json.dumps({"frames": n, "ms": tot / 10, "sort": st[0] / 10, "match": st[1] / 10, "path": st[2] / 10,
+                      "path_us_per_frame": st[2] / 10 / n * 1e3, "frames_per_s": n / (tot / 10) * 1e3}))
