@@ -42,7 +42,7 @@ struct fsdp_ctx {
   MatchOut* d_match = nullptr;
   PathOut* d_path = nullptr;
   double* d_default_path = nullptr;  // (40,4)
-  double* d_arena = nullptr;         // per-frame working polyline (3 x PATH_CAP doubles), HBM/L2 scratch
+  double* d_arena = nullptr;         // per-frame working polyline + basis cache (ARENA_DOUBLES doubles), HBM/L2 scratch
   double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
   double* d_prev = nullptr;          // optional per-frame previous paths (n_frames,40,4) for sequential replays
   bool use_prev = false;
@@ -95,7 +95,7 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
     HIP_TRY(c, hipMalloc(&c->d_sort, sizeof(SortOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_match, sizeof(MatchOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_path, sizeof(PathOut) * (size_t)n_frames));
-    HIP_TRY(c, hipMalloc(&c->d_arena, sizeof(double) * 3 * PATH_CAP * (size_t)n_frames));
+    HIP_TRY(c, hipMalloc(&c->d_arena, sizeof(double) * ARENA_DOUBLES * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n_frames));
     c->cap_frames = n_frames;
   }
@@ -204,7 +204,7 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
     double*& d_chord = c->d_chord;
     double* d_arena0 = nullptr;
     e = hipMalloc(&d_chord, sizeof(chord));
-    if (e == hipSuccess) e = hipMalloc(&d_arena0, sizeof(double) * 3 * PATH_CAP);
+    if (e == hipSuccess) e = hipMalloc(&d_arena0, sizeof(double) * ARENA_DOUBLES);
     if (e == hipSuccess) e = hipMemcpyAsync(d_chord, chord, sizeof(chord), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(default_path_kernel, dim3(1), dim3(WAVE), 0, c->stream, d_chord, d_arena0, c->d_default_path);

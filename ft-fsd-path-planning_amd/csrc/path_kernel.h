@@ -27,10 +27,13 @@ namespace fsdp {
 constexpr int PATH_CAP = 1152;  // points of the working polyline (dense fit-#1 output + extension)
 constexpr int SEG_CAP = 5 * DENSE_CAP;  // segment-length scratch in LDS (the "dense" region of the spline workspace)
 
+// per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
+constexpr int ARENA_DOUBLES = 7 * PATH_CAP + PATH_CAP / 2;
 struct Arena {
   double* x;
   double* y;
   double* u;
+  BasisCache bc;
 };
 
 // Per-frame LDS.  The region ws.dense aliases the fit-only part of the spline workspace (dead whenever no fit is
@@ -192,7 +195,7 @@ __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? 
 
 // chord lengths -> parameter values: A.u[off + i] = cumulative length (np.cumsum: sequential order); returns max_u.
 template <int G>
-__device__ inline double build_parameter(PathShared<G>& S, const Arena& A, int off, int m) {
+__device__ __forceinline__ double build_parameter(PathShared<G>& S, const Arena& A, int off, int m) {
   PROF(19);
   using GR = Grp<G>;
   constexpr int CH = SplineWS<G>::CH;
@@ -212,11 +215,17 @@ __device__ inline double build_parameter(PathShared<G>& S, const Arena& A, int o
 #pragma unroll
     for (int q = 0; q < NR; q++) {
       mine[q] = 0.0;
-      for (int rr = 0; rr < G; rr++) {
-        int r = q * G + rr;
-        if (r < cnt) {
-          acc += S.ws.term[r];
-          if (lane == rr) mine[q] = acc;  // lane rr keeps element q*G + rr
+      for (int r0 = 0; r0 < G; r0 += 8) {  // operands eight at a time, additions in order
+        double v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = S.ws.term[q * G + r0 + e];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int rr = r0 + e;
+          if (q * G + rr < cnt) {
+            acc += v[e];
+            if (lane == rr) mine[q] = acc;  // lane rr keeps element q*G + rr
+          }
         }
       }
     }
@@ -230,12 +239,12 @@ __device__ inline double build_parameter(PathShared<G>& S, const Arena& A, int o
 
 // utils/spline_fit.py:95-128 on the arena polyline [off, off+m).  rc: 0 ok, 1 ValueError, >=200 overflow
 template <int G>
-__device__ inline int fit_polyline(PathShared<G>& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
+__device__ __forceinline__ int fit_polyline(PathShared<G>& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
                                    double& max_u) {
   int k = m - 1;
   k = k < 1 ? 1 : (k > 3 ? 3 : k);
   max_u = build_parameter<G>(S, A, off, m);
-  f = spline_fit<G>(S.ws, A.u + off, A.x + off, A.y + off, m, k, smoothing);
+  f = spline_fit<G>(S.ws, A.bc, A.u + off, A.x + off, A.y + off, m, k, smoothing);
   return f.status;
 }
 
@@ -248,7 +257,7 @@ __device__ __forceinline__ int arange_len(double stop, double step) {
 // calculate_path/path_parameterization.py:297-328 on the arena polyline [off, off+n).
 // rc: 0 ok (out filled), 1 ValueError, ST_* otherwise.
 template <int G>
-__device__ inline int parameterize_path(PathShared<G>& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
+__device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
   using GR = Grp<G>;
   const int lane = GR::lane();
   if (n < 2) return ST_REF_UNDEFINED_PATH;
@@ -398,7 +407,7 @@ __device__ inline int parameterize_path(PathShared<G>& S, const Arena& A, int of
 // returns the running total; *first_over = index of the first segment whose cumulative length exceeds
 // `limit` (or n-1 if none).  Chunks of segments are staged in LDS; the additions keep np.cumsum's order.
 template <int G>
-__device__ inline double cumulative_length(PathShared<G>& S, const Arena& A, int off, int n, double limit, int* first_over) {
+__device__ __forceinline__ double cumulative_length(PathShared<G>& S, const Arena& A, int off, int n, double limit, int* first_over) {
   using GR = Grp<G>;
   constexpr int CH = SplineWS<G>::CH;
   const int lane = GR::lane();
@@ -413,12 +422,19 @@ __device__ inline double cumulative_length(PathShared<G>& S, const Arena& A, int
       S.ws.term[r] = sqrt(dx * dx + dy * dy);
     }
     GR::sync();
-    for (int r = 0; r < cnt; r++) {
-      acc += S.ws.term[r];
-      if (acc > limit) {
-        first = base + r;
-        stop = true;
-        break;
+    for (int r0 = 0; r0 < cnt && !stop; r0 += 8) {  // operands eight at a time, additions in order
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = S.ws.term[r0 + q];  // r0 + q < CH
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (!stop && r0 + q < cnt) {
+          acc += v[q];
+          if (acc > limit) {
+            first = base + r0 + q;
+            stop = true;
+          }
+        }
       }
     }
     GR::sync();
@@ -430,7 +446,7 @@ __device__ inline double cumulative_length(PathShared<G>& S, const Arena& A, int
 // core_calculate_path.py:380-417 do_all_mpc_parameter_calculations on the polyline [1, 1+n) of the arena
 // (slot 0 is reserved for the point connect_path_to_car may prepend).  rc as parameterize_path.
 template <int G>
-__device__ inline int do_all_mpc(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
+__device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
                                  double (*out)[4], int* fallback, int* n_dense) {
   using GR = Grp<G>;
   const int lane = GR::lane();
@@ -579,7 +595,7 @@ __device__ inline int do_all_mpc(PathShared<G>& S, const Arena& A, int n, double
 // core_calculate_path.py:555-575: too-far check + MPC step with its ValueError retry, on the dense path update stored
 // in the arena at [1, 1+n1); previous path xy in S.prevx/prevy.  Returns the frame status.
 template <int G>
-__device__ inline int finish_path(PathShared<G>& S, const Arena& A, int n1, double px, double py, double dx, double dy,
+__device__ __forceinline__ int finish_path(PathShared<G>& S, const Arena& A, int n1, double px, double py, double dx, double dy,
                                   double (*out)[4], int* fallback, int* n_dense) {
   using GR = Grp<G>;
   const int lane = GR::lane();
@@ -607,18 +623,23 @@ __device__ inline int finish_path(PathShared<G>& S, const Arena& A, int n1, doub
       GR::sync();
     }
   }
-  int rc = do_all_mpc<G>(S, A, n1, px, py, dx, dy, out, fallback, n_dense);
-  if (rc == 1) {  // ValueError -> redo with the previous path (:564-570)
-    *fallback |= 8;
-    GR::sync();
-    for (int i = lane; i < PATH_POINTS; i += G) {
-      A.x[1 + i] = S.prevx[i];
-      A.y[1 + i] = S.prevy[i];
+  // one call site (the stage is inlined into the kernel so that every LDS access is a DS instruction): the second
+  // round of the loop is the ValueError retry with the previous path (:564-570)
+  int rc = 1;
+  for (int attempt = 0; attempt < 2 && rc == 1; attempt++) {
+    if (attempt == 1) {
+      *fallback |= 8;
+      GR::sync();
+      for (int i = lane; i < PATH_POINTS; i += G) {
+        A.x[1 + i] = S.prevx[i];
+        A.y[1 + i] = S.prevy[i];
+      }
+      n1 = PATH_POINTS;
+      GR::sync();
     }
-    GR::sync();
-    rc = do_all_mpc<G>(S, A, PATH_POINTS, px, py, dx, dy, out, fallback, n_dense);
-    if (rc == 1) rc = ST_REF_UNDEFINED_PATH;
+    rc = do_all_mpc<G>(S, A, n1, px, py, dx, dy, out, fallback, n_dense);
   }
+  if (rc == 1) rc = ST_REF_UNDEFINED_PATH;
   return rc;
 }
 
@@ -639,8 +660,14 @@ inline void default_chord_points(double (*chord)[2]) {
 }
 
 __device__ __forceinline__ Arena frame_arena(double* arena, int frame) {
-  double* b = arena + (size_t)frame * (3 * PATH_CAP);
-  return Arena{b, b + PATH_CAP, b + 2 * PATH_CAP};
+  double* b = arena + (size_t)frame * ARENA_DOUBLES;
+  Arena A;
+  A.x = b;
+  A.y = b + PATH_CAP;
+  A.u = b + 2 * PATH_CAP;
+  for (int j = 0; j < 4; j++) A.bc.h[j] = b + (3 + j) * PATH_CAP;
+  A.bc.l = (int32_t*)(b + 7 * PATH_CAP);
+  return A;
 }
 
 // core_calculate_path.py:103-121: previous_paths[0] = parameterize_path(fit(chord).predict())
@@ -670,10 +697,13 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
 }
 
 // lanes per frame of the product path kernel: four frames per wavefront (see the header comment)
-constexpr int PATH_G = 16;
+#ifndef FSDP_PATH_G
+#define FSDP_PATH_G 16
+#endif
+constexpr int PATH_G = FSDP_PATH_G;
 
 template <int G>
-__device__ inline void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
+__device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
                                   const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
                                   const double* __restrict__ prev_paths, double* __restrict__ arena,
                                   PathOut* __restrict__ out) {

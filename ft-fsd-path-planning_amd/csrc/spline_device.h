@@ -46,6 +46,15 @@ struct SplineWS {
   double scal[4];  // lane-0 -> group broadcast of serial-section scalars
 };
 
+// Per-point basis cache in the frame's HBM/L2 scratch: the K+1 non-zero B-spline values and the knot interval of every
+// data point, written by the observation pass of the current knot set and re-read by the residual pass and by every
+// f(p) evaluation of the smoothing iteration (same knots => same values; saves the interval search and the de Boor
+// recursion with its six divisions per point and pass).
+struct BasisCache {
+  double* h[4];
+  int32_t* l;
+};
+
 struct SplineFit {
   int k, n, ier;
   double fp;
@@ -96,6 +105,44 @@ __device__ __forceinline__ void fprota(double cs, double sn, double& a, double& 
   a = cs * stor1 - sn * stor2;
 }
 
+// Sequential (data-order) accumulations over an LDS chunk buffer.  The operands are fetched eight at a time so the LDS
+// round trip is paid once per eight elements rather than once per element; the additions keep their order.
+__device__ __forceinline__ double seq_sum(const double* buf, int cnt, double acc) {
+  int r = 0;
+  for (; r + 8 <= cnt; r += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = buf[r + q];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc = acc + v[q];
+  }
+  for (; r < cnt; r++) acc = acc + buf[r];
+  return acc;
+}
+// acc = acc + x[r]^2; acc = acc + y[r]^2 for r = 0..cnt-1
+__device__ __forceinline__ double seq_sum_squares2(const double* x, const double* y, int cnt, double acc) {
+  int r = 0;
+  for (; r + 4 <= cnt; r += 4) {
+    double v[4], w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      v[q] = x[r + q];
+      w[q] = y[r + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      acc = acc + v[q] * v[q];
+      acc = acc + w[q] * w[q];
+    }
+  }
+  for (; r < cnt; r++) {
+    double v = x[r], w = y[r];
+    acc = acc + v * v;
+    acc = acc + w * w;
+  }
+  return acc;
+}
+
 // knot interval of x: largest l in [k1, nk1] with t(l) <= x (FITPACK's forward search)
 __device__ __forceinline__ int find_interval(const double* t, int k1, int nk1, double x) {
   int l = k1;
@@ -113,7 +160,7 @@ __device__ __forceinline__ int find_interval_from(const double* t, int lstart, i
 
 // back-substitution, band width k (fpback); a is either ws.a (5 cols) or ws.g (6 cols)
 template <int COLS>
-__device__ inline void fpback(double (*a)[COLS], const double* z, int n, int k, double* c) {
+__device__ __forceinline__ void fpback(double (*a)[COLS], const double* z, int n, int k, double* c) {
   int k1 = k - 1;
   c[n] = z[n] / a[n][1];
   int i = n - 1;
@@ -139,11 +186,19 @@ __device__ inline void fpback(double (*a)[COLS], const double* z, int n, int k, 
 // data rows are in flight.  Every band row still sees the data rows in data order and every data row still
 // visits its band rows in order: the arithmetic (fpgivs / fprota) and its sequence per element are exactly
 // FITPACK's, only independent rotations overlap in time.
+//
+// The running sum of squared rotated-out right-hand sides (fp, accumulated in data order) is a token that lives in
+// the lane where rows currently leave the pipeline (band row l, lane l mod 4); when the interval changes, the first
+// row of the new interval picks the token up on its way (every row visits every lane once, rows keep their order in
+// every lane) and delivers it to its own exit lane.  Nothing is parked in LDS on the way out, so consecutive chunks
+// of an observation pass run through the pipeline back to back without draining it.
 struct GivItem {
   double piv, r0, r1, r2, x1, x2;
-  int j;      // band row this stage rotates against
-  int info;   // stage (1..4, 0 = empty) | data-row slot << 8
+  double fpc;  // the fp token's value while it travels with this row
+  int j;       // band row this stage rotates against
+  int info;    // stage (1..4, 0 = empty) | GIV_TOK
 };
+constexpr int GIV_TOK = 0x100;
 
 template <int G>
 __device__ __forceinline__ GivItem quad_rot_prev(const GivItem& v) {
@@ -164,9 +219,30 @@ __device__ __forceinline__ GivItem quad_rot_prev(const GivItem& v) {
   o.r2 = rot(v.r2);
   o.x1 = rot(v.x1);
   o.x2 = rot(v.x2);
+  o.fpc = rot(v.fpc);
   o.j = __builtin_amdgcn_mov_dpp(v.j, 0x93, 0xf, 0xf, true);
   o.info = __builtin_amdgcn_mov_dpp(v.info, 0x93, 0xf, 0xf, true);
   return o;
+#endif
+}
+
+// sqrt for arguments in [1, 2] (1 + r^2 with |r| <= 1): the correctly rounded result, i.e. what sqrt() returns; on the
+// device this is the compiler's own v_rsq_f64 + Goldschmidt sequence without the range scaling that [1, 2] never needs
+__device__ __forceinline__ double sqrt_1_2(double x) {
+#ifdef FSDP_EMU
+  return sqrt(x);
+#else
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return g;
 #endif
 }
 
@@ -174,6 +250,34 @@ struct GivRow {  // the band row a lane currently owns
   int j;
   double a1, a2, a3, a4, z1, z2;
 };
+
+// per-lane pipeline state of one observation pass (carried across its chunks)
+struct GivState {
+  GivItem out;      // item leaving this lane, rotated to the next lane at the next step
+  GivRow row;
+  double fpl;       // fp token value (valid in the lane that has it)
+  int has;          // this lane holds the fp token
+  int tau;          // step counter
+  int t_base;       // step after the last injection
+  int l_prev;       // knot interval of the last injected row
+  int last_finish;  // step at which the last injected row leaves the pipeline
+  int first;        // no row injected yet
+};
+
+__device__ __forceinline__ void giv_init(GivState& st) {
+  st.out.piv = st.out.r0 = st.out.r1 = st.out.r2 = st.out.x1 = st.out.x2 = st.out.fpc = 0.0;
+  st.out.j = 0;
+  st.out.info = 0;
+  st.row.j = 0;
+  st.row.a1 = st.row.a2 = st.row.a3 = st.row.a4 = st.row.z1 = st.row.z2 = 0.0;
+  st.fpl = 0.0;
+  st.has = 0;
+  st.tau = 0;
+  st.t_base = 0;
+  st.l_prev = 0;
+  st.last_finish = -1;
+  st.first = 1;
+}
 
 template <int G>
 __device__ __forceinline__ void giv_flush(SplineWS<G>& ws, const GivRow& r, int n) {
@@ -187,85 +291,151 @@ __device__ __forceinline__ void giv_flush(SplineWS<G>& ws, const GivRow& r, int 
   }
 }
 
-// one chunk of `cnt` data rows (basis values / interval / data in ws.hq, ws.lq, ws.xq, ws.yq) through the pipeline;
-// leaves each row's rotated-out right-hand side in ws.xq/yq (for the residual sum).  All lanes of the group call.
+// one stage of one data row on this lane: rotate against the owned band row, hand the row on (or retire it)
 template <int G>
-__device__ inline void givens_chunk_pipelined(SplineWS<G>& ws, int cnt, int n, GivRow& row) {
+__device__ __forceinline__ void giv_process(SplineWS<G>& ws, GivState& st, const GivItem& in, int lane, int n) {
+  const int stage = in.info & 0xff;
+  const bool active = stage > 0;
+  if (active && st.row.j != in.j) {
+    // this lane moves on to its next band row (j + 4): the old one is complete, the new one has not been touched yet
+    // in this pass (rows arrive in increasing interval order), i.e. it is still all zero
+    giv_flush<G>(ws, st.row, n);
+    st.row.j = in.j;
+    st.row.a1 = st.row.a2 = st.row.a3 = st.row.a4 = st.row.z1 = st.row.z2 = 0.0;
+  }
+  // fp token: leaves with the first row that exits elsewhere, arrives with a row at its exit stage
+  const int exit_lane = (in.j + 4 - stage) & 3;
+  const bool tok_in = (in.info & GIV_TOK) != 0;
+  const bool arrive = active && tok_in && stage == 4;
+  const bool leave = active && st.has != 0 && exit_lane != lane;
+  const double fpc_out = leave ? st.fpl : in.fpc;
+  const bool tok_out = (tok_in && !arrive) || leave;
+  st.fpl = arrive ? in.fpc : st.fpl;
+  st.has = ((st.has != 0 && !leave) || arrive) ? 1 : 0;
+
+  double piv = in.piv, r0 = in.r0, r1 = in.r1, r2 = in.r2, x1 = in.x1, x2 = in.x2;
+  const bool rot = active && piv != 0.0;
+  {
+    // fpgivs.f: dd = |piv| * sqrt(1 + (ww/piv)^2) if |piv| >= ww else ww * sqrt(1 + (piv/ww)^2) — written with selects so
+    // that one division and one square root are issued (same operations, same operands, same bits); every lane runs
+    // the arithmetic, the results are kept where `rot` holds
+    const double ww = st.row.a1;
+    const double store = fabs(piv);
+    const bool big = store >= ww;
+    const double num = big ? ww : piv, den = big ? piv : ww, scale = big ? store : ww;
+    const double q = num / den;
+    const double dd = scale * sqrt_1_2(1.0 + q * q);
+    const double cs = ww / dd;
+    const double sn = piv / dd;
+    const double nz1 = cs * st.row.z1 + sn * x1, nx1 = cs * x1 - sn * st.row.z1;
+    const double nz2 = cs * st.row.z2 + sn * x2, nx2 = cs * x2 - sn * st.row.z2;
+    const double na2 = cs * st.row.a2 + sn * r0, nr0 = cs * r0 - sn * st.row.a2;
+    const double na3 = cs * st.row.a3 + sn * r1, nr1 = cs * r1 - sn * st.row.a3;
+    const double na4 = cs * st.row.a4 + sn * r2, nr2 = cs * r2 - sn * st.row.a4;
+    st.row.a1 = rot ? dd : st.row.a1;
+    st.row.z1 = rot ? nz1 : st.row.z1;
+    x1 = rot ? nx1 : x1;
+    st.row.z2 = rot ? nz2 : st.row.z2;
+    x2 = rot ? nx2 : x2;
+    const bool c3 = rot && stage <= 3, c2 = rot && stage <= 2, c1 = rot && stage <= 1;
+    st.row.a2 = c3 ? na2 : st.row.a2;
+    r0 = c3 ? nr0 : r0;
+    st.row.a3 = c2 ? na3 : st.row.a3;
+    r1 = c2 ? nr1 : r1;
+    st.row.a4 = c1 ? na4 : st.row.a4;
+    r2 = c1 ? nr2 : r2;
+  }
+  // retire: the rotated-out right-hand sides enter fp in data order
+  const bool retire = active && stage == 4;
+  {
+    double f = st.fpl + x1 * x1;
+    f = f + x2 * x2;
+    st.fpl = retire ? f : st.fpl;
+  }
+  const bool fwd = active && stage < 4;
+  st.out.piv = r0;
+  st.out.r0 = r1;
+  st.out.r1 = r2;
+  st.out.r2 = 0.0;
+  st.out.x1 = x1;
+  st.out.x2 = x2;
+  st.out.fpc = fpc_out;
+  st.out.j = in.j + 1;
+  st.out.info = fwd ? ((stage + 1) | (tok_out ? GIV_TOK : 0)) : 0;
+}
+
+// one chunk of `cnt` data rows (basis values / interval / data in ws.hq, ws.lq, ws.xq, ws.yq) into the pipeline; rows
+// still in flight at the end stay in `st` (the next chunk, or giv_drain, moves them on).  All lanes of the group call.
+template <int G>
+__device__ __forceinline__ void givens_chunk_pipelined(SplineWS<G>& ws, int cnt, int n, GivState& st) {
   const int lane = Grp<G>::lane();
   constexpr int k1 = 4;
-  GivItem out;
-  out.piv = out.r0 = out.r1 = out.r2 = out.x1 = out.x2 = 0.0;
-  out.j = 0;
-  out.info = 0;
-  int next_r = 0, t_next = 0, last_finish = -1;
-  for (int tau = 0; next_r < cnt || tau <= last_finish; tau++) {
-    GivItem in = quad_rot_prev<G>(out);
-    if (next_r < cnt && tau >= t_next) {
-      const int l = ws.lq[next_r];
-      const int j0 = l - k1 + 1;
+  int next_r = 0;
+  // the next row to inject is staged in registers one step ahead (group-uniform LDS reads), off the critical path
+  double p0 = 0, p1 = 0, p2 = 0, p3 = 0, px = 0, py = 0;
+  int pl = 0;
+  auto stage_row = [&](int r) {
+    p0 = ws.hq[r][0];
+    p1 = ws.hq[r][1];
+    p2 = ws.hq[r][2];
+    p3 = ws.hq[r][3];
+    px = ws.xq[r];
+    py = ws.yq[r];
+    pl = ws.lq[r];
+  };
+  if (cnt > 0) stage_row(0);
+  while (next_r < cnt) {
+    GivItem in = quad_rot_prev<G>(st.out);
+    // a row enters one step after its predecessor, later by the number of intervals it skipped (its first band row
+    // must have seen the predecessor)
+    const bool inject = st.first != 0 || st.tau >= st.t_base + (pl - st.l_prev);
+    if (inject) {
+      const int j0 = pl - k1 + 1;
       if (lane == (j0 & 3)) {
-        in.piv = ws.hq[next_r][0];
-        in.r0 = ws.hq[next_r][1];
-        in.r1 = ws.hq[next_r][2];
-        in.r2 = ws.hq[next_r][3];
-        in.x1 = ws.xq[next_r];
-        in.x2 = ws.yq[next_r];
+        in.piv = p0;
+        in.r0 = p1;
+        in.r1 = p2;
+        in.r2 = p3;
+        in.x1 = px;
+        in.x2 = py;
+        in.fpc = 0.0;
         in.j = j0;
-        in.info = 1 | (next_r << 8);
+        in.info = 1 | (st.first != 0 ? GIV_TOK : 0);
       }
-      last_finish = tau + k1 - 1;
-      int l_next = (next_r + 1 < cnt) ? ws.lq[next_r + 1] : l;
-      t_next = tau + 1 + (l_next - l);
+      st.first = 0;
+      st.last_finish = st.tau + k1 - 1;
+      st.l_prev = pl;
+      st.t_base = st.tau + 1;
       next_r++;
+      if (next_r < cnt) stage_row(next_r);
     }
-    const int stage = in.info & 0xff;
-    out = in;
-    out.info = 0;
-    if (stage > 0 && lane < 4) {
-      if (row.j != in.j) {
-        giv_flush(ws, row, n);
-        row.j = in.j;
-        row.a1 = ws.a[in.j][1];
-        row.a2 = ws.a[in.j][2];
-        row.a3 = ws.a[in.j][3];
-        row.a4 = ws.a[in.j][4];
-        row.z1 = ws.z[in.j];
-        row.z2 = ws.z[in.j + n];
-      }
-      double piv = in.piv, r0 = in.r0, r1 = in.r1, r2 = in.r2, x1 = in.x1, x2 = in.x2;
-      if (piv != 0.0) {
-        double cs, sn;
-        fpgivs(piv, row.a1, cs, sn);
-        fprota(cs, sn, x1, row.z1);
-        fprota(cs, sn, x2, row.z2);
-        if (stage <= 3) fprota(cs, sn, r0, row.a2);
-        if (stage <= 2) fprota(cs, sn, r1, row.a3);
-        if (stage <= 1) fprota(cs, sn, r2, row.a4);
-      }
-      if (stage == k1) {
-        int slot = in.info >> 8;
-        ws.xq[slot] = x1;
-        ws.yq[slot] = x2;
-      } else {
-        out.piv = r0;
-        out.r0 = r1;
-        out.r1 = r2;
-        out.r2 = 0.0;
-        out.x1 = x1;
-        out.x2 = x2;
-        out.j = in.j + 1;
-        out.info = (stage + 1) | (in.info & ~0xff);
-      }
-    }
+    giv_process<G>(ws, st, in, lane, n);
+    st.tau++;
   }
+}
+
+// empty the pipeline at the end of an observation pass and return fp (group-uniform)
+template <int G>
+__device__ __forceinline__ double giv_drain(SplineWS<G>& ws, int n, GivState& st) {
+  const int lane = Grp<G>::lane();
+  while (st.tau <= st.last_finish) {
+    GivItem in = quad_rot_prev<G>(st.out);
+    giv_process<G>(ws, st, in, lane, n);
+    st.tau++;
+  }
+  if (lane < 4) giv_flush<G>(ws, st.row, n);
+  // the token rests in the exit lane of the last row (interval l_prev)
+  return Grp<G>::bcast(st.fpl, st.l_prev & 3);
 }
 
 // parcur/fppara for idim=2, w=1, iopt=0.  Data (0-based arrays U = parameter, X, Y; m points) in LDS or HBM.
 // All lanes of the group call; result (t, c) left in ws; returns the group-uniform SplineFit.
 template <int K, int G>
-__device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const double* X, const double* Y, int m, double s) {
+__device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCache& bc, const double* U, const double* X, const double* Y,
+                                         int m, double s) {
   using GR = Grp<G>;
   constexpr int CH = SplineWS<G>::CH;
+  constexpr int NR = CH / G;  // rounds per chunk (points per lane and chunk)
   constexpr int k = K;
   const int lane = GR::lane();
   SplineFit R;
@@ -336,9 +506,8 @@ __device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const
         for (int j = 1; j <= k1; j++) ws.a[i][j] = 0.0;
       GR::sync();
       fp = 0.0;
-      GivRow grow;
-      grow.j = 0;
-      grow.a1 = grow.a2 = grow.a3 = grow.a4 = grow.z1 = grow.z2 = 0.0;
+      GivState gst;
+      giv_init(gst);
       int lres = k1;  // this lane's previous knot interval (data are increasing: the search resumes there)
       // ---- observation rows: basis values per lane, Givens rotations group-uniform in data order ----
       for (int base = 0; base < m; base += CH) {
@@ -353,26 +522,21 @@ __device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const
             double h[K + 2];
             fpbspl<K>(ws.t, ui, l, h);
 #pragma unroll
-            for (int q = 0; q < k1; q++) ws.hq[r][q] = h[q + 1];
+            for (int q = 0; q < k1; q++) {
+              ws.hq[r][q] = h[q + 1];
+              bc.h[q][it] = h[q + 1];
+            }
             ws.lq[r] = l;
+            bc.l[it] = l;
             ws.xq[r] = X[it];
             ws.yq[r] = Y[it];
           }
           GR::sync();
         }
         if constexpr (K == 3) {
-          {
-            PROF(11);
-            givens_chunk_pipelined<G>(ws, cnt, n, grow);
-            GR::sync();
-          }
-          PROF(12);
-          // sum of squared rotated-out right-hand sides, in data order
-          for (int r = 0; r < cnt; r++) {
-            double xi1 = ws.xq[r], xi2 = ws.yq[r];
-            fp = fp + xi1 * xi1;
-            fp = fp + xi2 * xi2;
-          }
+          PROF(11);
+          givens_chunk_pipelined<G>(ws, cnt, n, gst);
+          PROF_COUNT(20, G, cnt);
         } else {
           if (lane == 0) {  // serial section: rows enter the triangle in data order (single writer of a / z)
             for (int r = 0; r < cnt; r++) {
@@ -411,17 +575,13 @@ __device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const
             }
           }
           GR::sync();
-          for (int r = 0; r < cnt; r++) {
-            double xi1 = ws.xq[r], xi2 = ws.yq[r];
-            fp = fp + xi1 * xi1;
-            fp = fp + xi2 * xi2;
-          }
+          fp = seq_sum_squares2(ws.xq, ws.yq, cnt, fp);
         }
         GR::sync();
       }
       if constexpr (K == 3) {
-        if (lane < 4) giv_flush<G>(ws, grow, n);
-        grow.j = 0;
+        PROF(12);
+        fp = giv_drain<G>(ws, n, gst);
         GR::sync();
       }
       if (lane == 0) {
@@ -475,56 +635,72 @@ __device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const
         PROF(14);
         double fpart = 0.0;
         int ii = 1;
-        int lres2 = k1;
-        int lcarry = k2;  // FITPACK's running l after the last point of the previous round
         for (int base = 0; base < m; base += CH) {
           const int cnt = m - base < CH ? m - base : CH;
-          for (int r0 = 0; r0 < CH; r0 += G) {  // all lanes take every round (the shuffles below are group-wide)
-            const int r = r0 + lane;
-            const bool act = r < cnt;
-            const int it = base + r;
+          {
             // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
-            // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point
-            double ui = 0.0;
-            int l = lcarry;
-            if (act) {
-              ui = U[it];
-              lres2 = find_interval_from(ws.t, lres2, nk1, ui);
-              l = lres2 + 1;
-            }
-            int lprev = GR::shfl_up1(l);
-            if (lane == 0) lprev = lcarry;
-            lcarry = GR::bcast(l, G - 1);
-            if (act) {
-              double h[K + 2];
-              fpbspl<K>(ws.t, ui, l - 1, h);
-              int l0 = l - k2;
-              double term = 0.0;
-              for (int d = 0; d < 2; d++) {
-                double fac = 0.0;
-                int j1 = l0 + d * n;
+            // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point.
+            // Loads of all rounds first (independent), then the arithmetic.
+            double hv[NR][K + 1], xv[NR], yv[NR];
+            int lv[NR], lpv[NR];
 #pragma unroll
-                for (int j = 1; j <= k1; j++) {
-                  j1++;
-                  fac = fac + ws.c[j1] * h[j];
-                }
-                double dv = 1.0 * (fac - (d == 0 ? X[it] : Y[it]));
-                term = term + dv * dv;
+            for (int q = 0; q < NR; q++) {
+              const int r = q * G + lane;
+              const int it = base + r;
+              if (r < cnt) {
+#pragma unroll
+                for (int j = 0; j < k1; j++) hv[q][j] = bc.h[j][it];
+                lv[q] = bc.l[it] + 1;
+                lpv[q] = it > 0 ? bc.l[it - 1] + 1 : k2;
+                xv[q] = X[it];
+                yv[q] = Y[it];
               }
-              ws.term[r] = term;
-              ws.lq[r] = (l > lprev) ? 1 : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < NR; q++) {
+              const int r = q * G + lane;
+              if (r < cnt) {
+                const int l0 = lv[q] - k2;
+                double term = 0.0;
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                  double fac = 0.0;
+                  int j1 = l0 + d * n;
+#pragma unroll
+                  for (int j = 1; j <= k1; j++) {
+                    j1++;
+                    fac = fac + ws.c[j1] * hv[q][j - 1];
+                  }
+                  double dv = 1.0 * (fac - (d == 0 ? xv[q] : yv[q]));
+                  term = term + dv * dv;
+                }
+                ws.term[r] = term;
+                ws.lq[r] = (lv[q] > lpv[q]) ? 1 : 0;
+              }
             }
           }
           GR::sync();
-          for (int r = 0; r < cnt; r++) {
-            double term = ws.term[r];
-            if (ws.lq[r]) {
-              double store = term * half;
-              if (lane == 0) ws.fpint[ii] = fpart + store;
-              ii++;
-              fpart = store;
-            } else {
-              fpart = fpart + term;
+          for (int r0 = 0; r0 < cnt; r0 += 8) {  // operands eight at a time (one LDS round trip), order kept
+            double tv[8];
+            int fl[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              tv[q] = ws.term[r0 + q];  // r0 + q < CH always (CH is a multiple of 8)
+              fl[q] = ws.lq[r0 + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              if (r0 + q < cnt) {
+                double term = tv[q];
+                if (fl[q]) {
+                  double store = term * half;
+                  if (lane == 0) ws.fpint[ii] = fpart + store;
+                  ii++;
+                  fpart = store;
+                } else {
+                  fpart = fpart + term;
+                }
+              }
             }
           }
           GR::sync();
@@ -632,6 +808,7 @@ __device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const
     const int n8 = n - nmin;
     for (int iter = 1; iter <= maxit; iter++) {
       double pinv = one / p;
+      PROF_COUNT(24, G, 1);
       GR::sync();
       for (int i = 1 + lane; i <= 2 * n; i += G) ws.c[i] = ws.z[i];
       for (int i = 1 + lane; i <= nk1; i += G) {
@@ -682,33 +859,51 @@ __device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const
       // f(p): terms per lane, accumulation in data order
       PROF(17);
       fp = 0.;
-      int lres3 = k1;
       for (int base = 0; base < m; base += CH) {
         const int cnt = m - base < CH ? m - base : CH;
-        for (int r = lane; r < cnt; r += G) {
-          const int it = base + r;
-          double ui = U[it];
-          lres3 = find_interval_from(ws.t, lres3, nk1, ui);
-          const int l = lres3 + 1;
-          double h[K + 2];
-          fpbspl<K>(ws.t, ui, lres3, h);
-          int l0 = l - k2;
-          double term = 0.;
-          for (int d = 0; d < 2; d++) {
-            double fac = 0.;
-            int j1 = l0 + d * n;
+        {
+        PROF(28);
+        {
+          double hv[NR][K + 1], xv[NR], yv[NR];
+          int lv[NR];
 #pragma unroll
-            for (int j = 1; j <= k1; j++) {
-              j1++;
-              fac = fac + ws.c[j1] * h[j];
+          for (int q = 0; q < NR; q++) {
+            const int r = q * G + lane;
+            const int it = base + r;
+            if (r < cnt) {
+#pragma unroll
+              for (int j = 0; j < k1; j++) hv[q][j] = bc.h[j][it];
+              lv[q] = bc.l[it] + 1;
+              xv[q] = X[it];
+              yv[q] = Y[it];
             }
-            double dv = fac - (d == 0 ? X[it] : Y[it]);
-            term = term + dv * dv;
           }
-          ws.term[r] = term;
+#pragma unroll
+          for (int q = 0; q < NR; q++) {
+            const int r = q * G + lane;
+            if (r < cnt) {
+              const int l0 = lv[q] - k2;
+              double term = 0.;
+#pragma unroll
+              for (int d = 0; d < 2; d++) {
+                double fac = 0.;
+                int j1 = l0 + d * n;
+#pragma unroll
+                for (int j = 1; j <= k1; j++) {
+                  j1++;
+                  fac = fac + ws.c[j1] * hv[q][j - 1];
+                }
+                double dv = fac - (d == 0 ? xv[q] : yv[q]);
+                term = term + dv * dv;
+              }
+              ws.term[r] = term;
+            }
+          }
         }
         GR::sync();
-        for (int r = 0; r < cnt; r++) fp = fp + ws.term[r] * (1.0 * 1.0);
+        }
+        PROF(29);
+        fp = seq_sum(ws.term, cnt, fp);  // w = 1: term * w^2 is the term itself
         GR::sync();
       }
       fpms = fp - s;
@@ -777,18 +972,18 @@ __device__ inline SplineFit spline_fit_k(SplineWS<G>& ws, const double* U, const
 }
 
 template <int G>
-__device__ inline SplineFit spline_fit(SplineWS<G>& ws, const double* U, const double* X, const double* Y, int m, int k,
-                                       double s) {
-  if (k == 3) return spline_fit_k<3, G>(ws, U, X, Y, m, s);
-  if (k == 2) return spline_fit_k<2, G>(ws, U, X, Y, m, s);
-  return spline_fit_k<1, G>(ws, U, X, Y, m, s);
+__device__ __forceinline__ SplineFit spline_fit(SplineWS<G>& ws, const BasisCache& bc, const double* U, const double* X, const double* Y,
+                                       int m, int k, double s) {
+  if (k == 3) return spline_fit_k<3, G>(ws, bc, U, X, Y, m, s);
+  if (k == 2) return spline_fit_k<2, G>(ws, bc, U, X, Y, m, s);
+  return spline_fit_k<1, G>(ws, bc, U, X, Y, m, s);
 }
 
 // splev (der = 0, ext = 0) at arg = i * step for i in [0, count): one evaluation point per lane.
 // Outputs to OX/OY (LDS or global), optional parameter values to OU.  Reads only t / c, so the outputs may alias the
 // rest of the fit workspace (the dense samples of the final spline do).
 template <int K, int G>
-__device__ inline void spline_eval_k(const SplineWS<G>& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+__device__ __forceinline__ void spline_eval_k(const SplineWS<G>& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
                                      double* OU) {
   const int lane = Grp<G>::lane();
   const int n = f.n;
@@ -815,7 +1010,7 @@ __device__ inline void spline_eval_k(const SplineWS<G>& ws, const SplineFit& f, 
 }
 
 template <int G>
-__device__ inline void spline_eval(const SplineWS<G>& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+__device__ __forceinline__ void spline_eval(const SplineWS<G>& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
                                    double* OU) {
   if (f.k == 3)
     spline_eval_k<3, G>(ws, f, step, count, OX, OY, OU);

@@ -16,7 +16,7 @@ static std::once_flag g_once;
 static void build_default() {
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
-  std::vector<double> arena(3 * fsdp::PATH_CAP);
+  std::vector<double> arena(fsdp::ARENA_DOUBLES);
   emu::launch(1, 64, [&]() { fsdp::default_path_kernel(&chord[0][0], arena.data(), g_default_path); });
 }
 
@@ -52,7 +52,7 @@ __global__ void fit_test_kernel(const double* xy, int m, double smoothing, doubl
 
 extern "C" {
 void emu_fit(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
-  std::vector<double> arena(3 * fsdp::PATH_CAP);
+  std::vector<double> arena(fsdp::ARENA_DOUBLES);
   emu::launch(1, 64, [&]() { fsdp::fit_test_kernel(xy, m, smoothing, arena.data(), t_out, c_out, info, fp_out); });
 }
 int emu_sizeof_sort_out() { return (int)sizeof(fsdp::SortOut); }
@@ -86,7 +86,7 @@ void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, c
   T.mean_distance = mean_distance;
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
-  std::vector<double> arena((size_t)3 * fsdp::PATH_CAP * n_inst);
+  std::vector<double> arena((size_t)fsdp::ARENA_DOUBLES * n_inst);
   std::vector<int32_t> status(n_inst, 0);
   emu::launch((unsigned)n_inst, 64, [&]() { fsdp::skid_reloc_kernel(n_inst, offsets, cones, poses, states, T, arena.data(), status.data()); });
   emu::launch((unsigned)n_inst, 64, [&]() {
@@ -102,7 +102,7 @@ void emu_default_path(double* out) {
 }
 void emu_path(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
   std::call_once(g_once, build_default);
-  std::vector<double> arena((size_t)3 * fsdp::PATH_CAP * n_frames);
+  std::vector<double> arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
   const unsigned per = 64 / fsdp::PATH_G;
   emu::launch(((unsigned)n_frames + per - 1) / per, 64,
               [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, g_prev_paths, arena.data(), out); });

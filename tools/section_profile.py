@@ -19,17 +19,36 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 pkg._capi.LIB_PATH = so
 ctx = pkg.Context(device=0)
-off, cones, poses = pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+off, cones, poses = pkg.synth.make_replay_batch(N, 64, 0.15, seed=1, color=True)
 ctx.upload(off, cones, poses)
 ctx.run()
 ctx.sync()
-out = np.zeros((4096, 32), np.int64)
+out = np.zeros((N, 32), np.int64)
 rc = ctx._lib.fsdp_profile_path(ctx._h, ctypes.c_void_p(out.ctypes.data))
 assert rc == 0
+# the path kernel packs 4 frames into a wavefront: one row per wavefront (group 0's lane 0 keeps the clock; the groups
+# run in lock-step, so its sections span the wavefront's time in them)
+out = out[: (N + 3) // 4]
+tot = out[:, 0]
+rows = out[:, 20:24]   # data rows pushed through the Givens pipeline per frame (all passes, all fits)
+pits = out[:, 24:28]   # smoothing-parameter iterations per frame
+print(f"QR data rows per frame: min {rows.min()}, median {int(np.median(rows))}, p99 {int(np.percentile(rows, 99))}, max {rows.max()};"
+      f" per wavefront max-of-4: median {int(np.median(rows.max(axis=1)))}, max {rows.max(axis=1).max()}")
+print(f"p-iterations per frame: min {pits.min()}, median {int(np.median(pits))}, max {pits.max()}")
+cc = np.corrcoef(rows.max(axis=1), tot)[0, 1]
+print(f"correlation(wavefront cycles, max QR rows of its frames) = {cc:.3f}; cycles per max-row: {np.median(tot / rows.max(axis=1)):.0f}")
+order = np.argsort(tot)
+for q in (0, len(order) // 2, len(order) - 1):
+    w = order[q]
+    print(f"  wavefront {w}: cycles {tot[w]}, rows {rows[w].tolist()}, p-iters {pits[w].tolist()}")
+
+print(f"{N} frames, {len(out)} wavefronts; cycles per wavefront: min {tot.min()}, median {int(np.median(tot))}, "
+      f"p90 {int(np.percentile(tot, 90))}, p99 {int(np.percentile(tot, 99))}, max {tot.max()}")
 names = {0: "whole kernel", 1: "fit#1 (incl. parameter)", 4: "fit#2", 5: "eval#2 + cut", 7: "fit#3", 8: "eval#3", 9: "curvature windows",
          18: "filter + sample", 19: "build_parameter (all fits)", 10: "fit: basis prep (lanes)", 11: "fit: Givens pipeline", 12: "fit: fp serial sum",
-         13: "fit: back substitution", 14: "fit: residual pass", 15: "fit: fpknot", 16: "fit: part-2 Givens+back", 17: "fit: f(p) pass"}
+         13: "fit: back substitution", 14: "fit: residual pass", 15: "fit: fpknot", 16: "fit: part-2 Givens+back", 17: "fit: f(p) pass", 28: "  f(p): terms (lanes)", 29: "  f(p): serial sum"}
 m = out.mean(axis=0)
-print(f"{'section':<28}{'mean cycles/frame':>20}{'% of kernel':>14}")
+print(f"{'section':<28}{'mean cycles/wave ':>20}{'% of kernel':>14}")
 for k in sorted(names):
     print(f"{names[k]:<28}{m[k]:>20.0f}{100 * m[k] / m[0]:>13.1f}%")
