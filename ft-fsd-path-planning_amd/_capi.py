@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
     "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
-    "fsdp_plan_batch_sequential", "fsdp_set_previous_paths",
+    "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
 ]
 
@@ -175,6 +175,11 @@ class Context:
         self._check(self._lib.fsdp_upload(self._h, n, _ip(offsets), _dp(cones), _dp(poses)), "fsdp_upload")
         self._check(self._lib.fsdp_sync(self._h), "fsdp_sync")
         self.n_frames = n
+
+    def set_overlap(self, depth: int):
+        """depth 2: consecutive run() passes alternate between two streams / buffer sets and overlap (streams of batches);
+        depth 1 (default): one pass after the other."""
+        self._check(self._lib.fsdp_set_overlap(self._h, int(depth)), "fsdp_set_overlap")
 
     def run(self):
         self._check(self._lib.fsdp_run(self._h), "fsdp_run")

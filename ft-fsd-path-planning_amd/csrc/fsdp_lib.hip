@@ -46,6 +46,20 @@ struct fsdp_ctx {
   double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
   double* d_prev = nullptr;          // optional per-frame previous paths (n_frames,40,4) for sequential replays
   bool use_prev = false;
+  // further sets of intermediates + streams (fsdp_set_overlap): consecutive fsdp_run passes rotate through the sets, so
+  // the next passes start while the slowest wavefronts of the previous ones are still finishing
+  int overlap = 1;
+  unsigned turn = 0;
+  int last_slot = 0;
+  struct Extra {
+    hipStream_t stream = nullptr;
+    SortOut* d_sort = nullptr;
+    MatchOut* d_match = nullptr;
+    PathOut* d_path = nullptr;
+    double* d_arena = nullptr;
+    int cap_frames = 0;
+  } extra[FSDP_MAX_OVERLAP - 1];
+  std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
   // skidpad mission
   double* d_table = nullptr;
   double* d_noise = nullptr;
@@ -110,18 +124,66 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
   return 0;
 }
 
-static void launch_sort(fsdp_ctx* c) {
-  hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
-                     c->d_sort);
+struct Slot {
+  hipStream_t stream;
+  SortOut* d_sort;
+  MatchOut* d_match;
+  PathOut* d_path;
+  double* d_arena;
+};
+static Slot slot_of(fsdp_ctx* c, int i) {
+  if (i == 0) return Slot{c->stream, c->d_sort, c->d_match, c->d_path, c->d_arena};
+  const fsdp_ctx::Extra& x = c->extra[i - 1];
+  return Slot{x.stream, x.d_sort, x.d_match, x.d_path, x.d_arena};
 }
-static void launch_match(fsdp_ctx* c) {
-  hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), 0, c->stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
-                     c->d_sort, c->d_match);
+
+static int ensure_extra_slots(fsdp_ctx* c) {
+  for (int i = 0; i + 1 < c->overlap; i++) {
+    fsdp_ctx::Extra& x = c->extra[i];
+    if (!x.stream) HIP_TRY(c, hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+    if (x.cap_frames >= c->cap_frames) continue;
+    if (x.d_sort) (void)hipFree(x.d_sort);
+    if (x.d_match) (void)hipFree(x.d_match);
+    if (x.d_path) (void)hipFree(x.d_path);
+    if (x.d_arena) (void)hipFree(x.d_arena);
+    x.d_sort = nullptr;
+    x.d_match = nullptr;
+    x.d_path = nullptr;
+    x.d_arena = nullptr;
+    x.cap_frames = 0;
+    const size_t n = (size_t)c->cap_frames;
+    HIP_TRY(c, hipMalloc(&x.d_sort, sizeof(SortOut) * n));
+    HIP_TRY(c, hipMalloc(&x.d_match, sizeof(MatchOut) * n));
+    HIP_TRY(c, hipMalloc(&x.d_path, sizeof(PathOut) * n));
+    HIP_TRY(c, hipMalloc(&x.d_arena, sizeof(double) * ARENA_DOUBLES * n));
+    x.cap_frames = c->cap_frames;
+  }
+  return 0;
 }
-static void launch_path(fsdp_ctx* c) {
-  hipLaunchKernelGGL(path_kernel, dim3((c->n_frames + WAVE / PATH_G - 1) / (WAVE / PATH_G)), dim3(WAVE), 0, c->stream, c->n_frames, c->d_poses, c->d_match,
-                     c->d_default_path, c->use_prev ? c->d_prev : nullptr, c->d_arena, c->d_path);
+
+// wait for every pass in flight (all slots)
+static int sync_all(fsdp_ctx* c) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < FSDP_MAX_OVERLAP - 1; i++)
+    if (c->extra[i].stream) HIP_TRY(c, hipStreamSynchronize(c->extra[i].stream));
+  return 0;
 }
+
+static void launch_sort(fsdp_ctx* c, const Slot& q) {
+  hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
+                     q.d_sort);
+}
+static void launch_match(fsdp_ctx* c, const Slot& q) {
+  hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
+                     q.d_sort, q.d_match);
+}
+static void launch_path(fsdp_ctx* c, const Slot& q) {
+  hipLaunchKernelGGL(path_kernel, dim3((c->n_frames + WAVE / PATH_G - 1) / (WAVE / PATH_G)), dim3(WAVE), 0, q.stream,
+                     c->n_frames, c->d_poses, q.d_match, c->d_default_path, c->use_prev ? c->d_prev : nullptr, q.d_arena, q.d_path);
+}
+static void launch_sort(fsdp_ctx* c) { launch_sort(c, slot_of(c, 0)); }
+static void launch_match(fsdp_ctx* c) { launch_match(c, slot_of(c, 0)); }
+static void launch_path(fsdp_ctx* c) { launch_path(c, slot_of(c, 0)); }
 
 static void assemble(const SortOut* s, const MatchOut* m, const PathOut* p, fsdp_frame_result* r) {
   // r may already hold fields from earlier stages when only part of the pipeline ran
@@ -241,6 +303,16 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_skid_info);
   (void)hipFree(c->d_skid_status);
   (void)hipFree(c->d_default_path);
+  for (int i = 0; i < FSDP_MAX_OVERLAP - 1; i++) {
+    fsdp_ctx::Extra& x = c->extra[i];
+    if (x.stream) (void)hipStreamSynchronize(x.stream);
+    (void)hipFree(x.d_sort);
+    (void)hipFree(x.d_match);
+    (void)hipFree(x.d_path);
+    (void)hipFree(x.d_arena);
+    if (x.stream) (void)hipStreamDestroy(x.stream);
+  }
+  for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
   for (int i = 0; i < 8; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -255,31 +327,50 @@ int fsdp_upload(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
     c->err = "cone_offsets[0] must be 0";
     return 1;
   }
-  int rc = ensure_capacity(c, n_frames > 0 ? n_frames : 1, total);
+  int rc = sync_all(c);  // passes in flight still read the old inputs
+  if (rc) return rc;
+  rc = ensure_capacity(c, n_frames > 0 ? n_frames : 1, total);
+  if (rc) return rc;
+  rc = ensure_extra_slots(c);
   if (rc) return rc;
   c->n_frames = n_frames;
+  c->last_slot = 0;
   if (n_frames == 0) return 0;
   HIP_TRY(c, hipMemcpyAsync(c->d_off, off, sizeof(int32_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, c->stream));
   if (total) HIP_TRY(c, hipMemcpyAsync(c->d_cones, cones, sizeof(double) * 3 * total, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, c->stream));
+  if (c->overlap > 1) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the second stream reads these inputs too
   return 0;
+}
+
+int fsdp_set_overlap(fsdp_ctx* c, int depth) {
+  if (!c || depth < 1 || depth > FSDP_MAX_OVERLAP) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = sync_all(c);
+  if (rc) return rc;
+  c->overlap = depth;
+  c->turn = 0;
+  c->last_slot = 0;
+  return ensure_extra_slots(c);
 }
 
 int fsdp_run(fsdp_ctx* c) {
   if (!c) return 1;
   if (c->n_frames == 0) return 0;
   HIP_TRY(c, hipSetDevice(c->device));
-  launch_sort(c);
-  launch_match(c);
-  launch_path(c);
+  const int si = (c->overlap > 1) ? (int)(c->turn++ % (unsigned)c->overlap) : 0;
+  const Slot q = slot_of(c, si);
+  c->last_slot = si;
+  launch_sort(c, q);
+  launch_match(c, q);
+  launch_path(c, q);
   HIP_TRY(c, hipGetLastError());
   return 0;
 }
 
 int fsdp_sync(fsdp_ctx* c) {
   if (!c) return 1;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return sync_all(c);
 }
 
 int fsdp_download(fsdp_ctx* c, fsdp_frame_result* results) {
@@ -289,10 +380,12 @@ int fsdp_download(fsdp_ctx* c, fsdp_frame_result* results) {
   c->h_sort.resize(n);
   c->h_match.resize(n);
   c->h_path.resize(n);
-  HIP_TRY(c, hipMemcpyAsync(c->h_sort.data(), c->d_sort, sizeof(SortOut) * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_match.data(), c->d_match, sizeof(MatchOut) * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), c->d_path, sizeof(PathOut) * n, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const Slot q = slot_of(c, c->last_slot);  // the most recent pass
+  HIP_TRY(c, hipMemcpyAsync(c->h_sort.data(), q.d_sort, sizeof(SortOut) * n, hipMemcpyDeviceToHost, q.stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_match.data(), q.d_match, sizeof(MatchOut) * n, hipMemcpyDeviceToHost, q.stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), q.d_path, sizeof(PathOut) * n, hipMemcpyDeviceToHost, q.stream));
+  int rc = sync_all(c);
+  if (rc) return rc;
   for (int i = 0; i < n; i++) {
     memset(&results[i], 0, sizeof(fsdp_frame_result));
     assemble(&c->h_sort[i], &c->h_match[i], &c->h_path[i], &results[i]);
@@ -310,8 +403,11 @@ int fsdp_set_previous_paths(fsdp_ctx* c, const double* prev_paths) {
     c->err = "fsdp_set_previous_paths: upload a batch first";
     return 1;
   }
+  int rc = sync_all(c);
+  if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_prev, prev_paths, sizeof(double) * PATH_POINTS * 4 * (size_t)c->n_frames, hipMemcpyHostToDevice,
                             c->stream));
+  if (c->overlap > 1) HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->use_prev = true;
   return 0;
 }
@@ -345,26 +441,58 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
     return 0;
   }
   HIP_TRY(c, hipSetDevice(c->device));
+  int rc = sync_all(c);
+  if (rc) return rc;
+  // 4 events per pass (before sort | match | path | after); passes alternate between the slots when overlap is on and are
+  // NOT synchronised with the host in between
+  const size_t need = 4 * (size_t)iters + 2;
+  while (c->tev.size() < need) {
+    hipEvent_t e;
+    HIP_TRY(c, hipEventCreate(&e));
+    c->tev.push_back(e);
+  }
+  hipEvent_t ev_begin = c->tev[need - 2], ev_end = c->tev[need - 1];
+  HIP_TRY(c, hipEventRecord(ev_begin, c->stream));
+  int last_of_slot[FSDP_MAX_OVERLAP];
+  bool started[FSDP_MAX_OVERLAP];
+  for (int i = 0; i < FSDP_MAX_OVERLAP; i++) {
+    last_of_slot[i] = -1;
+    started[i] = false;
+  }
+  for (int it = 0; it < iters; it++) {
+    const int si = (c->overlap > 1) ? (int)(c->turn++ % (unsigned)c->overlap) : 0;
+    const Slot q = slot_of(c, si);
+    c->last_slot = si;
+    hipEvent_t* e = &c->tev[4 * (size_t)it];
+    if (!started[si] && si != 0) HIP_TRY(c, hipStreamWaitEvent(q.stream, ev_begin, 0));
+    started[si] = true;
+    HIP_TRY(c, hipEventRecord(e[0], q.stream));
+    launch_sort(c, q);
+    HIP_TRY(c, hipEventRecord(e[1], q.stream));
+    launch_match(c, q);
+    HIP_TRY(c, hipEventRecord(e[2], q.stream));
+    launch_path(c, q);
+    HIP_TRY(c, hipEventRecord(e[3], q.stream));
+    last_of_slot[si] = it;
+  }
+  // the end event follows the last pass of both slots
+  for (int i = 1; i < FSDP_MAX_OVERLAP; i++)
+    if (last_of_slot[i] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->tev[4 * (size_t)last_of_slot[i] + 3], 0));
+  HIP_TRY(c, hipEventRecord(ev_end, c->stream));
+  HIP_TRY(c, hipEventSynchronize(ev_end));
+  rc = sync_all(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipGetLastError());
   float acc[3] = {0, 0, 0};
   float total = 0;
+  HIP_TRY(c, hipEventElapsedTime(&total, ev_begin, ev_end));
   for (int it = 0; it < iters; it++) {
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    launch_sort(c);
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    launch_match(c);
-    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-    launch_path(c);
-    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
-    HIP_TRY(c, hipEventSynchronize(c->ev[3]));
     float t;
-    for (int s = 0; s < 3; s++) {
-      HIP_TRY(c, hipEventElapsedTime(&t, c->ev[s], c->ev[s + 1]));
-      acc[s] += t;
+    for (int st = 0; st < 3; st++) {
+      HIP_TRY(c, hipEventElapsedTime(&t, c->tev[4 * (size_t)it + st], c->tev[4 * (size_t)it + st + 1]));
+      acc[st] += t;
     }
-    HIP_TRY(c, hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
-    total += t;
   }
-  HIP_TRY(c, hipGetLastError());
   if (ms_total) *ms_total = total;
   if (ms_stage) {
     ms_stage[0] = acc[0];

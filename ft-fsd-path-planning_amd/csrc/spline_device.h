@@ -384,11 +384,12 @@ __device__ __forceinline__ void givens_chunk_pipelined(SplineWS<G>& ws, int cnt,
     pl = ws.lq[r];
   };
   if (cnt > 0) stage_row(0);
+  // a row enters one step after its predecessor, later by the number of intervals it skipped (its first band row must
+  // have seen the predecessor).  The test for the next step is evaluated after this step's arithmetic, so the staged
+  // row's interval (an LDS read issued at the previous injection) is consumed late.
+  bool inject = st.first != 0 || st.tau >= st.t_base + (pl - st.l_prev);
   while (next_r < cnt) {
     GivItem in = quad_rot_prev<G>(st.out);
-    // a row enters one step after its predecessor, later by the number of intervals it skipped (its first band row
-    // must have seen the predecessor)
-    const bool inject = st.first != 0 || st.tau >= st.t_base + (pl - st.l_prev);
     if (inject) {
       const int j0 = pl - k1 + 1;
       if (lane == (j0 & 3)) {
@@ -411,6 +412,7 @@ __device__ __forceinline__ void givens_chunk_pipelined(SplineWS<G>& ws, int cnt,
     }
     giv_process<G>(ws, st, in, lane, n);
     st.tau++;
+    inject = st.tau >= st.t_base + (pl - st.l_prev);
   }
 }
 
@@ -428,6 +430,58 @@ __device__ __forceinline__ double giv_drain(SplineWS<G>& ws, int n, GivState& st
   return Grp<G>::bcast(st.fpl, st.l_prev & 3);
 }
 
+// Residual terms sum_d (s_d(u_i) - x_d,i)^2 of the points [base, base + cnt) (cnt <= 4 * CH) from the basis cache, one
+// point per lane and round; written to tbuf[0..cnt) (the chunk's basis buffer, idle here) and, when FLAGS, the "a new
+// knot interval starts at this point" flags to fbuf.  Four rounds at a time: their (independent) scratch loads are
+// issued together, then the arithmetic — one memory round trip per 4 * G points.
+template <int K, int G, bool FLAGS>
+__device__ __forceinline__ void residual_terms(SplineWS<G>& ws, const BasisCache& bc, const double* X, const double* Y, int base,
+                                               int cnt, int n, double* tbuf, int32_t* fbuf) {
+  constexpr int k1 = K + 1, k2 = K + 2;
+  const int lane = Grp<G>::lane();
+  for (int r0 = 0; r0 < cnt; r0 += 4 * G) {
+    double hv[4][K + 1], xv[4], yv[4];
+    int lv[4], lpv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = r0 + q * G + lane;
+      const int it = base + r;
+      if (r < cnt) {
+#pragma unroll
+        for (int j = 0; j < k1; j++) hv[q][j] = bc.h[j][it];
+        // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
+        // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point
+        lv[q] = bc.l[it] + 1;
+        if constexpr (FLAGS) lpv[q] = it > 0 ? bc.l[it - 1] + 1 : k2;
+        xv[q] = X[it];
+        yv[q] = Y[it];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = r0 + q * G + lane;
+      if (r < cnt) {
+        const int l0 = lv[q] - k2;
+        double term = 0.0;
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+          double fac = 0.0;
+          int j1 = l0 + d * n;
+#pragma unroll
+          for (int j = 1; j <= k1; j++) {
+            j1++;
+            fac = fac + ws.c[j1] * hv[q][j - 1];
+          }
+          double dv = 1.0 * (fac - (d == 0 ? xv[q] : yv[q]));  // w = 1
+          term = term + dv * dv;
+        }
+        tbuf[r] = term;
+        if constexpr (FLAGS) fbuf[r] = (lv[q] > lpv[q]) ? 1 : 0;
+      }
+    }
+  }
+}
+
 // parcur/fppara for idim=2, w=1, iopt=0.  Data (0-based arrays U = parameter, X, Y; m points) in LDS or HBM.
 // All lanes of the group call; result (t, c) left in ws; returns the group-uniform SplineFit.
 template <int K, int G>
@@ -435,7 +489,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
                                          int m, double s) {
   using GR = Grp<G>;
   constexpr int CH = SplineWS<G>::CH;
-  constexpr int NR = CH / G;  // rounds per chunk (points per lane and chunk)
+  constexpr int SC = 4 * CH;  // points per residual "super-chunk" (the chunk's basis buffer holds 4 * CH terms)
   constexpr int k = K;
   const int lane = GR::lane();
   SplineFit R;
@@ -635,58 +689,19 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
         PROF(14);
         double fpart = 0.0;
         int ii = 1;
-        for (int base = 0; base < m; base += CH) {
-          const int cnt = m - base < CH ? m - base : CH;
-          {
-            // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
-            // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point.
-            // Loads of all rounds first (independent), then the arithmetic.
-            double hv[NR][K + 1], xv[NR], yv[NR];
-            int lv[NR], lpv[NR];
-#pragma unroll
-            for (int q = 0; q < NR; q++) {
-              const int r = q * G + lane;
-              const int it = base + r;
-              if (r < cnt) {
-#pragma unroll
-                for (int j = 0; j < k1; j++) hv[q][j] = bc.h[j][it];
-                lv[q] = bc.l[it] + 1;
-                lpv[q] = it > 0 ? bc.l[it - 1] + 1 : k2;
-                xv[q] = X[it];
-                yv[q] = Y[it];
-              }
-            }
-#pragma unroll
-            for (int q = 0; q < NR; q++) {
-              const int r = q * G + lane;
-              if (r < cnt) {
-                const int l0 = lv[q] - k2;
-                double term = 0.0;
-#pragma unroll
-                for (int d = 0; d < 2; d++) {
-                  double fac = 0.0;
-                  int j1 = l0 + d * n;
-#pragma unroll
-                  for (int j = 1; j <= k1; j++) {
-                    j1++;
-                    fac = fac + ws.c[j1] * hv[q][j - 1];
-                  }
-                  double dv = 1.0 * (fac - (d == 0 ? xv[q] : yv[q]));
-                  term = term + dv * dv;
-                }
-                ws.term[r] = term;
-                ws.lq[r] = (lv[q] > lpv[q]) ? 1 : 0;
-              }
-            }
-          }
+        double* const tbuf = &ws.hq[0][0];     // 4 * CH terms
+        int32_t* const fbuf = (int32_t*)ws.xq;  // xq | yq: 4 * CH flags
+        for (int base = 0; base < m; base += SC) {
+          const int cnt = m - base < SC ? m - base : SC;
+          residual_terms<K, G, true>(ws, bc, X, Y, base, cnt, n, tbuf, fbuf);
           GR::sync();
           for (int r0 = 0; r0 < cnt; r0 += 8) {  // operands eight at a time (one LDS round trip), order kept
             double tv[8];
             int fl[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-              tv[q] = ws.term[r0 + q];  // r0 + q < CH always (CH is a multiple of 8)
-              fl[q] = ws.lq[r0 + q];
+              tv[q] = tbuf[r0 + q];  // r0 + q < SC always (SC is a multiple of 8)
+              fl[q] = fbuf[r0 + q];
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -859,52 +874,19 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       // f(p): terms per lane, accumulation in data order
       PROF(17);
       fp = 0.;
-      for (int base = 0; base < m; base += CH) {
-        const int cnt = m - base < CH ? m - base : CH;
-        {
-        PROF(28);
-        {
-          double hv[NR][K + 1], xv[NR], yv[NR];
-          int lv[NR];
-#pragma unroll
-          for (int q = 0; q < NR; q++) {
-            const int r = q * G + lane;
-            const int it = base + r;
-            if (r < cnt) {
-#pragma unroll
-              for (int j = 0; j < k1; j++) hv[q][j] = bc.h[j][it];
-              lv[q] = bc.l[it] + 1;
-              xv[q] = X[it];
-              yv[q] = Y[it];
-            }
+      {
+        double* const tbuf = &ws.hq[0][0];  // 4 * CH terms
+        for (int base = 0; base < m; base += SC) {
+          const int cnt = m - base < SC ? m - base : SC;
+          {
+            PROF(28);
+            residual_terms<K, G, false>(ws, bc, X, Y, base, cnt, n, tbuf, nullptr);
+            GR::sync();
           }
-#pragma unroll
-          for (int q = 0; q < NR; q++) {
-            const int r = q * G + lane;
-            if (r < cnt) {
-              const int l0 = lv[q] - k2;
-              double term = 0.;
-#pragma unroll
-              for (int d = 0; d < 2; d++) {
-                double fac = 0.;
-                int j1 = l0 + d * n;
-#pragma unroll
-                for (int j = 1; j <= k1; j++) {
-                  j1++;
-                  fac = fac + ws.c[j1] * hv[q][j - 1];
-                }
-                double dv = fac - (d == 0 ? xv[q] : yv[q]);
-                term = term + dv * dv;
-              }
-              ws.term[r] = term;
-            }
-          }
+          PROF(29);
+          fp = seq_sum(tbuf, cnt, fp);  // w = 1: term * w^2 is the term itself
+          GR::sync();
         }
-        GR::sync();
-        }
-        PROF(29);
-        fp = seq_sum(ws.term, cnt, fp);  // w = 1: term * w^2 is the term itself
-        GR::sync();
       }
       fpms = fp - s;
       if (fabs(fpms) < acc) break;

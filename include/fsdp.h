@@ -117,9 +117,19 @@ int fsdp_run(fsdp_ctx* ctx);      /* enqueue sorting, matching, path kernels on 
 int fsdp_sync(fsdp_ctx* ctx);     /* wait for the stream */
 int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
 
-/* Enqueue `iters` back-to-back passes over the resident batch and time them with HIP events recorded on the
- * context's stream.  ms_total: whole region; ms_stage[3]: summed time of the sorting / matching / path kernels
- * (events around each launch).  Either pointer may be NULL. */
+/* Pass overlap for streams of batches (a replay feeds one batch after the other): depth d (<= FSDP_MAX_OVERLAP) gives
+ * the context d HIP streams and d sets of intermediate buffers; consecutive fsdp_run passes rotate through them, so the
+ * next passes fill the compute units that the slowest frames of the previous ones no longer occupy.  fsdp_sync waits for
+ * all passes in flight, fsdp_download returns the most recent one.  depth 1 (default) = strictly one pass after the
+ * other. */
+#define FSDP_MAX_OVERLAP 4
+int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
+
+/* Enqueue `iters` back-to-back passes over the resident batch (alternating slots when overlap is 2; no host
+ * synchronisation in between) and time them with HIP events recorded on the streams the kernels run on.
+ * ms_total: whole region; ms_stage[3]: summed durations of the sorting / matching / path kernel launches (events around
+ * each launch; with overlap these include the time a launch shares the chip with the other slot's kernels).
+ * Either pointer may be NULL. */
 int fsdp_time_runs(fsdp_ctx* ctx, int iters, float* ms_total, float* ms_stage);
 
 /* Stage-level entry points (README "parts of the pipeline are also available as individual classes"). */
