@@ -430,21 +430,23 @@ __device__ __forceinline__ double giv_drain(SplineWS<G>& ws, int n, GivState& st
   return Grp<G>::bcast(st.fpl, st.l_prev & 3);
 }
 
-// Residual terms sum_d (s_d(u_i) - x_d,i)^2 of the points [base, base + cnt) (cnt <= 4 * CH) from the basis cache, one
-// point per lane and round; written to tbuf[0..cnt) (the chunk's basis buffer, idle here) and, when FLAGS, the "a new
-// knot interval starts at this point" flags to fbuf.  Four rounds at a time: their (independent) scratch loads are
-// issued together, then the arithmetic — one memory round trip per 4 * G points.
+// Residual terms sum_d (s_d(u_i) - x_d,i)^2 of one "super-chunk" of points [base, base + cnt) (cnt <= 4 * CH), one point
+// per lane and round, from the basis cache.  load() issues every scratch load of the super-chunk (registers), compute()
+// does the arithmetic and writes the terms to tbuf[0..cnt) (the chunk's basis buffer, idle here) and, when FLAGS, the
+// "a new knot interval starts at this point" flags to fbuf.  The caller issues the next super-chunk's load() before
+// the serial accumulation of the current one, so the scratch round trip hides behind it.
 template <int K, int G, bool FLAGS>
-__device__ __forceinline__ void residual_terms(SplineWS<G>& ws, const BasisCache& bc, const double* X, const double* Y, int base,
-                                               int cnt, int n, double* tbuf, int32_t* fbuf) {
-  constexpr int k1 = K + 1, k2 = K + 2;
-  const int lane = Grp<G>::lane();
-  for (int r0 = 0; r0 < cnt; r0 += 4 * G) {
-    double hv[4][K + 1], xv[4], yv[4];
-    int lv[4], lpv[4];
+struct ResidualBatch {
+  static constexpr int ROUNDS = 4 * SplineWS<G>::CH / G;
+  static constexpr int k1 = K + 1, k2 = K + 2;
+  double hv[ROUNDS][K + 1], xv[ROUNDS], yv[ROUNDS];
+  int lv[ROUNDS], lpv[ROUNDS];
+
+  __device__ __forceinline__ void load(const BasisCache& bc, const double* X, const double* Y, int base, int cnt) {
+    const int lane = Grp<G>::lane();
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = r0 + q * G + lane;
+    for (int q = 0; q < ROUNDS; q++) {
+      const int r = q * G + lane;
       const int it = base + r;
       if (r < cnt) {
 #pragma unroll
@@ -457,9 +459,13 @@ __device__ __forceinline__ void residual_terms(SplineWS<G>& ws, const BasisCache
         yv[q] = Y[it];
       }
     }
+  }
+
+  __device__ __forceinline__ void compute(SplineWS<G>& ws, int cnt, int n, double* tbuf, int32_t* fbuf) const {
+    const int lane = Grp<G>::lane();
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = r0 + q * G + lane;
+    for (int q = 0; q < ROUNDS; q++) {
+      const int r = q * G + lane;
       if (r < cnt) {
         const int l0 = lv[q] - k2;
         double term = 0.0;
@@ -480,7 +486,7 @@ __device__ __forceinline__ void residual_terms(SplineWS<G>& ws, const BasisCache
       }
     }
   }
-}
+};
 
 // parcur/fppara for idim=2, w=1, iopt=0.  Data (0-based arrays U = parameter, X, Y; m points) in LDS or HBM.
 // All lanes of the group call; result (t, c) left in ws; returns the group-uniform SplineFit.
@@ -564,28 +570,49 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       giv_init(gst);
       int lres = k1;  // this lane's previous knot interval (data are increasing: the search resumes there)
       // ---- observation rows: basis values per lane, Givens rotations group-uniform in data order ----
+      // the chunk's points (parameter, x, y) are fetched one chunk ahead: the scratch round trip of chunk c + 1 hides
+      // behind the Givens pipeline of chunk c
+      constexpr int NRC = CH / G;
+      double pu[NRC], pxv[NRC], pyv[NRC];
+      auto fetch_chunk = [&](int base) {
+#pragma unroll
+        for (int q = 0; q < NRC; q++) {
+          const int it = base + q * G + lane;
+          if (it < m) {
+            pu[q] = U[it];
+            pxv[q] = X[it];
+            pyv[q] = Y[it];
+          }
+        }
+      };
+      fetch_chunk(0);
       for (int base = 0; base < m; base += CH) {
         const int cnt = m - base < CH ? m - base : CH;
         {
           PROF(10);
-          for (int r = lane; r < cnt; r += G) {
-            const int it = base + r;
-            double ui = U[it];
-            int l = find_interval_from(ws.t, lres, nk1, ui);
-            lres = l;
-            double h[K + 2];
-            fpbspl<K>(ws.t, ui, l, h);
 #pragma unroll
-            for (int q = 0; q < k1; q++) {
-              ws.hq[r][q] = h[q + 1];
-              bc.h[q][it] = h[q + 1];
+          for (int q = 0; q < NRC; q++) {
+            const int r = q * G + lane;
+            const int it = base + r;
+            if (r < cnt) {
+              double ui = pu[q];
+              int l = find_interval_from(ws.t, lres, nk1, ui);
+              lres = l;
+              double h[K + 2];
+              fpbspl<K>(ws.t, ui, l, h);
+#pragma unroll
+              for (int j = 0; j < k1; j++) {
+                ws.hq[r][j] = h[j + 1];
+                bc.h[j][it] = h[j + 1];
+              }
+              ws.lq[r] = l;
+              bc.l[it] = l;
+              ws.xq[r] = pxv[q];
+              ws.yq[r] = pyv[q];
             }
-            ws.lq[r] = l;
-            bc.l[it] = l;
-            ws.xq[r] = X[it];
-            ws.yq[r] = Y[it];
           }
           GR::sync();
+          if (base + CH < m) fetch_chunk(base + CH);
         }
         if constexpr (K == 3) {
           PROF(11);
@@ -691,10 +718,13 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
         int ii = 1;
         double* const tbuf = &ws.hq[0][0];     // 4 * CH terms
         int32_t* const fbuf = (int32_t*)ws.xq;  // xq | yq: 4 * CH flags
+        ResidualBatch<K, G, true> rb;
+        rb.load(bc, X, Y, 0, m < SC ? m : SC);
         for (int base = 0; base < m; base += SC) {
           const int cnt = m - base < SC ? m - base : SC;
-          residual_terms<K, G, true>(ws, bc, X, Y, base, cnt, n, tbuf, fbuf);
+          rb.compute(ws, cnt, n, tbuf, fbuf);
           GR::sync();
+          if (base + SC < m) rb.load(bc, X, Y, base + SC, (m - base - SC) < SC ? (m - base - SC) : SC);
           for (int r0 = 0; r0 < cnt; r0 += 8) {  // operands eight at a time (one LDS round trip), order kept
             double tv[8];
             int fl[8];
@@ -876,12 +906,15 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       fp = 0.;
       {
         double* const tbuf = &ws.hq[0][0];  // 4 * CH terms
+        ResidualBatch<K, G, false> rb;
+        rb.load(bc, X, Y, 0, m < SC ? m : SC);
         for (int base = 0; base < m; base += SC) {
           const int cnt = m - base < SC ? m - base : SC;
           {
             PROF(28);
-            residual_terms<K, G, false>(ws, bc, X, Y, base, cnt, n, tbuf, nullptr);
+            rb.compute(ws, cnt, n, tbuf, nullptr);
             GR::sync();
+            if (base + SC < m) rb.load(bc, X, Y, base + SC, (m - base - SC) < SC ? (m - base - SC) : SC);
           }
           PROF(29);
           fp = seq_sum(tbuf, cnt, fp);  // w = 1: term * w^2 is the term itself

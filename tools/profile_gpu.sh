@@ -9,7 +9,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+# kernel trace of the bench command itself (passes overlap as in the bench), then one with --no-overlap
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+echo "trace rc=$?"
+rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o trace -- $BENCH --no-overlap > $OUT/trace_serial.log 2>&1
+BENCH="$BENCH --no-overlap"
 echo "trace rc=$?"
 # PMC passes (separate runs; FETCH_SIZE and WRITE_SIZE do not fit one pass)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
@@ -20,5 +24,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 echo "sq rc=$?"
 cd $REPO
 find $OUT -name "*.csv" | head -40
-python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python tools/summarize_prof.py $OUT $OUT/pmc_traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -22,9 +22,10 @@ ctx = pkg.Context(device=0)
 out = {{}}
 for name, args in [('cfg2', dict(n=4096, k=64, tn=0.15, seed=1, color=True)), ('cfg3', dict(n=4096, k=64, tn=0.15, seed=1, color=False)), ('cfg4', dict(n=8192, k=100, tn=0.0, seed=7, color=True, fn=0.1, rp=True))]:
     off, cones, poses = pkg.synth.make_replay_batch(args['n'], args['k'], args['tn'], seed=args['seed'], color=args['color'], frame_noise=args.get('fn', 0.0), random_pose=args.get('rp', False))
-    ctx.upload(off, cones, poses); ctx.run(); ctx.sync()
+    ctx.set_overlap(1); ctx.upload(off, cones, poses); ctx.run(); ctx.sync()
     tot, st = ctx.time_runs(5)
-    out[name] = [round(x / 5, 3) for x in st]
+    ctx.set_overlap(2); ctx.time_runs(4); tot2, st2 = ctx.time_runs(12)
+    out[name] = [round(x / 5, 3) for x in st] + ['serial step', round(tot / 5, 3), 'overlapped step', round(tot2 / 12, 3)]
 print(json.dumps({{'so': Path({str(so)!r}).name, 'sort/match/path ms': out}}))
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
