@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64) skid_reloc_kernel(int n_inst, const int32_
   }
 }
 
-__global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, const double* __restrict__ poses,
+__global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const double* __restrict__ poses,
                                                           SkidState* __restrict__ states, SkidTables T,
                                                           const double* __restrict__ chord, double* __restrict__ arena,
                                                           const int32_t* __restrict__ status_in, PathOut* __restrict__ out,

@@ -17,6 +17,10 @@
 #pragma once
 #include "fsdp_device.h"
 
+#ifndef FSDP_SORT_WAVES
+#define FSDP_SORT_WAVES 3
+#endif
+
 namespace fsdp {
 
 struct SortShared {
@@ -837,7 +841,7 @@ __device__ inline void combine_sides(SortShared& S, int& nl, int& nr) {
 }
 
 // One workgroup (= one wavefront) per frame.
-__global__ void __launch_bounds__(64, 3) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
+__global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
                                                   const double* __restrict__ cones_xyt, const double* __restrict__ poses,
                                                   SortOut* __restrict__ out) {
   __shared__ SortShared S;

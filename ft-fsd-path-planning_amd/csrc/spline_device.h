@@ -573,7 +573,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       // the chunk's points (parameter, x, y) are fetched one chunk ahead: the scratch round trip of chunk c + 1 hides
       // behind the Givens pipeline of chunk c
       constexpr int NRC = CH / G;
-      double pu[NRC], pxv[NRC], pyv[NRC];
+      double pu[NRC] = {}, pxv[NRC] = {}, pyv[NRC] = {};
       auto fetch_chunk = [&](int base) {
 #pragma unroll
         for (int q = 0; q < NRC; q++) {
