@@ -48,6 +48,7 @@ struct fsdp_ctx {
   bool use_prev = false;
   // further sets of intermediates + streams (fsdp_set_overlap): consecutive fsdp_run passes rotate through the sets, so
   // the next passes start while the slowest wavefronts of the previous ones are still finishing
+  bool profile_sort = false;  // profiling build: which kernel fsdp_profile_path runs
   int overlap = 1;
   unsigned turn = 0;
   int last_slot = 0;
@@ -599,6 +600,11 @@ int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, fsdp_frame_r
 }
 
 #ifdef FSDP_PROFILE
+int fsdp_profile_select(fsdp_ctx* c, int sort_kernel_instead_of_path) {
+  if (!c) return 1;
+  c->profile_sort = sort_kernel_instead_of_path != 0;
+  return 0;
+}
 // profiling build only (tools/section_profile.py): per-frame per-section cycle sums of the path kernel
 int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
   if (!c || c->n_frames == 0) return 1;
@@ -607,7 +613,10 @@ int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
   HIP_TRY(c, hipMalloc(&d, bytes));
   HIP_TRY(c, hipMemset(d, 0, bytes));
   HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(fsdp::g_prof), &d, sizeof(d)));
-  launch_path(c);
+  if (c->profile_sort)
+    launch_sort(c);
+  else
+    launch_path(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(out32_per_frame, d, bytes, hipMemcpyDeviceToHost));
   long long* z = nullptr;

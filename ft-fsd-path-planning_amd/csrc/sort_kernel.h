@@ -23,6 +23,21 @@
 
 namespace fsdp {
 
+// section accounting of the profiling build: PROF_MARK(k) closes the running section and opens section k
+#if defined(FSDP_PROFILE) && !defined(FSDP_EMU)
+#define PROF_MARK(k)                                                                          \
+  do {                                                                                        \
+    long long now_ = clock64();                                                               \
+    if (g_prof && (threadIdx.x & 63) == 0) g_prof[(size_t)blockIdx.x * 32 + prof_cur_] += now_ - prof_t_; \
+    prof_cur_ = (k);                                                                          \
+    prof_t_ = now_;                                                                           \
+  } while (0)
+#define PROF_MARK_DECL(k) long long prof_t_ = clock64(); int prof_cur_ = (k)
+#else
+#define PROF_MARK(k)
+#define PROF_MARK_DECL(k)
+#endif
+
 struct SortShared {
   double x[MAX_CONES];
   double y[MAX_CONES];
@@ -108,8 +123,22 @@ __device__ inline bool inside_ellipse(double px, double py, double cx, double cy
 }
 
 // end_configurations.py:108-223 for ONE candidate neighbour `cand` of the popped node.
-__device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type, int pos, int node, int cand, int n_nb,
+// check_if_neighbor_lies_between_last_in_attempt_and_candidate (:226-257) for one (candidate, neighbour) pair
+__device__ __forceinline__ bool neighbour_lies_between(const SortShared& S, int node, int cand, int nb) {
+  if (nb == cand) return false;
+  const double lx = S.x[node], ly = S.y[node];
+  const double cx = S.x[cand], cy = S.y[cand];
+  double vlx = lx - S.x[nb], vly = ly - S.y[nb];
+  double vcx = cx - S.x[nb], vcy = cy - S.y[nb];
+  double dc = norm_blas(vcx, vcy), dl = norm_blas(vlx, vly);
+  return dc < 6.0 && dl < 6.0 && angle_between(vlx, vly, vcx, vcy) > 150 * FSDP_DEG;
+}
+
+// `between` = some neighbour of `node` lies between it and the candidate (evaluated by the caller, one (candidate,
+// neighbour) pair per lane); all tests are pure predicates, so their order does not matter
+__device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type, int pos, int node, int cand, bool between,
                                               double px, double py, double dx, double dy, double dnx, double dny) {
+  if (between) return false;
   for (int q = 0; q <= pos; q++)
     if (S.attempt[q] == cand) return false;
   const double lx = S.x[node], ly = S.y[node];
@@ -124,15 +153,6 @@ __device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type
     double diff = angle_difference(a_n, a_car);
     double want = (cone_type == T_LEFT) ? 1.0 : -1.0;
     if (!((sign_of(diff) == want) || (fabs(diff) < 5 * FSDP_DEG))) return false;
-  }
-  // check_if_neighbor_lies_between_last_in_attempt_and_candidate :226-257
-  for (int q = 0; q < n_nb; q++) {
-    int nb = S.nbr[node][q];
-    if (nb == cand) continue;
-    double vlx = lx - S.x[nb], vly = ly - S.y[nb];
-    double vcx = cx - S.x[nb], vcy = cy - S.y[nb];
-    double dc = norm_blas(vcx, vcy), dl = norm_blas(vlx, vly);
-    if (dc < 6.0 && dl < 6.0 && angle_between(vlx, vly, vcx, vcy) > 150 * FSDP_DEG) return false;
   }
   bool can = true;
   if (pos >= 1) {
@@ -200,6 +220,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   }
   __syncthreads();
   if (n < 3) return ST_OK;  // core_trace_sorter.py:272-273
+  PROF_MARK_DECL(1);
 
   // ---------------- S4: start cones (core_trace_sorter.py:344-465) ----------------
   const int want_bit = (cone_type == T_LEFT) ? 2 : 4;  // flags bit1 (angle>0) / bit2 (angle<0)
@@ -264,6 +285,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   const int start_idx = fk0;
 
   // ---------------- S5: mutual-kNN adjacency (adjacency_matrix.py:60-128) ----------------
+  PROF_MARK(2);
   const int k_nn = (n - 1 < KNN) ? (n - 1) : KNN;
   for (int i = lane; i < n; i += WAVE) {
     double bd[KNN];
@@ -276,21 +298,34 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     const double xi = S.x[i], yi = S.y[i];
     const bool row_inf = (S.type[i] == other_type);
     if (!row_inf) {
-      for (int j = 0; j < n; j++) {
-        if (j == i || S.type[j] == other_type) continue;
-        double d = cdist_sq(xi, yi, S.x[j], S.y[j]);
-        if (d < bd[KNN - 1]) {
-          // sorted insertion through registers; strict '<' keeps the earlier index first on ties
-          int cj = j;
+      for (int j0 = 0; j0 < n; j0 += 8) {  // operands eight at a time (group-uniform LDS reads, one round trip)
+        double xj[8], yj[8];
+        int tj8[8];
 #pragma unroll
-          for (int q = 0; q < KNN; q++) {
-            bool lt = d < bd[q];
-            double td = lt ? bd[q] : d;
-            int tj = lt ? bj[q] : cj;
-            bd[q] = lt ? d : bd[q];
-            bj[q] = lt ? cj : bj[q];
-            d = td;
-            cj = tj;
+        for (int e = 0; e < 8; e++) {
+          const int j = (j0 + e < n) ? j0 + e : n - 1;
+          xj[e] = S.x[j];
+          yj[e] = S.y[j];
+          tj8[e] = S.type[j];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int j = j0 + e;
+          if (j >= n || j == i || tj8[e] == other_type) continue;
+          double d = cdist_sq(xi, yi, xj[e], yj[e]);
+          if (d < bd[KNN - 1]) {
+            // sorted insertion through registers; strict '<' keeps the earlier index first on ties
+            int cj = j;
+#pragma unroll
+            for (int q = 0; q < KNN; q++) {
+              bool lt = d < bd[q];
+              double td = lt ? bd[q] : d;
+              int tj = lt ? bj[q] : cj;
+              bd[q] = lt ? d : bd[q];
+              bj[q] = lt ? cj : bj[q];
+              d = td;
+              cj = tj;
+            }
           }
         }
       }
@@ -367,6 +402,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   const int target_length = reach < MAX_LEN ? reach : MAX_LEN;
 
   // ---------------- S8: DFS over the cost tree (end_configurations.py:320-431) ----------------
+  PROF_MARK(3);
   const double nrm = norm_blas(dx, dy);
   const double dnx = dx / nrm, dny = dy / nrm;
   int sp = 0, n_ends = 0;
@@ -403,8 +439,15 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     }
     __syncthreads();
     const int n_nb = S.nbr_cnt[node];
+    // up to 5 x 5 (candidate, neighbour) pairs, one per lane; candidate c owns bits [c * n_nb, (c + 1) * n_nb)
+    bool btw = false;
+    if (lane < n_nb * n_nb) btw = neighbour_lies_between(S, node, S.nbr[node][lane / n_nb], S.nbr[node][lane % n_nb]);
+    const unsigned long long bm = __ballot(btw);
     bool can = false;
-    if (lane < n_nb) can = candidate_can_be_added(S, cone_type, pos, node, S.nbr[node][lane], n_nb, px, py, dx, dy, dnx, dny);
+    if (lane < n_nb) {
+      const bool between = ((bm >> (lane * n_nb)) & ((1ull << n_nb) - 1ull)) != 0ull;
+      can = candidate_can_be_added(S, cone_type, pos, node, S.nbr[node][lane], between, px, py, dx, dy, dnx, dny);
+    }
     unsigned long long m = __ballot(can);
     bool has_valid = (pos < target_length - 1) && (m != 0ull);
     if (has_valid) {
@@ -428,6 +471,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   if (status != ST_OK) return status;
 
   // ---------------- S10: post filters (end_configurations.py:420-515), lane = raw configuration ----------------
+  PROF_MARK(4);
   const int L = target_length;
   bool keep = false;
   int16_t cfg[MAX_LEN];
@@ -493,6 +537,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   if (C == 0) return ST_OK;  // NoPathError -> side has no result
 
   // ---------------- S12: cones on either side (nearby_cone_search.py:213-297) ----------------
+  PROF_MARK(5);
   const int n_words = (n + WAVE - 1) / WAVE;
   if (lane < MAX_CONES / WAVE) {
     S.all_mask[lane] = 0ull;
@@ -553,52 +598,59 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     __syncthreads();
     if (undefined) return ST_REF_UNDEFINED_SET_DIFF;
   }
-  // per kept configuration (wave-uniform loop), per cone of it, lanes scan the candidate cones
-  for (int c = 0; c < n_ends; c++) {
-    if (!((keepm >> c) & 1ull)) continue;
-    int clen = 0;
-    for (int l = 0; l < MAX_LEN; l++) clen += (S.ends[c][l] != -1);
-    int good = 0, bad = 0;
-    for (int j = 0; j < clen; j++) {
-      int a, b;
-      if (j == 0) {
-        a = S.ends[c][0];
-        b = S.ends[c][1];
-      } else if (j == clen - 1) {
-        a = S.ends[c][j - 1];
-        b = S.ends[c][j];
-      } else {
-        a = S.ends[c][j - 1];
-        b = S.ends[c][j + 1];
-      }
-      double sdx, sdy;
-      search_direction(S.x[a], S.y[a], S.x[b], S.y[b], cone_type, sdx, sdy);
-      const int cj = S.ends[c][j];
-      const double xc = S.x[cj], yc = S.y[cj];
-      for (int w = 0; w < n_words; w++) {
-        // other = close ∪ (all \ config)
-        unsigned long long cm = 0ull;
-        for (int l = 0; l < clen; l++) {
-          int v = S.ends[c][l];
-          if ((v >> 6) == w) cm |= (1ull << (v & 63));
+  // counts per kept configuration: lane = (configuration, position in it); every lane walks the candidate cones of
+  // its pair ("other" = close ∪ (all \ configuration), a few dozen bits) and tests the few that lie within 6 m.
+  // (Integer counts of order-independent predicates: same values as the reference's per-cone loops.)
+  if (lane < MAX_ENDS) {
+    S.good[lane] = 0;
+    S.bad[lane] = 0;
+  }
+  __syncthreads();
+  for (int p0 = 0; p0 < n_ends * MAX_LEN; p0 += WAVE) {
+    const int p = p0 + lane;
+    const int c = p / MAX_LEN, j = p - c * MAX_LEN;
+    if (c < n_ends && ((keepm >> c) & 1ull)) {
+      const int16_t* e = S.ends[c];
+      int clen = 0;
+      for (int l = 0; l < MAX_LEN; l++) clen += (e[l] != -1);
+      if (j < clen) {
+        int a, b;
+        if (j == 0) {
+          a = e[0];
+          b = e[1];
+        } else if (j == clen - 1) {
+          a = e[j - 1];
+          b = e[j];
+        } else {
+          a = e[j - 1];
+          b = e[j + 1];
         }
-        unsigned long long om = S.close_mask[w] | (S.all_mask[w] & ~cm);
-        int idx = w * WAVE + lane;
-        bool g = false, bd = false;
-        if (((om >> lane) & 1ull) && idx < n && idx != cj) {
-          if (cdist_sq(xc, yc, S.x[idx], S.y[idx]) < 36.0) {
-            double vx = S.x[idx] - xc, vy = S.y[idx] - yc;
-            g = angle_between(vx, vy, sdx, sdy) < (FSDP_PI / 1.5) / 2;
-            bd = angle_between(vx, vy, -sdx, -sdy) < (FSDP_PI / 1.5) / 2;
+        double sdx, sdy;
+        search_direction(S.x[a], S.y[a], S.x[b], S.y[b], cone_type, sdx, sdy);
+        const int cj = e[j];
+        const double xc = S.x[cj], yc = S.y[cj];
+        int good = 0, bad = 0;
+        for (int w = 0; w < n_words; w++) {
+          unsigned long long cm = 0ull;
+          for (int l = 0; l < clen; l++) {
+            int v = e[l];
+            if ((v >> 6) == w) cm |= (1ull << (v & 63));
+          }
+          unsigned long long om = S.close_mask[w] | (S.all_mask[w] & ~cm);
+          if ((cj >> 6) == w) om &= ~(1ull << (cj & 63));
+          while (om) {
+            const int idx = w * WAVE + (__ffsll(om) - 1);
+            om &= om - 1ull;
+            if (idx < n && cdist_sq(xc, yc, S.x[idx], S.y[idx]) < 36.0) {
+              double vx = S.x[idx] - xc, vy = S.y[idx] - yc;
+              good += angle_between(vx, vy, sdx, sdy) < (FSDP_PI / 1.5) / 2;
+              bad += angle_between(vx, vy, -sdx, -sdy) < (FSDP_PI / 1.5) / 2;
+            }
           }
         }
-        good += __popcll(__ballot(g));
-        bad += __popcll(__ballot(bd));
+        if (good) atomicAdd(&S.good[c], good);
+        if (bad) atomicAdd(&S.bad[c], bad);
       }
-    }
-    if (lane == 0) {
-      S.good[c] = good;
-      S.bad[c] = bad;
     }
   }
   __syncthreads();
@@ -610,6 +662,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     }
 
   // ---------------- S11: cost per configuration (cost_function.py:213-304), lane = configuration ----------------
+  PROF_MARK(6);
   double my_cost = 0.0;
   if (keep) {
     const int16_t* ccfg = S.ends[lane];  // this lane's configuration (LDS; dynamic indexing stays out of registers)
@@ -739,6 +792,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     }
   }
   __syncthreads();
+  PROF_MARK(7);  // closes section 6 (slot 7 unused)
   return ST_OK;
 }
 
