@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,6 +49,7 @@ struct fsdp_ctx {
   bool use_prev = false;
   // further sets of intermediates + streams (fsdp_set_overlap): consecutive fsdp_run passes rotate through the sets, so
   // the next passes start while the slowest wavefronts of the previous ones are still finishing
+  int force_path_g = 0;       // 0 = automatic; 8 / 16 / 64 = test / tuning override (FSDP_PATH_G environment variable)
   bool profile_sort = false;  // profiling build: which kernel fsdp_profile_path runs
   int overlap = 1;
   unsigned turn = 0;
@@ -178,9 +180,19 @@ static void launch_match(fsdp_ctx* c, const Slot& q) {
   hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
                      q.d_sort, q.d_match);
 }
+template <int G>
+static void launch_path_g(fsdp_ctx* c, const Slot& q) {
+  hipLaunchKernelGGL(path_kernel<G>, dim3((c->n_frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, c->n_frames,
+                     c->d_poses, q.d_match, c->d_default_path, c->use_prev ? c->d_prev : nullptr, q.d_arena, q.d_path);
+}
+// lanes per frame: see path_kernel.h (results do not depend on the choice)
 static void launch_path(fsdp_ctx* c, const Slot& q) {
-  hipLaunchKernelGGL(path_kernel, dim3((c->n_frames + WAVE / PATH_G - 1) / (WAVE / PATH_G)), dim3(WAVE), 0, q.stream,
-                     c->n_frames, c->d_poses, q.d_match, c->d_default_path, c->use_prev ? c->d_prev : nullptr, q.d_arena, q.d_path);
+  if (c->force_path_g == 8 || (c->force_path_g == 0 && c->overlap > 1))
+    launch_path_g<PATH_G_THROUGHPUT>(c, q);
+  else if (c->force_path_g == 64 || (c->force_path_g == 0 && c->n_frames <= PATH_SMALL_BATCH))
+    launch_path_g<PATH_G_SMALL>(c, q);
+  else
+    launch_path_g<PATH_G_LATENCY>(c, q);
 }
 static void launch_sort(fsdp_ctx* c) { launch_sort(c, slot_of(c, 0)); }
 static void launch_match(fsdp_ctx* c) { launch_match(c, slot_of(c, 0)); }
@@ -250,6 +262,10 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
   fsdp_ctx* c = new fsdp_ctx();
   c->device = device;
   c->mission = mission;
+  if (const char* e = getenv("FSDP_PATH_G")) {
+    int g = atoi(e);
+    if (g == 8 || g == 16 || g == 64) c->force_path_g = g;
+  }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);

@@ -25,31 +25,29 @@
 namespace fsdp {
 
 constexpr int PATH_CAP = 1152;  // points of the working polyline (dense fit-#1 output + extension)
-constexpr int SEG_CAP = 5 * DENSE_CAP;  // segment-length scratch in LDS (the "dense" region of the spline workspace)
+constexpr int SEG_CAP = 3 * DENSE_CAP;  // segment-length scratch in LDS (the dense-sample region of the spline workspace)
 
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
-constexpr int ARENA_DOUBLES = 7 * PATH_CAP + PATH_CAP / 2;
+constexpr int ARENA_B = 192;  // >= (NK + 2) * 5 rows of the smoothness matrix
+constexpr int ARENA_DOUBLES = 7 * PATH_CAP + PATH_CAP / 2 + ARENA_B + DENSE_CAP;
 struct Arena {
   double* x;
   double* y;
   double* u;
   BasisCache bc;
+  double* filt;  // filtered curvature of the dense samples
 };
 
-// Per-frame LDS.  The region ws.dense aliases the fit-only part of the spline workspace (dead whenever no fit is
-// running): segment lengths before fit #3, the <= 20 tail points of the extension, and after fit #3 the dense
-// samples x | y | u | raw curvature | filtered curvature.
+// Per-frame LDS = the spline workspace; while no fit is running the path stage uses its bytes for segment lengths (before
+// fit #3), the <= 20 tail points of the extension, and after fit #3 the dense samples x | y | u and the raw curvature.
 template <int G>
 struct PathShared {
-  double cxp[PATH_POINTS], cyp[PATH_POINTS];      // centre points (<= 24) or previous path (40)
-  double prevx[PATH_POINTS], prevy[PATH_POINTS];  // previous path xy
   SplineWS<G> ws;
-  __device__ __forceinline__ double* seg() { return ws.dense; }
-  __device__ __forceinline__ double* dx() { return ws.dense; }
-  __device__ __forceinline__ double* dy() { return ws.dense + DENSE_CAP; }
-  __device__ __forceinline__ double* du() { return ws.dense + 2 * DENSE_CAP; }
-  __device__ __forceinline__ double* curv() { return ws.dense + 3 * DENSE_CAP; }
-  __device__ __forceinline__ double* filt() { return ws.dense + 4 * DENSE_CAP; }
+  __device__ __forceinline__ double* seg() { return ws.dxyu; }
+  __device__ __forceinline__ double* dx() { return ws.dxyu; }
+  __device__ __forceinline__ double* dy() { return ws.dxyu + DENSE_CAP; }
+  __device__ __forceinline__ double* du() { return ws.dxyu + 2 * DENSE_CAP; }
+  __device__ __forceinline__ double* curv() { return ws.curv; }
 };
 
 // np.sum of a contiguous run (NumPy pairwise summation) — wave-uniform.  The recursion of
@@ -323,7 +321,7 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
     spline_eval<G>(S.ws, f, predict_every, L, DX, DY, DU);
   }
   double* curv = S.curv();
-  double* filt = S.filt();
+  double* filt = A.filt;
   int window = (L / 5) < 30 ? (L / 5) : 30;
   if (window % 2 == 0) window += 1;
   const int half = window / 2;
@@ -593,10 +591,10 @@ __device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int 
 }
 
 // core_calculate_path.py:555-575: too-far check + MPC step with its ValueError retry, on the dense path update stored
-// in the arena at [1, 1+n1); previous path xy in S.prevx/prevy.  Returns the frame status.
+// in the arena at [1, 1+n1); prev = previous path (40,4) rows [s, x, y, curvature].  Returns the frame status.
 template <int G>
 __device__ __forceinline__ int finish_path(PathShared<G>& S, const Arena& A, int n1, double px, double py, double dx, double dy,
-                                  double (*out)[4], int* fallback, int* n_dense) {
+                                           const double* prev, double (*out)[4], int* fallback, int* n_dense) {
   using GR = Grp<G>;
   const int lane = GR::lane();
   if (n1 == 0) return ST_REF_UNDEFINED_PATH;  // min() of an empty array
@@ -616,8 +614,8 @@ __device__ __forceinline__ int finish_path(PathShared<G>& S, const Arena& A, int
       *fallback |= 4;
       GR::sync();
       for (int i = lane; i < PATH_POINTS; i += G) {
-        A.x[1 + i] = S.prevx[i];
-        A.y[1 + i] = S.prevy[i];
+        A.x[1 + i] = prev[4 * i + 1];
+        A.y[1 + i] = prev[4 * i + 2];
       }
       n1 = PATH_POINTS;
       GR::sync();
@@ -631,8 +629,8 @@ __device__ __forceinline__ int finish_path(PathShared<G>& S, const Arena& A, int
       *fallback |= 8;
       GR::sync();
       for (int i = lane; i < PATH_POINTS; i += G) {
-        A.x[1 + i] = S.prevx[i];
-        A.y[1 + i] = S.prevy[i];
+        A.x[1 + i] = prev[4 * i + 1];
+        A.y[1 + i] = prev[4 * i + 2];
       }
       n1 = PATH_POINTS;
       GR::sync();
@@ -667,6 +665,8 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame) {
   A.u = b + 2 * PATH_CAP;
   for (int j = 0; j < 4; j++) A.bc.h[j] = b + (3 + j) * PATH_CAP;
   A.bc.l = (int32_t*)(b + 7 * PATH_CAP);
+  A.bc.b = b + 7 * PATH_CAP + PATH_CAP / 2;
+  A.filt = A.bc.b + ARENA_B;
   return A;
 }
 
@@ -696,11 +696,14 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
     for (int q = 0; q < 4; q++) out[4 * lane + q] = NAN;
 }
 
-// lanes per frame of the product path kernel: four frames per wavefront (see the header comment)
-#ifndef FSDP_PATH_G
-#define FSDP_PATH_G 16
-#endif
-constexpr int PATH_G = FSDP_PATH_G;
+// Lanes per frame of the product path kernel (see the header comment).  Three instantiations, chosen per launch by the
+// host (fsdp_lib.hip launch_path): G = 8 (eight frames per wavefront) when passes overlap — the regime is throughput
+// and a serial instruction should advance as many frames as the LDS allows; G = 16 for a single large pass (one
+// wavefront per SIMD at 4096 frames, lowest latency); G = 64 for small batches (one frame per wavefront).
+constexpr int PATH_G_THROUGHPUT = 8;
+constexpr int PATH_G_LATENCY = 16;
+constexpr int PATH_G_SMALL = 64;
+constexpr int PATH_SMALL_BATCH = 1024;  // frames at or below which every frame gets its own wavefront
 
 template <int G>
 __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
@@ -719,13 +722,8 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
   // previous_paths[-1]: the constant initial path (fresh planner) or, for sequential replays, the caller-supplied
   // previous output of this planner (core_calculate_path.py:572-573)
   const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
-  for (int i = lane; i < PATH_POINTS; i += G) {
-    S.prevx[i] = prev[4 * i + 1];
-    S.prevy[i] = prev[4 * i + 2];
-  }
-  GR::sync();
   const int nl = mo->n_left_v, nr = mo->n_right_v;
-  int nc = 0;  // centre points in S.cxp/cyp
+  int nc = 0;  // centre points, written to the arena polyline [0, nc)
   if (status == ST_OK) {
     bool use_prev = false;
     if (nl < 3 && nr < 3) {
@@ -763,8 +761,8 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
           if (j < 0 || j >= no) {
             bad = true;
           } else if (mine != -1 && !bad && lane == 0) {
-            S.cxp[p] = (sv[i][0] + ov[j][0]) / 2;
-            S.cyp[p] = (sv[i][1] + ov[j][1]) / 2;
+            A.x[p] = (sv[i][0] + ov[j][0]) / 2;
+            A.y[p] = (sv[i][1] + ov[j][1]) / 2;
           }
           if (mine != -1) p++;
         }
@@ -777,8 +775,8 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
     if (use_prev) {
       fallback |= 1;
       for (int i = lane; i < PATH_POINTS; i += G) {
-        S.cxp[i] = S.prevx[i];
-        S.cyp[i] = S.prevy[i];
+        A.x[i] = prev[4 * i + 1];
+        A.y[i] = prev[4 * i + 2];
       }
       nc = PATH_POINTS;
     }
@@ -788,11 +786,6 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
   int n1 = 0;
   if (status == ST_OK) {
     for (int attempt = 0; attempt < 2; attempt++) {
-      for (int i = lane; i < nc; i += G) {
-        A.x[i] = S.cxp[i];
-        A.y[i] = S.cyp[i];
-      }
-      GR::sync();
       SplineFit f;
       double max_u;
       PROF(1);
@@ -816,14 +809,14 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
       }
       fallback |= 2;
       for (int i = lane; i < PATH_POINTS; i += G) {
-        S.cxp[i] = S.prevx[i];
-        S.cyp[i] = S.prevy[i];
+        A.x[i] = prev[4 * i + 1];
+        A.y[i] = prev[4 * i + 2];
       }
       nc = PATH_POINTS;
       GR::sync();
     }
   }
-  if (status == ST_OK) status = finish_path<G>(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
+  if (status == ST_OK) status = finish_path<G>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
   GR::sync();
   if (status != ST_OK)
     for (int i = lane; i < PATH_POINTS; i += G)
@@ -836,13 +829,13 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
   }
 }
 
-// grid = ceil(n_frames / (64 / PATH_G)) workgroups of one wavefront; group g of block b plans frame b * 4 + g
+// grid = ceil(n_frames / (64 / G)) workgroups of one wavefront; group g of block b plans frame b * (64 / G) + g
+template <int G>
 __global__ void __launch_bounds__(64, 1) path_kernel(int n_frames, const double* __restrict__ poses,
                                                      const MatchOut* __restrict__ matched,
                                                      const double* __restrict__ default_path,
                                                      const double* __restrict__ prev_paths, double* __restrict__ arena,
                                                      PathOut* __restrict__ out) {
-  constexpr int G = PATH_G;
   __shared__ PathShared<G> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
   if (frame >= n_frames) return;

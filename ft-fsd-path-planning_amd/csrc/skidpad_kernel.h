@@ -359,11 +359,6 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
   double px = poses[4 * inst + 0], py = poses[4 * inst + 1], dx = poses[4 * inst + 2], dy = poses[4 * inst + 3];
   int status = status_in[inst];
   int fallback = 0, n_dense = 0;
-  if (lane < PATH_POINTS) {
-    S.prevx[lane] = st->prev[lane][1];
-    S.prevy[lane] = st->prev[lane][2];
-  }
-  __syncthreads();
   const bool reloc = st->relocalized != 0;
   const double rotation = st->rotation, tx = st->translation[0], ty = st->translation[1];
   const double rcx = st->right_calc[0], rcy = st->right_calc[1];
@@ -423,7 +418,7 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
     }
     __syncthreads();
   }
-  if (status == ST_OK) status = finish_path<WAVE>(S, A, n1, px, py, dx, dy, o->path, &fallback, &n_dense);
+  if (status == ST_OK) status = finish_path<WAVE>(S, A, n1, px, py, dx, dy, &st->prev[0][0], o->path, &fallback, &n_dense);
   __syncthreads();
   if (status == ST_OK) {
     // previous_paths[-1] <- this result (map frame); then path xy back to the original frame (full_pipeline.py:178-194)

@@ -22,28 +22,40 @@ constexpr int NK = 32;  // max number of knots kept in LDS (FITPACK's nest is m+
 
 constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121 in practice)
 
+// LDS workspace of one frame: 4.8 KB at G = 16/32, 4 KB at G = 8 (eight frames of a wavefront: five workgroups per CU).  Three
+// lifetimes share the bytes: what a running fit always needs (knots, coefficients, the band triangle and its
+// right-hand sides), what only its observation / residual passes need (chunk buffers, knot bookkeeping), what only the
+// smoothing iteration needs (the extended triangle g; the f(p) term buffer overlays it while it is dead), and — when no
+// fit is running — the path stage's dense samples.  The rows of the smoothness matrix b live in the frame's scratch.
 template <int G>
 struct SplineWS {
-  static constexpr int CH = (G >= 32) ? G : 32;  // data rows staged per chunk
-  double t[NK + 2];
-  double c[2 * (NK + 2)];
+  static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : 16);  // data rows staged per chunk
   union {
-    struct {  // alive during a fit
+    struct {  // ---- a fit in progress ----
+      double t[NK + 2];
+      double c[2 * (NK + 2)];
       double z[2 * (NK + 2)];
-      double fpint[NK + 2];
-      double a[NK + 2][5];
-      double b[NK + 2][6];
-      double g[NK + 2][6];
-      int32_t nrdata[NK + 2];
-      double hq[CH][4];          // per-chunk basis values
-      double xq[CH], yq[CH];     // per-chunk data points (the polyline itself lives in HBM/L2)
-      double term[CH];           // per-chunk residual terms / segment lengths
-      int32_t lq[CH];            // per-chunk knot interval / "new knot" flags
+      double a_[NK + 2][4];  // band columns 1..4 of FITPACK's a (see A())
+      union {
+        struct {  // part 1: observation passes, residual pass, knot selection
+          double hq[CH][4];       // per-chunk basis values; residual terms of a super-chunk in the residual / f(p) passes
+          double xq[CH], yq[CH];  // per-chunk data points (K < 3: rotated-out right-hand sides); "new interval" flags
+          double term[CH];        // per-chunk segment lengths (path stage)
+          int32_t lq[CH];         // per-chunk knot interval
+          double fpint[NK + 2];
+          int32_t nrdata[NK + 2];
+        };
+        double g_[NK + 2][5];  // part 2: columns 1..5 of the extended triangle (see Gm())
+      };
     };
-    // between / after fits (path stage): segment lengths, later dense samples x | y | u | raw | filtered curvature
-    double dense[5 * DENSE_CAP];
+    struct {  // ---- no fit running (path stage) ----
+      double curv[DENSE_CAP];      // raw curvature; overlays t | c: written only after the last spline evaluation
+      double dxyu[3 * DENSE_CAP];  // dense samples x | y | u of the final spline; before fit #3 the segment lengths
+                                   // (<= 3 * DENSE_CAP), in the extension the tail points of the polyline
+    };
   };
-  double scal[4];  // lane-0 -> group broadcast of serial-section scalars
+  __device__ __forceinline__ double& A(int i, int j) { return a_[i][j - 1]; }
+  __device__ __forceinline__ double& Gm(int i, int j) { return g_[i][j - 1]; }
 };
 
 // Per-point basis cache in the frame's HBM/L2 scratch: the K+1 non-zero B-spline values and the knot interval of every
@@ -53,6 +65,7 @@ struct SplineWS {
 struct BasisCache {
   double* h[4];
   int32_t* l;
+  double* b;  // (NK + 2) x 5 rows of the smoothness matrix (fpdisc) of the running fit, row-major, element (i, j) at 5 i + j - 1
 };
 
 struct SplineFit {
@@ -158,11 +171,11 @@ __device__ __forceinline__ int find_interval_from(const double* t, int lstart, i
   return l;
 }
 
-// back-substitution, band width k (fpback); a is either ws.a (5 cols) or ws.g (6 cols)
-template <int COLS>
-__device__ __forceinline__ void fpback(double (*a)[COLS], const double* z, int n, int k, double* c) {
+// back-substitution, band width k (fpback); el(i, j) = element j (1-based) of band row i
+template <class EL>
+__device__ __forceinline__ void fpback(EL el, const double* z, int n, int k, double* c) {
   int k1 = k - 1;
-  c[n] = z[n] / a[n][1];
+  c[n] = z[n] / el(n, 1);
   int i = n - 1;
   if (i == 0) return;
   for (int j = 2; j <= n; j++) {
@@ -172,9 +185,9 @@ __device__ __forceinline__ void fpback(double (*a)[COLS], const double* z, int n
     int m = i;
     for (int l = 1; l <= i1; l++) {
       m = m + 1;
-      store = store - c[m] * a[i][l + 1];
+      store = store - c[m] * el(i, l + 1);
     }
-    c[i] = store / a[i][1];
+    c[i] = store / el(i, 1);
     i = i - 1;
   }
 }
@@ -282,10 +295,10 @@ __device__ __forceinline__ void giv_init(GivState& st) {
 template <int G>
 __device__ __forceinline__ void giv_flush(SplineWS<G>& ws, const GivRow& r, int n) {
   if (r.j > 0) {
-    ws.a[r.j][1] = r.a1;
-    ws.a[r.j][2] = r.a2;
-    ws.a[r.j][3] = r.a3;
-    ws.a[r.j][4] = r.a4;
+    ws.A(r.j, 1) = r.a1;
+    ws.A(r.j, 2) = r.a2;
+    ws.A(r.j, 3) = r.a3;
+    ws.A(r.j, 4) = r.a4;
     ws.z[r.j] = r.z1;
     ws.z[r.j + n] = r.z2;
   }
@@ -435,9 +448,12 @@ __device__ __forceinline__ double giv_drain(SplineWS<G>& ws, int n, GivState& st
 // does the arithmetic and writes the terms to tbuf[0..cnt) (the chunk's basis buffer, idle here) and, when FLAGS, the
 // "a new knot interval starts at this point" flags to fbuf.  The caller issues the next super-chunk's load() before
 // the serial accumulation of the current one, so the scratch round trip hides behind it.
+#ifndef RB_MAX_ROUNDS
+#define RB_MAX_ROUNDS 4  // rounds of a residual super-chunk held in registers
+#endif
 template <int K, int G, bool FLAGS>
 struct ResidualBatch {
-  static constexpr int ROUNDS = 4 * SplineWS<G>::CH / G;
+  static constexpr int ROUNDS = (4 * SplineWS<G>::CH / G > RB_MAX_ROUNDS) ? RB_MAX_ROUNDS : 4 * SplineWS<G>::CH / G;
   static constexpr int k1 = K + 1, k2 = K + 2;
   double hv[ROUNDS][K + 1], xv[ROUNDS], yv[ROUNDS];
   int lv[ROUNDS], lpv[ROUNDS];
@@ -495,7 +511,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
                                          int m, double s) {
   using GR = Grp<G>;
   constexpr int CH = SplineWS<G>::CH;
-  constexpr int SC = 4 * CH;  // points per residual "super-chunk" (the chunk's basis buffer holds 4 * CH terms)
+  constexpr int SC = ResidualBatch<K, G, false>::ROUNDS * G;  // points per residual "super-chunk" (<= 4 * CH: the chunk's basis buffer holds its terms)
   constexpr int k = K;
   const int lane = GR::lane();
   SplineFit R;
@@ -563,7 +579,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       }
       for (int i = 1 + lane; i <= 2 * (NK + 1); i += G) ws.z[i] = 0.0;
       for (int i = 1 + lane; i <= nk1; i += G)
-        for (int j = 1; j <= k1; j++) ws.a[i][j] = 0.0;
+        for (int j = 1; j <= k1; j++) ws.A(i, j) = 0.0;
       GR::sync();
       fp = 0.0;
       GivState gst;
@@ -633,9 +649,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
                 double piv = h[i];
                 if (piv == 0.0) continue;
                 double cs, sn;
-                double ww = ws.a[j][1];
+                double ww = ws.A(j, 1);
                 fpgivs(piv, ww, cs, sn);
-                ws.a[j][1] = ww;
+                ws.A(j, 1) = ww;
                 double z1 = ws.z[j], z2 = ws.z[j + n];
                 fprota(cs, sn, xi1, z1);
                 fprota(cs, sn, xi2, z2);
@@ -646,9 +662,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
 #pragma unroll
                 for (int i1 = i + 1; i1 <= k1; i1++) {
                   i2++;
-                  double av = ws.a[j][i2];
+                  double av = ws.A(j, i2);
                   fprota(cs, sn, h[i1], av);
-                  ws.a[j][i2] = av;
+                  ws.A(j, i2) = av;
                 }
               }
               ws.xq[r] = xi1;
@@ -668,8 +684,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       if (lane == 0) {
         PROF(13);
         // back substitution (both coordinates)
-        fpback<5>(ws.a, &ws.z[0], nk1, k1, &ws.c[0]);
-        fpback<5>(ws.a, &ws.z[n], nk1, k1, &ws.c[n]);
+        auto ael = [&](int i, int j) { return ws.A(i, j); };
+        fpback(ael, &ws.z[0], nk1, k1, &ws.c[0]);
+        fpback(ael, &ws.z[n], nk1, k1, &ws.c[n]);
       }
       GR::sync();
       if (ier == -2) fp0 = fp;
@@ -839,14 +856,14 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
             prod = prod * h[jk] * fac;
           }
           int lk = lp + k1;
-          ws.b[lmk][j] = (ws.t[lk] - ws.t[lp]) / prod;
+          bc.b[5 * lmk + j - 1] = (ws.t[lk] - ws.t[lp]) / prod;
           lp = lp + 1;
         }
       }
       GR::sync();
     }
     double p1 = 0., f1 = fp0 - s, p3 = -one, f3 = fpms, p = 0.;
-    for (int i = 1; i <= nk1; i++) p = p + ws.a[i][1];
+    for (int i = 1; i <= nk1; i++) p = p + ws.A(i, 1);
     double rn = nk1;
     p = rn / p;
     int ich1 = 0, ich3 = 0;
@@ -857,23 +874,30 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       GR::sync();
       for (int i = 1 + lane; i <= 2 * n; i += G) ws.c[i] = ws.z[i];
       for (int i = 1 + lane; i <= nk1; i += G) {
-        ws.g[i][k2] = 0.;
-        for (int j = 1; j <= k1; j++) ws.g[i][j] = ws.a[i][j];
+        ws.Gm(i, k2) = 0.;
+        for (int j = 1; j <= k1; j++) ws.Gm(i, j) = ws.A(i, j);
       }
       GR::sync();
       if (lane == 0) {  // serial section (single writer of g / c)
         PROF(16);
+        double bn[K + 3];  // next row of b, fetched from scratch one row ahead
+#pragma unroll
+        for (int i = 1; i <= k2; i++) bn[i] = (n8 >= 1) ? bc.b[5 * 1 + i - 1] : 0.0;
         for (int it = 1; it <= n8; it++) {
           double h[K + 4];
 #pragma unroll
-          for (int i = 1; i <= k2; i++) h[i] = ws.b[it][i] * pinv;
+          for (int i = 1; i <= k2; i++) h[i] = bn[i] * pinv;
+          if (it < n8) {
+#pragma unroll
+            for (int i = 1; i <= k2; i++) bn[i] = bc.b[5 * (it + 1) + i - 1];
+          }
           double xi1 = 0., xi2 = 0.;
           for (int j = it; j <= nk1; j++) {
             double piv = h[1];
             double cs, sn;
-            double ww = ws.g[j][1];
+            double ww = ws.Gm(j, 1);
             fpgivs(piv, ww, cs, sn);
-            ws.g[j][1] = ww;
+            ws.Gm(j, 1) = ww;
             double c1 = ws.c[j], c2 = ws.c[j + n];
             fprota(cs, sn, xi1, c1);
             fprota(cs, sn, xi2, c2);
@@ -886,9 +910,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
             for (int i = 1; i <= k1; i++) {
               if (i <= i2) {
                 int i1 = i + 1;
-                double gv = ws.g[j][i1];
+                double gv = ws.Gm(j, i1);
                 fprota(cs, sn, h[i1], gv);
-                ws.g[j][i1] = gv;
+                ws.Gm(j, i1) = gv;
                 h[i] = h[i1];
               }
             }
@@ -897,8 +921,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
               if (i == i2 + 1) h[i] = 0.;
           }
         }
-        fpback<6>(ws.g, &ws.c[0], nk1, k2, &ws.c[0]);
-        fpback<6>(ws.g, &ws.c[n], nk1, k2, &ws.c[n]);
+        auto gel = [&](int i, int j) { return ws.Gm(i, j); };
+        fpback(gel, &ws.c[0], nk1, k2, &ws.c[0]);
+        fpback(gel, &ws.c[n], nk1, k2, &ws.c[n]);
       }
       GR::sync();
       // f(p): terms per lane, accumulation in data order

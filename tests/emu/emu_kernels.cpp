@@ -50,6 +50,14 @@ __global__ void fit_test_kernel(const double* xy, int m, double smoothing, doubl
 }
 }  // namespace fsdp
 
+template <int G>
+static void emu_path_launch(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
+  std::vector<double> arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
+  const unsigned per = 64 / G;
+  emu::launch(((unsigned)n_frames + per - 1) / per, 64,
+              [&]() { fsdp::path_kernel<G>(n_frames, poses, matched, g_default_path, g_prev_paths, arena.data(), out); });
+}
+
 extern "C" {
 void emu_fit(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
   std::vector<double> arena(fsdp::ARENA_DOUBLES);
@@ -100,11 +108,20 @@ void emu_default_path(double* out) {
   std::call_once(g_once, build_default);
   for (int i = 0; i < fsdp::PATH_POINTS * 4; i++) out[i] = g_default_path[i];
 }
-void emu_path(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
+// lanes per frame G: 8 / 16 / 64 (the three instantiations the product library launches)
+int emu_path_g(int G, int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
   std::call_once(g_once, build_default);
-  std::vector<double> arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
-  const unsigned per = 64 / fsdp::PATH_G;
-  emu::launch(((unsigned)n_frames + per - 1) / per, 64,
-              [&]() { fsdp::path_kernel(n_frames, poses, matched, g_default_path, g_prev_paths, arena.data(), out); });
+  if (G == 8)
+    emu_path_launch<8>(n_frames, poses, matched, out);
+  else if (G == 16)
+    emu_path_launch<16>(n_frames, poses, matched, out);
+  else if (G == 64)
+    emu_path_launch<64>(n_frames, poses, matched, out);
+  else
+    return 1;
+  return 0;
+}
+void emu_path(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
+  emu_path_g(fsdp::PATH_G_THROUGHPUT, n_frames, poses, matched, out);
 }
 }

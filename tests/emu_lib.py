@@ -76,12 +76,17 @@ def match(offsets, cones, poses, sorted_out):
     return out
 
 
-def path(poses, matched):
+PATH_GROUP_SIZES = (8, 16, 64)  # lanes per frame of the three path-kernel instantiations the library launches
+
+
+def path(poses, matched, group=8):
     poses = np.ascontiguousarray(poses, np.float64)
     n = len(poses)
     assert lib().emu_sizeof_path_out() == PATH_DTYPE.itemsize
     out = np.zeros(n, PATH_DTYPE)
-    lib().emu_path(ctypes.c_int(n), _p(poses), ctypes.c_void_p(matched.ctypes.data), ctypes.c_void_p(out.ctypes.data))
+    rc = lib().emu_path_g(ctypes.c_int(group), ctypes.c_int(n), _p(poses), ctypes.c_void_p(matched.ctypes.data),
+                          ctypes.c_void_p(out.ctypes.data))
+    assert rc == 0, f"no path kernel for group size {group}"
     return out
 
 
@@ -91,13 +96,14 @@ def default_path():
     return out
 
 
-def plan(offsets, cones, poses):
-    """Full emulated pipeline; returns a structured array shaped like oracle_lib.RESULT_DTYPE."""
+def plan(offsets, cones, poses, group=8):
+    """Full emulated pipeline; returns a structured array shaped like oracle_lib.RESULT_DTYPE.  group = lanes per frame
+    of the path kernel (8: eight frames per wavefront, 16, or 64: one frame per wavefront)."""
     import oracle_lib
 
     s = sort(offsets, cones, poses)
     m = match(offsets, cones, poses, s)
-    p = path(poses, m)
+    p = path(poses, m, group)
     res = np.zeros(len(s), oracle_lib.RESULT_DTYPE)
     for k in ("n_left", "n_right", "left_idx", "right_idx", "n_configs_left", "n_configs_right", "first_k_left",
               "first_k_right", "best_cost_left", "best_cost_right"):

@@ -263,3 +263,18 @@ def test_overlapped_passes_equal_serial_passes(pkg):
     assert got2["path"].tobytes() == ref2["path"].tobytes() and (got2["status"] == ref2["status"]).all()
     ctx.set_overlap(1)
     assert ctx.plan_batch(off, cones, poses)["path"].tobytes() == ref["path"].tobytes()
+
+
+@pytest.mark.parametrize("group", [8, 16, 64])
+def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, group):
+    """The library launches the path kernel with 8, 16 or 64 lanes per frame depending on batch size and pass overlap
+    (path_kernel.h); FSDP_PATH_G pins the choice.  All three must reproduce the oracle bit for bit."""
+    monkeypatch.setenv("FSDP_PATH_G", str(group))
+    ctx = pkg.Context(device=0)
+    off, cones, poses = pkg.synth.make_replay_batch(300, 64, 0.15, seed=21, color=True)
+    off2, cones2, poses2 = pkg.synth.make_replay_batch(211, 100, 0.0, seed=22, frame_noise=0.3, random_pose=True, color=False)
+    for o, c, p in ((off, cones, poses), (off2, cones2, poses2)):
+        res = ctx.plan_batch(o, c, p)
+        with oracle_lib.math_mode(1):
+            ref = oracle_lib.plan_batch(o, c, p, n_threads=os.cpu_count() or 1)
+        _assert_equal_to_oracle(res, ref)

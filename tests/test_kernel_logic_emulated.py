@@ -11,13 +11,16 @@ import oracle_lib
 
 @pytest.mark.parametrize("name,stride", [("scenarios", 1), ("cfg2_color", 4), ("cfg3_nocolor", 8), ("cfg4_200cones", 8),
                                           ("cfg4_noisy_nocolor", 6), ("fuzz", 5)])
-def test_emulated_kernels_equal_oracle(golden_dir, name, stride):
+@pytest.mark.parametrize("group", emu_lib.PATH_GROUP_SIZES)
+def test_emulated_kernels_equal_oracle(golden_dir, name, stride, group):
     g = np.load(golden_dir / f"{name}.npz")
+    if group != 8:
+        stride *= 3  # the other two instantiations on a thinner sample
     idx = np.arange(0, len(g["ok"]), stride)
     off = np.concatenate([[0], np.cumsum([g["offsets"][i + 1] - g["offsets"][i] for i in idx])]).astype(np.int32)
     cones = np.concatenate([g["cones"][g["offsets"][i] : g["offsets"][i + 1]] for i in idx])
     poses = g["poses"][idx]
-    res, n_dense = emu_lib.plan(off, cones, poses)
+    res, n_dense = emu_lib.plan(off, cones, poses, group)
     with oracle_lib.math_mode(1):  # the kernels use det_math.h for the arc extension
         ref = oracle_lib.plan_batch(off, cones, poses)
     assert np.array_equal(res["status"], ref["status"])
