@@ -31,7 +31,7 @@ FRAMES_PER_GPU = 4096
 CONES_PER_SIDE = 64
 # algorithmic bytes per frame = read N*24 + 32 (cones, pose) + write 1280 + 96 + 8
 ALGO_BYTES_PER_FRAME = 2 * CONES_PER_SIDE * 24 + 32 + 1280 + 96 + 8  # 4488 at N = 128
-PASS_OVERLAP = 2  # passes in flight in the timed region (fsdp_set_overlap)
+PASS_OVERLAP = 3  # passes in flight in the timed region (fsdp_set_overlap); measured best of 1..4
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -149,7 +149,9 @@ def main():
     if rank == 0:
         frames_total = FRAMES_PER_GPU * world * args.steps
         value = frames_total / elapsed
-        names = ["sort_kernel", "match_kernel", "path_kernel"]
+        # the library launches the path kernel with 8 lanes per frame when passes overlap, 16 for one 4096-frame pass
+        path_name = "path_kernel<16>" if args.no_overlap or args.overlap == 1 else "path_kernel<8>"
+        names = ["sort_kernel", "match_kernel", path_name]
         dom = int(np.argmax(stage_ms))
         achieved = ALGO_BYTES_PER_FRAME * FRAMES_PER_GPU / (stage_ms[dom] * 1e-3) / 1e9
         out = {
@@ -181,7 +183,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": _pmc_traffic(names[dom]),
                 "kernel_ms": {n: m for n, m in zip(names, stage_ms)},
-                "kernel_ms_serial": {n: m for n, m in zip(names, serial_ms)},
+                "kernel_ms_serial": {n: m for n, m in zip(["sort_kernel", "match_kernel", "path_kernel<16>"], serial_ms)},
                 "ms_per_step_serial": ser_total_ms / n_ser,
                 "traffic_unit": "GB per launch (PMC, profiles/pmc_traffic.json)",
                 "note": "algorithmic bytes/frame = 4488 (SURVEY 8d) x 4096 frames / average duration of the dominant kernel's "

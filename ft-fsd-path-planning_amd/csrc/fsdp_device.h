@@ -182,7 +182,8 @@ struct ProfScope {
 // per-frame counters of the profiling build: slot + (group index of the frame inside its wavefront), lane 0 of the group
 #define PROF_COUNT(slot, G, value)                                                                              \
   do {                                                                                                          \
-    if (g_prof && (threadIdx.x & ((G) - 1)) == 0) g_prof[(size_t)blockIdx.x * 32 + (slot) + (threadIdx.x & 63) / (G)] += (value); \
+    if (g_prof && (threadIdx.x & ((G) - 1)) == 0 && (threadIdx.x & 63) / (G) < 4)                                    \
+      g_prof[(size_t)blockIdx.x * 32 + (slot) + (threadIdx.x & 63) / (G)] += (value);                              \
   } while (0)
 #else
 #define PROF(slot)

@@ -187,9 +187,18 @@ static void launch_path_g(fsdp_ctx* c, const Slot& q) {
 }
 // lanes per frame: see path_kernel.h (results do not depend on the choice)
 static void launch_path(fsdp_ctx* c, const Slot& q) {
-  if (c->force_path_g == 8 || (c->force_path_g == 0 && c->overlap > 1))
+  int g = c->force_path_g;
+  if (g == 0) {
+    if (c->overlap > 1 || c->n_frames > PATH_LATENCY_BATCH)
+      g = PATH_G_THROUGHPUT;  // more wavefronts than SIMDs in flight: throughput regime
+    else if (c->n_frames <= PATH_SMALL_BATCH)
+      g = PATH_G_SMALL;
+    else
+      g = PATH_G_LATENCY;
+  }
+  if (g == PATH_G_THROUGHPUT)
     launch_path_g<PATH_G_THROUGHPUT>(c, q);
-  else if (c->force_path_g == 64 || (c->force_path_g == 0 && c->n_frames <= PATH_SMALL_BATCH))
+  else if (g == PATH_G_SMALL)
     launch_path_g<PATH_G_SMALL>(c, q);
   else
     launch_path_g<PATH_G_LATENCY>(c, q);

@@ -697,13 +697,15 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
 }
 
 // Lanes per frame of the product path kernel (see the header comment).  Three instantiations, chosen per launch by the
-// host (fsdp_lib.hip launch_path): G = 8 (eight frames per wavefront) when passes overlap — the regime is throughput
-// and a serial instruction should advance as many frames as the LDS allows; G = 16 for a single large pass (one
-// wavefront per SIMD at 4096 frames, lowest latency); G = 64 for small batches (one frame per wavefront).
+// host (fsdp_lib.hip launch_path): G = 8 (eight frames per wavefront) when passes overlap or a pass has more than
+// 4096 frames — the regime is throughput and a serial instruction should advance as many frames as the LDS allows;
+// G = 16 for a single pass of up to 4096 frames (one wavefront per SIMD, lowest latency); G = 64 for small batches
+// (one frame per wavefront).  Measured: tools/batch_sweep.py, FSDP_PATH_G=8|16|64 pins the choice.
 constexpr int PATH_G_THROUGHPUT = 8;
 constexpr int PATH_G_LATENCY = 16;
 constexpr int PATH_G_SMALL = 64;
-constexpr int PATH_SMALL_BATCH = 1024;  // frames at or below which every frame gets its own wavefront
+constexpr int PATH_SMALL_BATCH = 1024;    // frames at or below which every frame gets its own wavefront
+constexpr int PATH_LATENCY_BATCH = 4096;  // largest single pass that G = 16 serves with one wavefront per SIMD
 
 template <int G>
 __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
@@ -830,8 +832,11 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
 }
 
 // grid = ceil(n_frames / (64 / G)) workgroups of one wavefront; group g of block b plans frame b * (64 / G) + g
+#ifndef FSDP_PATH_WAVES
+#define FSDP_PATH_WAVES 1
+#endif
 template <int G>
-__global__ void __launch_bounds__(64, 1) path_kernel(int n_frames, const double* __restrict__ poses,
+__global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames, const double* __restrict__ poses,
                                                      const MatchOut* __restrict__ matched,
                                                      const double* __restrict__ default_path,
                                                      const double* __restrict__ prev_paths, double* __restrict__ arena,

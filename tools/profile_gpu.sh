@@ -13,7 +13,7 @@ BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o trace -- $BENCH --no-overlap > $OUT/trace_serial.log 2>&1
-BENCH="$BENCH --no-overlap"
+# (the PMC passes run the bench command as is: its timed region launches path_kernel<8>, its serial reference leg path_kernel<16>)
 echo "trace rc=$?"
 # PMC passes (separate runs; FETCH_SIZE and WRITE_SIZE do not fit one pass)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1

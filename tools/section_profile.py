@@ -27,14 +27,18 @@ ctx.sync()
 out = np.zeros((N, 32), np.int64)
 rc = ctx._lib.fsdp_profile_path(ctx._h, ctypes.c_void_p(out.ctypes.data))
 assert rc == 0
-# the path kernel packs 4 frames into a wavefront: one row per wavefront (group 0's lane 0 keeps the clock; the groups
-# run in lock-step, so its sections span the wavefront's time in them)
-out = out[: (N + 3) // 4]
+# the path kernel packs several frames into a wavefront (FSDP_PATH_G lanes per frame; default for one pass of <= 4096
+# frames: 16): one row per wavefront (group 0's lane 0 keeps the clock; the groups run in lock-step, so its sections span
+# the wavefront's time in them)
+import os
+G = int(os.environ.get("FSDP_PATH_G", "16" if N > 1024 else "64"))
+FPW = 64 // G
+out = out[: (N + FPW - 1) // FPW]
 tot = out[:, 0]
-rows = out[:, 20:24]   # data rows pushed through the Givens pipeline per frame (all passes, all fits)
-pits = out[:, 24:28]   # smoothing-parameter iterations per frame
+rows = out[:, 20 : 20 + min(FPW, 4)]   # data rows pushed through the Givens pipeline per frame (first 4 frames of the wavefront)
+pits = out[:, 24 : 24 + min(FPW, 4)]   # smoothing-parameter iterations per frame
 print(f"QR data rows per frame: min {rows.min()}, median {int(np.median(rows))}, p99 {int(np.percentile(rows, 99))}, max {rows.max()};"
-      f" per wavefront max-of-4: median {int(np.median(rows.max(axis=1)))}, max {rows.max(axis=1).max()}")
+      f" per wavefront max: median {int(np.median(rows.max(axis=1)))}, max {rows.max(axis=1).max()}")
 print(f"p-iterations per frame: min {pits.min()}, median {int(np.median(pits))}, max {pits.max()}")
 cc = np.corrcoef(rows.max(axis=1), tot)[0, 1]
 print(f"correlation(wavefront cycles, max QR rows of its frames) = {cc:.3f}; cycles per max-row: {np.median(tot / rows.max(axis=1)):.0f}")

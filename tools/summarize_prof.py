@@ -18,7 +18,7 @@ def db(sub):
     return sqlite3.connect(files[0]) if files else None
 
 
-for sub, label in (("trace", "python bench.py --steps 5 --warmup 1 --no-cpu-baseline  [passes overlap 2 deep, as the bench runs]"),
+for sub, label in (("trace", "python bench.py --steps 5 --warmup 1 --no-cpu-baseline  [passes overlap 3 deep, as the bench runs]"),
                    ("trace_serial", "same command with --no-overlap  [one pass after the other]")):
   con = db(sub)
   print(f"== rocprofv3 --kernel-trace --stats ({label}) ==")
@@ -54,7 +54,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
             extra = f"  (KB -> {v / 1024:.2f} MB/launch; algorithmic write {FRAMES * 1384 / 1e6:.2f} MB)"
         print(f"{k.split('(')[0]:<28}{c:<22}{v:>16.1f}  n={n}{extra}")
         if c in ("FETCH_SIZE", "WRITE_SIZE"):
-            short = k.split("(")[0].split("::")[-1]
+            short = k.split("(")[0].replace("void ", "").split("::")[-1]
             traffic.setdefault(short, {})[c + "_KB"] = round(v, 1)
 
 if json_out and traffic:
