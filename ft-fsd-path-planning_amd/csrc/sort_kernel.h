@@ -55,7 +55,9 @@ struct SortShared {
   int32_t good[MAX_ENDS];
   int32_t bad[MAX_ENDS];
   int16_t stack[MAX_STACK][2];
+  double stack_ang[MAX_STACK];     // direction (atan2) of the edge parent -> stacked cone
   int16_t attempt[MAX_LEN];
+  double attempt_ang[MAX_LEN];     // direction of the edge attempt[p-1] -> attempt[p]
   int16_t all_list[MAX_ENDS * MAX_LEN > MAX_CONES ? MAX_CONES : MAX_ENDS * MAX_LEN];
   unsigned long long all_mask[MAX_CONES / 64];
   unsigned long long near_mask[MAX_CONES / 64];
@@ -135,20 +137,25 @@ __device__ __forceinline__ bool neighbour_lies_between(const SortShared& S, int 
 }
 
 // `between` = some neighbour of `node` lies between it and the candidate (evaluated by the caller, one (candidate,
-// neighbour) pair per lane); all tests are pure predicates, so their order does not matter
+// neighbour) pair per lane); all tests are pure predicates, so their order does not matter.  The directions of the last
+// two edges of the attempt (ang_sl: attempt[pos-1] -> node, ang_tl: attempt[pos-2] -> attempt[pos-1]) are the atan2
+// values computed when those cones were candidates themselves (same operands, same bits); ang_cand returns the direction
+// of the edge node -> candidate for the candidate's own children.
 __device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type, int pos, int node, int cand, bool between,
-                                              double px, double py, double dx, double dy, double dnx, double dny) {
+                                              double px, double py, double dx, double dy, double dnx, double dny, double a_car,
+                                              double ang_sl, double ang_tl, double& ang_cand) {
+  const double lx = S.x[node], ly = S.y[node];
+  const double cx = S.x[cand], cy = S.y[cand];
+  const double l2cx = cx - lx, l2cy = cy - ly;
+  ang_cand = atan2(l2cy, l2cx);
   if (between) return false;
   for (int q = 0; q <= pos; q++)
     if (S.attempt[q] == cand) return false;
-  const double lx = S.x[node], ly = S.y[node];
-  const double cx = S.x[cand], cy = S.y[cand];
   int sl = (pos >= 1) ? S.attempt[pos - 1] : 0;
   if (pos >= 1) {
     if (!inside_ellipse(cx, cy, lx, ly, lx - S.x[sl], ly - S.y[sl], 6, 3)) return false;
   }
   if (pos == 0) {
-    double a_car = atan2(dny, dnx);
     double a_n = atan2(cy - py, cx - px);
     double diff = angle_difference(a_n, a_car);
     double want = (cone_type == T_LEFT) ? 1.0 : -1.0;
@@ -156,10 +163,8 @@ __device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type
   }
   bool can = true;
   if (pos >= 1) {
-    double s2lx = lx - S.x[sl], s2ly = ly - S.y[sl];
-    double l2cx = cx - lx, l2cy = cy - ly;
-    double angle_1 = atan2(s2ly, s2lx);
-    double angle_2 = atan2(l2cy, l2cx);
+    double angle_1 = ang_sl;
+    double angle_2 = ang_cand;
     double difference = angle_difference(angle_2, angle_1);
     double len = norm_blas(l2cx, l2cy);
     if (fabs(difference) > 65 * FSDP_DEG)
@@ -169,8 +174,7 @@ __device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type
     else
       can = (difference > -(40 * FSDP_DEG)) || (len < 4.0);
     if (pos >= 2) {
-      int tl = S.attempt[pos - 2];
-      double angle_3 = atan2(S.y[sl] - S.y[tl], S.x[sl] - S.x[tl]);
+      double angle_3 = ang_tl;
       double difference_2 = angle_difference(angle_1, angle_3);
       if (sign_of(difference) != sign_of(difference_2) && fabs(difference - difference_2) > 1.3) can = false;
     }
@@ -409,17 +413,20 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   int status = ST_OK;
   if (lane < MAX_LEN) S.attempt[lane] = -1;
   __syncthreads();
+  const double a_car = atan2(dny, dnx);
   if (n_first == 2) {
     if (target_length < 1) status = ST_REF_UNDEFINED_DFS_OOB;
     if (lane == 0) {
       S.attempt[0] = (int16_t)fk0;
       S.stack[0][0] = (int16_t)fk1;
       S.stack[0][1] = 1;
+      S.stack_ang[0] = atan2(S.y[fk1] - S.y[fk0], S.x[fk1] - S.x[fk0]);
     }
   } else {
     if (lane == 0) {
       S.stack[0][0] = (int16_t)start_idx;
       S.stack[0][1] = 0;
+      S.stack_ang[0] = 0.0;  // unused at position 0
     }
   }
   sp = 1;
@@ -428,13 +435,17 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     sp--;
     const int node = S.stack[sp][0];
     const int pos = S.stack[sp][1];
+    const double node_ang = S.stack_ang[sp];
     if (pos >= target_length) {  // numpy IndexError at current_attempt[position_in_stack]
       status = ST_REF_UNDEFINED_DFS_OOB;
       break;
     }
     __syncthreads();
     if (lane < MAX_LEN) {
-      if (lane == pos) S.attempt[lane] = (int16_t)node;
+      if (lane == pos) {
+        S.attempt[lane] = (int16_t)node;
+        S.attempt_ang[lane] = node_ang;
+      }
       if (lane > pos) S.attempt[lane] = -1;
     }
     __syncthreads();
@@ -444,9 +455,12 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     if (lane < n_nb * n_nb) btw = neighbour_lies_between(S, node, S.nbr[node][lane / n_nb], S.nbr[node][lane % n_nb]);
     const unsigned long long bm = __ballot(btw);
     bool can = false;
+    double cand_ang = 0.0;
     if (lane < n_nb) {
       const bool between = ((bm >> (lane * n_nb)) & ((1ull << n_nb) - 1ull)) != 0ull;
-      can = candidate_can_be_added(S, cone_type, pos, node, S.nbr[node][lane], between, px, py, dx, dy, dnx, dny);
+      const double ang_tl = (pos >= 2) ? S.attempt_ang[pos - 1] : 0.0;
+      can = candidate_can_be_added(S, cone_type, pos, node, S.nbr[node][lane], between, px, py, dx, dy, dnx, dny, a_car, node_ang,
+                                   ang_tl, cand_ang);
     }
     unsigned long long m = __ballot(can);
     bool has_valid = (pos < target_length - 1) && (m != 0ull);
@@ -455,6 +469,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
         int slot = sp + __popcll(m & ((1ull << lane) - 1ull));
         S.stack[slot][0] = (int16_t)S.nbr[node][lane];
         S.stack[slot][1] = (int16_t)(pos + 1);
+        S.stack_ang[slot] = cand_ang;
       }
       sp += __popcll(m);
     } else {
