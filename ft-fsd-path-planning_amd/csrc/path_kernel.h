@@ -87,29 +87,52 @@ __device__ inline double pw_rec(const double* a, int n) {
 }
 __device__ inline double np_sum_run(const double* a, int n) { return 0.0 + pw_rec<4>(a, n); }
 
-// NumPy pairwise sum of f(0..n-1) for n <= 128 without materialising the operands
-template <class F>
-__device__ __forceinline__ double np_sum_fn(int n, F f) {
+// NumPy pairwise sums (n <= 128: 8 interleaved accumulators, then the tail) of NS series at once: f(i, v) fills v[0..NS)
+// with the i-th element of every series.  Each series is summed exactly as np_sum_fn sums it; the operands are fetched
+// and the shared sub-expressions evaluated once per i instead of once per series.
+template <int NS, class F>
+__device__ __forceinline__ void np_sum_multi(int n, F f, double (&out)[NS]) {
+  double v[NS];
   if (n < 8) {
-    double r = 0.0;
-    for (int i = 0; i < n; i++) r += f(i);
-    return 0.0 + r;
+    double r[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) r[s] = 0.0;
+    for (int i = 0; i < n; i++) {
+      f(i, v);
+#pragma unroll
+      for (int s = 0; s < NS; s++) r[s] += v[s];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) out[s] = 0.0 + r[s];
+    return;
   }
-  double r0 = f(0), r1 = f(1), r2 = f(2), r3 = f(3), r4 = f(4), r5 = f(5), r6 = f(6), r7 = f(7);
+  double acc[8][NS];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    f(e, v);
+#pragma unroll
+    for (int s = 0; s < NS; s++) acc[e][s] = v[s];
+  }
   int i = 8;
   for (; i < n - (n % 8); i += 8) {
-    r0 += f(i);
-    r1 += f(i + 1);
-    r2 += f(i + 2);
-    r3 += f(i + 3);
-    r4 += f(i + 4);
-    r5 += f(i + 5);
-    r6 += f(i + 6);
-    r7 += f(i + 7);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      f(i + e, v);
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[e][s] += v[s];
+    }
   }
-  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-  for (; i < n; i++) res += f(i);
-  return 0.0 + res;
+  double res[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++)
+    res[s] = ((acc[0][s] + acc[1][s]) + (acc[2][s] + acc[3][s])) + ((acc[4][s] + acc[5][s]) + (acc[6][s] + acc[7][s]));
+  for (; i < n; i++) {
+    f(i, v);
+#pragma unroll
+    for (int s = 0; s < NS; s++) res[s] += v[s];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; s++) out[s] = 0.0 + res[s];
 }
 
 // utils/math_utils.py:579-646 circle_fit of points (px[idx0 + i], py[idx0 + i]), i < n (n <= 128)
@@ -118,20 +141,25 @@ __device__ inline void circle_fit(const double* px, const double* py, int idx0, 
   const double* X = px + idx0;
   const double* Y = py + idx0;
   const double dn = (double)n;
-  double xm = np_sum_fn(n, [&](int i) { return X[i]; }) / dn;
-  double ym = np_sum_fn(n, [&](int i) { return Y[i]; }) / dn;
-  auto Xi = [&](int i) { return X[i] - xm; };
-  auto Yi = [&](int i) { return Y[i] - ym; };
-  auto Zi = [&](int i) {
-    double a = X[i] - xm, b = Y[i] - ym;
-    return a * a + b * b;
-  };
-  double Mxy = np_sum_fn(n, [&](int i) { return Xi(i) * Yi(i); }) / dn;
-  double Mxx = np_sum_fn(n, [&](int i) { return Xi(i) * Xi(i); }) / dn;
-  double Myy = np_sum_fn(n, [&](int i) { return Yi(i) * Yi(i); }) / dn;
-  double Mxz = np_sum_fn(n, [&](int i) { return Xi(i) * Zi(i); }) / dn;
-  double Myz = np_sum_fn(n, [&](int i) { return Yi(i) * Zi(i); }) / dn;
-  double Mzz = np_sum_fn(n, [&](int i) { return Zi(i) * Zi(i); }) / dn;
+  double m2[2];
+  np_sum_multi<2>(n, [&](int i, double (&v)[2]) {
+    v[0] = X[i];
+    v[1] = Y[i];
+  }, m2);
+  const double xm = m2[0] / dn, ym = m2[1] / dn;
+  // Mxy, Mxx, Myy, Mxz, Myz, Mzz: six np.sum calls over Xi*Yi, Xi*Xi, Yi*Yi, Xi*Zi, Yi*Zi, Zi*Zi
+  double m6[6];
+  np_sum_multi<6>(n, [&](int i, double (&v)[6]) {
+    const double a = X[i] - xm, b = Y[i] - ym;
+    const double z = a * a + b * b;
+    v[0] = a * b;
+    v[1] = a * a;
+    v[2] = b * b;
+    v[3] = a * z;
+    v[4] = b * z;
+    v[5] = z * z;
+  }, m6);
+  double Mxy = m6[0] / dn, Mxx = m6[1] / dn, Myy = m6[2] / dn, Mxz = m6[3] / dn, Myz = m6[4] / dn, Mzz = m6[5] / dn;
   double Mz = Mxx + Myy;
   double Cov_xy = Mxx * Myy - Mxy * Mxy;
   double Var_z = Mzz - Mz * Mz;
