@@ -1,12 +1,11 @@
 // Device-side common definitions for the MI355X (gfx950) PathPlanner kernels.
 //
-// Execution model: ONE WAVEFRONT (64 lanes) PER FRAME, one wavefront per workgroup.  Frame
-// state lives in LDS; wave-uniform control flow drives the inherently serial parts (DFS stack,
-// Givens QR of the smoothing spline) while the data-parallel parts (pairwise distances, kNN,
-// side counting, B-spline evaluation, curvature windows) run one element per lane.  Cross-lane
-// traffic uses ballot / shuffles; LDS hand-offs between lanes are fenced by __syncthreads()
-// (a single-wave workgroup: s_barrier is a no-op in hardware, the fence orders LDS for the
-// compiler).
+// Execution model: one wavefront per workgroup; a frame owns the whole wavefront (sorting, matching) or a lane
+// group of it (path stage: Grp<G> below, up to eight frames per wavefront).  Frame state lives in LDS; group-uniform
+// control flow drives the inherently serial parts (DFS stack, Givens QR of the smoothing spline) while the
+// data-parallel parts (pairwise distances, kNN, side counting, B-spline evaluation, curvature windows) run one
+// element per lane.  Cross-lane traffic uses ballot / shuffles; LDS hand-offs between lanes are fenced (a single-wave
+// workgroup: s_barrier is a no-op in hardware, the fence orders LDS for the compiler).
 //
 // Arithmetic contract: float64 throughout, compiled with -ffp-contract=off so every + - * /
 // sqrt is the IEEE operation the reference performs; fused multiply-adds appear only where

@@ -1,4 +1,4 @@
-// calculate_path step as a wave-per-frame HIP kernel (gfx950).
+// calculate_path step as a HIP kernel with several frames per wavefront (gfx950).
 //
 // Replaces CalculatePath.run_path_calculation for independent frames (fresh-planner semantics: the
 // "previous path" is the constant initial path), reference calculate_path/core_calculate_path.py:514-575:
@@ -11,12 +11,14 @@
 // Every float that feeds the sample-count decision ceil(max_u / predict_every) is produced in the
 // reference's rounding order (see DESIGN.md "arithmetic contract").
 //
-// Lanes: the stage is templated on the group size G (lanes per frame).  The product kernel runs G = 16, four
-// frames per wavefront (fsdp_device.h Grp<G>): the stage is dominated by serial FP64 chains, and a serial
-// instruction then advances four frames.  Results do not depend on G (sums keep the reference's order).
-// Memory: the working polyline (up to PATH_CAP points: x, y, parameter) lives in a per-frame HBM/L2
-// scratch arena (3 x PATH_CAP doubles, lane-coalesced access, L2/MALL resident); the serial sections
-// consume it through LDS chunk buffers.  LDS per frame (G = 16): 9.6 KB.
+// Lanes: the stage is templated on the group size G (lanes per frame, fsdp_device.h Grp<G>) and instantiated for
+// G = 8, 16 and 64 (eight, four, one frame per wavefront; the host picks per launch, see the end of this file): the
+// stage is dominated by serial FP64 chains, and a serial instruction then advances all frames of the wavefront.
+// Results do not depend on G (sums keep the reference's order).
+// Memory: the working polyline (up to PATH_CAP points: x, y, parameter), the basis cache of the running fit, the rows
+// of its smoothness matrix and the filtered curvature live in a per-frame HBM/L2 scratch arena (ARENA_DOUBLES
+// doubles, lane-coalesced access); the serial sections consume it through LDS chunk buffers.  LDS per frame: the
+// spline workspace, 4 KB (G = 8) to 6.7 KB (G = 64).
 #pragma once
 #include "fsdp_device.h"
 #include "spline_device.h"
