@@ -25,6 +25,8 @@ struct MatchShared {
   double d1x[MAX_MATCH], d1y[MAX_MATCH];  // search directions (own side)
   double d2x[MAX_MATCH], d2y[MAX_MATCH];  // search directions (other side)
   double key[MAX_MATCH];
+  double rc[MAX_MATCH], rs[MAX_MATCH];  // cos / sin of the rotation into each own cone's search frame
+  int32_t anyok[MAX_MATCH];            // some other-side cone passes the candidate test
   int32_t match[MAX_MATCH];
   int32_t order[MAX_MATCH];
 };
@@ -60,34 +62,47 @@ __device__ inline void matches_for_side(MatchShared& S, const double* px, const 
   const int other_type = (cone_type == T_RIGHT) ? T_LEFT : T_RIGHT;
   if (m > 1) match_dirs(qx, qy, m, other_type, S.d2x, S.d2y);
   if (m == 0) return;
+  // per own cone: rotation into its search frame (:100-104)
+  if (lane < n) {
+    const double ang = atan2(S.d1y[lane], S.d1x[lane]);
+    const Rot2 rot = make_rot(-ang);
+    S.rc[lane] = rot.c;
+    S.rs[lane] = rot.s;
+    S.anyok[lane] = 0;
+  }
+  __syncthreads();
+  // candidate test, one (own cone, other-side cone) pair per lane: ellipse, search angle, opposing directions
+  for (int p = lane; p < n * m; p += WAVE) {
+    const int i = p / m, j = p - i * m;
+    const double sx = px[i], sy = py[i];
+    const Rot2 rot{S.rc[i], S.rs[i]};
+    const double r0 = (5 * 1.5) * (5 * 1.5), r1 = 3.0 * 3.0;
+    double vx, vy;
+    rot_apply(rot, qx[j] - sx, qy[j] - sy, vx, vy);
+    double sc = (vx * vx) / r0 + (vy * vy) / r1;
+    bool ok = sc < 1;
+    double a = atan2(vy, vx);
+    if (fabs(a / 2) > 50 * FSDP_DEG) ok = false;
+    if (m > 1) {  // with a single other-side cone the reference's direction mask is empty
+      double dd = angle_between(S.d1x[i], S.d1y[i], S.d2x[j], S.d2y[j]);
+      if (dd < FSDP_PI / 2) ok = false;
+    }
+    if (ok) atomicOr(&S.anyok[i], 1);
+  }
+  __syncthreads();
+  // nearest other-side cone (first smallest), lane = own cone
   if (lane < n) {
     const double sx = px[lane], sy = py[lane];
-    const double ddx = S.d1x[lane], ddy = S.d1y[lane];
-    const double ang = atan2(ddy, ddx);
-    const Rot2 rot = make_rot(-ang);
-    const double r0 = (5 * 1.5) * (5 * 1.5), r1 = 3.0 * 3.0;
-    bool any = false;
     int best = 0;
     double bd = 0.0;
     for (int j = 0; j < m; j++) {
-      double vx, vy;
-      rot_apply(rot, qx[j] - sx, qy[j] - sy, vx, vy);
-      double s = (vx * vx) / r0 + (vy * vy) / r1;
-      bool ok = s < 1;
-      double a = atan2(vy, vx);
-      if (fabs(a / 2) > 50 * FSDP_DEG) ok = false;
-      if (m > 1) {  // with a single other-side cone the reference's direction mask is empty
-        double dd = angle_between(ddx, ddy, S.d2x[j], S.d2y[j]);
-        if (dd < FSDP_PI / 2) ok = false;
-      }
-      any = any || ok;
       double d = cdist_sq(sx, sy, qx[j], qy[j]);
       if (j == 0 || d < bd) {
         bd = d;
         best = j;
       }
     }
-    S.match[lane] = any ? best : -1;
+    S.match[lane] = S.anyok[lane] ? best : -1;
   }
   __syncthreads();
 }
