@@ -67,6 +67,7 @@ struct SortShared {
   int32_t n_configs[2];
   double best_cost[2];
   int32_t first_k[2][2];
+  int32_t adj_built;               // the mutual-kNN lists below have been built for this frame
 };
 
 // ---- trace_sorter/line_segment_intersection.py:136-200 (epsilon 1e-6) ----
@@ -211,8 +212,10 @@ __device__ __forceinline__ double np_sum_reg(const double (&a)[MAX_LEN], int n) 
 
 // one side (cone_type LEFT or RIGHT); side = 0 (left) / 1 (right).  All lanes call.
 // Returns status (wave-uniform).
+// reuse_adjacency: the mutual-kNN lists in S (knn, nbr, ...) were built by the other side's call and no cone of the
+// frame carries a side colour, so they are the same for this side (no-colour mode builds them once per frame)
 __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int side, double px, double py, double dx,
-                                    double dy) {
+                                    double dy, bool reuse_adjacency) {
   const int lane = lane_id();
   const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
   if (lane == 0) {
@@ -290,93 +293,97 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
 
   // ---------------- S5: mutual-kNN adjacency (adjacency_matrix.py:60-128) ----------------
   PROF_MARK(2);
-  const int k_nn = (n - 1 < KNN) ? (n - 1) : KNN;
-  for (int i = lane; i < n; i += WAVE) {
-    double bd[KNN];
-    int bj[KNN];
+  if (!reuse_adjacency) {
+    const int k_nn = (n - 1 < KNN) ? (n - 1) : KNN;
+    for (int i = lane; i < n; i += WAVE) {
+      double bd[KNN];
+      int bj[KNN];
 #pragma unroll
-    for (int q = 0; q < KNN; q++) {
-      bd[q] = INFINITY;
-      bj[q] = 255;
-    }
-    const double xi = S.x[i], yi = S.y[i];
-    const bool row_inf = (S.type[i] == other_type);
-    if (!row_inf) {
-      for (int j0 = 0; j0 < n; j0 += 8) {  // operands eight at a time (group-uniform LDS reads, one round trip)
-        double xj[8], yj[8];
-        int tj8[8];
+      for (int q = 0; q < KNN; q++) {
+        bd[q] = INFINITY;
+        bj[q] = 255;
+      }
+      const double xi = S.x[i], yi = S.y[i];
+      const bool row_inf = (S.type[i] == other_type);
+      if (!row_inf) {
+        for (int j0 = 0; j0 < n; j0 += 8) {  // operands eight at a time (group-uniform LDS reads, one round trip)
+          double xj[8], yj[8];
+          int tj8[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int j = (j0 + e < n) ? j0 + e : n - 1;
-          xj[e] = S.x[j];
-          yj[e] = S.y[j];
-          tj8[e] = S.type[j];
-        }
+          for (int e = 0; e < 8; e++) {
+            const int j = (j0 + e < n) ? j0 + e : n - 1;
+            xj[e] = S.x[j];
+            yj[e] = S.y[j];
+            tj8[e] = S.type[j];
+          }
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int j = j0 + e;
-          if (j >= n || j == i || tj8[e] == other_type) continue;
-          double d = cdist_sq(xi, yi, xj[e], yj[e]);
-          if (d < bd[KNN - 1]) {
-            // sorted insertion through registers; strict '<' keeps the earlier index first on ties
-            int cj = j;
+          for (int e = 0; e < 8; e++) {
+            const int j = j0 + e;
+            if (j >= n || j == i || tj8[e] == other_type) continue;
+            double d = cdist_sq(xi, yi, xj[e], yj[e]);
+            if (d < bd[KNN - 1]) {
+              // sorted insertion through registers; strict '<' keeps the earlier index first on ties
+              int cj = j;
 #pragma unroll
-            for (int q = 0; q < KNN; q++) {
-              bool lt = d < bd[q];
-              double td = lt ? bd[q] : d;
-              int tj = lt ? bj[q] : cj;
-              bd[q] = lt ? d : bd[q];
-              bj[q] = lt ? cj : bj[q];
-              d = td;
-              cj = tj;
+              for (int q = 0; q < KNN; q++) {
+                bool lt = d < bd[q];
+                double td = lt ? bd[q] : d;
+                int tj = lt ? bj[q] : cj;
+                bd[q] = lt ? d : bd[q];
+                bj[q] = lt ? cj : bj[q];
+                d = td;
+                cj = tj;
+              }
             }
           }
         }
       }
-    }
-    int okm = 0;
+      int okm = 0;
 #pragma unroll
-    for (int q = 0; q < KNN; q++) {
-      bool in_k = (q < k_nn) && (bj[q] != 255);
-      S.knn[i][q] = in_k ? (uint8_t)bj[q] : (uint8_t)255;
-      if (in_k && !(bd[q] > 6.5 * 6.5)) okm |= (1 << q);
-    }
-    S.knn_ok[i] = (uint8_t)okm;
-  }
-  __syncthreads();
-  for (int i = lane; i < n; i += WAVE) {
-    int cnt = 0;
-    int lst[KNN];
-#pragma unroll
-    for (int q = 0; q < KNN; q++) lst[q] = 255;
-    int okm = S.knn_ok[i];
-#pragma unroll
-    for (int q = 0; q < KNN; q++) {
-      int j = S.knn[i][q];
-      if (j == 255 || !(okm & (1 << q))) continue;
-      int okj = S.knn_ok[j];
-      bool mutual = false;
-#pragma unroll
-      for (int r = 0; r < KNN; r++)
-        if (S.knn[j][r] == i && (okj & (1 << r))) mutual = true;
-      if (mutual) {
-        // ascending insertion (255 = empty sorts last)
-        int v = j;
-#pragma unroll
-        for (int p = 0; p < KNN; p++) {
-          bool lt = v < lst[p];
-          int tv = lt ? lst[p] : v;
-          lst[p] = lt ? v : lst[p];
-          v = tv;
-        }
-        cnt++;
+      for (int q = 0; q < KNN; q++) {
+        bool in_k = (q < k_nn) && (bj[q] != 255);
+        S.knn[i][q] = in_k ? (uint8_t)bj[q] : (uint8_t)255;
+        if (in_k && !(bd[q] > 6.5 * 6.5)) okm |= (1 << q);
       }
+      S.knn_ok[i] = (uint8_t)okm;
     }
+    __syncthreads();
+    for (int i = lane; i < n; i += WAVE) {
+      int cnt = 0;
+      int lst[KNN];
 #pragma unroll
-    for (int q = 0; q < KNN; q++) S.nbr[i][q] = (uint8_t)lst[q];
-    S.nbr_cnt[i] = (uint8_t)cnt;
-    S.vis[i] = (i == start_idx) ? 1 : 0;
+      for (int q = 0; q < KNN; q++) lst[q] = 255;
+      int okm = S.knn_ok[i];
+#pragma unroll
+      for (int q = 0; q < KNN; q++) {
+        int j = S.knn[i][q];
+        if (j == 255 || !(okm & (1 << q))) continue;
+        int okj = S.knn_ok[j];
+        bool mutual = false;
+#pragma unroll
+        for (int r = 0; r < KNN; r++)
+          if (S.knn[j][r] == i && (okj & (1 << r))) mutual = true;
+        if (mutual) {
+          // ascending insertion (255 = empty sorts last)
+          int v = j;
+#pragma unroll
+          for (int p = 0; p < KNN; p++) {
+            bool lt = v < lst[p];
+            int tv = lt ? lst[p] : v;
+            lst[p] = lt ? v : lst[p];
+            v = tv;
+          }
+          cnt++;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < KNN; q++) S.nbr[i][q] = (uint8_t)lst[q];
+      S.nbr_cnt[i] = (uint8_t)cnt;
+    }
+    __syncthreads();
+    if (lane == 0) S.adj_built = 1;
   }
+  for (int i = lane; i < n; i += WAVE) S.vis[i] = (i == start_idx) ? 1 : 0;
   __syncthreads();
   // BFS reachability from start_idx (common.py:36-67); only min(len, 12) is consumed
   int reach = 1;
@@ -962,9 +969,16 @@ __global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames,
     }
   }
   __syncthreads();
-  if (status == ST_OK) status = sort_one_side(S, n, T_LEFT, 0, px, py, dx, dy);
+  if (lane == 0) S.adj_built = 0;
+  // no cone with a side colour: both sides see the same distance matrix and hence the same mutual-kNN adjacency
+  bool coloured = false;
+  for (int i = lane; i < n; i += WAVE) coloured = coloured || S.type[i] == T_LEFT || S.type[i] == T_RIGHT;
+  const bool colourless = __ballot(coloured) == 0ull;
+  if (status == ST_OK) status = sort_one_side(S, n, T_LEFT, 0, px, py, dx, dy, false);
   __syncthreads();
-  if (status == ST_OK) status = sort_one_side(S, n, T_RIGHT, 1, px, py, dx, dy);
+  // (the left call returns before building the adjacency when it finds no start cone or n < 3)
+  const bool left_built = S.adj_built != 0;
+  if (status == ST_OK) status = sort_one_side(S, n, T_RIGHT, 1, px, py, dx, dy, colourless && left_built);
   __syncthreads();
   int nl = 0, nr = 0;
   if (status == ST_OK) combine_sides(S, nl, nr);
