@@ -167,14 +167,20 @@ __device__ __forceinline__ double np_sum_small(const double* a, int n) {
 // optional per-section cycle accounting (tools/section_profile.py builds with -DFSDP_PROFILE)
 // ------------------------------------------------------------------------------------------
 #if defined(FSDP_PROFILE) && !defined(FSDP_EMU)
-__device__ long long* g_prof = nullptr;  // [n_frames][32] cycle sums
+__device__ long long* g_prof = nullptr;  // [n_blocks][32] cycle sums / counters
+// Sections accumulate in LDS (a scope costs two s_memtime and one LDS read-modify-write) and are written to g_prof once
+// per wavefront by PROF_FLUSH(); accumulating in global memory would charge every scope a memory round trip.
+__device__ __forceinline__ long long* prof_lds() {
+  __shared__ long long acc[32];
+  return acc;
+}
 struct ProfScope {
   long long t0;
   int slot;
   __device__ ProfScope(int s) : t0(clock64()), slot(s) {}
   __device__ ~ProfScope() {
     long long t1 = clock64();
-    if (g_prof && (threadIdx.x & 63) == 0) g_prof[(size_t)blockIdx.x * 32 + slot] += (t1 - t0);
+    if (g_prof && (threadIdx.x & 63) == 0) prof_lds()[slot] += (t1 - t0);
   }
 };
 #define PROF(slot) ProfScope prof_scope_##slot(slot)
@@ -182,11 +188,23 @@ struct ProfScope {
 #define PROF_COUNT(slot, G, value)                                                                              \
   do {                                                                                                          \
     if (g_prof && (threadIdx.x & ((G) - 1)) == 0 && (threadIdx.x & 63) / (G) < 4)                                    \
-      g_prof[(size_t)blockIdx.x * 32 + (slot) + (threadIdx.x & 63) / (G)] += (value);                              \
+      prof_lds()[(slot) + (threadIdx.x & 63) / (G)] += (value);                                                  \
+  } while (0)
+#define PROF_INIT()                                           \
+  do {                                                        \
+    if ((threadIdx.x & 63) < 32) prof_lds()[threadIdx.x & 63] = 0; \
+    __syncthreads();                                          \
+  } while (0)
+#define PROF_FLUSH()                                                                                  \
+  do {                                                                                                \
+    __syncthreads();                                                                                  \
+    if (g_prof && (threadIdx.x & 63) < 32) g_prof[(size_t)blockIdx.x * 32 + (threadIdx.x & 63)] += prof_lds()[threadIdx.x & 63]; \
   } while (0)
 #else
 #define PROF(slot)
 #define PROF_COUNT(slot, G, value)
+#define PROF_INIT()
+#define PROF_FLUSH()
 #endif
 
 // ------------------------------------------------------------------------------------------

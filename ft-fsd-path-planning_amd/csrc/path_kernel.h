@@ -873,8 +873,9 @@ __global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames,
                                                      PathOut* __restrict__ out) {
   __shared__ PathShared<G> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
-  if (frame >= n_frames) return;
-  path_frame<G>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, arena, out);
+  PROF_INIT();
+  if (frame < n_frames) path_frame<G>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, arena, out);
+  PROF_FLUSH();
 }
 
 }  // namespace fsdp

@@ -28,7 +28,7 @@ namespace fsdp {
 #define PROF_MARK(k)                                                                          \
   do {                                                                                        \
     long long now_ = clock64();                                                               \
-    if (g_prof && (threadIdx.x & 63) == 0) g_prof[(size_t)blockIdx.x * 32 + prof_cur_] += now_ - prof_t_; \
+    if (g_prof && (threadIdx.x & 63) == 0) prof_lds()[prof_cur_] += now_ - prof_t_;            \
     prof_cur_ = (k);                                                                          \
     prof_t_ = now_;                                                                           \
   } while (0)
@@ -923,6 +923,7 @@ __global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames,
   __shared__ SortShared S;
   const int frame = blockIdx.x;
   if (frame >= n_frames) return;
+  PROF_INIT();
   const int lane = lane_id();
   const int off = cone_offsets[frame];
   int n = cone_offsets[frame + 1] - off;
@@ -999,6 +1000,7 @@ __global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames,
     o->left_idx[lane] = (status == ST_OK && lane < nl) ? (int32_t)S.best[0][lane] : -1;
     o->right_idx[lane] = (status == ST_OK && lane < nr) ? (int32_t)S.best[1][lane] : -1;
   }
+  PROF_FLUSH();
 }
 
 }  // namespace fsdp

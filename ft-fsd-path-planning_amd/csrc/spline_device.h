@@ -511,7 +511,8 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
                                          int m, double s) {
   using GR = Grp<G>;
   constexpr int CH = SplineWS<G>::CH;
-  constexpr int SC = ResidualBatch<K, G, false>::ROUNDS * G;  // points per residual "super-chunk" (<= 4 * CH: the chunk's basis buffer holds its terms)
+  constexpr int SC = ResidualBatch<K, G, false>::ROUNDS * G;  // points per residual half "super-chunk"
+  constexpr int HALVES = (2 * SC <= 4 * CH) ? 2 : 1;             // the chunk's basis buffer holds 4 * CH terms
   constexpr int k = K;
   const int lane = GR::lane();
   SplineFit R;
@@ -735,13 +736,18 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
         int ii = 1;
         double* const tbuf = &ws.hq[0][0];     // 4 * CH terms
         int32_t* const fbuf = (int32_t*)ws.xq;  // xq | yq: 4 * CH flags
-        ResidualBatch<K, G, true> rb;
-        rb.load(bc, X, Y, 0, m < SC ? m : SC);
-        for (int base = 0; base < m; base += SC) {
-          const int cnt = m - base < SC ? m - base : SC;
-          rb.compute(ws, cnt, n, tbuf, fbuf);
+        ResidualBatch<K, G, true> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
+        auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
+        ra.load(bc, X, Y, 0, clampc(m));
+        for (int base = 0; base < m; base += HALVES * SC) {
+          const int cnt_a = clampc(m - base);
+          const int cnt_b = (HALVES == 2) ? clampc(m - base - SC) : 0;
+          const int cnt = cnt_a + cnt_b;
+          if (cnt_b > 0) rb.load(bc, X, Y, base + SC, cnt_b);
+          ra.compute(ws, cnt_a, n, tbuf, fbuf);
+          if (base + HALVES * SC < m) ra.load(bc, X, Y, base + HALVES * SC, clampc(m - base - HALVES * SC));
+          if (cnt_b > 0) rb.compute(ws, cnt_b, n, tbuf + SC, fbuf + SC);
           GR::sync();
-          if (base + SC < m) rb.load(bc, X, Y, base + SC, (m - base - SC) < SC ? (m - base - SC) : SC);
           for (int r0 = 0; r0 < cnt; r0 += 8) {  // operands eight at a time (one LDS round trip), order kept
             double tv[8];
             int fl[8];
@@ -931,18 +937,22 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       fp = 0.;
       {
         double* const tbuf = &ws.hq[0][0];  // 4 * CH terms
-        ResidualBatch<K, G, false> rb;
-        rb.load(bc, X, Y, 0, m < SC ? m : SC);
-        for (int base = 0; base < m; base += SC) {
-          const int cnt = m - base < SC ? m - base : SC;
+        ResidualBatch<K, G, false> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
+        auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
+        ra.load(bc, X, Y, 0, clampc(m));
+        for (int base = 0; base < m; base += HALVES * SC) {
+          const int cnt_a = clampc(m - base);
+          const int cnt_b = (HALVES == 2) ? clampc(m - base - SC) : 0;
           {
             PROF(28);
-            rb.compute(ws, cnt, n, tbuf, nullptr);
+            if (cnt_b > 0) rb.load(bc, X, Y, base + SC, cnt_b);
+            ra.compute(ws, cnt_a, n, tbuf, nullptr);
+            if (base + HALVES * SC < m) ra.load(bc, X, Y, base + HALVES * SC, clampc(m - base - HALVES * SC));
+            if (cnt_b > 0) rb.compute(ws, cnt_b, n, tbuf + SC, nullptr);
             GR::sync();
-            if (base + SC < m) rb.load(bc, X, Y, base + SC, (m - base - SC) < SC ? (m - base - SC) : SC);
           }
           PROF(29);
-          fp = seq_sum(tbuf, cnt, fp);  // w = 1: term * w^2 is the term itself
+          fp = seq_sum(tbuf, cnt_a + cnt_b, fp);  // w = 1: term * w^2 is the term itself
           GR::sync();
         }
       }

@@ -1,0 +1,15 @@
+import importlib, sys, json
+from pathlib import Path
+ROOT = Path('/root/repo'); sys.path.insert(0, str(ROOT))
+pkg = importlib.import_module('ft-fsd-path-planning_amd')
+so = sys.argv[1]
+if so != 'default':
+    pkg._capi.LIB_PATH = Path(so)
+ctx = pkg.Context(device=0)
+off, cones, poses = pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
+res = {}
+for d in (2, 3, 4):
+    ctx.set_overlap(d); ctx.upload(off, cones, poses); ctx.time_runs(6)
+    tot, st = ctx.time_runs(24)
+    res[d] = round(tot / 24, 3)
+print(so.split('/')[-1], res)
