@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
     "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
-    "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap",
+    "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
 ]
 
@@ -175,6 +175,14 @@ class Context:
         self._check(self._lib.fsdp_upload(self._h, n, _ip(offsets), _dp(cones), _dp(poses)), "fsdp_upload")
         self._check(self._lib.fsdp_sync(self._h), "fsdp_sync")
         self.n_frames = n
+
+    def set_global_path(self, xy):
+        """PathPlanner.set_global_path: (n,2) array, or None to plan from the matched cones again."""
+        if xy is None:
+            self._check(self._lib.fsdp_set_global_path(self._h, None, 0), "fsdp_set_global_path")
+            return
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        self._check(self._lib.fsdp_set_global_path(self._h, _dp(xy), ctypes.c_int(len(xy))), "fsdp_set_global_path")
 
     def set_overlap(self, depth: int):
         """depth 2: consecutive run() passes alternate between two streams / buffer sets and overlap (streams of batches);

@@ -44,9 +44,12 @@ struct fsdp_ctx {
   PathOut* d_path = nullptr;
   double* d_default_path = nullptr;  // (40,4)
   double* d_arena = nullptr;         // per-frame working polyline + basis cache (ARENA_DOUBLES doubles), HBM/L2 scratch
+  int* d_retry = nullptr;            // retry list of the packed path kernels (n_frames + 1 ints)
   double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
   double* d_prev = nullptr;          // optional per-frame previous paths (n_frames,40,4) for sequential replays
   bool use_prev = false;
+  double* d_gpath = nullptr;         // PathPlanner.global_path (n_gpath,2), or NULL
+  int n_gpath = 0;
   // further sets of intermediates + streams (fsdp_set_overlap): consecutive fsdp_run passes rotate through the sets, so
   // the next passes start while the slowest wavefronts of the previous ones are still finishing
   int force_path_g = 0;       // 0 = automatic; 8 / 16 / 64 = test / tuning override (FSDP_PATH_G environment variable)
@@ -60,6 +63,7 @@ struct fsdp_ctx {
     MatchOut* d_match = nullptr;
     PathOut* d_path = nullptr;
     double* d_arena = nullptr;
+    int* d_retry = nullptr;
     int cap_frames = 0;
   } extra[FSDP_MAX_OVERLAP - 1];
   std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
@@ -97,6 +101,8 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
     if (c->d_match) (void)hipFree(c->d_match);
     if (c->d_path) (void)hipFree(c->d_path);
     if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->d_retry) (void)hipFree(c->d_retry);
+    c->d_retry = nullptr;
     if (c->d_prev) (void)hipFree(c->d_prev);
     c->d_prev = nullptr;
     c->use_prev = false;
@@ -113,6 +119,7 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
     HIP_TRY(c, hipMalloc(&c->d_match, sizeof(MatchOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_path, sizeof(PathOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_arena, sizeof(double) * ARENA_DOUBLES * (size_t)n_frames));
+    HIP_TRY(c, hipMalloc(&c->d_retry, sizeof(int) * ((size_t)n_frames + 1)));
     HIP_TRY(c, hipMalloc(&c->d_prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n_frames));
     c->cap_frames = n_frames;
   }
@@ -133,11 +140,12 @@ struct Slot {
   MatchOut* d_match;
   PathOut* d_path;
   double* d_arena;
+  int* d_retry;  // [0] counter + frames the packed path kernel could not finish (knot capacity)
 };
 static Slot slot_of(fsdp_ctx* c, int i) {
-  if (i == 0) return Slot{c->stream, c->d_sort, c->d_match, c->d_path, c->d_arena};
+  if (i == 0) return Slot{c->stream, c->d_sort, c->d_match, c->d_path, c->d_arena, c->d_retry};
   const fsdp_ctx::Extra& x = c->extra[i - 1];
-  return Slot{x.stream, x.d_sort, x.d_match, x.d_path, x.d_arena};
+  return Slot{x.stream, x.d_sort, x.d_match, x.d_path, x.d_arena, x.d_retry};
 }
 
 static int ensure_extra_slots(fsdp_ctx* c) {
@@ -149,6 +157,8 @@ static int ensure_extra_slots(fsdp_ctx* c) {
     if (x.d_match) (void)hipFree(x.d_match);
     if (x.d_path) (void)hipFree(x.d_path);
     if (x.d_arena) (void)hipFree(x.d_arena);
+    if (x.d_retry) (void)hipFree(x.d_retry);
+    x.d_retry = nullptr;
     x.d_sort = nullptr;
     x.d_match = nullptr;
     x.d_path = nullptr;
@@ -159,6 +169,7 @@ static int ensure_extra_slots(fsdp_ctx* c) {
     HIP_TRY(c, hipMalloc(&x.d_match, sizeof(MatchOut) * n));
     HIP_TRY(c, hipMalloc(&x.d_path, sizeof(PathOut) * n));
     HIP_TRY(c, hipMalloc(&x.d_arena, sizeof(double) * ARENA_DOUBLES * n));
+    HIP_TRY(c, hipMalloc(&x.d_retry, sizeof(int) * (n + 1)));
     x.cap_frames = c->cap_frames;
   }
   return 0;
@@ -181,9 +192,10 @@ static void launch_match(fsdp_ctx* c, const Slot& q) {
                      q.d_sort, q.d_match);
 }
 template <int G>
-static void launch_path_g(fsdp_ctx* c, const Slot& q) {
+static void launch_path_g(fsdp_ctx* c, const Slot& q, int* retry) {
   hipLaunchKernelGGL(path_kernel<G>, dim3((c->n_frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, c->n_frames,
-                     c->d_poses, q.d_match, c->d_default_path, c->use_prev ? c->d_prev : nullptr, q.d_arena, q.d_path);
+                     c->d_poses, q.d_match, c->d_default_path, c->use_prev ? c->d_prev : nullptr, c->d_gpath, c->n_gpath, q.d_arena,
+                     q.d_path, retry);
 }
 // lanes per frame: see path_kernel.h (results do not depend on the choice)
 static void launch_path(fsdp_ctx* c, const Slot& q) {
@@ -196,12 +208,35 @@ static void launch_path(fsdp_ctx* c, const Slot& q) {
     else
       g = PATH_G_LATENCY;
   }
+  if (g == PATH_G_SMALL) {
+    launch_path_g<PATH_G_SMALL>(c, q, nullptr);
+    return;
+  }
+  // The packed kernels keep 32 knots per fit in LDS; a frame that needs more (long polylines with sharp corners, e.g.
+  // the acceleration mission's known path) ends with status 204.  Such frames are rare and results are only visible
+  // after a download, so they are finished there (finish_knot_overflow) instead of stalling every pass with a second
+  // launch that needs whole SIMDs.
   if (g == PATH_G_THROUGHPUT)
-    launch_path_g<PATH_G_THROUGHPUT>(c, q);
-  else if (g == PATH_G_SMALL)
-    launch_path_g<PATH_G_SMALL>(c, q);
+    launch_path_g<PATH_G_THROUGHPUT>(c, q, nullptr);
   else
-    launch_path_g<PATH_G_LATENCY>(c, q);
+    launch_path_g<PATH_G_LATENCY>(c, q, nullptr);
+}
+
+// After the path records of slot q are on the host (h_path): frames the packed path kernels left at ST_OVERFLOW_KNOTS are
+// planned again by the one-frame-per-wavefront instantiation (64 knots) and their records fetched again.
+static int finish_knot_overflow(fsdp_ctx* c, const Slot& q) {
+  std::vector<int> list(1, 0);
+  for (int i = 0; i < c->n_frames; i++)
+    if (c->h_path[i].status == ST_OVERFLOW_KNOTS) list.push_back(i);
+  list[0] = (int)list.size() - 1;
+  if (list[0] == 0) return 0;
+  HIP_TRY(c, hipMemcpyAsync(q.d_retry, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, q.stream));
+  const int blocks = list[0] < 1024 ? list[0] : 1024;
+  hipLaunchKernelGGL(path_retry_kernel, dim3(blocks), dim3(WAVE), 0, q.stream, c->d_poses, q.d_match, c->d_default_path,
+                     c->use_prev ? c->d_prev : nullptr, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry);
+  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), q.d_path, sizeof(PathOut) * (size_t)c->n_frames, hipMemcpyDeviceToHost, q.stream));
+  HIP_TRY(c, hipStreamSynchronize(q.stream));
+  return 0;
 }
 static void launch_sort(fsdp_ctx* c) { launch_sort(c, slot_of(c, 0)); }
 static void launch_match(fsdp_ctx* c) { launch_match(c, slot_of(c, 0)); }
@@ -263,11 +298,10 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
     g_create_error = "device index out of range";
     return 1;
   }
-  // utils/mission_types.py:11-25: acceleration=1, skidpad=2, ebs_test=5 use a relocalizer (full_pipeline.py:46-50)
-  if (mission == 1 || mission == 5) {
-    g_create_error = "acceleration / ebs_test use the unseeded AccelerationRelocalizer (SURVEY.md 2 row 6b): out of scope";
-    return 1;
-  }
+  // utils/mission_types.py:11-25: acceleration = 1, skidpad = 2, ebs_test = 5 use a relocalizer (full_pipeline.py:46-50).
+  // Skidpad state lives on the device (fsdp_skidpad_*).  The acceleration relocalizer is a one-off line fit per planner
+  // that the host does (acceleration.py, explicit seed); the device side of those two missions is the ordinary path
+  // stage with fsdp_set_global_path and empty cone lists.
   fsdp_ctx* c = new fsdp_ctx();
   c->device = device;
   c->mission = mission;
@@ -320,7 +354,9 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_match);
   (void)hipFree(c->d_path);
   (void)hipFree(c->d_arena);
+  (void)hipFree(c->d_retry);
   (void)hipFree(c->d_prev);
+  (void)hipFree(c->d_gpath);
   (void)hipFree(c->d_chord);
   (void)hipFree(c->d_table);
   (void)hipFree(c->d_noise);
@@ -336,6 +372,7 @@ void fsdp_destroy(fsdp_ctx* c) {
     (void)hipFree(x.d_match);
     (void)hipFree(x.d_path);
     (void)hipFree(x.d_arena);
+    (void)hipFree(x.d_retry);
     if (x.stream) (void)hipStreamDestroy(x.stream);
   }
   for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
@@ -412,6 +449,8 @@ int fsdp_download(fsdp_ctx* c, fsdp_frame_result* results) {
   HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), q.d_path, sizeof(PathOut) * n, hipMemcpyDeviceToHost, q.stream));
   int rc = sync_all(c);
   if (rc) return rc;
+  rc = finish_knot_overflow(c, q);
+  if (rc) return rc;
   for (int i = 0; i < n; i++) {
     memset(&results[i], 0, sizeof(fsdp_frame_result));
     assemble(&c->h_sort[i], &c->h_match[i], &c->h_path[i], &results[i]);
@@ -435,6 +474,21 @@ int fsdp_set_previous_paths(fsdp_ctx* c, const double* prev_paths) {
                             c->stream));
   if (c->overlap > 1) HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->use_prev = true;
+  return 0;
+}
+
+int fsdp_set_global_path(fsdp_ctx* c, const double* xy, int n) {
+  if (!c || n < 0 || (n > 0 && !xy)) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = sync_all(c);
+  if (rc) return rc;
+  if (c->d_gpath) (void)hipFree(c->d_gpath);
+  c->d_gpath = nullptr;
+  c->n_gpath = 0;
+  if (n == 0) return 0;
+  HIP_TRY(c, hipMalloc(&c->d_gpath, sizeof(double) * 2 * (size_t)n));
+  HIP_TRY(c, hipMemcpy(c->d_gpath, xy, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice));
+  c->n_gpath = n;
   return 0;
 }
 
@@ -617,6 +671,8 @@ int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, fsdp_frame_r
   c->h_path.resize(n_frames);
   HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), c->d_path, sizeof(PathOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  rc = finish_knot_overflow(c, slot_of(c, 0));
+  if (rc) return rc;
   for (int i = 0; i < n_frames; i++) {
     results[i].status = 0;
     assemble(nullptr, nullptr, &c->h_path[i], &results[i]);

@@ -26,11 +26,12 @@
 
 namespace fsdp {
 
-constexpr int PATH_CAP = 1152;  // points of the working polyline (dense fit-#1 output + extension)
+constexpr int PATH_CAP = 1408;  // points of the working polyline (dense fit-#1 output + extension); the acceleration
+                                // mission reaches ~1300 (outbound + return lane of its known path within 30 m)
 constexpr int SEG_CAP = 3 * DENSE_CAP;  // segment-length scratch in LDS (the dense-sample region of the spline workspace)
 
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
-constexpr int ARENA_B = 192;  // >= (NK + 2) * 5 rows of the smoothness matrix
+constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
 constexpr int ARENA_DOUBLES = 7 * PATH_CAP + PATH_CAP / 2 + ARENA_B + DENSE_CAP;
 struct Arena {
   double* x;
@@ -740,8 +741,8 @@ constexpr int PATH_LATENCY_BATCH = 4096;  // largest single pass that G = 16 ser
 template <int G>
 __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
                                   const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
-                                  const double* __restrict__ prev_paths, double* __restrict__ arena,
-                                  PathOut* __restrict__ out) {
+                                  const double* __restrict__ prev_paths, const double* __restrict__ gpath, int n_gpath,
+                                  double* __restrict__ arena, PathOut* __restrict__ out) {
   using GR = Grp<G>;
   PROF(0);
   const int lane = GR::lane();
@@ -756,7 +757,54 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
   const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
   const int nl = mo->n_left_v, nr = mo->n_right_v;
   int nc = 0;  // centre points, written to the arena polyline [0, nc)
-  if (status == ST_OK) {
+  if (status == ST_OK && gpath != nullptr) {
+    // PathPlanner.global_path is set (full_pipeline.py:81-82,181-183; core_calculate_path.py:514-529): the basis of the
+    // path is the part of the global path within 30 m of the car, rolled so that it starts a third of the table before
+    // the closest point (np.roll); the matches are ignored
+    if (n_gpath <= 0) {
+      status = ST_REF_UNDEFINED_PATH;  // argmin of an empty array
+    } else {
+      double bv = 0.0;
+      int bi = -1;
+      for (int i = lane; i < n_gpath; i += G) {
+        double d = norm_axis(px - gpath[2 * i], py - gpath[2 * i + 1]);
+        if (bi < 0 || d < bv) {
+          bv = d;
+          bi = i;
+        }
+      }
+      GR::argmin(bv, bi);  // first smallest
+      const int roll = -bi + n_gpath / 3;
+      bool overflow = false;
+      for (int base = 0; base < n_gpath; base += G) {
+        const int k = base + lane;
+        bool keep = false;
+        double gx = 0.0, gy = 0.0;
+        if (k < n_gpath) {
+          int src = (k - roll) % n_gpath;  // np.roll: out[k] = in[(k - roll) mod n]
+          if (src < 0) src += n_gpath;
+          gx = gpath[2 * src];
+          gy = gpath[2 * src + 1];
+          keep = norm_axis(px - gx, py - gy) < 30;
+        }
+        const unsigned long long km = GR::ballot(keep);
+        if (keep) {
+          const int p = nc + __popcll(km & ((1ull << lane) - 1ull));
+          if (p < PATH_CAP) {
+            A.x[p] = gx;
+            A.y[p] = gy;
+          }
+        }
+        nc += __popcll(km);
+      }
+      if (nc > PATH_CAP) overflow = true;
+      if (overflow)
+        status = ST_OVERFLOW_PATH;
+      else if (nc < 2)
+        status = ST_REF_UNDEFINED_PATH;  // NullSplineEvaluator -> empty path update -> min() of an empty array (:232)
+    }
+    GR::sync();
+  } else if (status == ST_OK) {
     bool use_prev = false;
     if (nl < 3 && nr < 3) {
       use_prev = true;
@@ -861,7 +909,9 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
   }
 }
 
-// grid = ceil(n_frames / (64 / G)) workgroups of one wavefront; group g of block b plans frame b * (64 / G) + g
+// grid = ceil(n_frames / (64 / G)) workgroups of one wavefront; group g of block b plans frame b * (64 / G) + g.
+// retry (optional): [0] = counter, [1..] = frames that ended with ST_OVERFLOW_KNOTS (the packed kernels keep 32 knots per
+// fit); path_retry_kernel plans those again with the one-frame-per-wavefront instantiation (64 knots).
 #ifndef FSDP_PATH_WAVES
 #define FSDP_PATH_WAVES 1
 #endif
@@ -869,13 +919,33 @@ template <int G>
 __global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames, const double* __restrict__ poses,
                                                      const MatchOut* __restrict__ matched,
                                                      const double* __restrict__ default_path,
-                                                     const double* __restrict__ prev_paths, double* __restrict__ arena,
-                                                     PathOut* __restrict__ out) {
+                                                     const double* __restrict__ prev_paths,
+                                                     const double* __restrict__ gpath, int n_gpath,
+                                                     double* __restrict__ arena, PathOut* __restrict__ out,
+                                                     int* __restrict__ retry) {
   __shared__ PathShared<G> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
   PROF_INIT();
-  if (frame < n_frames) path_frame<G>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, arena, out);
+  if (frame < n_frames) {
+    path_frame<G>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out);
+    if (retry != nullptr && Grp<G>::lane() == 0 && out[frame].status == ST_OVERFLOW_KNOTS) retry[1 + atomicAdd(&retry[0], 1)] = frame;
+  }  // (retry list on the device: used by the emulator harness; the library collects the list on the host)
   PROF_FLUSH();
+}
+
+// the host's list of frames a packed launch left at ST_OVERFLOW_KNOTS (fsdp_lib.hip finish_knot_overflow)
+__global__ void __launch_bounds__(64, 1) path_retry_kernel(const double* __restrict__ poses, const MatchOut* __restrict__ matched,
+                                                           const double* __restrict__ default_path,
+                                                           const double* __restrict__ prev_paths,
+                                                           const double* __restrict__ gpath, int n_gpath,
+                                                           double* __restrict__ arena, PathOut* __restrict__ out,
+                                                           const int* __restrict__ retry) {
+  __shared__ PathShared<WAVE> S;
+  const int n = retry[0];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    path_frame<WAVE>(S, retry[1 + i], poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out);
+    __syncthreads();
+  }
 }
 
 }  // namespace fsdp

@@ -18,7 +18,14 @@
 
 namespace fsdp {
 
-constexpr int NK = 32;  // max number of knots kept in LDS (FITPACK's nest is m+2k; OVERFLOW_KNOTS beyond)
+// Max number of knots kept in LDS (FITPACK's nest is m + 2k; OVERFLOW_KNOTS beyond): 32 where several frames share a
+// wavefront's LDS, 64 where a frame has the wavefront to itself.  The host re-runs frames that overflow the packed
+// kernels through the G = 64 kernel (fsdp_lib.hip launch_path), so results do not depend on the packing.
+template <int G>
+constexpr int knot_capacity() {
+  return G == 64 ? 64 : 32;
+}
+constexpr int NK_MAX = 64;
 
 constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121 in practice)
 
@@ -29,6 +36,7 @@ constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121
 // fit is running — the path stage's dense samples.  The rows of the smoothness matrix b live in the frame's scratch.
 template <int G>
 struct SplineWS {
+  static constexpr int NK = knot_capacity<G>();
   static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : 16);  // data rows staged per chunk
   union {
     struct {  // ---- a fit in progress ----
@@ -524,6 +532,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
   constexpr int k1 = K + 1, k2 = K + 2;
   constexpr int nmin = 2 * k1;
   int nest = m + 2 * k;
+  constexpr int NK = SplineWS<G>::NK;
   if (nest > NK) nest = NK;
   if (m < k1 || nest < nmin) {
     R.status = 1;

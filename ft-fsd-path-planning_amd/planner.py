@@ -82,22 +82,26 @@ def pack_frames(frames: Sequence[Tuple[Any, Any, Any]]):
 
 
 class PathPlanner:
-    """Drop-in for fsd_path_planning.PathPlanner on the relocalizer-free missions.
+    """Drop-in for fsd_path_planning.PathPlanner.
 
     ``calculate_path_in_global_frame`` keeps the reference signature and return values
-    (full_pipeline.py:84-207); ``plan_batch`` is the batched form of the same call.
+    (full_pipeline.py:84-207); ``plan_batch`` is the batched form of the same call.  ``relocalization_seed`` feeds the
+    random subset search of the acceleration / ebs_test relocalizer (acceleration.py; the reference draws from
+    NumPy's global generator there).
     """
 
     def __init__(self, mission: MissionTypes, experimental_performance_improvements: bool = False, device: int | None = None,
-                 stateful: bool = True):
+                 stateful: bool = True, relocalization_seed: int | None = 0):
         if experimental_performance_improvements:
             # reference README.md:24-27: off by default, changes results, meaningless for independent frames
             raise NotImplementedError("the experimental sorting cache is out of scope (SURVEY.md §2 row 15)")
         self.mission = MissionTypes(mission)
-        if self.mission in (MissionTypes.acceleration, MissionTypes.ebs_test):
-            # AccelerationRelocalizer draws from an unseeded RNG (acceleration_relocalization.py:32): parity unpinnable
-            raise NotImplementedError("acceleration / ebs_test missions are out of scope (SURVEY.md §2 row 6b)")
         self.global_path = None
+        self._accel = None
+        if self.mission in (MissionTypes.acceleration, MissionTypes.ebs_test):
+            from .acceleration import AccelerationRelocalizer
+
+            self._accel = AccelerationRelocalizer(relocalization_seed)
         # like the reference object, consecutive calls chain the previous path (core_calculate_path.py:572-573);
         # stateful=False gives every call a fresh planner (what plan_batch does for every frame)
         self.stateful = stateful
@@ -115,16 +119,61 @@ class PathPlanner:
     @property
     def relocalization_info(self):
         """reference full_pipeline.py:209-217: None without a relocalizer or before relocalization."""
-        if self._skid is None or self._skid_info is None or not int(self._skid_info["relocalized"]):
-            return None
         from .skidpad import RelocalizationInformation
 
+        if self._accel is not None:
+            if not self._accel.is_relocalized:
+                return None
+            # relocalization_information.py:17-35: images of (0, 0) and (1, 0) under the transform to the known frame
+            o, _ = self._accel.to_known_frame(np.array([0.0, 0.0]), 0)
+            e, _ = self._accel.to_known_frame(np.array([1.0, 0.0]), 0)
+            return RelocalizationInformation(np.array([o[0], o[1]]), float(np.arctan2(e[1] - o[1], e[0] - o[0])))
+        if self._skid is None or self._skid_info is None or not int(self._skid_info["relocalized"]):
+            return None
         return RelocalizationInformation(np.array(self._skid_info["translation"]), float(self._skid_info["rotation"]))
 
     def set_global_path(self, global_path):  # reference full_pipeline.py:81-82
-        if global_path is not None:
-            raise NotImplementedError("global_path (skidpad) is not on the MI355X path yet")
-        self.global_path = None
+        """With a global path (n,2) every following path is drawn from it (core_calculate_path.py:514-529); None
+        switches back to planning from the matched cones."""
+        if self._skid is not None:
+            raise RuntimeError("the skidpad mission plans along its own known path")
+        self.global_path = None if global_path is None else np.ascontiguousarray(global_path, dtype=np.float64).reshape(-1, 2)
+        self._ctx.set_global_path(self.global_path)
+
+    def _accelerate(self, cones, xyt, pose, return_intermediate_results):
+        """acceleration / ebs_test (full_pipeline.py:118-140,178-194): relocalize once on the host, then plan along the
+        known path in the known frame; sorting and matching are skipped, the path goes back to the caller's frame."""
+        acc = self._accel
+        position, direction = pose[:2], pose[2:]
+        by_type = cones if not (isinstance(cones, np.ndarray) and cones.ndim == 2 and cones.shape[1] == 3) else [xyt[:, :2]]
+        acc.attempt(by_type, position, direction)
+        if acc.is_relocalized:
+            yaw = np.arctan2(direction[1], direction[0])
+            position, yaw = acc.to_known_frame(position, yaw)
+            direction = np.array([np.cos(yaw), np.sin(yaw)])
+            if self.global_path is None:
+                from .acceleration import known_path
+
+                self.set_global_path(known_path())
+        pose_k = np.concatenate([position, direction])[None]
+        off0, none = np.zeros(2, np.int32), np.zeros((0, 3))
+        if self._prev is not None:
+            r = self._ctx.plan_batch_sequential(off0, none, pose_k, self._prev[None])[0]
+        else:
+            r = self._ctx.plan_batch(off0, none, pose_k)[0]
+        st = int(r["status"])
+        if 100 <= st < 200:
+            raise ReferenceUndefinedError(st)
+        if st != 0:
+            raise _capi.FsdpError(f"device capacity exceeded (status {st}, see include/fsdp.h)")
+        path = np.array(r["path"])
+        self._prev = path.copy()  # the path stage keeps its history in the frame it computed in
+        if acc.is_relocalized:
+            path[:, 1:3], _ = acc.to_original_frame(path[:, 1:3], np.zeros(len(path)))
+        if not return_intermediate_results:
+            return path
+        e2, ei = np.zeros((0, 2)), np.zeros(0, dtype=int)
+        return (path, e2, e2.copy(), e2.copy(), e2.copy(), ei, ei.copy())
 
     # ---- batched form -------------------------------------------------------------------
     def plan_batch(self, cone_offsets, cones_xyt, poses) -> np.ndarray:
@@ -158,6 +207,8 @@ class PathPlanner:
                 return path
             e2, ei = np.zeros((0, 2)), np.zeros(0, dtype=int)
             return (path, e2, e2.copy(), e2.copy(), e2.copy(), ei, ei.copy())
+        if self._accel is not None:
+            return self._accelerate(cones, xyt, pose, return_intermediate_results)
         off1 = np.array([0, len(xyt)], np.int32)
         if self.stateful and self._prev is not None:
             r = self._ctx.plan_batch_sequential(off1, xyt, pose[None], self._prev[None])[0]

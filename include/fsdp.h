@@ -48,7 +48,7 @@ enum {
   FSDP_OVERFLOW_CONES = 201,
   FSDP_OVERFLOW_ENDS = 202,
   FSDP_OVERFLOW_PATH = 203,
-  FSDP_OVERFLOW_KNOTS = 204,
+  FSDP_OVERFLOW_KNOTS = 204, /* more than 64 knots (fits beyond 32 are re-planned by the one-frame-per-wavefront kernel) */
   FSDP_OVERFLOW_CLUSTERS = 205 /* skidpad relocalization: more than 64 centre clusters */
 };
 
@@ -90,8 +90,8 @@ int fsdp_device_count(void);                /* number of visible HIP devices (0 
 
 /* PathPlanner(mission) — full_pipeline.py:54-69.  Creates the per-GPU context (device buffers,
  * stream, the constant initial previous path of core_calculate_path.py:103-107 computed on device).
- * Only relocalizer-free missions (trackdrive / autocross, mission >= 3 of utils/mission_types.py) are
- * on this path; others return an error. */
+ * mission = a value of utils/mission_types.py; 2 (skidpad) makes the context a set of stateful planner instances
+ * (fsdp_skidpad_*), every other mission runs the batch entry points below. */
 int fsdp_create(int device, int mission, fsdp_ctx** out);
 void fsdp_destroy(fsdp_ctx* ctx);
 const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creation error */
@@ -110,6 +110,13 @@ int fsdp_plan_batch_sequential(fsdp_ctx* ctx, int n_frames, const int32_t* cone_
                                const double* poses, const double* prev_paths, fsdp_frame_result* results);
 /* the resident form of the above: applies to the next fsdp_run calls until reset with NULL */
 int fsdp_set_previous_paths(fsdp_ctx* ctx, const double* prev_paths);
+
+/* PathPlanner.set_global_path (full_pipeline.py:81-82) / the known path of a relocalized planner (:118-136): with a
+ * global path (n,2) the path of every following frame is drawn from it (core_calculate_path.py:514-529: the part within
+ * 30 m of the car, rolled to start a third of the table before the closest point) instead of from the matched cones.
+ * n = 0 / xy = NULL switches back.  The acceleration / ebs_test missions run on this: their relocalizer (one line fit per
+ * planner) is host code, the device gets the transformed pose, empty cone lists and the relocalizer's known path. */
+int fsdp_set_global_path(fsdp_ctx* ctx, const double* xy, int n);
 
 /* The same in three steps so a caller (bench, pipelined replay) can keep inputs resident in HBM. */
 int fsdp_upload(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses);

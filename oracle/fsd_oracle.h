@@ -51,6 +51,9 @@ typedef struct {
 
 // cones_xyt: (n,3) row-major [x,y,type]; pose: [px,py,dx,dy].
 void fsdo_plan_frame(const double* cones_xyt, int n, const double* pose, fsdo_frame_result* out);
+// the same with a previous path (40,4) (or NULL) and PathPlanner.global_path (n_gpath,2) (or NULL)
+void fsdo_plan_frame_global(const double* cones_xyt, int n, const double* pose, const double* prev40x4, const double* gpath_xy,
+                            int n_gpath, fsdo_frame_result* out);
 
 // batch over CSR offsets; n_threads <= 1 runs serially, otherwise std::thread workers.
 void fsdo_plan_batch(int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses,

@@ -122,13 +122,25 @@ void fsdo_path(const double* left_v, int nl, const double* right_v, int nr, cons
   }
 }
 
-void fsdo_plan_frame_prev(const double* xyt, int n, const double* pose, const double* prev40x4, fsdo_frame_result* o);
+void fsdo_plan_frame_global(const double* xyt, int n, const double* pose, const double* prev40x4, const double* gpath_xy,
+                            int n_gpath, fsdo_frame_result* o);
 
-void fsdo_plan_frame(const double* xyt, int n, const double* pose, fsdo_frame_result* o) { fsdo_plan_frame_prev(xyt, n, pose, nullptr, o); }
+void fsdo_plan_frame(const double* xyt, int n, const double* pose, fsdo_frame_result* o) {
+  fsdo_plan_frame_global(xyt, n, pose, nullptr, nullptr, 0, o);
+}
 
 // sequential-replay form: prev40x4 = the previous output of this planner (CalculatePath.previous_paths[-1]) or NULL
 void fsdo_plan_frame_prev(const double* xyt, int n, const double* pose, const double* prev40x4, fsdo_frame_result* o) {
+  fsdo_plan_frame_global(xyt, n, pose, prev40x4, nullptr, 0, o);
+}
+
+// the same with PathPlanner.global_path set (full_pipeline.py:81-82,181-183): gpath_xy (n_gpath,2) or NULL
+void fsdo_plan_frame_global(const double* xyt, int n, const double* pose, const double* prev40x4, const double* gpath_xy,
+                            int n_gpath, fsdo_frame_result* o) {
   clear_result(o);
+  Pts gp;
+  if (gpath_xy)
+    for (int i = 0; i < n_gpath; i++) gp.push_back(Vec2{gpath_xy[2 * i], gpath_xy[2 * i + 1]});
   try {
     Frame f = make_frame(xyt, n, pose);
     std::vector<int> l, r;
@@ -142,7 +154,7 @@ void fsdo_plan_frame_prev(const double* xyt, int n, const double* pose, const do
     match_cones(sl, sr, Vec2{f.px, f.py}, lv, rv, l2r, r2l);
     fill_match(lv, rv, l2r, r2l, o);
     PathOut po;
-    calculate_path(lv, rv, l2r, r2l, Vec2{f.px, f.py}, Vec2{f.dx, f.dy}, po, (const double(*)[4])prev40x4);
+    calculate_path(lv, rv, l2r, r2l, Vec2{f.px, f.py}, Vec2{f.dx, f.dy}, po, (const double(*)[4])prev40x4, gpath_xy ? &gp : nullptr);
     std::memcpy(o->path, po.p, sizeof(po.p));
     o->path_fallback = po.fallback;
   } catch (RefUndefined& e) {

@@ -47,7 +47,7 @@ struct PathOut {
 };
 const double (*default_previous_path())[4];
 void calculate_path(const Pts& left_v, const Pts& right_v, const std::vector<int>& l2r, const std::vector<int>& r2l,
-                    Vec2 pos, Vec2 dir, PathOut& out, const double (*prev)[4] = nullptr);
+                    Vec2 pos, Vec2 dir, PathOut& out, const double (*prev)[4] = nullptr, const Pts* global_path = nullptr);
 
 void finish_path(Pts path_update, const Pts& prev_xy, Vec2 pos, Vec2 dir, PathOut& out);
 Pts almost_straight_path();

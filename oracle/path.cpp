@@ -389,14 +389,32 @@ const double (*default_previous_path())[4] {
 }
 
 // core_calculate_path.py:514-575 run_path_calculation (global_path is None)
+// global_path (core_calculate_path.py:514-529, set through PathPlanner.set_global_path / the relocalizers): when given, the
+// basis of the path is the part of it within 30 m of the car, rolled so that it starts a third of the table before the
+// closest point; sorting / matching results are ignored.
 void calculate_path(const Pts& left_v, const Pts& right_v, const std::vector<int>& l2r, const std::vector<int>& r2l,
-                    Vec2 pos, Vec2 dir, PathOut& out, const double (*prev_in)[4]) {
+                    Vec2 pos, Vec2 dir, PathOut& out, const double (*prev_in)[4], const Pts* global_path) {
   const double(*prev)[4] = prev_in ? prev_in : default_previous_path();
   Pts prev_xy(HORIZON);
   for (int i = 0; i < HORIZON; i++) prev_xy[i] = Vec2{prev[i][1], prev[i][2]};
   out.fallback = 0;
   Pts center;
-  if (left_v.size() < 3 && right_v.size() < 3) {
+  if (global_path) {
+    const Pts& gp = *global_path;
+    const long n = (long)gp.size();
+    if (n == 0) throw RefUndefined{FSDO_REF_UNDEFINED_PATH};  // argmin of an empty array
+    std::vector<double> dist(n);
+    long imin = 0;
+    for (long i = 0; i < n; i++) {
+      dist[i] = norm2_axis(pos.x - gp[i].x, pos.y - gp[i].y);  // np.linalg.norm(position - path, axis=1)
+      if (dist[i] < dist[imin]) imin = i;                      // first smallest
+    }
+    const long roll = -imin + n / 3;
+    for (long k = 0; k < n; k++) {
+      long src = ((k - roll) % n + n) % n;  // np.roll: out[k] = in[(k - roll) mod n]
+      if (dist[src] < 30) center.push_back(gp[src]);
+    }
+  } else if (left_v.size() < 3 && right_v.size() < 3) {
     center = prev_xy;
     out.fallback |= 1;
   } else {

@@ -12,6 +12,8 @@
 
 static double g_default_path[fsdp::PATH_POINTS * 4];
 static const double* g_prev_paths = nullptr;
+static const double* g_gpath = nullptr;
+static int g_n_gpath = 0;
 static std::once_flag g_once;
 static void build_default() {
   double chord[fsdp::PATH_POINTS][2];
@@ -41,6 +43,7 @@ __global__ void fit_test_kernel(const double* xy, int m, double smoothing, doubl
     info[3] = f.k;
     fp_out[0] = f.fp;
     fp_out[1] = max_u;
+    constexpr int NK = SplineWS<WAVE>::NK;
     for (int i = 1; i <= f.n && i <= NK; i++) {
       t_out[i - 1] = S.ws.t[i];
       c_out[i - 1] = S.ws.c[i];
@@ -54,8 +57,15 @@ template <int G>
 static void emu_path_launch(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
   std::vector<double> arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
   const unsigned per = 64 / G;
-  emu::launch(((unsigned)n_frames + per - 1) / per, 64,
-              [&]() { fsdp::path_kernel<G>(n_frames, poses, matched, g_default_path, g_prev_paths, arena.data(), out); });
+  std::vector<int> retry((size_t)n_frames + 1, 0);
+  emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() {
+    fsdp::path_kernel<G>(n_frames, poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out,
+                         G != 64 ? retry.data() : nullptr);
+  });
+  if (G != 64)  // like fsdp_lib.hip launch_path: frames beyond the packed kernels' knot capacity go through the G = 64 code
+    emu::launch(8, 64, [&]() {
+      fsdp::path_retry_kernel(poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out, retry.data());
+    });
 }
 
 extern "C" {
@@ -103,6 +113,10 @@ void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, c
 }
 
 void emu_set_prev_paths(const double* p) { g_prev_paths = p; }
+void emu_set_global_path(const double* xy, int n) {
+  g_gpath = xy;
+  g_n_gpath = n;
+}
 
 void emu_default_path(double* out) {
   std::call_once(g_once, build_default);

@@ -243,9 +243,6 @@ def main():
     skidpad_golden()
 
 
-if __name__ == "__main__" and "--skidpad-only" not in sys.argv and "--sequence-only" not in sys.argv:
-    main()
-    trackdrive_sequence_golden()
 
 
 def skidpad_golden():
@@ -317,3 +314,82 @@ def trackdrive_sequence_golden():
 
 if __name__ == "__main__" and "--sequence-only" in sys.argv:
     trackdrive_sequence_golden()
+
+
+def global_path_golden():
+    """(1) ONE reference PathPlanner(trackdrive) with set_global_path(centre line of a synthetic loop): 40 consecutive
+    frames (core_calculate_path.py:514-529: the path follows the global path, sorting / matching results are ignored).
+    (2) ONE reference PathPlanner(acceleration) driven down a synthetic acceleration lane.  Its relocalizer draws from
+    NumPy's global RNG (acceleration_relocalization.py:32); np.random.seed(ACCEL_SEED) right before the first call pins
+    the draw, which is what the build's explicit seed parameter reproduces.  Also stored: the relocalizer's known path
+    table BASE_ACCELERATION_PATH (data) and the relocalization angle."""
+    m = refharness.load()
+    # ---- (1) trackdrive + global path
+    left, right, centre_fn = synth.closed_track(40, 33)
+    gp = np.array([centre_fn(s)[0] for s in np.linspace(0, 1, 600, endpoint=False)])
+    pp = m["PathPlanner"](m["MissionTypes"].trackdrive)
+    pp.set_global_path(gp)
+    cones_all, off, poses, paths = [], [0], [], []
+    rng = np.random.default_rng(5)
+    for t in range(40):
+        pos, tan = centre_fn(0.05 + t * 0.004)
+        pos = np.array(pos) + rng.normal(0, 0.3, 2)
+        xyt = np.concatenate([np.column_stack([right, np.full(len(right), 1.0)]), np.column_stack([left, np.full(len(left), 2.0)])])
+        path = pp.calculate_path_in_global_frame(xyt, pos, np.array(tan))
+        cones_all.append(xyt)
+        off.append(off[-1] + len(xyt))
+        poses.append(np.concatenate([pos, tan]))
+        paths.append(np.array(path))
+    out = dict(gp_track=gp, gp_offsets=np.array(off, np.int32), gp_cones=np.concatenate(cones_all), gp_poses=np.array(poses),
+               gp_path=np.array(paths))
+    # ---- (2) acceleration mission
+    from fsd_path_planning.relocalization.acceleration.acceleration_relocalization import BASE_ACCELERATION_PATH
+
+    ACCEL_SEED = 1234
+    world_yaw, world_t = 0.7, np.array([12.0, -3.0])
+    c, s = np.cos(world_yaw), np.sin(world_yaw)
+    R = np.array([[c, -s], [s, c]])
+    xs = np.arange(-5.0, 80.0, 5.0)
+    rng = np.random.default_rng(6)
+    lane_l = np.column_stack([xs, np.full(len(xs), 1.5)]) + rng.normal(0, 0.05, (len(xs), 2))
+    lane_r = np.column_stack([xs, np.full(len(xs), -1.5)]) + rng.normal(0, 0.05, (len(xs), 2))
+    to_world = lambda p: p @ R.T + world_t
+    pp = m["PathPlanner"](m["MissionTypes"].acceleration)
+    cones_all, off, poses, paths, reloc, angle = [], [0], [], [], [], []
+    np.random.seed(ACCEL_SEED)
+    for t in range(30):
+        x = -8.0 + 1.5 * t  # the first frames see fewer than 4 cones in the left band: relocalization comes later
+        pos_l = np.array([x, 0.1 * np.sin(0.3 * t)])
+        yaw_l = 0.02 * np.cos(0.2 * t)
+        vis = lambda lane: lane[(lane[:, 0] > x + 0.5) & (lane[:, 0] < x + 0.5 + (6.0 if t < 3 else 25.0))]
+        cones = [np.zeros((0, 2)), to_world(vis(lane_r)), to_world(vis(lane_l)), np.zeros((0, 2)), np.zeros((0, 2))]
+        pos = to_world(pos_l[None])[0]
+        dr = np.array([np.cos(yaw_l + world_yaw), np.sin(yaw_l + world_yaw)])
+        path = pp.calculate_path_in_global_frame(cones, pos, dr)
+        xyt = np.concatenate([np.column_stack([cc, np.full(len(cc), float(tt))]) for tt, cc in enumerate(cones)])
+        cones_all.append(xyt.reshape(-1, 3))
+        off.append(off[-1] + len(xyt))
+        poses.append(np.concatenate([pos, dr]))
+        paths.append(np.array(path))
+        reloc.append(pp.relocalizer.is_relocalized)
+        if pp.relocalizer.is_relocalized:
+            p0, y0 = pp.relocalizer.transform_to_known_map_frame(np.zeros(2), 0.0)
+            angle.append(-y0)
+        else:
+            angle.append(np.nan)
+    out.update(acc_table=np.array(BASE_ACCELERATION_PATH), acc_seed=np.array(ACCEL_SEED), acc_offsets=np.array(off, np.int32),
+               acc_cones=np.concatenate(cones_all), acc_poses=np.array(poses), acc_path=np.array(paths),
+               acc_relocalized=np.array(reloc), acc_angle=np.array(angle))
+    np.savez_compressed(HERE / "global_path.npz", **out)
+    print("global_path: trackdrive frames", len(out["gp_path"]), "| acceleration frames", len(paths), "relocalized from frame",
+          int(np.argmax(reloc)), "angle", angle[-1])
+
+
+if __name__ == "__main__" and "--global-path-only" in sys.argv:
+    global_path_golden()
+
+
+if __name__ == "__main__" and not any(a.endswith("-only") for a in sys.argv[1:]):
+    main()
+    trackdrive_sequence_golden()
+    global_path_golden()

@@ -128,6 +128,18 @@ def plan_frame_prev(xyt: np.ndarray, pose: np.ndarray, prev: np.ndarray | None) 
     return out[0]
 
 
+def plan_frame_global(xyt: np.ndarray, pose: np.ndarray, prev: np.ndarray | None, global_path: np.ndarray | None) -> np.ndarray:
+    """plan_frame_prev with PathPlanner.global_path set (full_pipeline.py:81-82): global_path (n,2) or None."""
+    xyt = np.ascontiguousarray(xyt, dtype=np.float64).reshape(-1, 3)
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    out = np.zeros(1, dtype=RESULT_DTYPE)
+    pp = None if prev is None else _p(np.ascontiguousarray(prev, dtype=np.float64))
+    gp = None if global_path is None else np.ascontiguousarray(global_path, dtype=np.float64).reshape(-1, 2)
+    lib().fsdo_plan_frame_global(_p(xyt), ctypes.c_int(len(xyt)), _p(pose), pp, None if gp is None else _p(gp),
+                                 ctypes.c_int(0 if gp is None else len(gp)), ctypes.c_void_p(out.ctypes.data))
+    return out[0]
+
+
 def plan_batch(offsets, xyt, poses, n_threads: int = 1) -> np.ndarray:
     offsets = np.ascontiguousarray(offsets, dtype=np.int32)
     xyt = np.ascontiguousarray(xyt, dtype=np.float64)

@@ -1,0 +1,179 @@
+"""PathPlanner.set_global_path (core_calculate_path.py:514-529) and the acceleration / ebs_test missions that run on it
+(full_pipeline.py:118-136,178-194; relocalizer = one host-side line fit with an explicit seed, acceleration.py).
+Golden: tests/golden/global_path.npz — a reference trackdrive planner with a global path over 40 frames, and a reference
+acceleration planner over 30 frames preceded by np.random.seed(acc_seed)."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+
+def _frames(g, key):
+    off = g[f"{key}_offsets"]
+    for t in range(len(off) - 1):
+        yield t, g[f"{key}_cones"][off[t] : off[t + 1]], g[f"{key}_poses"][t]
+
+
+def test_oracle_global_path_matches_reference(golden_dir):
+    g = np.load(golden_dir / "global_path.npz")
+    prev = None
+    for t, xyt, pose in _frames(g, "gp"):
+        r = oracle_lib.plan_frame_global(xyt, pose, prev, g["gp_track"])
+        assert r["status"] == 0
+        assert np.abs(r["path"] - g["gp_path"][t]).max() < 1e-9, t
+        prev = r["path"].copy()
+    # the global path really decides: without it the same frame gives another path
+    free = oracle_lib.plan_frame_global(*next(iter(_frames(g, "gp")))[1:], None, None)
+    assert free["status"] != 0 or np.abs(free["path"] - g["gp_path"][0]).max() > 1e-3
+
+
+def _accelerate_with(plan, g, seed):
+    """The host flow of planner.PathPlanner._accelerate with `plan(pose, prev, global_path)` as the path stage."""
+    acc = importlib.import_module("ft-fsd-path-planning_amd.acceleration")
+    reloc = acc.AccelerationRelocalizer(seed)
+    prev, out, flags = None, [], []
+    for t, xyt, pose in _frames(g, "acc"):
+        position, direction = pose[:2], pose[2:]
+        reloc.attempt([xyt[xyt[:, 2] == k, :2] for k in range(5)], position, direction)
+        gp = None
+        if reloc.is_relocalized:
+            yaw = np.arctan2(direction[1], direction[0])
+            position, yaw = reloc.to_known_frame(position, yaw)
+            direction = np.array([np.cos(yaw), np.sin(yaw)])
+            gp = acc.known_path()
+        path = plan(np.concatenate([position, direction]), prev, gp)
+        prev = path.copy()
+        if reloc.is_relocalized:
+            path = path.copy()
+            path[:, 1:3], _ = reloc.to_original_frame(path[:, 1:3], np.zeros(len(path)))
+        out.append(path)
+        flags.append(reloc.is_relocalized)
+    return np.array(out), np.array(flags), reloc
+
+
+def test_acceleration_mission_host_flow_with_oracle_matches_reference(golden_dir):
+    g = np.load(golden_dir / "global_path.npz")
+    acc = importlib.import_module("ft-fsd-path-planning_amd.acceleration")
+    assert np.array_equal(acc.known_path(), g["acc_table"])
+
+    def plan(pose, prev, gp):
+        r = oracle_lib.plan_frame_global(np.zeros((0, 3)), pose, prev, gp)
+        assert r["status"] == 0
+        return r["path"]
+
+    paths, flags, reloc = _accelerate_with(plan, g, int(g["acc_seed"]))
+    assert np.array_equal(flags, g["acc_relocalized"]) and flags.any() and not flags.all()
+    assert reloc.angle_to_fix == g["acc_angle"][-1]  # same draws, same polyfit: the same bits
+    assert np.abs(paths - g["acc_path"]).max() < 1e-5
+    # another seed draws other subsets; with a handful of cones in the band the best subset is usually found anyway
+    _, _, other = _accelerate_with(plan, g, int(g["acc_seed"]) + 1)
+    assert other.is_relocalized and abs(other.angle_to_fix - reloc.angle_to_fix) < 0.05
+
+
+def test_emulated_path_kernel_with_global_path(golden_dir):
+    import emu_lib
+
+    g = np.load(golden_dir / "global_path.npz")
+    gp = np.ascontiguousarray(g["gp_track"])
+    prev = None
+    with oracle_lib.math_mode(1):
+        for t, xyt, pose in list(_frames(g, "gp"))[:12]:
+            r = oracle_lib.plan_frame_global(xyt, pose, prev, gp)
+            p = None if prev is None else np.ascontiguousarray(prev)
+            L = emu_lib.lib()
+            L.emu_set_prev_paths(None if p is None else p.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+            L.emu_set_global_path(gp.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_int(len(gp)))
+            try:
+                for group in emu_lib.PATH_GROUP_SIZES:
+                    e, _ = emu_lib.plan(np.array([0, len(xyt)], np.int32), xyt, pose[None], group)
+                    assert int(e[0]["status"]) == int(r["status"]) and np.array_equal(e[0]["path"], r["path"]), (t, group)
+            finally:
+                L.emu_set_prev_paths(None)
+                L.emu_set_global_path(None, ctypes.c_int(0))
+            prev = r["path"].copy()
+
+
+def test_emulated_acceleration_frames_beyond_the_packed_knot_capacity(golden_dir):
+    """The acceleration mission fits a 128 m U-shaped polyline (out lane + return lane of its known path): more than the
+    32 knots the packed path kernels keep per fit.  Those frames come back from the packed launch with status 204 and are
+    planned again by the one-frame-per-wavefront kernel (64 knots) — same result as the oracle either way."""
+    import emu_lib
+
+    g = np.load(golden_dir / "global_path.npz")
+    L = emu_lib.lib()
+    seen = []
+
+    def plan(pose, prev, gp):
+        r = oracle_lib.plan_frame_global(np.zeros((0, 3)), pose, prev, gp)
+        if gp is not None and len(seen) < 4:
+            p = np.ascontiguousarray(prev)
+            gpc = np.ascontiguousarray(gp)
+            L.emu_set_prev_paths(p.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+            L.emu_set_global_path(gpc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_int(len(gpc)))
+            try:
+                e, _ = emu_lib.plan(np.zeros(2, np.int32), np.zeros((0, 3)), pose[None], 8)
+            finally:
+                L.emu_set_prev_paths(None)
+                L.emu_set_global_path(None, ctypes.c_int(0))
+            assert int(e[0]["status"]) == 0 and np.array_equal(e[0]["path"], r["path"])
+            seen.append(1)
+        return r["path"]
+
+    with oracle_lib.math_mode(1):
+        _accelerate_with(plan, g, int(g["acc_seed"]))
+    assert len(seen) == 4
+
+
+@pytest.mark.gpu
+def test_planner_with_global_path_on_gpu(golden_dir):
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    g = np.load(golden_dir / "global_path.npz")
+    planner = pkg.PathPlanner(pkg.MissionTypes.trackdrive, device=0)
+    planner.set_global_path(g["gp_track"])
+    for t, xyt, pose in _frames(g, "gp"):
+        path = planner.calculate_path_in_global_frame(xyt, pose[:2], pose[2:])
+        assert np.abs(path - g["gp_path"][t]).max() < 1e-9, t
+    planner.set_global_path(None)
+    t, xyt, pose = next(iter(_frames(g, "gp")))
+    assert np.abs(planner.calculate_path_in_global_frame(xyt, pose[:2], pose[2:]) - g["gp_path"][0]).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mission", ["acceleration", "ebs_test"])
+def test_acceleration_mission_on_gpu(golden_dir, mission):
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    g = np.load(golden_dir / "global_path.npz")
+    planner = pkg.PathPlanner(pkg.MissionTypes[mission], device=0, relocalization_seed=int(g["acc_seed"]))
+    for t, xyt, pose in _frames(g, "acc"):
+        cones = [xyt[xyt[:, 2] == k, :2] for k in range(5)]
+        res = planner.calculate_path_in_global_frame(cones, pose[:2], pose[2:], return_intermediate_results=True)
+        assert np.abs(res[0] - g["acc_path"][t]).max() < 1e-5, t
+        assert all(len(a) == 0 for a in res[1:])  # sorting and matching are skipped for relocalizer missions
+        assert (planner.relocalization_info is not None) == bool(g["acc_relocalized"][t])
+    assert abs(planner.relocalization_info.rotation + g["acc_angle"][-1]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_large_batch_beyond_the_packed_knot_capacity_on_gpu(golden_dir):
+    """A batch large enough for the packed path kernels (> 1024 frames) in global-path mode on the acceleration table:
+    fits that need more than 32 knots are finished through the 64-knot kernel at download time — every frame equals the
+    oracle, none keeps status 204."""
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    acc = importlib.import_module("ft-fsd-path-planning_amd.acceleration")
+    gp = acc.known_path()
+    n = 1100
+    rng = np.random.default_rng(3)
+    xs = rng.uniform(0.0, 120.0, n)
+    poses = np.column_stack([xs, rng.normal(0, 0.1, n), np.ones(n), np.zeros(n)])
+    off = np.zeros(n + 1, np.int32)
+    ctx = pkg.Context(device=0)
+    ctx.set_global_path(gp)
+    res = ctx.plan_batch(off, np.zeros((0, 3)), poses)
+    assert (res["status"] == 0).all()
+    with oracle_lib.math_mode(1):
+        for i in range(0, n, 37):
+            r = oracle_lib.plan_frame_global(np.zeros((0, 3)), poses[i], None, gp)
+            assert r["status"] == 0 and np.array_equal(res["path"][i], r["path"]), i
