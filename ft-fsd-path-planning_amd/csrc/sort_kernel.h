@@ -46,18 +46,24 @@ struct SortShared {
   uint8_t flags[MAX_CONES];        // bit0 in ellipse, bit1 angle>0, bit2 angle<0, bit3 angle window, bit4 "in front" (skip for 2nd cone)
   uint8_t knn[MAX_CONES][KNN];     // k nearest (index), 255 = none
   uint8_t knn_ok[MAX_CONES];       // bit q: knn[q] within max_dist
-  uint8_t nbr[MAX_CONES][KNN];     // mutual neighbours, ascending
-  uint8_t nbr_cnt[MAX_CONES];
+  uint8_t nbr[2][MAX_CONES][KNN];  // mutual neighbours, ascending — one adjacency per side (both DFS run together)
+  uint8_t nbr_cnt[2][MAX_CONES];
   uint8_t vis[MAX_CONES];
-  int16_t ends[MAX_ENDS][MAX_LEN]; // raw / filtered end configurations, -1 padded
+  int16_t ends[2][MAX_ENDS][MAX_LEN];  // raw / filtered end configurations per side, -1 padded
   uint8_t keep[MAX_ENDS];
   double cost[MAX_ENDS];
   int32_t good[MAX_ENDS];
   int32_t bad[MAX_ENDS];
-  int16_t stack[MAX_STACK][2];
-  double stack_ang[MAX_STACK];     // direction (atan2) of the edge parent -> stacked cone
-  int16_t attempt[MAX_LEN];
-  double attempt_ang[MAX_LEN];     // direction of the edge attempt[p-1] -> attempt[p]
+  int16_t stack[2][MAX_STACK][2];
+  double stack_ang[2][MAX_STACK];  // direction (atan2) of the edge parent -> stacked cone
+  int16_t attempt[2][MAX_LEN];
+  double attempt_ang[2][MAX_LEN];  // direction of the edge attempt[p-1] -> attempt[p]
+  struct SideCtl {                 // hand-over between the per-side phases
+    int32_t active;                // the side has a start cone (else: no result)
+    int32_t n_first, fk0, fk1, target_length;
+    int32_t adj;                   // which adjacency the DFS walks (0 for both sides of a colourless frame)
+    int32_t n_ends, status;
+  } ctl[2];
   int16_t all_list[MAX_ENDS * MAX_LEN > MAX_CONES ? MAX_CONES : MAX_ENDS * MAX_LEN];
   unsigned long long all_mask[MAX_CONES / 64];
   unsigned long long near_mask[MAX_CONES / 64];
@@ -127,7 +133,7 @@ __device__ inline bool inside_ellipse(double px, double py, double cx, double cy
 
 // end_configurations.py:108-223 for ONE candidate neighbour `cand` of the popped node.
 // check_if_neighbor_lies_between_last_in_attempt_and_candidate (:226-257) for one (candidate, neighbour) pair
-__device__ __forceinline__ bool neighbour_lies_between(const SortShared& S, int node, int cand, int nb) {
+__device__ __forceinline__ bool neighbour_lies_between(const SortShared& S, int node, int cand, int nb) {  // (cone indices only)
   if (nb == cand) return false;
   const double lx = S.x[node], ly = S.y[node];
   const double cx = S.x[cand], cy = S.y[cand];
@@ -142,7 +148,7 @@ __device__ __forceinline__ bool neighbour_lies_between(const SortShared& S, int 
 // two edges of the attempt (ang_sl: attempt[pos-1] -> node, ang_tl: attempt[pos-2] -> attempt[pos-1]) are the atan2
 // values computed when those cones were candidates themselves (same operands, same bits); ang_cand returns the direction
 // of the edge node -> candidate for the candidate's own children.
-__device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type, int pos, int node, int cand, bool between,
+__device__ inline bool candidate_can_be_added(const SortShared& S, int side, int cone_type, int pos, int node, int cand, bool between,
                                               double px, double py, double dx, double dy, double dnx, double dny, double a_car,
                                               double ang_sl, double ang_tl, double& ang_cand) {
   const double lx = S.x[node], ly = S.y[node];
@@ -151,8 +157,8 @@ __device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type
   ang_cand = atan2(l2cy, l2cx);
   if (between) return false;
   for (int q = 0; q <= pos; q++)
-    if (S.attempt[q] == cand) return false;
-  int sl = (pos >= 1) ? S.attempt[pos - 1] : 0;
+    if (S.attempt[side][q] == cand) return false;
+  int sl = (pos >= 1) ? S.attempt[side][pos - 1] : 0;
   if (pos >= 1) {
     if (!inside_ellipse(cx, cy, lx, ly, lx - S.x[sl], ly - S.y[sl], 6, 3)) return false;
   }
@@ -181,7 +187,7 @@ __device__ inline bool candidate_can_be_added(const SortShared& S, int cone_type
     }
   }
   if (can && pos == 1) {
-    int st = S.attempt[0];
+    int st = S.attempt[side][0];
     double off = angle_between(dx, dy, cx - S.x[st], cy - S.y[st]);
     can = off < FSDP_PI / 2;
   }
@@ -212,10 +218,11 @@ __device__ __forceinline__ double np_sum_reg(const double (&a)[MAX_LEN], int n) 
 
 // one side (cone_type LEFT or RIGHT); side = 0 (left) / 1 (right).  All lanes call.
 // Returns status (wave-uniform).
-// reuse_adjacency: the mutual-kNN lists in S (knn, nbr, ...) were built by the other side's call and no cone of the
-// frame carries a side colour, so they are the same for this side (no-colour mode builds them once per frame)
-__device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int side, double px, double py, double dx,
-                                    double dy, bool reuse_adjacency) {
+// Phase 1 of a side (S4-S7): start cones, mutual-kNN adjacency, reachability -> S.ctl[side].
+// reuse_adjacency: the mutual-kNN lists were built by the other side's call and no cone of the frame carries a side
+// colour, so they are the same for this side (no-colour mode builds them once per frame).
+__device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, int side, double px, double py, double dx,
+                                         double dy, bool reuse_adjacency) {
   const int lane = lane_id();
   const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
   if (lane == 0) {
@@ -224,9 +231,12 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     S.first_k[side][0] = -1;
     S.first_k[side][1] = -1;
     S.best_cost[side] = 0.0;
+    S.ctl[side].active = 0;
+    S.ctl[side].n_ends = 0;
+    S.ctl[side].status = ST_OK;
   }
   __syncthreads();
-  if (n < 3) return ST_OK;  // core_trace_sorter.py:272-273
+  if (n < 3) return;  // core_trace_sorter.py:272-273
   PROF_MARK_DECL(1);
 
   // ---------------- S4: start cones (core_trace_sorter.py:344-465) ----------------
@@ -246,7 +256,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   wave_argmin(bv, bi);
   int index_1 = bi;
   if (index_1 >= 0 && bv > 6.0) index_1 = -1;
-  if (index_1 < 0) return ST_OK;  // no start cone -> side has no result
+  if (index_1 < 0) return;  // no start cone -> side has no result
   bv = 0.0;
   bi = -1;
   for (int i = lane; i < n; i += WAVE) {
@@ -293,6 +303,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
 
   // ---------------- S5: mutual-kNN adjacency (adjacency_matrix.py:60-128) ----------------
   PROF_MARK(2);
+  const int adj = reuse_adjacency ? 0 : side;
   if (!reuse_adjacency) {
     const int k_nn = (n - 1 < KNN) ? (n - 1) : KNN;
     for (int i = lane; i < n; i += WAVE) {
@@ -377,8 +388,8 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
         }
       }
 #pragma unroll
-      for (int q = 0; q < KNN; q++) S.nbr[i][q] = (uint8_t)lst[q];
-      S.nbr_cnt[i] = (uint8_t)cnt;
+      for (int q = 0; q < KNN; q++) S.nbr[adj][i][q] = (uint8_t)lst[q];
+      S.nbr_cnt[adj][i] = (uint8_t)cnt;
     }
     __syncthreads();
     if (lane == 0) S.adj_built = 1;
@@ -394,9 +405,9 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
       int i = w * WAVE + lane;
       bool nv = false;
       if (i < n && !S.vis[i]) {
-        int c = S.nbr_cnt[i];
+        int c = S.nbr_cnt[adj][i];
         for (int q = 0; q < c; q++)
-          if (S.vis[S.nbr[i][q]]) nv = true;
+          if (S.vis[S.nbr[adj][i][q]]) nv = true;
       }
       newbits[w] = __ballot(nv);
       add += __popcll(newbits[w]);
@@ -411,89 +422,130 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     reach += add;
   }
   const int target_length = reach < MAX_LEN ? reach : MAX_LEN;
+  PROF_MARK(7);  // closes section 2
+  if (lane == 0) {
+    S.ctl[side].active = 1;
+    S.ctl[side].n_first = n_first;
+    S.ctl[side].fk0 = fk0;
+    S.ctl[side].fk1 = fk1;
+    S.ctl[side].target_length = target_length;
+    S.ctl[side].adj = adj;
+  }
+  __syncthreads();
+}
 
-  // ---------------- S8: DFS over the cost tree (end_configurations.py:320-431) ----------------
-  PROF_MARK(3);
+// Phase 2 (S8): DFS over the cost tree (end_configurations.py:320-431) of BOTH sides at once, one half-wavefront per
+// side.  A pop keeps at most 5 candidate lanes and 25 (candidate, neighbour) lanes busy, so the two independent searches
+// share every instruction; the loop runs until both stacks are empty.
+__device__ inline void sort_dfs_both(SortShared& S, double px, double py, double dx, double dy) {
+  const int lane = lane_id();
+  const int side = lane >> 5, sl = lane & 31;
+  const int cone_type = (side == 0) ? T_LEFT : T_RIGHT;
+  const bool active = S.ctl[side].active != 0;
+  const int n_first = S.ctl[side].n_first, fk0 = S.ctl[side].fk0, fk1 = S.ctl[side].fk1;
+  const int target_length = S.ctl[side].target_length, adj = S.ctl[side].adj;
   const double nrm = norm_blas(dx, dy);
   const double dnx = dx / nrm, dny = dy / nrm;
+  const double a_car = atan2(dny, dnx);
   int sp = 0, n_ends = 0;
   int status = ST_OK;
-  if (lane < MAX_LEN) S.attempt[lane] = -1;
+  PROF_MARK_DECL(3);
+  if (active && sl < MAX_LEN) S.attempt[side][sl] = -1;
   __syncthreads();
-  const double a_car = atan2(dny, dnx);
-  if (n_first == 2) {
-    if (target_length < 1) status = ST_REF_UNDEFINED_DFS_OOB;
-    if (lane == 0) {
-      S.attempt[0] = (int16_t)fk0;
-      S.stack[0][0] = (int16_t)fk1;
-      S.stack[0][1] = 1;
-      S.stack_ang[0] = atan2(S.y[fk1] - S.y[fk0], S.x[fk1] - S.x[fk0]);
-    }
-  } else {
-    if (lane == 0) {
-      S.stack[0][0] = (int16_t)start_idx;
-      S.stack[0][1] = 0;
-      S.stack_ang[0] = 0.0;  // unused at position 0
-    }
-  }
-  sp = 1;
-  __syncthreads();
-  while (sp > 0 && status == ST_OK) {
-    sp--;
-    const int node = S.stack[sp][0];
-    const int pos = S.stack[sp][1];
-    const double node_ang = S.stack_ang[sp];
-    if (pos >= target_length) {  // numpy IndexError at current_attempt[position_in_stack]
-      status = ST_REF_UNDEFINED_DFS_OOB;
-      break;
-    }
-    __syncthreads();
-    if (lane < MAX_LEN) {
-      if (lane == pos) {
-        S.attempt[lane] = (int16_t)node;
-        S.attempt_ang[lane] = node_ang;
+  if (active) {
+    if (n_first == 2) {
+      if (target_length < 1) status = ST_REF_UNDEFINED_DFS_OOB;
+      if (sl == 0) {
+        S.attempt[side][0] = (int16_t)fk0;
+        S.stack[side][0][0] = (int16_t)fk1;
+        S.stack[side][0][1] = 1;
+        S.stack_ang[side][0] = atan2(S.y[fk1] - S.y[fk0], S.x[fk1] - S.x[fk0]);
       }
-      if (lane > pos) S.attempt[lane] = -1;
+    } else if (sl == 0) {
+      S.stack[side][0][0] = (int16_t)fk0;
+      S.stack[side][0][1] = 0;
+      S.stack_ang[side][0] = 0.0;  // unused at position 0
+    }
+    sp = 1;
+  }
+  __syncthreads();
+  for (;;) {
+    const bool run = active && sp > 0 && status == ST_OK;
+    if (__ballot(run) == 0ull) break;
+    int node = 0, pos = 0;
+    double node_ang = 0.0;
+    if (run) {
+      sp--;
+      node = S.stack[side][sp][0];
+      pos = S.stack[side][sp][1];
+      node_ang = S.stack_ang[side][sp];
+      if (pos >= target_length) status = ST_REF_UNDEFINED_DFS_OOB;  // numpy IndexError at current_attempt[position_in_stack]
+    }
+    const bool go = run && status == ST_OK;
+    __syncthreads();
+    if (go && sl < MAX_LEN) {
+      if (sl == pos) {
+        S.attempt[side][sl] = (int16_t)node;
+        S.attempt_ang[side][sl] = node_ang;
+      }
+      if (sl > pos) S.attempt[side][sl] = -1;
     }
     __syncthreads();
-    const int n_nb = S.nbr_cnt[node];
+    const int n_nb = go ? S.nbr_cnt[adj][node] : 0;
     // up to 5 x 5 (candidate, neighbour) pairs, one per lane; candidate c owns bits [c * n_nb, (c + 1) * n_nb)
     bool btw = false;
-    if (lane < n_nb * n_nb) btw = neighbour_lies_between(S, node, S.nbr[node][lane / n_nb], S.nbr[node][lane % n_nb]);
-    const unsigned long long bm = __ballot(btw);
+    if (sl < n_nb * n_nb) btw = neighbour_lies_between(S, node, S.nbr[adj][node][sl / n_nb], S.nbr[adj][node][sl % n_nb]);
+    const unsigned bm = (unsigned)(__ballot(btw) >> (32 * side));
     bool can = false;
     double cand_ang = 0.0;
-    if (lane < n_nb) {
-      const bool between = ((bm >> (lane * n_nb)) & ((1ull << n_nb) - 1ull)) != 0ull;
-      const double ang_tl = (pos >= 2) ? S.attempt_ang[pos - 1] : 0.0;
-      can = candidate_can_be_added(S, cone_type, pos, node, S.nbr[node][lane], between, px, py, dx, dy, dnx, dny, a_car, node_ang,
-                                   ang_tl, cand_ang);
+    if (sl < n_nb) {
+      const bool between = ((bm >> (sl * n_nb)) & ((1u << n_nb) - 1u)) != 0u;
+      const double ang_tl = (pos >= 2) ? S.attempt_ang[side][pos - 1] : 0.0;
+      can = candidate_can_be_added(S, side, cone_type, pos, node, S.nbr[adj][node][sl], between, px, py, dx, dy, dnx, dny, a_car,
+                                   node_ang, ang_tl, cand_ang);
     }
-    unsigned long long m = __ballot(can);
-    bool has_valid = (pos < target_length - 1) && (m != 0ull);
-    if (has_valid) {
-      if (can) {
-        int slot = sp + __popcll(m & ((1ull << lane) - 1ull));
-        S.stack[slot][0] = (int16_t)S.nbr[node][lane];
-        S.stack[slot][1] = (int16_t)(pos + 1);
-        S.stack_ang[slot] = cand_ang;
-      }
-      sp += __popcll(m);
-    } else {
-      if (n_ends >= MAX_ENDS) {
+    const unsigned m = (unsigned)(__ballot(can) >> (32 * side));
+    if (go) {
+      const bool has_valid = (pos < target_length - 1) && (m != 0u);
+      if (has_valid) {
+        if (can) {
+          int slot = sp + __popc(m & ((1u << sl) - 1u));
+          S.stack[side][slot][0] = (int16_t)S.nbr[adj][node][sl];
+          S.stack[side][slot][1] = (int16_t)(pos + 1);
+          S.stack_ang[side][slot] = cand_ang;
+        }
+        sp += __popc(m);
+      } else if (n_ends >= MAX_ENDS) {
         status = ST_OVERFLOW_ENDS;
-        break;
+      } else {
+        if (sl < MAX_LEN) S.ends[side][n_ends][sl] = (sl < target_length) ? S.attempt[side][sl] : (int16_t)-1;
+        n_ends++;
       }
-      if (lane < MAX_LEN) S.ends[n_ends][lane] = (lane < target_length) ? S.attempt[lane] : (int16_t)-1;
-      n_ends++;
     }
     __syncthreads();
   }
+  PROF_MARK(7);  // closes section 3
+  if (sl == 0) {
+    S.ctl[side].n_ends = n_ends;
+    S.ctl[side].status = status;
+  }
   __syncthreads();
-  if (status != ST_OK) return status;
+}
 
+// Phase 3 of a side (S10-S12): post filters, side counting, costs, pick.  Returns the frame status of this side.
+__device__ inline int sort_side_finish(SortShared& S, int n, int cone_type, int side, double px, double py, double dx,
+                                       double dy) {
+  const int lane = lane_id();
+  const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
+  if (S.ctl[side].status != ST_OK) return S.ctl[side].status;
+  if (!S.ctl[side].active) return ST_OK;
+  const int n_first = S.ctl[side].n_first, fk0 = S.ctl[side].fk0, fk1 = S.ctl[side].fk1;
+  const int target_length = S.ctl[side].target_length, n_ends = S.ctl[side].n_ends;
+  (void)other_type;
+  (void)px;
+  (void)py;
+  PROF_MARK_DECL(4);
   // ---------------- S10: post filters (end_configurations.py:420-515), lane = raw configuration ----------------
-  PROF_MARK(4);
   const int L = target_length;
   bool keep = false;
   int16_t cfg[MAX_LEN];
@@ -501,7 +553,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   if (lane < n_ends) {
 #pragma unroll
     for (int l = 0; l < MAX_LEN; l++) {
-      cfg[l] = S.ends[lane][l];
+      cfg[l] = S.ends[side][lane][l];
       len += (cfg[l] != -1);
     }
     keep = len > 2;
@@ -530,7 +582,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
       }
       keep = len >= 3;
     }
-    for (int l = 0; l < MAX_LEN; l++) S.ends[lane][l] = cfg[l];
+    for (int l = 0; l < MAX_LEN; l++) S.ends[side][lane][l] = cfg[l];
   }
   if (lane < MAX_ENDS) S.keep[lane] = keep ? 1 : 0;
   __syncthreads();
@@ -541,7 +593,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
       if (o == lane || !S.keep[o]) continue;
       bool same = true, prefix = true;
       for (int l = 0; l < MAX_LEN; l++) {
-        int a = S.ends[o][l], b = cfg[l];
+        int a = S.ends[side][o][l], b = cfg[l];
         if (a != b) same = false;
         if (!(a == b || b == -1)) prefix = false;
       }
@@ -632,7 +684,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
     const int p = p0 + lane;
     const int c = p / MAX_LEN, j = p - c * MAX_LEN;
     if (c < n_ends && ((keepm >> c) & 1ull)) {
-      const int16_t* e = S.ends[c];
+      const int16_t* e = S.ends[side][c];
       int clen = 0;
       for (int l = 0; l < MAX_LEN; l++) clen += (e[l] != -1);
       if (j < clen) {
@@ -687,7 +739,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
   PROF_MARK(6);
   double my_cost = 0.0;
   if (keep) {
-    const int16_t* ccfg = S.ends[lane];  // this lane's configuration (LDS; dynamic indexing stays out of registers)
+    const int16_t* ccfg = S.ends[side][lane];  // this lane's configuration (LDS; dynamic indexing stays out of registers)
     auto PX = [&](int l) -> double {
       int idx = ccfg[l];
       if (idx < 0) idx = n + idx;  // NumPy wrap-around of -1
@@ -792,7 +844,7 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
         // lexicographic comparison of rows (ints, -1 padded)
         bool less = false;
         for (int l = 0; l < MAX_LEN; l++) {
-          int a = S.ends[c][l], b = S.ends[best][l];
+          int a = S.ends[side][c][l], b = S.ends[side][best][l];
           if (a != b) {
             less = a < b;
             break;
@@ -806,8 +858,8 @@ __device__ inline int sort_one_side(SortShared& S, int n, int cone_type, int sid
       }
     }
     int blen = 0;
-    for (int l = 0; l < MAX_LEN; l++) blen += (S.ends[best][l] != -1);
-    if (lane < MAX_LEN) S.best[side][lane] = S.ends[best][lane];
+    for (int l = 0; l < MAX_LEN; l++) blen += (S.ends[side][best][l] != -1);
+    if (lane < MAX_LEN) S.best[side][lane] = S.ends[side][best][lane];
     if (lane == 0) {
       S.best_len[side] = blen;
       S.best_cost[side] = bc;
@@ -975,11 +1027,16 @@ __global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames,
   bool coloured = false;
   for (int i = lane; i < n; i += WAVE) coloured = coloured || S.type[i] == T_LEFT || S.type[i] == T_RIGHT;
   const bool colourless = __ballot(coloured) == 0ull;
-  if (status == ST_OK) status = sort_one_side(S, n, T_LEFT, 0, px, py, dx, dy, false);
-  __syncthreads();
-  // (the left call returns before building the adjacency when it finds no start cone or n < 3)
-  const bool left_built = S.adj_built != 0;
-  if (status == ST_OK) status = sort_one_side(S, n, T_RIGHT, 1, px, py, dx, dy, colourless && left_built);
+  if (status == ST_OK) {
+    sort_side_prepare(S, n, T_LEFT, 0, px, py, dx, dy, false);
+    // (the left call returns before building the adjacency when it finds no start cone or n < 3)
+    const bool left_built = S.adj_built != 0;
+    sort_side_prepare(S, n, T_RIGHT, 1, px, py, dx, dy, colourless && left_built);
+    sort_dfs_both(S, px, py, dx, dy);
+    status = sort_side_finish(S, n, T_LEFT, 0, px, py, dx, dy);
+    __syncthreads();
+    if (status == ST_OK) status = sort_side_finish(S, n, T_RIGHT, 1, px, py, dx, dy);
+  }
   __syncthreads();
   int nl = 0, nr = 0;
   if (status == ST_OK) combine_sides(S, nl, nr);

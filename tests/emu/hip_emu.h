@@ -263,6 +263,7 @@ inline T __shfl_up(T v, unsigned d, int width = 64) {
   return emu::exchange(v, s >= 0 ? s : emu::B->cur);
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 template <class T>

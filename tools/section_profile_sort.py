@@ -29,7 +29,7 @@ ctx.sync()
 out = np.zeros((N, 32), np.int64)
 assert ctx._lib.fsdp_profile_select(ctx._h, 1) == 0
 assert ctx._lib.fsdp_profile_path(ctx._h, ctypes.c_void_p(out.ctypes.data)) == 0
-names = {1: "S4 start cones", 2: "S5 kNN adjacency + reach", 3: "S8 DFS", 4: "S10 post filters", 5: "S12 cones on either side",
+names = {1: "S4 start cones", 2: "S5 kNN adjacency + reach", 3: "S8 DFS (both sides at once)", 4: "S10 post filters", 5: "S12 cones on either side",
          6: "S11 costs + pick"}
 m = out.mean(axis=0)
 tot = sum(m[k] for k in names)
