@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""ms per 4096-frame pass with 2 / 3 / 4 passes in flight (fsdp_set_overlap) for a library build (path of a .so, or
+`default`).  Usage on the GPU box: python tools/overlap_depths.py default"""
 import importlib, sys, json
 from pathlib import Path
 ROOT = Path('/root/repo'); sys.path.insert(0, str(ROOT))
