@@ -138,8 +138,6 @@ class CalculatePath:
 
     def run_path_calculation(self):
         i = self.input
-        if i.global_path is not None:
-            raise NotImplementedError("global_path belongs to the skidpad mission: use PathPlanner(MissionTypes.skidpad)")
         res = np.zeros(1, dtype=_capi.RESULT_DTYPE)
         lv, rv = np.asarray(i.left_cones, float).reshape(-1, 2), np.asarray(i.right_cones, float).reshape(-1, 2)
         if len(lv) > 24 or len(rv) > 24:
@@ -149,7 +147,14 @@ class CalculatePath:
         res["l2r"][0, : len(lv)] = np.asarray(i.left_to_right_matches, dtype=np.int32)
         res["r2l"][0, : len(rv)] = np.asarray(i.right_to_left_matches, dtype=np.int32)
         pose = np.concatenate([np.asarray(i.position_global, float).reshape(2), np.asarray(i.direction_global, float).reshape(2)])
-        out = _ctx(self._device).path_batch(pose[None], res)[0]
+        ctx = _ctx(self._device)
+        if i.global_path is not None:  # core_calculate_path.py:514-529: the path is drawn from the global path
+            ctx.set_global_path(i.global_path)
+        try:
+            out = ctx.path_batch(pose[None], res)[0]
+        finally:
+            if i.global_path is not None:
+                ctx.set_global_path(None)
         _check(out["status"])
         self.last_result = out
         return np.array(out["path"]), None
