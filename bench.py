@@ -14,10 +14,15 @@ Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
+import os
+
+# four passes in flight = four HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+# RCCL / the null stream take queues too — must be set before the HIP runtime starts in this process
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import argparse
 import importlib
 import json
-import os
 import sys
 import time
 from pathlib import Path
@@ -31,7 +36,7 @@ FRAMES_PER_GPU = 4096
 CONES_PER_SIDE = 64
 # algorithmic bytes per frame = read N*24 + 32 (cones, pose) + write 1280 + 96 + 8
 ALGO_BYTES_PER_FRAME = 2 * CONES_PER_SIDE * 24 + 32 + 1280 + 96 + 8  # 4488 at N = 128
-PASS_OVERLAP = 3  # passes in flight in the timed region (fsdp_set_overlap); measured best of 1..4
+PASS_OVERLAP = 4  # passes in flight in the timed region (fsdp_set_overlap); measured best of 1..8 (profiles/README.md)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 

@@ -93,6 +93,14 @@ struct fsdp_ctx {
     }                                                                                            \
   } while (0)
 
+// Synchronous copies go through the context's own stream: the library never touches the null stream (every stream the
+// process uses takes one of the runtime's GPU_MAX_HW_QUEUES hardware queues, and overlapped passes need theirs).
+static hipError_t copy_sync(fsdp_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(c->stream);
+}
+
 static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
   if (n_frames > c->cap_frames) {
     if (c->d_off) (void)hipFree(c->d_off);
@@ -487,7 +495,7 @@ int fsdp_set_global_path(fsdp_ctx* c, const double* xy, int n) {
   c->n_gpath = 0;
   if (n == 0) return 0;
   HIP_TRY(c, hipMalloc(&c->d_gpath, sizeof(double) * 2 * (size_t)n));
-  HIP_TRY(c, hipMemcpy(c->d_gpath, xy, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(c, copy_sync(c, c->d_gpath, xy, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice));
   c->n_gpath = n;
   return 0;
 }
@@ -692,14 +700,14 @@ int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
   long long* d = nullptr;
   size_t bytes = sizeof(long long) * 32 * (size_t)c->n_frames;
   HIP_TRY(c, hipMalloc(&d, bytes));
-  HIP_TRY(c, hipMemset(d, 0, bytes));
+  HIP_TRY(c, hipMemsetAsync(d, 0, bytes, c->stream));
   HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(fsdp::g_prof), &d, sizeof(d)));
   if (c->profile_sort)
     launch_sort(c);
   else
     launch_path(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(out32_per_frame, d, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(c, copy_sync(c, out32_per_frame, d, bytes, hipMemcpyDeviceToHost));
   long long* z = nullptr;
   HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(fsdp::g_prof), &z, sizeof(z)));
   (void)hipFree(d);
@@ -721,8 +729,8 @@ int fsdp_skidpad_set_tables(fsdp_ctx* c, const double* table_xy, int n_table, co
   if (c->d_noise) (void)hipFree(c->d_noise);
   HIP_TRY(c, hipMalloc(&c->d_table, sizeof(double) * half.size()));
   HIP_TRY(c, hipMalloc(&c->d_noise, sizeof(double) * (size_t)n_noise));
-  HIP_TRY(c, hipMemcpy(c->d_table, half.data(), sizeof(double) * half.size(), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(c->d_noise, noise, sizeof(double) * (size_t)n_noise, hipMemcpyHostToDevice));
+  HIP_TRY(c, copy_sync(c, c->d_table, half.data(), sizeof(double) * half.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, copy_sync(c, c->d_noise, noise, sizeof(double) * (size_t)n_noise, hipMemcpyHostToDevice));
   c->tables.path = c->d_table;
   c->tables.n_path = (int)(half.size() / 2);
   c->tables.noise = c->d_noise;
@@ -754,12 +762,12 @@ int fsdp_skidpad_reset(fsdp_ctx* c, int n_instances) {
   // fresh planners: nothing latched, previous path = the constant initial path
   std::vector<SkidState> init(n_instances);
   double def[PATH_POINTS][4];
-  HIP_TRY(c, hipMemcpy(def, c->d_default_path, sizeof(def), hipMemcpyDeviceToHost));
+  HIP_TRY(c, copy_sync(c, def, c->d_default_path, sizeof(def), hipMemcpyDeviceToHost));
   for (auto& s : init) {
     memset(&s, 0, sizeof(s));
     memcpy(s.prev, def, sizeof(def));
   }
-  HIP_TRY(c, hipMemcpy(c->d_skid, init.data(), sizeof(SkidState) * (size_t)n_instances, hipMemcpyHostToDevice));
+  HIP_TRY(c, copy_sync(c, c->d_skid, init.data(), sizeof(SkidState) * (size_t)n_instances, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -823,7 +831,7 @@ int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
 
 int fsdp_default_path(fsdp_ctx* c, double* out) {
   if (!c || !out) return 1;
-  HIP_TRY(c, hipMemcpy(out, c->d_default_path, sizeof(double) * PATH_POINTS * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, copy_sync(c, out, c->d_default_path, sizeof(double) * PATH_POINTS * 4, hipMemcpyDeviceToHost));
   return 0;
 }
 }

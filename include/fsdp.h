@@ -128,7 +128,9 @@ int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
  * the context d HIP streams and d sets of intermediate buffers; consecutive fsdp_run passes rotate through them, so the
  * next passes fill the compute units that the slowest frames of the previous ones no longer occupy.  fsdp_sync waits for
  * all passes in flight, fsdp_download returns the most recent one.  depth 1 (default) = strictly one pass after the
- * other. */
+ * other.  Every stream takes one of the HIP runtime's hardware queues (environment variable GPU_MAX_HW_QUEUES, default 4):
+ * with depth 4 and any other stream in the process (the null stream, RCCL) two passes share a queue and serialize —
+ * raise GPU_MAX_HW_QUEUES (bench.py sets 8) or use depth 3. */
 #define FSDP_MAX_OVERLAP 4
 int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
 

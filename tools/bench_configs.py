@@ -21,9 +21,9 @@ def run(name, off, cones, poses, steps=10):
     ctx.upload(off, cones, poses)
     ctx.time_runs(2)
     tot, st = ctx.time_runs(steps)  # one pass after the other: per-launch kernel durations
-    ctx.set_overlap(3)
-    ctx.time_runs(3)
-    tot2, _ = ctx.time_runs(2 * steps)  # three passes in flight (how bench.py runs)
+    ctx.set_overlap(4)
+    ctx.time_runs(4)
+    tot2, _ = ctx.time_runs(2 * steps)  # four passes in flight (how bench.py runs)
     res = ctx.download()
     ctx.set_overlap(1)
     n = len(off) - 1

@@ -18,7 +18,7 @@ def db(sub):
     return sqlite3.connect(files[0]) if files else None
 
 
-for sub, label in (("trace", "python bench.py --steps 5 --warmup 1 --no-cpu-baseline  [passes overlap 3 deep, as the bench runs]"),
+for sub, label in (("trace", "python bench.py --steps 5 --warmup 1 --no-cpu-baseline  [passes overlap 4 deep, as the bench runs]"),
                    ("trace_serial", "same command with --no-overlap  [one pass after the other]")):
   con = db(sub)
   print(f"== rocprofv3 --kernel-trace --stats ({label}) ==")
