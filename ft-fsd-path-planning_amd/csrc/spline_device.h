@@ -762,7 +762,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
             int fl[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-              tv[q] = tbuf[r0 + q];  // r0 + q < SC always (SC is a multiple of 8)
+              tv[q] = tbuf[r0 + q];  // r0 + q < HALVES * SC always (a multiple of 8)
               fl[q] = fbuf[r0 + q];
             }
 #pragma unroll

@@ -523,7 +523,6 @@ bool parcur_fit(const double* u0, const double* x0, const double* y0, int m, int
     (void)finished;
   }
 
-  if (getenv("FSDO_DBG2")) { double hu=0; for (int i=1;i<=m;i++) hu += u[i]*i + xx[2*i-1]*0.25*i + xx[2*i]*0.125*i; fprintf(stderr, "PARCUR m=%d k=%d s=%.17g n=%d hu=%.17g fp0=%.17g fp=%.17g\n", m,k,s,n,hu,fp0,fp); }
   out.k = k;
   out.n = n;
   out.ier = ier;

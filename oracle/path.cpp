@@ -105,13 +105,6 @@ static Fitted spline_fit(const Pts& trace, double smoothing, double predict_ever
   }
   if (!parcur_fit(u.data(), x.data(), y.data(), m, k, smoothing, f.sp)) throw PyValueError{1};
   f.max_u = u[m - 1];
-  if (getenv("FSDO_DBG")) {
-    double hx = 0, hc = 0;
-    for (int i = 0; i < m; i++) hx += x[i] * (i + 1) + y[i] * 0.5 * (i + 1);
-    if (m < 20) for (int i = 0; i < m; i++) fprintf(stderr, "  u[%d]=%.17g x=%.17g y=%.17g\n", i, u[i], x[i], y[i]);
-    for (int i = 0; i < f.sp.n - k - 1; i++) hc += f.sp.cx[i] * (i + 1) + f.sp.cy[i] * 0.5 * (i + 1);
-    fprintf(stderr, "FIT m=%d k=%d s=%g n=%d ier=%d max_u=%.17g hx=%.17g hc=%.17g fp=%.17g\n", m, k, smoothing, f.sp.n, f.sp.ier, f.max_u, hx, hc, f.sp.fp);
-  }
   return f;
 }
 
