@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--latency", action="store_true", help="also measure p50 single-frame latency (batch = 1)")
+    ap.add_argument("--latency", action="store_true", help="(always measured at N = 1; kept for compatibility)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
     ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..4)")
     args = ap.parse_args()
@@ -198,7 +198,7 @@ def main():
             },
             "status_histogram": status_hist,
         }
-        if args.latency:
+        if args.latency or world == 1:  # BASELINE metric, second half: p50 single-frame latency (batch = 1, host buffers)
             o1, c1, p1 = off[:2], cones[: off[1]], poses[:1]
             lat = []
             for _ in range(200):
