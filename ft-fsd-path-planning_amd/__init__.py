@@ -4,7 +4,8 @@
 ``from fsd_path_planning import ...`` of the reference.  The compute lives in
 lib/libfsdp_hip.so (hand-written HIP kernels, C ABI in include/fsdp.h).
 """
-from .planner import ConeTypes, MissionTypes, PathPlanner, ReferenceUndefinedError, flatten_cones_by_type_array, pack_frames  # noqa: F401
+from .planner import (CapacityError, ConeTypes, MissionTypes, PathPlanner, ReferenceIndexError, ReferenceLinAlgError,  # noqa: F401
+                      ReferenceUndefinedError, flatten_cones_by_type_array, pack_frames, raise_for_status)
 from . import dist, replay, skidpad, stages, synth  # noqa: F401
 from .stages import CalculatePath, ConeMatching, ConeSorting, ConeMatchingInput, ConeSortingInput, PathCalculationInput  # noqa: F401
 from .skidpad import SkidpadBatch  # noqa: F401

@@ -68,6 +68,7 @@ def load() -> ctypes.CDLL:
     lib.fsdp_last_error.argtypes = [ctypes.c_void_p]
     lib.fsdp_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.fsdp_destroy.argtypes = [ctypes.c_void_p]
+    lib.fsdp_resident_frames.argtypes = [ctypes.c_void_p]
     if lib.fsdp_result_size() != RESULT_DTYPE.itemsize:
         raise FsdpError(f"fsdp_frame_result layout mismatch: {lib.fsdp_result_size()} != {RESULT_DTYPE.itemsize}")
     _lib = lib
@@ -76,10 +77,10 @@ def load() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
-    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs",
+    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_resident_frames",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
-    "fsdp_skidpad_set_tables", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
+    "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
 ]
 
 
@@ -125,8 +126,10 @@ class Context:
         cones = np.ascontiguousarray(cones, dtype=np.float64).reshape(-1, 3)
         poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4)
         n = len(offsets) - 1
-        if n < 0 or len(poses) != n or (n > 0 and int(offsets[-1]) != len(cones)):
+        if n < 0 or len(poses) != n or (n > 0 and (int(offsets[0]) != 0 or int(offsets[-1]) != len(cones))):
             raise ValueError("inconsistent batch: offsets / cones / poses")
+        if n > 0 and np.any(np.diff(offsets) < 0):
+            raise ValueError("cone_offsets must be non-decreasing")
         return offsets, cones, poses, n
 
     def plan_batch(self, offsets, cones, poses) -> np.ndarray:
@@ -162,11 +165,13 @@ class Context:
         self._check(self._lib.fsdp_match_batch(self._h, n, _dp(sorted_left), _ip(n_left), _dp(sorted_right), _ip(n_right), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_match_batch")
         return out
 
-    def path_batch(self, poses, results: np.ndarray) -> np.ndarray:
+    def path_batch(self, poses, results: np.ndarray, prev_paths=None) -> np.ndarray:
+        """prev_paths (n,40,4): CalculatePath.previous_paths[-1] of every frame's planner (None = fresh planners)."""
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 4)
         results = np.ascontiguousarray(results)
         assert results.dtype == RESULT_DTYPE and len(results) == len(poses)
-        self._check(self._lib.fsdp_path_batch(self._h, len(poses), _dp(poses), ctypes.c_void_p(results.ctypes.data)), "fsdp_path_batch")
+        prev = None if prev_paths is None else _dp(np.ascontiguousarray(prev_paths, np.float64).reshape(len(poses), PATH_POINTS, 4))
+        self._check(self._lib.fsdp_path_batch(self._h, len(poses), _dp(poses), prev, ctypes.c_void_p(results.ctypes.data)), "fsdp_path_batch")
         return results
 
     # resident API
@@ -185,8 +190,8 @@ class Context:
         self._check(self._lib.fsdp_set_global_path(self._h, _dp(xy), ctypes.c_int(len(xy))), "fsdp_set_global_path")
 
     def set_overlap(self, depth: int):
-        """depth 2: consecutive run() passes alternate between two streams / buffer sets and overlap (streams of batches);
-        depth 1 (default): one pass after the other."""
+        """depth d (1..4): consecutive run() passes rotate through d HIP streams / buffer sets and overlap (a replay is a
+        stream of batches); depth 1 (default): one pass after the other."""
         self._check(self._lib.fsdp_set_overlap(self._h, int(depth)), "fsdp_set_overlap")
 
     def run(self):
@@ -196,7 +201,8 @@ class Context:
         self._check(self._lib.fsdp_sync(self._h), "fsdp_sync")
 
     def download(self) -> np.ndarray:
-        out = np.zeros(self.n_frames, dtype=RESULT_DTYPE)
+        # sized from the library's own count: stage-level calls change the resident batch behind this object's back
+        out = np.zeros(int(self._lib.fsdp_resident_frames(self._h)), dtype=RESULT_DTYPE)
         self._check(self._lib.fsdp_download(self._h, ctypes.c_void_p(out.ctypes.data)), "fsdp_download")
         return out
 

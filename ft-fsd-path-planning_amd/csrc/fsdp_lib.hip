@@ -35,6 +35,7 @@ struct fsdp_ctx {
   int cap_frames = 0;
   size_t cap_cones = 0;
   int n_frames = 0;
+  bool resident = false;  // d_off / d_cones / d_poses describe n_frames frames fsdp_run may plan
   // device buffers
   int32_t* d_off = nullptr;
   double* d_cones = nullptr;
@@ -71,17 +72,21 @@ struct fsdp_ctx {
   double* d_table = nullptr;
   double* d_noise = nullptr;
   SkidTables tables = {};
+  double skid_consts[5] = {};  // reference centres (right xy, left xy) + table spacing, computed on the device
   bool have_tables = false;
   SkidState* d_skid = nullptr;
   SkidState* d_skid_backup = nullptr;
   SkidInfo* d_skid_info = nullptr;
   int32_t* d_skid_status = nullptr;
   int n_instances = 0;
-  std::vector<SkidInfo> h_skid_info;
-  // pinned host staging for results
-  std::vector<SortOut> h_sort;
-  std::vector<MatchOut> h_match;
-  std::vector<PathOut> h_path;
+  // pinned host staging for results (hipHostMalloc; grown by ensure_staging): D2H copies are true async DMA
+  SortOut* h_sort = nullptr;
+  MatchOut* h_match = nullptr;
+  PathOut* h_path = nullptr;
+  SkidInfo* h_skid_info = nullptr;
+  int cap_staging = 0;
+  // previous-path pointer the most recent launch of each slot used (the knot-overflow re-plan must see the same one)
+  const double* slot_prev[FSDP_MAX_OVERLAP] = {};
 };
 
 #define HIP_TRY(ctx, call)                                                                       \
@@ -142,7 +147,29 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
   return 0;
 }
 
+// pinned result staging for n frames
+static int ensure_staging(fsdp_ctx* c, int n) {
+  if (n <= c->cap_staging) return 0;
+  if (c->h_sort) (void)hipHostFree(c->h_sort);
+  if (c->h_match) (void)hipHostFree(c->h_match);
+  if (c->h_path) (void)hipHostFree(c->h_path);
+  if (c->h_skid_info) (void)hipHostFree(c->h_skid_info);
+  c->h_sort = nullptr;
+  c->h_match = nullptr;
+  c->h_path = nullptr;
+  c->h_skid_info = nullptr;
+  c->cap_staging = 0;
+  const size_t want = (size_t)(n < 64 ? 64 : n);
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_sort, sizeof(SortOut) * want, hipHostMallocDefault));
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_match, sizeof(MatchOut) * want, hipHostMallocDefault));
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_path, sizeof(PathOut) * want, hipHostMallocDefault));
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_skid_info, sizeof(SkidInfo) * want, hipHostMallocDefault));
+  c->cap_staging = (int)want;
+  return 0;
+}
+
 struct Slot {
+  int index;
   hipStream_t stream;
   SortOut* d_sort;
   MatchOut* d_match;
@@ -151,9 +178,9 @@ struct Slot {
   int* d_retry;  // [0] counter + frames the packed path kernel could not finish (knot capacity)
 };
 static Slot slot_of(fsdp_ctx* c, int i) {
-  if (i == 0) return Slot{c->stream, c->d_sort, c->d_match, c->d_path, c->d_arena, c->d_retry};
+  if (i == 0) return Slot{0, c->stream, c->d_sort, c->d_match, c->d_path, c->d_arena, c->d_retry};
   const fsdp_ctx::Extra& x = c->extra[i - 1];
-  return Slot{x.stream, x.d_sort, x.d_match, x.d_path, x.d_arena, x.d_retry};
+  return Slot{i, x.stream, x.d_sort, x.d_match, x.d_path, x.d_arena, x.d_retry};
 }
 
 static int ensure_extra_slots(fsdp_ctx* c) {
@@ -201,9 +228,10 @@ static void launch_match(fsdp_ctx* c, const Slot& q) {
 }
 template <int G>
 static void launch_path_g(fsdp_ctx* c, const Slot& q, int* retry) {
+  const double* prev = c->use_prev ? c->d_prev : nullptr;
+  c->slot_prev[q.index] = prev;  // finish_knot_overflow re-plans with the previous paths this launch saw
   hipLaunchKernelGGL(path_kernel<G>, dim3((c->n_frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, c->n_frames,
-                     c->d_poses, q.d_match, c->d_default_path, c->use_prev ? c->d_prev : nullptr, c->d_gpath, c->n_gpath, q.d_arena,
-                     q.d_path, retry);
+                     c->d_poses, q.d_match, c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, retry);
 }
 // lanes per frame: see path_kernel.h (results do not depend on the choice)
 static void launch_path(fsdp_ctx* c, const Slot& q) {
@@ -241,8 +269,8 @@ static int finish_knot_overflow(fsdp_ctx* c, const Slot& q) {
   HIP_TRY(c, hipMemcpyAsync(q.d_retry, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, q.stream));
   const int blocks = list[0] < 1024 ? list[0] : 1024;
   hipLaunchKernelGGL(path_retry_kernel, dim3(blocks), dim3(WAVE), 0, q.stream, c->d_poses, q.d_match, c->d_default_path,
-                     c->use_prev ? c->d_prev : nullptr, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry);
-  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), q.d_path, sizeof(PathOut) * (size_t)c->n_frames, hipMemcpyDeviceToHost, q.stream));
+                     c->slot_prev[q.index], c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry);
+  HIP_TRY(c, hipMemcpyAsync(c->h_path, q.d_path, sizeof(PathOut) * (size_t)c->n_frames, hipMemcpyDeviceToHost, q.stream));
   HIP_TRY(c, hipStreamSynchronize(q.stream));
   return 0;
 }
@@ -373,6 +401,10 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_skid_info);
   (void)hipFree(c->d_skid_status);
   (void)hipFree(c->d_default_path);
+  if (c->h_sort) (void)hipHostFree(c->h_sort);
+  if (c->h_match) (void)hipHostFree(c->h_match);
+  if (c->h_path) (void)hipHostFree(c->h_path);
+  if (c->h_skid_info) (void)hipHostFree(c->h_skid_info);
   for (int i = 0; i < FSDP_MAX_OVERLAP - 1; i++) {
     fsdp_ctx::Extra& x = c->extra[i];
     if (x.stream) (void)hipStreamSynchronize(x.stream);
@@ -398,6 +430,15 @@ int fsdp_upload(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
     c->err = "cone_offsets[0] must be 0";
     return 1;
   }
+  for (int i = 0; i < n_frames; i++)
+    if (off[i + 1] < off[i]) {
+      c->err = "cone_offsets must be non-decreasing";
+      return 1;
+    }
+  if (total > 0 && !cones) {
+    c->err = "cones_xyt is NULL";
+    return 1;
+  }
   int rc = sync_all(c);  // passes in flight still read the old inputs
   if (rc) return rc;
   rc = ensure_capacity(c, n_frames > 0 ? n_frames : 1, total);
@@ -405,6 +446,7 @@ int fsdp_upload(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
   rc = ensure_extra_slots(c);
   if (rc) return rc;
   c->n_frames = n_frames;
+  c->resident = true;
   c->last_slot = 0;
   if (n_frames == 0) return 0;
   HIP_TRY(c, hipMemcpyAsync(c->d_off, off, sizeof(int32_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, c->stream));
@@ -428,6 +470,10 @@ int fsdp_set_overlap(fsdp_ctx* c, int depth) {
 int fsdp_run(fsdp_ctx* c) {
   if (!c) return 1;
   if (c->n_frames == 0) return 0;
+  if (!c->resident) {
+    c->err = "fsdp_run: no resident batch (fsdp_upload first; stage-level calls replace the resident batch)";
+    return 1;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
   const int si = (c->overlap > 1) ? (int)(c->turn++ % (unsigned)c->overlap) : 0;
   const Slot q = slot_of(c, si);
@@ -439,8 +485,11 @@ int fsdp_run(fsdp_ctx* c) {
   return 0;
 }
 
+int fsdp_resident_frames(const fsdp_ctx* c) { return c ? c->n_frames : 0; }
+
 int fsdp_sync(fsdp_ctx* c) {
   if (!c) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
   return sync_all(c);
 }
 
@@ -448,13 +497,13 @@ int fsdp_download(fsdp_ctx* c, fsdp_frame_result* results) {
   if (!c || (c->n_frames > 0 && !results)) return 1;
   const int n = c->n_frames;
   if (n == 0) return 0;
-  c->h_sort.resize(n);
-  c->h_match.resize(n);
-  c->h_path.resize(n);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rcs = ensure_staging(c, n);
+  if (rcs) return rcs;
   const Slot q = slot_of(c, c->last_slot);  // the most recent pass
-  HIP_TRY(c, hipMemcpyAsync(c->h_sort.data(), q.d_sort, sizeof(SortOut) * n, hipMemcpyDeviceToHost, q.stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_match.data(), q.d_match, sizeof(MatchOut) * n, hipMemcpyDeviceToHost, q.stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), q.d_path, sizeof(PathOut) * n, hipMemcpyDeviceToHost, q.stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_sort, q.d_sort, sizeof(SortOut) * n, hipMemcpyDeviceToHost, q.stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_match, q.d_match, sizeof(MatchOut) * n, hipMemcpyDeviceToHost, q.stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_path, q.d_path, sizeof(PathOut) * n, hipMemcpyDeviceToHost, q.stream));
   int rc = sync_all(c);
   if (rc) return rc;
   rc = finish_knot_overflow(c, q);
@@ -468,6 +517,7 @@ int fsdp_download(fsdp_ctx* c, fsdp_frame_result* results) {
 
 int fsdp_set_previous_paths(fsdp_ctx* c, const double* prev_paths) {
   if (!c) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
   if (!prev_paths) {
     c->use_prev = false;
     return 0;
@@ -507,9 +557,9 @@ int fsdp_plan_batch_sequential(fsdp_ctx* c, int n_frames, const int32_t* off, co
   rc = fsdp_set_previous_paths(c, prev_paths);
   if (rc) return rc;
   rc = fsdp_run(c);
-  c->use_prev = false;
-  if (rc) return rc;
-  return fsdp_download(c, results);
+  if (rc == 0) rc = fsdp_download(c, results);
+  c->use_prev = false;  // one-shot: the resident form keeps them until fsdp_set_previous_paths(NULL)
+  return rc;
 }
 
 int fsdp_plan_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses,
@@ -527,6 +577,10 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
     if (ms_total) *ms_total = 0;
     if (ms_stage) ms_stage[0] = ms_stage[1] = ms_stage[2] = 0;
     return 0;
+  }
+  if (!c->resident) {
+    c->err = "fsdp_time_runs: no resident batch";
+    return 1;
   }
   HIP_TRY(c, hipSetDevice(c->device));
   int rc = sync_all(c);
@@ -596,8 +650,8 @@ int fsdp_sort_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double*
   if (rc) return rc;
   if (n_frames == 0) return 0;
   launch_sort(c);
-  c->h_sort.resize(n_frames);
-  HIP_TRY(c, hipMemcpyAsync(c->h_sort.data(), c->d_sort, sizeof(SortOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
+  if (int rcs = ensure_staging(c, n_frames)) return rcs;
+  HIP_TRY(c, hipMemcpyAsync(c->h_sort, c->d_sort, sizeof(SortOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n_frames; i++) {
     memset(&results[i], 0, sizeof(fsdp_frame_result));
@@ -610,6 +664,7 @@ int fsdp_match_batch(fsdp_ctx* c, int n_frames, const double* sorted_left, const
                      const int32_t* n_right, const double* poses, fsdp_frame_result* results) {
   if (!c || n_frames < 0) return 1;
   if (n_frames == 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
   // express the already sorted cones as a tiny frame each: cones = [left..., right...], indices 0..nl-1 / nl..nl+nr-1
   std::vector<int32_t> off(n_frames + 1, 0);
   std::vector<double> cones;
@@ -642,8 +697,8 @@ int fsdp_match_batch(fsdp_ctx* c, int n_frames, const double* sorted_left, const
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_sort, so.data(), sizeof(SortOut) * n_frames, hipMemcpyHostToDevice, c->stream));
   launch_match(c);
-  c->h_match.resize(n_frames);
-  HIP_TRY(c, hipMemcpyAsync(c->h_match.data(), c->d_match, sizeof(MatchOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
+  if (int rcs = ensure_staging(c, n_frames)) return rcs;
+  HIP_TRY(c, hipMemcpyAsync(c->h_match, c->d_match, sizeof(MatchOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n_frames; i++) {
     memset(&results[i], 0, sizeof(fsdp_frame_result));
@@ -652,12 +707,17 @@ int fsdp_match_batch(fsdp_ctx* c, int n_frames, const double* sorted_left, const
   return 0;
 }
 
-int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, fsdp_frame_result* results) {
+int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, const double* prev_paths, fsdp_frame_result* results) {
   if (!c || n_frames < 0) return 1;
   if (n_frames == 0) return 0;
-  int rc = ensure_capacity(c, n_frames, 1);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = sync_all(c);  // passes in flight still use the buffers ensure_capacity may replace
+  if (rc) return rc;
+  rc = ensure_capacity(c, n_frames, 1);
   if (rc) return rc;
   c->n_frames = n_frames;
+  c->resident = false;  // offsets / cones of an earlier upload no longer describe this batch
+  c->last_slot = 0;
   std::vector<MatchOut> mo(n_frames);
   for (int f = 0; f < n_frames; f++) {
     memset(&mo[f], 0, sizeof(MatchOut));
@@ -675,9 +735,14 @@ int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, fsdp_frame_r
   }
   HIP_TRY(c, hipMemcpyAsync(c->d_match, mo.data(), sizeof(MatchOut) * n_frames, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, c->stream));
+  if (prev_paths)
+    HIP_TRY(c, hipMemcpyAsync(c->d_prev, prev_paths, sizeof(double) * PATH_POINTS * 4 * (size_t)n_frames, hipMemcpyHostToDevice,
+                              c->stream));
+  c->use_prev = prev_paths != nullptr;
   launch_path(c);
-  c->h_path.resize(n_frames);
-  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), c->d_path, sizeof(PathOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
+  c->use_prev = false;  // resident previous paths belonged to the batch this call replaced
+  if (int rcs = ensure_staging(c, n_frames)) return rcs;
+  HIP_TRY(c, hipMemcpyAsync(c->h_path, c->d_path, sizeof(PathOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   rc = finish_knot_overflow(c, slot_of(c, 0));
   if (rc) return rc;
@@ -715,10 +780,11 @@ int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
 }
 #endif
 
-int fsdp_skidpad_set_tables(fsdp_ctx* c, const double* table_xy, int n_table, const double* noise, int n_noise,
-                            const double* ref4, double mean_distance) {
-  if (!c || !table_xy || n_table < 20 || !noise || n_noise < 6 || !ref4) return 1;
+int fsdp_skidpad_set_tables(fsdp_ctx* c, const double* table_xy, int n_table, const double* noise, int n_noise) {
+  if (!c || !table_xy || n_table < 20 || n_table > 8192 || !noise || n_noise < 6) return 1;
   HIP_TRY(c, hipSetDevice(c->device));
+  int rc = sync_all(c);
+  if (rc) return rc;
   // known global path = table[::2] (skidpad_relocalizer.py:242-243)
   std::vector<double> half;
   for (int i = 0; i < n_table; i += 2) {
@@ -727,20 +793,41 @@ int fsdp_skidpad_set_tables(fsdp_ctx* c, const double* table_xy, int n_table, co
   }
   if (c->d_table) (void)hipFree(c->d_table);
   if (c->d_noise) (void)hipFree(c->d_noise);
+  c->d_table = c->d_noise = nullptr;
+  c->have_tables = false;
   HIP_TRY(c, hipMalloc(&c->d_table, sizeof(double) * half.size()));
   HIP_TRY(c, hipMalloc(&c->d_noise, sizeof(double) * (size_t)n_noise));
   HIP_TRY(c, copy_sync(c, c->d_table, half.data(), sizeof(double) * half.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, copy_sync(c, c->d_noise, noise, sizeof(double) * (size_t)n_noise, hipMemcpyHostToDevice));
+  // the two reference centres and the table spacing are derived from the table on the device (skid_centers_kernel)
+  double *d_full = nullptr, *d_scratch = nullptr, *d_out = nullptr;
+  HIP_TRY(c, hipMalloc(&d_full, sizeof(double) * 2 * (size_t)n_table));
+  HIP_TRY(c, hipMalloc(&d_scratch, sizeof(double) * 3 * (size_t)n_table));
+  HIP_TRY(c, hipMalloc(&d_out, sizeof(double) * 5));
+  HIP_TRY(c, hipMemcpyAsync(d_full, table_xy, sizeof(double) * 2 * (size_t)n_table, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(skid_centers_kernel, dim3(1), dim3(WAVE), 0, c->stream, d_full, n_table, d_scratch, d_out);
+  hipError_t e = hipMemcpyAsync(c->skid_consts, d_out, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_full);
+  (void)hipFree(d_scratch);
+  (void)hipFree(d_out);
+  HIP_TRY(c, e);
   c->tables.path = c->d_table;
   c->tables.n_path = (int)(half.size() / 2);
   c->tables.noise = c->d_noise;
   c->tables.n_noise = n_noise;
-  c->tables.ref_right[0] = ref4[0];
-  c->tables.ref_right[1] = ref4[1];
-  c->tables.ref_left[0] = ref4[2];
-  c->tables.ref_left[1] = ref4[3];
-  c->tables.mean_distance = mean_distance;
+  c->tables.ref_right[0] = c->skid_consts[0];
+  c->tables.ref_right[1] = c->skid_consts[1];
+  c->tables.ref_left[0] = c->skid_consts[2];
+  c->tables.ref_left[1] = c->skid_consts[3];
+  c->tables.mean_distance = c->skid_consts[4];
   c->have_tables = true;
+  return 0;
+}
+
+int fsdp_skidpad_constants(fsdp_ctx* c, double* out5) {
+  if (!c || !out5 || !c->have_tables) return 1;
+  memcpy(out5, c->skid_consts, sizeof(double) * 5);
   return 0;
 }
 
@@ -787,12 +874,12 @@ int fsdp_skidpad_step(fsdp_ctx* c, int n_instances, const int32_t* off, const do
   }
   int rc = fsdp_upload(c, n_instances, off, cones, poses);
   if (rc) return rc;
+  c->resident = false;  // skidpad frames are not a batch fsdp_run may replay
   launch_skid(c, true);
   HIP_TRY(c, hipGetLastError());
-  c->h_path.resize(n_instances);
-  c->h_skid_info.resize(n_instances);
-  HIP_TRY(c, hipMemcpyAsync(c->h_path.data(), c->d_path, sizeof(PathOut) * n_instances, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_skid_info.data(), c->d_skid_info, sizeof(SkidInfo) * n_instances, hipMemcpyDeviceToHost, c->stream));
+  if (int rcs = ensure_staging(c, n_instances)) return rcs;
+  HIP_TRY(c, hipMemcpyAsync(c->h_path, c->d_path, sizeof(PathOut) * n_instances, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_skid_info, c->d_skid_info, sizeof(SkidInfo) * n_instances, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n_instances; i++) {
     if (results) {
@@ -831,6 +918,7 @@ int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
 
 int fsdp_default_path(fsdp_ctx* c, double* out) {
   if (!c || !out) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, copy_sync(c, out, c->d_default_path, sizeof(double) * PATH_POINTS * 4, hipMemcpyDeviceToHost));
   return 0;
 }

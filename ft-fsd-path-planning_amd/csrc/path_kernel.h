@@ -89,6 +89,8 @@ __device__ inline double pw_rec(const double* a, int n) {
   }
 }
 __device__ inline double np_sum_run(const double* a, int n) { return 0.0 + pw_rec<4>(a, n); }
+// the same for runs of up to 8192 elements (the skidpad table's circle fits)
+__device__ inline double np_sum_long(const double* a, int n) { return 0.0 + pw_rec<6>(a, n); }
 
 // NumPy pairwise sums (n <= 128: 8 interleaved accumulators, then the tail) of NS series at once: f(i, v) fills v[0..NS)
 // with the i-th element of every series.  Each series is summed exactly as np_sum_fn sums it; the operands are fetched

@@ -54,6 +54,90 @@ struct SkidShared {
   int32_t n_roots;
 };
 
+// calculate_reference_centers_for_skidpad_path (skidpad_relocalizer.py:172-183): hyper circle fits
+// (utils/math_utils.py:579-646) of the table points with y < -2 (right circle) and y > 2 (left circle).  One-off per
+// context, one wavefront: lanes compact the points and form the element-wise products, the np.sum reductions run in
+// NumPy's pairwise order (uniform across the wave).  scratch: 3 * n_table doubles.  out4[0..5) = right xy, left xy, and
+// the mean spacing of the known path.
+__global__ void __launch_bounds__(64) skid_centers_kernel(const double* __restrict__ table, int n_table,
+                                                          double* __restrict__ scratch, double* __restrict__ out4) {
+  const int lane = lane_id();
+  double* X = scratch;
+  double* Y = scratch + n_table;
+  double* P = scratch + 2 * (size_t)n_table;
+  for (int side = 0; side < 2; side++) {
+    int n = 0;
+    for (int base = 0; base < n_table; base += WAVE) {
+      const int i = base + lane;
+      double x = 0, y = 0;
+      bool keep = false;
+      if (i < n_table) {
+        x = table[2 * i];
+        y = table[2 * i + 1];
+        keep = side == 0 ? (y < -2) : (y > 2);
+      }
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int p = n + __popcll(m & ((1ull << lane) - 1ull));
+        X[p] = x;
+        Y[p] = y;
+      }
+      n += __popcll(m);
+    }
+    __syncthreads();
+    const double dn = (double)n;
+    const double xm = np_sum_long(X, n) / dn, ym = np_sum_long(Y, n) / dn;
+    // Mxy, Mxx, Myy, Mxz, Myz, Mzz: each product array is materialised, then np.sum'ed
+    double M[6];
+    for (int q = 0; q < 6; q++) {
+      __syncthreads();
+      for (int i = lane; i < n; i += WAVE) {
+        const double a = X[i] - xm, b = Y[i] - ym;
+        const double z = a * a + b * b;
+        P[i] = q == 0 ? a * b : q == 1 ? a * a : q == 2 ? b * b : q == 3 ? a * z : q == 4 ? b * z : z * z;
+      }
+      __syncthreads();
+      M[q] = np_sum_long(P, n) / dn;
+    }
+    const double Mxy = M[0], Mxx = M[1], Myy = M[2], Mxz = M[3], Myz = M[4], Mzz = M[5];
+    const double Mz = Mxx + Myy;
+    const double Cov_xy = Mxx * Myy - Mxy * Mxy;
+    const double Var_z = Mzz - Mz * Mz;
+    const double A2 = 4 * Cov_xy - 3 * Mz * Mz - Mzz;
+    const double A1 = Var_z * Mz + 4.0 * Cov_xy * Mz - Mxz * Mxz - Myz * Myz;
+    const double A0 = Mxz * (Mxz * Myy - Myz * Mxy) + Myz * (Myz * Mxx - Mxz * Mxy) - Var_z * Cov_xy;
+    const double A22 = A2 + A2;
+    double y = A0, x = 0.0;
+    for (int it = 0; it < 99; it++) {
+      const double Dy = A1 + x * (A22 + 16.0 * x * x);
+      const double x_new = x - y / Dy;
+      if (x_new == x || !isfinite(x_new)) break;
+      const double y_new = A0 + x_new * (A1 + x_new * (A2 + 4.0 * x_new * x_new));
+      if (fabs(y_new) >= fabs(y)) break;
+      x = x_new;
+      y = y_new;
+    }
+    const double det = x * x - x * Mz + Cov_xy;
+    const double Xc = (Mxz * (Myy - x) - Myz * Mxy) / det / 2.0;
+    const double Yc = (Myz * (Mxx - x) - Mxz * Mxy) / det / 2.0;
+    if (lane == 0) {
+      out4[2 * side] = Xc + xm;
+      out4[2 * side + 1] = Yc + ym;
+    }
+    __syncthreads();
+  }
+  // skidpad_calculate_path.py:58: np.mean(np.linalg.norm(np.diff(path[:10], axis=-2), axis=-1)) of the known path
+  // (= table[::2]); nine segment lengths, np.mean = pairwise sum / 9
+  if (lane == 0) {
+    double seg[9];
+    for (int i = 0; i < 9; i++) {
+      const double dx = table[2 * (2 * (i + 1))] - table[2 * (2 * i)], dy = table[2 * (2 * (i + 1)) + 1] - table[2 * (2 * i) + 1];
+      seg[i] = sqrt(dx * dx + dy * dy);
+    }
+    out4[4] = np_sum_small(seg, 9) / 9.0;
+  }
+}
+
 // unrank the s-th 3-subset of {0..m-1} in itertools.combinations order
 __device__ inline void unrank3(int s, int m, int& a, int& b, int& c) {
   a = 0;

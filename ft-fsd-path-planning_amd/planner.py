@@ -40,11 +40,44 @@ class MissionTypes(IntEnum):
 
 
 class ReferenceUndefinedError(RuntimeError):
-    """The reference raises on this input (status 101-104); which exception is reported in .status"""
+    """The reference raises on this input (status 101-104, include/fsdp.h).  ``raise_for_status`` raises the subclass
+    that is also an instance of the exception type the reference raises, so a caller's ``except IndexError`` /
+    ``except np.linalg.LinAlgError`` written against the reference keeps firing."""
 
     def __init__(self, status: int):
         super().__init__(f"the reference implementation raises on this frame (status {status}, see include/fsdp.h)")
         self.status = status
+
+
+class ReferenceIndexError(ReferenceUndefinedError, IndexError):
+    """101: nearby_cone_search.py:88-94 (searchsorted index == len); 102: end_configurations.py:369 (DFS position past
+    target_length); 104: core_calculate_path.py:544 (index into an empty array) — IndexError in the reference."""
+
+
+class ReferenceLinAlgError(ReferenceUndefinedError, np.linalg.LinAlgError):
+    """103: core_calculate_path.py:482-483 hands a (40,4) array on in a (n,2) context -> numpy.linalg.LinAlgError
+    (a ValueError) raised from the second do_all_mpc_parameter_calculations call, outside the try (:564-570)."""
+
+
+class CapacityError(_capi.FsdpError):
+    """status 2xx: a fixed device capacity was exceeded (the reference's buffers grow without bound)."""
+
+    def __init__(self, status: int):
+        super().__init__(f"device capacity exceeded (status {status}, see include/fsdp.h)")
+        self.status = status
+
+
+_STATUS_EXC = {101: ReferenceIndexError, 102: ReferenceIndexError, 103: ReferenceLinAlgError, 104: ReferenceIndexError}
+
+
+def raise_for_status(status) -> None:
+    """Per-frame status -> the exception the reference-shaped single-frame calls raise (0 returns)."""
+    status = int(status)
+    if status == 0:
+        return
+    if 100 <= status < 200:
+        raise _STATUS_EXC.get(status, ReferenceUndefinedError)(status)
+    raise CapacityError(status)
 
 
 def flatten_cones_by_type_array(cones_by_type) -> np.ndarray:
@@ -52,8 +85,6 @@ def flatten_cones_by_type_array(cones_by_type) -> np.ndarray:
     if isinstance(cones_by_type, np.ndarray) and cones_by_type.ndim == 2 and cones_by_type.shape[1] == 3:
         return np.ascontiguousarray(cones_by_type, dtype=np.float64)
     parts = []
-    for t in ConeTypes.__members__.values():
-        pass
     for t in (0, 1, 2, 3, 4):
         c = np.asarray(cones_by_type[t], dtype=np.float64).reshape(-1, 2)
         parts.append(np.column_stack([c, np.full(len(c), float(t))]))
@@ -151,21 +182,19 @@ class PathPlanner:
             yaw = np.arctan2(direction[1], direction[0])
             position, yaw = acc.to_known_frame(position, yaw)
             direction = np.array([np.cos(yaw), np.sin(yaw)])
-            if self.global_path is None:
-                from .acceleration import known_path
+            # full_pipeline.py:134: the known path replaces whatever global path was set before, on every call
+            from .acceleration import known_path
 
-                self.set_global_path(known_path())
+            kp = known_path()
+            if self.global_path is None or self.global_path.shape != kp.shape or not np.array_equal(self.global_path, kp):
+                self.set_global_path(kp)
         pose_k = np.concatenate([position, direction])[None]
         off0, none = np.zeros(2, np.int32), np.zeros((0, 3))
         if self._prev is not None:
             r = self._ctx.plan_batch_sequential(off0, none, pose_k, self._prev[None])[0]
         else:
             r = self._ctx.plan_batch(off0, none, pose_k)[0]
-        st = int(r["status"])
-        if 100 <= st < 200:
-            raise ReferenceUndefinedError(st)
-        if st != 0:
-            raise _capi.FsdpError(f"device capacity exceeded (status {st}, see include/fsdp.h)")
+        raise_for_status(r["status"])
         path = np.array(r["path"])
         self._prev = path.copy()  # the path stage keeps its history in the frame it computed in
         if acc.is_relocalized:
@@ -197,11 +226,7 @@ class PathPlanner:
             # skidpad: stateful call; sorting and matching are skipped (full_pipeline.py:138-140)
             res, info = self._skid.step(np.array([0, len(xyt)], np.int32), xyt, pose[None])
             self._skid_info = info[0]
-            st = int(res[0]["status"])
-            if 100 <= st < 200:
-                raise ReferenceUndefinedError(st)
-            if st != 0:
-                raise _capi.FsdpError(f"device capacity exceeded (status {st}, see include/fsdp.h)")
+            raise_for_status(res[0]["status"])
             path = np.array(res[0]["path"])
             if not return_intermediate_results:
                 return path
@@ -214,11 +239,7 @@ class PathPlanner:
             r = self._ctx.plan_batch_sequential(off1, xyt, pose[None], self._prev[None])[0]
         else:
             r = self._ctx.plan_batch(off1, xyt, pose[None])[0]
-        st = int(r["status"])
-        if 100 <= st < 200:
-            raise ReferenceUndefinedError(st)
-        if st != 0:
-            raise _capi.FsdpError(f"device capacity exceeded (status {st}, see include/fsdp.h)")
+        raise_for_status(r["status"])
         path = np.array(r["path"])
         if self.stateful:
             self._prev = path.copy()

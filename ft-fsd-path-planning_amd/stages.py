@@ -16,7 +16,7 @@ from typing import List, Tuple
 import numpy as np
 
 from . import _capi
-from .planner import ConeTypes, ReferenceUndefinedError, flatten_cones_by_type_array
+from .planner import ConeTypes, flatten_cones_by_type_array, raise_for_status
 
 _shared_ctx = {}
 
@@ -28,12 +28,7 @@ def _ctx(device=None):
     return _shared_ctx[key]
 
 
-def _check(status):
-    status = int(status)
-    if 100 <= status < 200:
-        raise ReferenceUndefinedError(status)
-    if status != 0:
-        raise _capi.FsdpError(f"device capacity exceeded (status {status})")
+_check = raise_for_status
 
 
 @dataclass
@@ -122,16 +117,19 @@ class PathCalculationInput:
 
 class CalculatePath:
     """Defaults of config.py:48,55-59 (smoothing 0.2, predict_every 0.1, max_deg 3, max valid distance 5 m, MPC length
-    20 m, horizon 40).  Each call starts from the constant initial previous path (fresh-planner semantics)."""
+    20 m, horizon 40).  Stateful like the reference object: the path a call returns is ``previous_paths[-1]`` of the next
+    call (core_calculate_path.py:572-573); ``stateful=False`` gives every call a fresh object."""
 
     DEFAULTS = dict(smoothing=0.2, predict_every=0.1, max_deg=3, maximal_distance_for_valid_path=5, mpc_path_length=20, mpc_prediction_horizon=40)
 
-    def __init__(self, device=None, **kwargs):
+    def __init__(self, device=None, stateful: bool = True, **kwargs):
         for k, v in kwargs.items():
             if k not in self.DEFAULTS or self.DEFAULTS[k] != v:
                 raise NotImplementedError(f"only the reference defaults are compiled into the kernel ({k}={v!r})")
         self.input = PathCalculationInput()
         self._device = device
+        self.stateful = stateful
+        self._prev = None
 
     def set_new_input(self, new_input: PathCalculationInput) -> None:
         self.input = new_input
@@ -151,10 +149,13 @@ class CalculatePath:
         if i.global_path is not None:  # core_calculate_path.py:514-529: the path is drawn from the global path
             ctx.set_global_path(i.global_path)
         try:
-            out = ctx.path_batch(pose[None], res)[0]
+            out = ctx.path_batch(pose[None], res, None if self._prev is None else self._prev[None])[0]
         finally:
             if i.global_path is not None:
                 ctx.set_global_path(None)
         _check(out["status"])
         self.last_result = out
-        return np.array(out["path"]), None
+        path = np.array(out["path"])
+        if self.stateful:
+            self._prev = path.copy()
+        return path, None

@@ -16,8 +16,8 @@
  * Conventions: plain C types, caller-allocated buffers, no exceptions across the ABI.
  * Return value 0 = success; non-zero = API misuse or HIP error (fsdp_last_error()).  Per-frame
  * conditions are reported in fsdp_frame_result.status, never through the return code.
- * A context is bound to one GPU and one HIP stream; contexts are independent (one per GPU /
- * per host thread).  All floating point is IEEE float64.
+ * A context is bound to one GPU and its own HIP streams; contexts are independent and may be interleaved from one host
+ * thread (every entry point selects its context's device first).  All floating point is IEEE float64.
  */
 #ifndef FSDP_H
 #define FSDP_H
@@ -122,6 +122,7 @@ int fsdp_set_global_path(fsdp_ctx* ctx, const double* xy, int n);
 int fsdp_upload(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses);
 int fsdp_run(fsdp_ctx* ctx);      /* enqueue sorting, matching, path kernels on the context stream (async) */
 int fsdp_sync(fsdp_ctx* ctx);     /* wait for the stream */
+int fsdp_resident_frames(const fsdp_ctx* ctx); /* frames of the batch the context currently holds (what fsdp_download writes) */
 int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
 
 /* Pass overlap for streams of batches (a replay feeds one batch after the other): depth d (<= FSDP_MAX_OVERLAP) gives
@@ -150,8 +151,9 @@ int fsdp_match_batch(fsdp_ctx* ctx, int n_frames, const double* sorted_left, con
                      const double* sorted_right, const int32_t* n_right, const double* poses,
                      fsdp_frame_result* results);
 /* CalculatePath.run_path_calculation — inputs: the matching fields of `results` (left_v, right_v, l2r, r2l,
- * counts) and poses; fills path, path_fallback, n_dense, status. */
-int fsdp_path_batch(fsdp_ctx* ctx, int n_frames, const double* poses, fsdp_frame_result* results);
+ * counts) and poses; prev_paths (n_frames,40,4) = CalculatePath.previous_paths[-1] of every frame's planner, or NULL for
+ * fresh planners; fills path, path_fallback, n_dense, status. */
+int fsdp_path_batch(fsdp_ctx* ctx, int n_frames, const double* poses, const double* prev_paths, fsdp_frame_result* results);
 
 /* ---- skidpad mission (BASELINE config 5): stateful planner instances ------------------------------------------------
  * PathPlanner(MissionTypes.skidpad) keeps state across calls (relocalizer transform, SkidpadCalculatePath.index_along_path,
@@ -166,12 +168,14 @@ typedef struct {
 } fsdp_skidpad_info;
 
 /* Constant inputs (data, not code): table_xy = the known skidpad path BASE_SKIDPAD_PATH (n_table,2)
- * (relocalization/skidpad/skidpad_path_data.py); noise_randn = numpy.random.RandomState(42).randn(1140,3,2) flattened
- * (circle_fit_powerset re-seeds on every call, skidpad_relocalizer.py:38,52); ref_centers = [right xy, left xy] of
- * calculate_reference_centers_for_skidpad_path (:172-183); mean_distance = np.mean of the first 9 segment lengths of
- * table_xy[::2] (skidpad_calculate_path.py:58).  The Python host computes the last three with NumPy. */
-int fsdp_skidpad_set_tables(fsdp_ctx* ctx, const double* table_xy, int n_table, const double* noise_randn, int n_noise,
-                            const double* ref_centers4, double mean_distance);
+ * (relocalization/skidpad/skidpad_path_data.py:10-5799); noise_randn = numpy.random.RandomState(42).randn(1140,3,2) flattened
+ * (circle_fit_powerset re-seeds on every call, skidpad_relocalizer.py:38,52).  What the reference derives from the table
+ * is derived here on the device: the two reference circle centres (calculate_reference_centers_for_skidpad_path,
+ * skidpad_relocalizer.py:172-183 -> utils/math_utils.py:579-646 hyper circle fit) and the table spacing
+ * (skidpad_calculate_path.py:58). */
+int fsdp_skidpad_set_tables(fsdp_ctx* ctx, const double* table_xy, int n_table, const double* noise_randn, int n_noise);
+/* out5 = [right centre xy, left centre xy, mean spacing] as the device computed them */
+int fsdp_skidpad_constants(fsdp_ctx* ctx, double* out5);
 /* (re)create n_instances fresh planners (PathPlanner.__init__ / "reset = construct a new object", README.md:153-154) */
 int fsdp_skidpad_reset(fsdp_ctx* ctx, int n_instances);
 /* one frame for every instance; results[i].path is in the caller's (original) frame like the reference's return value */

@@ -112,6 +112,12 @@ void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, c
   });
 }
 
+// calculate_reference_centers_for_skidpad_path + table spacing as the device derives them (out5)
+void emu_skidpad_constants(const double* table_xy, int n_table, double* out5) {
+  std::vector<double> scratch((size_t)3 * n_table);
+  emu::launch(1, 64, [&]() { fsdp::skid_centers_kernel(table_xy, n_table, scratch.data(), out5); });
+}
+
 void emu_set_prev_paths(const double* p) { g_prev_paths = p; }
 void emu_set_global_path(const double* xy, int n) {
   g_gpath = xy;

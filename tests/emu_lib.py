@@ -127,6 +127,14 @@ SKID_STATE_DTYPE = np.dtype(
 SKID_INFO_DTYPE = np.dtype([("relocalized", "<i4"), ("index_along_path", "<i4"), ("translation", "<f8", (2,)), ("rotation", "<f8")], align=True)
 
 
+def skidpad_constants(table):
+    """(reference centres (2,2) [right, left], table spacing) from csrc/skidpad_kernel.h skid_centers_kernel."""
+    table = np.ascontiguousarray(table, np.float64)
+    out = np.zeros(5)
+    lib().emu_skidpad_constants(_p(table), ctypes.c_int(len(table)), _p(out))
+    return out[:4].reshape(2, 2).copy(), float(out[4])
+
+
 class SkidpadEmu:
     """The skidpad kernels under the emulator: n planner instances, stateful."""
 

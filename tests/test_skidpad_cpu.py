@@ -17,15 +17,20 @@ def pkg():
 
 @pytest.fixture(scope="module")
 def tables(pkg):
-    return pkg.skidpad.load_tables()
+    table, noise = pkg.skidpad.load_tables()
+    ref, md = emu_lib.skidpad_constants(table)
+    return table, noise, ref, md
 
 
-def test_host_tables_match_reference(tables, golden_dir):
+def test_device_constants_match_reference(tables, golden_dir):
+    """skid_centers_kernel (kernel source under the emulator): the two reference centres the device derives from the table
+    are the reference's bits (skidpad_relocalizer.py:172-183), the spacing is NumPy's (skidpad_calculate_path.py:58)."""
     table, noise, ref, md = tables
     g = sk.load_sequence(golden_dir)
-    # skidpad_relocalizer.py:172-183 reference centres, host NumPy restatement == reference bits
     assert np.array_equal(ref, g["reference_centers"])
+    assert np.array_equal(ref.ravel(), oracle_lib.SkidpadPlanner(table, noise).reference_centers().ravel())
     assert table.shape == (5786, 2) and noise.shape == (1140, 3, 2)
+    assert md == float(np.mean(np.linalg.norm(np.diff(table[::2][:10], axis=-2), axis=-1)))
     assert int(20 / md) == 199 and int(25 / md) == 249  # SURVEY 8a K6
 
 

@@ -41,7 +41,11 @@ def test_perturbed_instances_equal_oracle(pkg, golden_dir):
     n = 64
     tf = sk.perturbed_instances(g, n)
     batch = pkg.SkidpadBatch(n, device=0)
-    table, noise, ref, md = batch.tables
+    table, noise = batch.tables
+    # the constants the device derived from the table == the reference's (golden) bits
+    ref, md = batch.constants
+    assert np.array_equal(ref, g["reference_centers"])
+    assert md == float(np.mean(np.linalg.norm(np.diff(table[::2][:10], axis=-2), axis=-1)))
     with oracle_lib.math_mode(1):
         ops = [oracle_lib.SkidpadPlanner(table, noise) for _ in range(n)]
         for t in range(80):
