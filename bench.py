@@ -2,13 +2,19 @@
 """bench.py — PathPlanner frames/s at 128 cones/frame on N MI355X (BASELINE.json metric).
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched by
-``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU).  A *step* is one pass of
-the whole hot path (sorting -> matching -> path kernels) over one batch of synthetic frames that is
-already resident in HBM.  Workload at N = 1: BASELINE configs[1] — batch 4096 synthetic replay frames,
-64 left + 64 right coloured cones (the FSG recording itself is absent from the reference checkout,
-.MISSING_LARGE_BLOBS).  Frames are independent, so ranks shard them with no data-path
-collective (weak scaling: 4096 frames per GPU); RCCL is used only to broadcast/verify the constant
-previous-path table at start-up and for the timing barrier.
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU; the launcher only provides RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_*: this process never imports torch — the communicator is RCCL behind the C ABI,
+include/fsdp.h fsdp_comm_*).  A *step* is one pass of the whole hot path (sorting -> matching -> path kernels) over
+one batch of synthetic frames that is already resident in HBM.
+
+``--config 2`` (default; the configuration the metric is quoted on): BASELINE configs[1] — batch 4096 synthetic replay
+frames per GPU, 64 left + 64 right coloured cones (the FSG recording itself is absent from the reference checkout,
+.MISSING_LARGE_BLOBS); weak scaling, every rank replays its own track.
+``--config 4``: BASELINE configs[3] — ONE global batch of 65 536 frames x 200 cones (Gaussian xy perturbation, sigma
+0.1 m) cut into contiguous frame ranges [g*B/G, (g+1)*B/G), one per rank; strong scaling.
+
+Frames are independent, so ranks shard them with no data-path collective; RCCL carries only the start-up broadcast /
+check of the constant previous-path table, the timing barrier and the max-reduction of the elapsed time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,10 +38,14 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-FRAMES_PER_GPU = 4096
+FRAMES_PER_GPU = 4096        # config 2
 CONES_PER_SIDE = 64
-# algorithmic bytes per frame = read N*24 + 32 (cones, pose) + write 1280 + 96 + 8
-ALGO_BYTES_PER_FRAME = 2 * CONES_PER_SIDE * 24 + 32 + 1280 + 96 + 8  # 4488 at N = 128
+CFG4_FRAMES, CFG4_CONES_PER_SIDE = 65536, 100  # config 4 (global batch)
+
+
+def algo_bytes_per_frame(cones_per_frame: int) -> int:
+    """read N*24 + 32 (cones, pose) + write 1280 + 96 + 8: 4488 at N = 128, 6216 at N = 200."""
+    return cones_per_frame * 24 + 32 + 1280 + 96 + 8
 PASS_OVERLAP = 4  # passes in flight in the timed region (fsdp_set_overlap); measured best of 1..8 (profiles/README.md)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -92,14 +102,42 @@ def cpu_baseline(off, cones, poses, budget_s: float = 12.0):
     }
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    produced by tools/profile_gpu.sh; FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); None if absent."""
+def _lib_hash(pkg) -> str:
+    import hashlib
+
+    return hashlib.sha256(Path(pkg._capi.LIB_PATH).read_bytes()).hexdigest()[:16]
+
+
+def _pmc(pkg):
+    """The committed rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by tools/profile_gpu.sh), but only when
+    they were collected from the very library this run loaded (recorded sha256): a stale file yields None."""
     try:
         d = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
-        return d[kernel]["hbm_bytes_per_launch"] / 1e9 if kernel in d else None
+        return d if d.get("lib_sha256_16") == _lib_hash(pkg) else None
     except Exception:
         return None
+
+
+def golden_flip_count(pkg, ctx):
+    """Sample-count flips (120 <-> 121 dense samples, DESIGN.md "arithmetic contract") against the REFERENCE on the
+    committed golden fuzz set (tests/golden/fuzz.npz: reference outputs captured by tests/golden/make_golden.py):
+    frames whose path differs from the reference's by more than 1e-5.  They can only be arc-extension frames."""
+    try:
+        g = np.load(ROOT / "tests" / "golden" / "fuzz.npz")
+        res = ctx.plan_batch(g["offsets"], g["cones"], g["poses"])
+        ok = g["ok"].astype(bool) & (res["status"] == 0)
+        err = np.zeros(len(res))
+        for k in np.nonzero(ok)[0]:
+            e = np.abs(res["path"][k] - g["path"][k])
+            err[k] = np.nanmax(e) if not np.isnan(e).all() else 0.0
+        arc = (res["path_fallback"] & 16) != 0
+        flips = ok & (err > 1e-5)
+        return {"frames": int(ok.sum()), "arc_frames": int((ok & arc).sum()), "flips": int(flips.sum()),
+                "flips_outside_arc_frames": int((flips & ~arc).sum()),
+                "max_err_other_frames": float(err[ok & ~flips].max()) if (ok & ~flips).any() else 0.0,
+                "set": "tests/golden/fuzz.npz (synthetic fuzz frames with the reference's outputs)"}
+    except Exception as e:  # the bench line must not die on a fixture problem
+        return {"error": repr(e)}
 
 
 def main():
@@ -107,6 +145,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="2: 4096 frames x 128 cones per GPU (weak; the metric's configuration); 4: 65536 x 200 cones in contiguous shards (strong)")
+    ap.add_argument("--frames", type=int, default=0, help="override the frame count (per GPU for config 2, global for config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="(always measured at N = 1; kept for compatibility)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
@@ -114,20 +155,42 @@ def main():
     args = ap.parse_args()
 
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
-    d = pkg.dist.Dist()  # nccl (= RCCL over xGMI) when WORLD_SIZE > 1
-    rank, local_rank, world = d.rank, d.local_rank, d.world
-
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ctx = pkg.Context(device=local_rank, mission=int(pkg.MissionTypes.trackdrive))
+    d = pkg.dist.Dist(ctx)  # WORLD_SIZE > 1: ncclCommInitRank on this rank's GPU (RCCL over xGMI), id exchange over TCP
+    world = d.world
+    assert "torch" not in sys.modules, "the product path must not pull in PyTorch"
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
 
-    # the only collective on this path: rank 0 broadcasts the constant previous-path table (RCCL over xGMI);
-    # every rank checks it against the table its own GPU computed at context creation.
+    # the only collectives on this path: rank 0 broadcasts the constant previous-path table (RCCL over xGMI), every
+    # rank checks it against the table its own GPU computed at context creation; then barriers / one max-reduction
     assert d.broadcast_check_table(ctx.default_path()), "previous-path table differs across ranks"
 
-    # this rank's shard: an independent 4096-frame replay (different track per rank)
-    off, cones, poses = pkg.synth.make_replay_batch(FRAMES_PER_GPU, CONES_PER_SIDE, 0.15, seed=d.shard_seed(1), color=True)
-    # a replay is a stream of batches: consecutive passes alternate between two HIP streams / buffer sets so that the
-    # next pass fills the compute units the slowest frames of the previous pass no longer occupy (fsdp_set_overlap)
-    ctx.set_overlap(1 if args.no_overlap else args.overlap)
+    if args.config == 2:
+        # weak scaling: this rank's own 4096-frame replay (a different track per rank)
+        per_gpu = args.frames or FRAMES_PER_GPU
+        cones_per_frame = 2 * CONES_PER_SIDE
+        off, cones, poses = pkg.synth.make_replay_batch(per_gpu, CONES_PER_SIDE, 0.15, seed=d.shard_seed(1), color=True)
+        frames_global = per_gpu * world
+        workload = f"BASELINE configs[1]: batch={per_gpu} synthetic autocross replay frames per GPU, 64 L + 64 R coloured cones"
+        scaling = "weak"
+    else:
+        # strong scaling: contiguous shard [lo, hi) of ONE global batch; frame f depends on (seed, f) only
+        frames_global = args.frames or CFG4_FRAMES
+        cones_per_frame = 2 * CFG4_CONES_PER_SIDE
+        lo, hi = d.frame_range(frames_global)
+        off, cones, poses = pkg.synth.make_config4_shard(lo, hi, CFG4_CONES_PER_SIDE, 0.1, seed=7)
+        workload = (f"BASELINE configs[3]: {frames_global} synthetic frames x 200 cones, Gaussian xy perturbation sigma 0.1 m, "
+                    f"contiguous shards of {hi - lo} frames per GPU")
+        scaling = "strong"
+    n_local = len(off) - 1
+    algo_bytes = algo_bytes_per_frame(cones_per_frame)
+    # a replay is a stream of batches: consecutive passes rotate through `overlap` HIP streams / buffer sets so that the
+    # next passes fill the compute units the slowest frames of the previous ones no longer occupy (fsdp_set_overlap)
+    overlap = 1 if args.no_overlap else args.overlap
+    ctx.set_overlap(overlap)
     ctx.upload(off, cones, poses)
 
     for _ in range(args.warmup):
@@ -141,26 +204,27 @@ def main():
     ctx.sync()
     d.barrier()
     elapsed = d.max_over_ranks(time.perf_counter() - t0)
+    names = ctx.stage_names()
     stage_ms = [x / args.steps for x in ev_stage_ms]
 
     # for reference: the same kernels one pass after the other (no overlap) — per-launch durations without chip sharing
     ctx.set_overlap(1)
     n_ser = max(3, min(args.steps, 10))
     ser_total_ms, ser_stage_ms = ctx.time_runs(n_ser)
+    names_serial = ctx.stage_names()
     serial_ms = [x / n_ser for x in ser_stage_ms]
     res = ctx.download()
     status_hist = {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}
+    arc_frames = int(((res["path_fallback"] & 16) != 0).sum())
 
     if rank == 0:
-        frames_total = FRAMES_PER_GPU * world * args.steps
-        value = frames_total / elapsed
-        # the library launches the path kernel with 8 lanes per frame when passes overlap, 16 for one 4096-frame pass
-        path_name = "path_kernel<16>" if args.no_overlap or args.overlap == 1 else "path_kernel<8>"
-        names = ["sort_kernel", "match_kernel", path_name]
+        value = frames_global * args.steps / elapsed
         dom = int(np.argmax(stage_ms))
-        achieved = ALGO_BYTES_PER_FRAME * FRAMES_PER_GPU / (stage_ms[dom] * 1e-3) / 1e9
+        achieved = algo_bytes * n_local / (stage_ms[dom] * 1e-3) / 1e9
+        pmc = _pmc(pkg)
+        pk = (pmc or {}).get(names[dom], {})
         out = {
-            "metric": "PathPlanner frames/s at 128 cones/frame",
+            "metric": "PathPlanner frames/s at 128 cones/frame" if args.config == 2 else "PathPlanner frames/s at 200 cones/frame (config 4)",
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -168,16 +232,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: batch=4096 synthetic autocross replay frames per GPU, 64 L + 64 R coloured cones",
-                "frames_per_gpu": FRAMES_PER_GPU,
-                "cones_per_frame": 2 * CONES_PER_SIDE,
-                "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
-                "pass_overlap": 1 if args.no_overlap else args.overlap,
+                "workload": workload,
+                "frames_per_gpu": n_local,
+                "frames_global": frames_global,
+                "cones_per_frame": cones_per_frame,
+                "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; communicator: "
+                               + (f"RCCL, {d.comm_size} rank(s) (ncclCommCount)" if d._active else "none (single process)"),
+                "pass_overlap": overlap,
             },
             "roofline": {
                 "bound": "hbm",
@@ -186,29 +252,38 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": _pmc_traffic(names[dom]),
+                "traffic": pk.get("hbm_bytes_per_launch", 0) / 1e9 if pk.get("hbm_bytes_per_launch") else None,
                 "kernel_ms": {n: m for n, m in zip(names, stage_ms)},
-                "kernel_ms_serial": {n: m for n, m in zip(["sort_kernel", "match_kernel", "path_kernel<16>"], serial_ms)},
+                "kernel_ms_serial": {n: m for n, m in zip(names_serial, serial_ms)},
                 "ms_per_step_serial": ser_total_ms / n_ser,
-                "traffic_unit": "GB per launch (PMC, profiles/pmc_traffic.json)",
-                "note": "algorithmic bytes/frame = 4488 (SURVEY 8d) x 4096 frames / average duration of the dominant kernel's "
-                        "launches in the timed region (HIP events on the streams the kernels run on; passes overlap, "
-                        "so a launch shares the chip with the other stream's kernels — kernel_ms_serial is the same launch "
+                "traffic_unit": "GB per launch (rocprofv3 PMC passes of this very library build, profiles/pmc_traffic.json; null when the recorded library hash differs)",
+                "valu_insts_per_frame": pk.get("valu_insts_per_frame"),
+                "valu_issue_util": pk.get("valu_issue_util"),
+                "note": f"algorithmic bytes/frame = {algo_bytes} (SURVEY 8d) x {n_local} frames / average duration of the dominant "
+                        "kernel's launches in the timed region (HIP events on the streams the kernels run on; passes overlap, "
+                        "so a launch shares the chip with the other streams' kernels — kernel_ms_serial is the same launch "
                         "alone); the path is FP64-issue/latency bound (serial spline QR), not HBM bound",
             },
             "status_histogram": status_hist,
+            "arc_extension_frames": arc_frames,
+            "lib_sha256_16": _lib_hash(pkg),
         }
-        if args.latency or world == 1:  # BASELINE metric, second half: p50 single-frame latency (batch = 1, host buffers)
+        if world == 1:
+            # sample-count flips against the reference, measured on the committed golden fuzz set
+            out["flip_count"] = golden_flip_count(pkg, ctx)
+            # BASELINE metric, second half: p50 single-frame latency (batch = 1, host buffers, PCIe-inclusive)
             o1, c1, p1 = off[:2], cones[: off[1]], poses[:1]
             lat = []
-            for _ in range(200):
+            for _ in range(300):
                 t1 = time.perf_counter()
                 ctx.plan_batch(o1, c1, p1)
                 lat.append(time.perf_counter() - t1)
-            out["p50_single_frame_us"] = float(np.median(lat) * 1e6)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(off, cones, poses)
+            out["p50_single_frame_us"] = float(np.median(lat[50:]) * 1e6)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(off, cones, poses)
+                out["p50_single_frame_vs_cpu_1thread"] = out["p50_single_frame_us"] / out["cpu_baseline"]["single_thread_us_per_frame"]
         print(json.dumps(out))
+    d.barrier()
     d.close()
 
 

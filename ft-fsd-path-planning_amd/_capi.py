@@ -69,6 +69,13 @@ def load() -> ctypes.CDLL:
     lib.fsdp_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.fsdp_destroy.argtypes = [ctypes.c_void_p]
     lib.fsdp_resident_frames.argtypes = [ctypes.c_void_p]
+    lib.fsdp_stage_names.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    lib.fsdp_comm_unique_id.argtypes = [ctypes.c_void_p]
+    lib.fsdp_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    lib.fsdp_comm_broadcast.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    lib.fsdp_comm_allreduce.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
+    for name in ("fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_barrier", "fsdp_comm_destroy"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
     if lib.fsdp_result_size() != RESULT_DTYPE.itemsize:
         raise FsdpError(f"fsdp_frame_result layout mismatch: {lib.fsdp_result_size()} != {RESULT_DTYPE.itemsize}")
     _lib = lib
@@ -77,9 +84,11 @@ def load() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
-    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_resident_frames",
+    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_stage_names", "fsdp_resident_frames",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
+    "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
+    "fsdp_comm_barrier", "fsdp_comm_destroy",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
 ]
 
@@ -211,6 +220,13 @@ class Context:
         st = (ctypes.c_float * 3)()
         self._check(self._lib.fsdp_time_runs(self._h, int(iters), ctypes.byref(tot), st), "fsdp_time_runs")
         return float(tot.value), [float(x) for x in st]
+
+    def stage_names(self):
+        """Kernel names behind the per-stage times of the most recent time_runs (the path kernel's lane-group
+        instantiation depends on how the batch was launched)."""
+        buf = ctypes.create_string_buffer(256)
+        self._check(self._lib.fsdp_stage_names(self._h, buf, 256), "fsdp_stage_names")
+        return buf.value.decode().split(",")
 
     def default_path(self) -> np.ndarray:
         out = np.zeros((PATH_POINTS, 4))

@@ -16,6 +16,7 @@
 #include "match_kernel.h"
 #include "path_kernel.h"
 #include "skidpad_kernel.h"
+#include "fsdp_comm.h"
 
 using namespace fsdp;
 
@@ -53,6 +54,7 @@ struct fsdp_ctx {
   int n_gpath = 0;
   // further sets of intermediates + streams (fsdp_set_overlap): consecutive fsdp_run passes rotate through the sets, so
   // the next passes start while the slowest wavefronts of the previous ones are still finishing
+  int last_path_g = 0;        // lanes per frame of the most recent path-kernel launch
   int force_path_g = 0;       // 0 = automatic; 8 / 16 / 64 = test / tuning override (FSDP_PATH_G environment variable)
   bool profile_sort = false;  // profiling build: which kernel fsdp_profile_path runs
   int overlap = 1;
@@ -72,6 +74,7 @@ struct fsdp_ctx {
   double* d_table = nullptr;
   double* d_noise = nullptr;
   SkidTables tables = {};
+  fsdp_comm::Comm comm;  // RCCL communicator of this rank (fsdp_comm_init), or none
   double skid_consts[5] = {};  // reference centres (right xy, left xy) + table spacing, computed on the device
   bool have_tables = false;
   SkidState* d_skid = nullptr;
@@ -244,6 +247,7 @@ static void launch_path(fsdp_ctx* c, const Slot& q) {
     else
       g = PATH_G_LATENCY;
   }
+  c->last_path_g = g;
   if (g == PATH_G_SMALL) {
     launch_path_g<PATH_G_SMALL>(c, q, nullptr);
     return;
@@ -383,6 +387,7 @@ void fsdp_destroy(fsdp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)fsdp_comm_destroy(c);
   (void)hipFree(c->d_off);
   (void)hipFree(c->d_cones);
   (void)hipFree(c->d_poses);
@@ -641,6 +646,12 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
     ms_stage[1] = acc[1];
     ms_stage[2] = acc[2];
   }
+  return 0;
+}
+
+int fsdp_stage_names(fsdp_ctx* c, char* out, int cap) {
+  if (!c || !out || cap < 64) return 1;
+  snprintf(out, (size_t)cap, "sort_kernel,match_kernel,path_kernel<%d>", c->last_path_g);
   return 0;
 }
 
@@ -913,6 +924,134 @@ int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
   HIP_TRY(c, hipMemcpyAsync(c->d_skid, c->d_skid_backup, bytes, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (ms_total) *ms_total = t;
+  return 0;
+}
+
+// ---- multi-GPU: RCCL over xGMI (see fsdp_comm.h) ----------------------------------------------------------------------
+#define NCCL_TRY(ctx, call)                                                                                    \
+  do {                                                                                                         \
+    ncclResult_t r_ = (call);                                                                                  \
+    if (r_ != ncclSuccess) {                                                                                   \
+      (ctx)->err = std::string(#call) + ": " + fsdp_comm::api().GetErrorString(r_);                            \
+      return 3;                                                                                                \
+    }                                                                                                          \
+  } while (0)
+
+int fsdp_comm_unique_id(void* out128) {
+  if (!out128) return 1;
+  if (!fsdp_comm::load()) {
+    g_create_error = fsdp_comm::api().error;
+    return 3;
+  }
+  static_assert(sizeof(ncclUniqueId) == FSDP_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  ncclResult_t r = fsdp_comm::api().GetUniqueId(&id);
+  if (r != ncclSuccess) {
+    g_create_error = std::string("ncclGetUniqueId: ") + fsdp_comm::api().GetErrorString(r);
+    return 3;
+  }
+  memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+int fsdp_comm_init(fsdp_ctx* c, int rank, int world, const void* id128) {
+  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return 1;
+  if (c->comm.comm) {
+    c->err = "fsdp_comm_init: communicator already initialised";
+    return 1;
+  }
+  if (!fsdp_comm::load()) {
+    c->err = fsdp_comm::api().error;
+    return 3;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  NCCL_TRY(c, fsdp_comm::api().CommInitRank(&c->comm.comm, world, id, rank));
+  c->comm.rank = rank;
+  c->comm.world = world;
+  return 0;
+}
+
+int fsdp_comm_size(fsdp_ctx* c) {
+  if (!c || !c->comm.comm) return 0;
+  int n = 0;
+  if (fsdp_comm::api().CommCount(c->comm.comm, &n) != ncclSuccess) return 0;
+  return n;
+}
+
+int fsdp_comm_rank(fsdp_ctx* c) {
+  if (!c || !c->comm.comm) return -1;
+  int r = -1;
+  if (fsdp_comm::api().CommUserRank(c->comm.comm, &r) != ncclSuccess) return -1;
+  return r;
+}
+
+static int comm_staging(fsdp_ctx* c, size_t bytes) {
+  if (bytes <= c->comm.cap) return 0;
+  if (c->comm.d_buf) (void)hipFree(c->comm.d_buf);
+  c->comm.d_buf = nullptr;
+  c->comm.cap = 0;
+  HIP_TRY(c, hipMalloc(&c->comm.d_buf, bytes));
+  c->comm.cap = bytes;
+  return 0;
+}
+
+int fsdp_comm_broadcast(fsdp_ctx* c, void* host_buf, size_t bytes, int root) {
+  if (!c || !c->comm.comm || (bytes > 0 && !host_buf) || root < 0 || root >= c->comm.world) return 1;
+  if (bytes == 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = comm_staging(c, bytes);
+  if (rc) return rc;
+  if (c->comm.rank == root) HIP_TRY(c, hipMemcpyAsync(c->comm.d_buf, host_buf, bytes, hipMemcpyHostToDevice, c->stream));
+  NCCL_TRY(c, fsdp_comm::api().Broadcast(c->comm.d_buf, c->comm.d_buf, bytes, ncclUint8, root, c->comm.comm, c->stream));
+  if (c->comm.rank != root) HIP_TRY(c, hipMemcpyAsync(host_buf, c->comm.d_buf, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int fsdp_comm_allreduce(fsdp_ctx* c, double* values, int n, int op) {
+  if (!c || !c->comm.comm || n < 0 || (n > 0 && !values) || op < 0 || op > 2) return 1;
+  if (n == 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t bytes = sizeof(double) * (size_t)n;
+  int rc = comm_staging(c, bytes);
+  if (rc) return rc;
+  const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+  HIP_TRY(c, hipMemcpyAsync(c->comm.d_buf, values, bytes, hipMemcpyHostToDevice, c->stream));
+  NCCL_TRY(c, fsdp_comm::api().AllReduce(c->comm.d_buf, c->comm.d_buf, (size_t)n, ncclFloat64, ops[op], c->comm.comm, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(values, c->comm.d_buf, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int fsdp_comm_barrier(fsdp_ctx* c) {
+  if (!c || !c->comm.comm) return 1;
+  int rc = sync_all(c);  // everything this rank has enqueued is done before it reports in
+  if (rc) return rc;
+  double one = 1.0;
+  rc = fsdp_comm_allreduce(c, &one, 1, 0);
+  if (rc) return rc;
+  if ((int)one != c->comm.world) {
+    c->err = "fsdp_comm_barrier: rank count mismatch";
+    return 3;
+  }
+  return 0;
+}
+
+int fsdp_comm_destroy(fsdp_ctx* c) {
+  if (!c) return 1;
+  if (c->comm.comm) {
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)fsdp_comm::api().CommDestroy(c->comm.comm);
+    c->comm.comm = nullptr;
+  }
+  if (c->comm.d_buf) (void)hipFree(c->comm.d_buf);
+  c->comm.d_buf = nullptr;
+  c->comm.cap = 0;
+  c->comm.rank = 0;
+  c->comm.world = 1;
   return 0;
 }
 

@@ -139,6 +139,26 @@ def make_replay_batch(
     return _pack(frames, poses)
 
 
+def make_config4_shard(lo: int, hi: int, n_per_side: int = 100, sigma: float = 0.1, seed: int = 7):
+    """Frames [lo, hi) of BASELINE config 4 (65 536 frames x 200 cones, Gaussian xy perturbation): frame f
+    is a function of (seed, f) alone — its own pose along the centreline and its own N(0, sigma^2) noise on every cone — so
+    every rank can build exactly its contiguous shard of the global batch and the union does not depend on the rank count.
+    """
+    left, right, centre_fn = closed_track(n_per_side, seed)
+    frames, poses = [], np.zeros((hi - lo, 4))
+    for k, f in enumerate(range(lo, hi)):
+        rng = np.random.default_rng([seed, f])
+        pos, tan = centre_fn(rng.uniform(0, 1))
+        poses[k, :2], poses[k, 2:] = pos, tan
+        l = left + rng.normal(0, sigma, left.shape)
+        r = right + rng.normal(0, sigma, right.shape)
+        frames.append(np.concatenate([np.column_stack([r, np.full(len(r), float(RIGHT))]),
+                                      np.column_stack([l, np.full(len(l), float(LEFT))])]))
+    if not frames:
+        return np.zeros(1, np.int32), np.zeros((0, 3)), poses
+    return _pack(frames, poses)
+
+
 def split_by_type(xyt: np.ndarray) -> List[np.ndarray]:
     """(N,3) flattened cones -> list of 5 (n,2) arrays indexed by ConeTypes value."""
     return [np.ascontiguousarray(xyt[xyt[:, 2] == t, :2]) for t in range(5)]

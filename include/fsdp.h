@@ -22,6 +22,7 @@
 #ifndef FSDP_H
 #define FSDP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -141,6 +142,8 @@ int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
  * each launch; with overlap these include the time a launch shares the chip with the other slot's kernels).
  * Either pointer may be NULL. */
 int fsdp_time_runs(fsdp_ctx* ctx, int iters, float* ms_total, float* ms_stage);
+/* comma-separated kernel names behind ms_stage of the most recent launches, e.g. "sort_kernel,match_kernel,path_kernel<8>" */
+int fsdp_stage_names(fsdp_ctx* ctx, char* out, int cap);
 
 /* Stage-level entry points (README "parts of the pipeline are also available as individual classes"). */
 /* ConeSorting.run_cone_sorting — fills status, n_left/right, left/right_idx and the sorting diagnostics. */
@@ -183,6 +186,25 @@ int fsdp_skidpad_step(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offset
                       const double* poses, fsdp_frame_result* results, fsdp_skidpad_info* info);
 /* time `iters` repetitions of the path kernel of the last step with HIP events (state is restored afterwards) */
 int fsdp_skidpad_time_path(fsdp_ctx* ctx, int iters, float* ms_total);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------------------------------------------
+ * The reference is single-process Python with no distributed layer ("distributed communication backend: none");
+ * frames are independent, so ranks shard them with NO data-path collective (contiguous frame ranges).  RCCL
+ * carries only the start-up broadcast of constant tables — the skidpad track table of
+ * relocalization/skidpad/skidpad_path_data.py:10-5799 (root rank loads it, the others receive it), the consistency check
+ * of the constant previous path (core_calculate_path.py:103-107) — and the timing barrier / reductions of a benchmark.
+ * Usage: rank 0 calls fsdp_comm_unique_id and hands the 128 bytes to every rank out of band (the Python host: one TCP
+ * exchange at MASTER_ADDR:MASTER_PORT+1, dist.py); every rank then calls fsdp_comm_init on its context.  Collectives run
+ * on the context's own stream and return when complete on this rank.  librccl is dlopen'ed on first use. */
+#define FSDP_COMM_ID_BYTES 128
+int fsdp_comm_unique_id(void* out128);                                          /* ncclGetUniqueId                      */
+int fsdp_comm_init(fsdp_ctx* ctx, int rank, int world, const void* id128);      /* ncclCommInitRank on the ctx's GPU    */
+int fsdp_comm_size(fsdp_ctx* ctx);                                              /* ncclCommCount (0 = no communicator)  */
+int fsdp_comm_rank(fsdp_ctx* ctx);                                              /* ncclCommUserRank (-1 = none)         */
+int fsdp_comm_broadcast(fsdp_ctx* ctx, void* host_buf, size_t bytes, int root); /* ncclBroadcast of a host buffer       */
+int fsdp_comm_allreduce(fsdp_ctx* ctx, double* values, int n, int op);          /* in place; op 0 sum, 1 max, 2 min     */
+int fsdp_comm_barrier(fsdp_ctx* ctx);        /* waits for this rank's passes in flight, then an all-reduce rendezvous */
+int fsdp_comm_destroy(fsdp_ctx* ctx);        /* also done by fsdp_destroy */
 
 /* The constant initial previous path (core_calculate_path.py:103-107), (40,4), as computed on the device. */
 int fsdp_default_path(fsdp_ctx* ctx, double* out40x4);

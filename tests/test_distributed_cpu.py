@@ -1,14 +1,15 @@
-"""The N > 1 plumbing (ft-fsd-path-planning_amd/dist.py, used by bench.py) on CPU: two gloo processes.
-Checks sharding, the previous-path-table broadcast check, barrier and max/sum reductions."""
+"""The N > 1 plumbing (ft-fsd-path-planning_amd/dist.py, used by bench.py) on CPU with two real processes:
+the RCCL unique-id exchange over TCP (what fsdp_comm_init needs out of band), the launch-key handshake, contiguous
+frame-range sharding of a global batch (BASELINE config 4) and weak-scaling seeds.  The RCCL calls themselves need GPUs:
+tests/test_gpu_parity.py::test_rccl_single_rank_communicator runs them with a one-rank communicator."""
 import importlib
+import multiprocessing as mp
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
-
-torch = pytest.importorskip("torch")
-import torch.multiprocessing as mp  # noqa: E402
 
 
 def _free_port():
@@ -19,43 +20,78 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, table, tamper, q):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, key, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      FSDP_LAUNCH_KEY=key)
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
-    d = pkg.dist.Dist(backend="gloo")
-    mine = table.copy()
-    if tamper and rank == 1:
-        mine[3, 2] += 1e-12
-    same = d.broadcast_check_table(mine)
-    # track-map broadcast: only rank 0 holds the skidpad path table
-    tbl = pkg.skidpad.load_tables()[0] if rank == 0 else None
-    got = d.broadcast_array(tbl, (5786, 2))
-    assert got.shape == (5786, 2) and np.array_equal(got, pkg.skidpad.load_tables()[0])
-    lo, hi = d.frame_range(10)
-    d.barrier()
-    mx = d.max_over_ranks(float(rank + 1))
-    sm = d.sum_over_ranks(float(hi - lo))
-    # each rank plans its own shard: different seeds -> different synthetic tracks, same shapes
-    off, cones, poses = pkg.synth.make_replay_batch(8, 16, 0.1, seed=d.shard_seed(5))
-    q.put((rank, same, (lo, hi), mx, sm, float(cones[:, :2].sum()), cones.shape))
-    d.close()
+    d = pkg.dist.Dist()  # no context: rank bookkeeping only (no GPU here)
+    assert (d.rank, d.world) == (rank, world)
+    # rank 0 makes the 128 "unique id" bytes (on a GPU box: fsdp_comm_unique_id), the others fetch them
+    uid = pkg.dist.exchange_unique_id(rank, world, lambda: bytes((7 * i + 3) % 256 for i in range(128)))
+    lo, hi = d.frame_range(65536)
+    off, cones, poses = pkg.synth.make_config4_shard(lo, lo + 4, 100, 0.1, seed=7)  # the first 4 frames of this rank's shard
+    off2, cones2, _ = pkg.synth.make_replay_batch(8, 16, 0.1, seed=d.shard_seed(5))
+    q.put((rank, uid, (lo, hi), float(cones[:, :2].sum()), cones.shape, float(cones2[:, :2].sum()), "torch" in sys.modules))
 
 
-@pytest.mark.parametrize("tamper", [False, True])
-def test_two_rank_gloo(golden_dir, tamper):
-    table = np.load(golden_dir / "default_path.npz")["path"]
+@pytest.mark.parametrize("world", [2, 3])
+def test_unique_id_exchange_and_sharding(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, table, tamper, q)) for r in range(2)]
-    for p in procs:
+    procs = [ctx.Process(target=_worker, args=(r, world, port, f"test-{port}", q)) for r in range(world)]
+    for p in procs[::-1]:  # clients first: they must retry until rank 0 listens
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, same0, fr0, mx0, sm0, cs0, sh0), (r1, same1, fr1, mx1, sm1, cs1, sh1) = res
-    assert same0 == same1 == (not tamper)
-    assert fr0 == (0, 5) and fr1 == (5, 10)
-    assert mx0 == mx1 == 2.0 and sm0 == sm1 == 10.0
-    assert sh0 == sh1 and cs0 != cs1
+    want = bytes((7 * i + 3) % 256 for i in range(128))
+    assert all(r[1] == want for r in res)
+    per = -(-65536 // world)
+    assert [r[2] for r in res] == [(min(k * per, 65536), min((k + 1) * per, 65536)) for k in range(world)]
+    assert res[-1][2][1] == 65536 and sum(hi - lo for _, _, (lo, hi), *_ in res) == 65536
+    assert len({r[3] for r in res}) == world and len({r[5] for r in res}) == world  # different shards / tracks
+    assert all(r[4] == (800, 3) for r in res)
+    assert not any(r[6] for r in res), "dist.py must not import torch"
+
+
+def test_stranger_on_the_port_is_skipped():
+    """A listener that is not rank 0 of this launch (wrong key) must not be mistaken for it."""
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    port = _free_port()
+    os.environ["FSDP_LAUNCH_KEY"] = "launch-A"
+    # a stranger holds base_port + 1 and answers garbage
+    stranger = socket.socket()
+    stranger.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    stranger.bind(("127.0.0.1", port + 1))
+    stranger.listen(4)
+    import threading
+
+    def babble():
+        for _ in range(2):
+            try:
+                c, _ = stranger.accept()
+                c.recv(64)
+                c.sendall(b"??")
+                c.close()
+            except OSError:
+                return
+
+    threading.Thread(target=babble, daemon=True).start()
+    uid = bytes(range(128))
+    t = threading.Thread(target=pkg.dist.serve_unique_id, args=(uid, 2, "127.0.0.1", port), daemon=True)
+    t.start()
+    got = pkg.dist.fetch_unique_id(1, 2, "127.0.0.1", port, timeout=30)
+    t.join(timeout=30)
+    stranger.close()
+    del os.environ["FSDP_LAUNCH_KEY"]
+    assert got == uid
+
+
+def test_config4_union_does_not_depend_on_rank_count():
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    whole = pkg.synth.make_config4_shard(0, 12, 100, 0.1, seed=7)
+    parts = [pkg.synth.make_config4_shard(*pkg.dist.frame_range(r, 3, 12), 100, 0.1, seed=7) for r in range(3)]
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), whole[1])
+    assert np.array_equal(np.concatenate([p[2] for p in parts]), whole[2])

