@@ -41,6 +41,7 @@ constexpr int ST_OVERFLOW_CONES = 201;
 constexpr int ST_OVERFLOW_ENDS = 202;
 constexpr int ST_OVERFLOW_PATH = 203;
 constexpr int ST_OVERFLOW_KNOTS = 204;
+constexpr int ST_RETRY = 299;  // internal: the fast kernels hand the frame to the exact one-frame-per-wavefront kernel (never leaves the library)
 
 #define FSDP_PI 3.14159265358979323846
 #define FSDP_DEG (FSDP_PI / 180.0)

@@ -267,7 +267,7 @@ static void launch_path(fsdp_ctx* c, const Slot& q) {
 static int finish_knot_overflow(fsdp_ctx* c, const Slot& q) {
   std::vector<int> list(1, 0);
   for (int i = 0; i < c->n_frames; i++)
-    if (c->h_path[i].status == ST_OVERFLOW_KNOTS) list.push_back(i);
+    if (c->h_path[i].status == ST_OVERFLOW_KNOTS || c->h_path[i].status == ST_RETRY) list.push_back(i);
   list[0] = (int)list.size() - 1;
   if (list[0] == 0) return 0;
   HIP_TRY(c, hipMemcpyAsync(q.d_retry, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, q.stream));
@@ -968,6 +968,7 @@ int fsdp_comm_init(fsdp_ctx* c, int rank, int world, const void* id128) {
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   NCCL_TRY(c, fsdp_comm::api().CommInitRank(&c->comm.comm, world, id, rank));
+  fflush(stdout);  // RCCL prints its version banner through C stdio: out now, not after the caller's own last line
   c->comm.rank = rank;
   c->comm.world = world;
   return 0;

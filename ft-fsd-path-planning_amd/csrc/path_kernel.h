@@ -269,13 +269,13 @@ __device__ __forceinline__ double build_parameter(PathShared<G>& S, const Arena&
 }
 
 // utils/spline_fit.py:95-128 on the arena polyline [off, off+m).  rc: 0 ok, 1 ValueError, >=200 overflow
-template <int G>
+template <int G, bool FAST>
 __device__ __forceinline__ int fit_polyline(PathShared<G>& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
                                    double& max_u) {
   int k = m - 1;
   k = k < 1 ? 1 : (k > 3 ? 3 : k);
   max_u = build_parameter<G>(S, A, off, m);
-  f = spline_fit<G>(S.ws, A.bc, A.u + off, A.x + off, A.y + off, m, k, smoothing);
+  f = spline_fit<FAST>(S.ws, A.bc, A.u + off, A.x + off, A.y + off, m, k, smoothing);
   return f.status;
 }
 
@@ -287,7 +287,7 @@ __device__ __forceinline__ int arange_len(double stop, double step) {
 
 // calculate_path/path_parameterization.py:297-328 on the arena polyline [off, off+n).
 // rc: 0 ok (out filled), 1 ValueError, ST_* otherwise.
-template <int G>
+template <int G, bool FAST>
 __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
   using GR = Grp<G>;
   const int lane = GR::lane();
@@ -339,7 +339,7 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
   int rc;
   {
     PROF(7);
-    rc = fit_polyline<G>(S, A, off, ns, 0.01, f, max_u);
+    rc = fit_polyline<G, FAST>(S, A, off, ns, 0.01, f, max_u);
   }
   if (rc) return rc;
   // _calculate_path_curvature :163-193 — dense samples into LDS
@@ -351,7 +351,7 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
   double* const DU = S.du();
   {
     PROF(8);
-    spline_eval<G>(S.ws, f, predict_every, L, DX, DY, DU);
+    spline_eval(S.ws, f, predict_every, L, DX, DY, DU);
   }
   double* curv = S.curv();
   double* filt = A.filt;
@@ -476,7 +476,7 @@ __device__ __forceinline__ double cumulative_length(PathShared<G>& S, const Aren
 
 // core_calculate_path.py:380-417 do_all_mpc_parameter_calculations on the polyline [1, 1+n) of the arena
 // (slot 0 is reserved for the point connect_path_to_car may prepend).  rc as parameterize_path.
-template <int G>
+template <int G, bool FAST>
 __device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
                                  double (*out)[4], int* fallback, int* n_dense) {
   using GR = Grp<G>;
@@ -607,12 +607,12 @@ __device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int 
       int rc;
       {
         PROF(4);
-        rc = fit_polyline<G>(S, A, off, n, 0.2, f, max_u);
+        rc = fit_polyline<G, FAST>(S, A, off, n, 0.2, f, max_u);
       }
       if (rc) return rc;
       PROF(5);
       n4 = arange_len(20.0 * 1.5, 0.1);
-      spline_eval<G>(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
+      spline_eval(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
     }
     int nseg = n4 - 1;
     if (nseg <= 1) return 1;  // previous (40,4) array handed on -> LinAlgError (a ValueError) downstream
@@ -620,12 +620,12 @@ __device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int 
     cumulative_length<G>(S, A, 0, n4, 20.0, &first);
     n5 = first;
   }
-  return parameterize_path<G>(S, A, 0, n5, out, n_dense);
+  return parameterize_path<G, FAST>(S, A, 0, n5, out, n_dense);
 }
 
 // core_calculate_path.py:555-575: too-far check + MPC step with its ValueError retry, on the dense path update stored
 // in the arena at [1, 1+n1); prev = previous path (40,4) rows [s, x, y, curvature].  Returns the frame status.
-template <int G>
+template <int G, bool FAST>
 __device__ __forceinline__ int finish_path(PathShared<G>& S, const Arena& A, int n1, double px, double py, double dx, double dy,
                                            const double* prev, double (*out)[4], int* fallback, int* n_dense) {
   using GR = Grp<G>;
@@ -668,7 +668,7 @@ __device__ __forceinline__ int finish_path(PathShared<G>& S, const Arena& A, int
       n1 = PATH_POINTS;
       GR::sync();
     }
-    rc = do_all_mpc<G>(S, A, n1, px, py, dx, dy, out, fallback, n_dense);
+    rc = do_all_mpc<G, FAST>(S, A, n1, px, py, dx, dy, out, fallback, n_dense);
   }
   if (rc == 1) rc = ST_REF_UNDEFINED_PATH;
   return rc;
@@ -717,13 +717,14 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
   __syncthreads();
   SplineFit f;
   double max_u;
-  int rc = fit_polyline<G>(S, A, 0, PATH_POINTS, 0.2, f, max_u);
+  constexpr bool FAST = false;  // one-off per context: plain divisions
+  int rc = fit_polyline<G, FAST>(S, A, 0, PATH_POINTS, 0.2, f, max_u);
   int n1 = arange_len(max_u, 0.1);
   if (rc == 0 && n1 <= PATH_CAP) {
-    spline_eval<G>(S.ws, f, 0.1, n1, A.x, A.y, nullptr);
+    spline_eval(S.ws, f, 0.1, n1, A.x, A.y, nullptr);
     int nd = 0;
     double(*o)[4] = (double(*)[4])out;
-    rc = parameterize_path<G>(S, A, 0, n1, o, &nd);
+    rc = parameterize_path<G, FAST>(S, A, 0, n1, o, &nd);
   }
   if (rc != 0 && lane < PATH_POINTS)
     for (int q = 0; q < 4; q++) out[4 * lane + q] = NAN;
@@ -740,7 +741,7 @@ constexpr int PATH_G_SMALL = 64;
 constexpr int PATH_SMALL_BATCH = 1024;    // frames at or below which every frame gets its own wavefront
 constexpr int PATH_LATENCY_BATCH = 4096;  // largest single pass that G = 16 serves with one wavefront per SIMD
 
-template <int G>
+template <int G, bool FAST>
 __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
                                   const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
                                   const double* __restrict__ prev_paths, const double* __restrict__ gpath, int n_gpath,
@@ -871,13 +872,13 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
       SplineFit f;
       double max_u;
       PROF(1);
-      int rc = fit_polyline<G>(S, A, 0, nc, 0.2, f, max_u);
+      int rc = fit_polyline<G, FAST>(S, A, 0, nc, 0.2, f, max_u);
       if (rc == 0) {
         n1 = arange_len(max_u, 0.1);
         if (n1 + 1 + 50 > PATH_CAP) {
           status = ST_OVERFLOW_PATH;
         } else {
-          spline_eval<G>(S.ws, f, 0.1, n1, A.x + 1, A.y + 1, nullptr);
+          spline_eval(S.ws, f, 0.1, n1, A.x + 1, A.y + 1, nullptr);
         }
         break;
       }
@@ -898,7 +899,7 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
       GR::sync();
     }
   }
-  if (status == ST_OK) status = finish_path<G>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
+  if (status == ST_OK) status = finish_path<G, FAST>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
   GR::sync();
   if (status != ST_OK)
     for (int i = lane; i < PATH_POINTS; i += G)
@@ -929,8 +930,9 @@ __global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames,
   const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
   PROF_INIT();
   if (frame < n_frames) {
-    path_frame<G>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out);
-    if (retry != nullptr && Grp<G>::lane() == 0 && out[frame].status == ST_OVERFLOW_KNOTS) retry[1 + atomicAdd(&retry[0], 1)] = frame;
+    path_frame<G, true>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out);
+    if (retry != nullptr && Grp<G>::lane() == 0 && (out[frame].status == ST_OVERFLOW_KNOTS || out[frame].status == ST_RETRY))
+      retry[1 + atomicAdd(&retry[0], 1)] = frame;
   }  // (retry list on the device: used by the emulator harness; the library collects the list on the host)
   PROF_FLUSH();
 }
@@ -945,7 +947,7 @@ __global__ void __launch_bounds__(64, 1) path_retry_kernel(const double* __restr
   __shared__ PathShared<WAVE> S;
   const int n = retry[0];
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    path_frame<WAVE>(S, retry[1 + i], poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out);
+    path_frame<WAVE, false>(S, retry[1 + i], poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out);
     __syncthreads();
   }
 }

@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
     }
     __syncthreads();
   }
-  if (status == ST_OK) status = finish_path<WAVE>(S, A, n1, px, py, dx, dy, &st->prev[0][0], o->path, &fallback, &n_dense);
+  if (status == ST_OK) status = finish_path<WAVE, false>(S, A, n1, px, py, dx, dy, &st->prev[0][0], o->path, &fallback, &n_dense);
   __syncthreads();
   if (status == ST_OK) {
     // previous_paths[-1] <- this result (map frame); then path xy back to the original frame (full_pipeline.py:178-194)

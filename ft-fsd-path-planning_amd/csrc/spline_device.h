@@ -34,9 +34,10 @@ constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121
 // right-hand sides), what only its observation / residual passes need (chunk buffers, knot bookkeeping), what only the
 // smoothing iteration needs (the extended triangle g; the f(p) term buffer overlays it while it is dead), and — when no
 // fit is running — the path stage's dense samples.  The rows of the smoothness matrix b live in the frame's scratch.
-template <int G>
+template <int G, int NKC = knot_capacity<G>()>
 struct SplineWS {
-  static constexpr int NK = knot_capacity<G>();
+  static constexpr int GRP = G;
+  static constexpr int NK = NKC;
   static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : 16);  // data rows staged per chunk
   union {
     struct {  // ---- a fit in progress ----
@@ -200,55 +201,52 @@ __device__ __forceinline__ void fpback(EL el, const double* z, int n, int k, dou
   }
 }
 
-// ---- 4-stage systolic Givens pipeline (degree 3) ------------------------------------------------------
-// A data row touches the 4 consecutive band rows l-3..l, one rotation each, in that order; consecutive data
-// rows touch (almost always) the same band rows.  Lane p of the group's first quad owns band row j with j mod 4 = p and
-// keeps it in registers; a data row travels lane -> lane (quad rotate, DPP) one stage per step, so up to 4
-// data rows are in flight.  Every band row still sees the data rows in data order and every data row still
-// visits its band rows in order: the arithmetic (fpgivs / fprota) and its sequence per element are exactly
-// FITPACK's, only independent rotations overlap in time.
-//
-// The running sum of squared rotated-out right-hand sides (fp, accumulated in data order) is a token that lives in
-// the lane where rows currently leave the pipeline (band row l, lane l mod 4); when the interval changes, the first
-// row of the new interval picks the token up on its way (every row visits every lane once, rows keep their order in
-// every lane) and delivers it to its own exit lane.  Nothing is parked in LDS on the way out, so consecutive chunks
-// of an observation pass run through the pipeline back to back without draining it.
-struct GivItem {
-  double piv, r0, r1, r2, x1, x2;
-  double fpc;  // the fp token's value while it travels with this row
-  int j;       // band row this stage rotates against
-  int info;    // stage (1..4, 0 = empty) | GIV_TOK
-};
-constexpr int GIV_TOK = 0x100;
-
-template <int G>
-__device__ __forceinline__ GivItem quad_rot_prev(const GivItem& v) {
+// ---- exact division without the range scaling ---------------------------------------------------------
+// An IEEE double division on gfx950 is a software sequence: v_div_scale (x2), v_rcp_f64, two Newton steps, a quotient
+// with one correction (v_div_fmas) and v_div_fixup.  The scaling and the fix-up only act when an exponent sits near the
+// limits of the format; for operands in a safe band the sequence below is the same arithmetic on the same operands and
+// returns the same (correctly rounded) bits with 8 instead of 11 instructions — and two quotients over one denominator
+// share the refined reciprocal (11 instead of 22).  div_safe() is the guard: callers count operands outside
+// [2^-256, 2^256] and such a frame is re-planned with plain divisions (ST_RETRY, path_kernel.h).
+__device__ __forceinline__ unsigned hi_word(double v) {
 #ifdef FSDP_EMU
-  int l = emu::B->cur;
-  return emu::gexchange_struct(v, (l & ~3) | ((l + 3) & 3), G);
+  uint64_t u;
+  memcpy(&u, &v, sizeof(u));
+  return (unsigned)(u >> 32);
 #else
-  GivItem o;
-  auto rot = [](double d) {
-    int lo = __double2loint(d), hi = __double2hiint(d);
-    lo = __builtin_amdgcn_mov_dpp(lo, 0x93, 0xf, 0xf, true);  // quad_perm:[3,0,1,2] -> lane p reads lane p-1
-    hi = __builtin_amdgcn_mov_dpp(hi, 0x93, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-  };
-  o.piv = rot(v.piv);
-  o.r0 = rot(v.r0);
-  o.r1 = rot(v.r1);
-  o.r2 = rot(v.r2);
-  o.x1 = rot(v.x1);
-  o.x2 = rot(v.x2);
-  o.fpc = rot(v.fpc);
-  o.j = __builtin_amdgcn_mov_dpp(v.j, 0x93, 0xf, 0xf, true);
-  o.info = __builtin_amdgcn_mov_dpp(v.info, 0x93, 0xf, 0xf, true);
-  return o;
+  return (unsigned)__double2hiint(v);
+#endif
+}
+__device__ __forceinline__ bool div_safe(double v) {  // finite, non-zero, exponent in [-256, 256]
+  return (((hi_word(v) >> 20) & 0x7ffu) - 0x2ffu) <= 0x200u;
+}
+__device__ __forceinline__ double rcp_refined(double d) {
+#ifdef FSDP_EMU
+  return d;  // (the emulator divides directly, see div_rcp)
+#else
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+#endif
+}
+// n / d given r = rcp_refined(d)
+__device__ __forceinline__ double div_rcp(double n, double d, double r) {
+#ifdef FSDP_EMU
+  (void)r;
+  return n / d;
+#else
+  const double q = n * r;
+  const double rem = fma(-d, q, n);
+  return fma(rem, r, q);
 #endif
 }
 
 // sqrt for arguments in [1, 2] (1 + r^2 with |r| <= 1): the correctly rounded result, i.e. what sqrt() returns; on the
 // device this is the compiler's own v_rsq_f64 + Goldschmidt sequence without the range scaling that [1, 2] never needs
+// (checked against sqrt() on the GPU: tests/test_gpu_parity.py::test_device_math_helpers)
 __device__ __forceinline__ double sqrt_1_2(double x) {
 #ifdef FSDP_EMU
   return sqrt(x);
@@ -267,188 +265,183 @@ __device__ __forceinline__ double sqrt_1_2(double x) {
 #endif
 }
 
-struct GivRow {  // the band row a lane currently owns
-  int j;
-  double a1, a2, a3, a4, z1, z2;
+// ---- 4-stage systolic Givens pipeline (degree 3) ------------------------------------------------------
+// A data row of knot interval l touches the 4 consecutive band rows l-3..l, one rotation each, in that order;
+// consecutive data rows fall (almost always) into the same interval.  Lane p of the group's first quad owns the band
+// row j with j mod 4 = p and keeps it in registers; a data row travels lane -> lane (quad rotate, DPP) one stage per
+// step, so up to 4 data rows are in flight.  Every band row still sees the data rows in data order and every data row
+// still visits its band rows in order: the arithmetic (fpgivs / fprota) and its sequence per element are exactly
+// FITPACK's, only independent rotations overlap in time.
+//
+// The rows of one knot interval form a *run*: inside a run a lane's stage is fixed (lane - (l-3) mod 4), a row's
+// validity follows from the step counter, and the sum of squared rotated-out right-hand sides (fp, accumulated in data
+// order) stays in the stage-4 lane.  When the interval changes (a handful of times per pass: intervals <= knots) the
+// three rows in flight are drained, fp moves to the new stage-4 lane, the lane whose band row falls out of the window
+// writes it back to LDS and starts the next one from zero.  A run may pause between the chunks of an observation pass
+// (rows in flight wait in registers).
+//
+// Entries of a data row beyond its band (and of a band row beyond the interval reached so far) are exact zeros and rotate
+// to exact zeros, and a step that must not rotate (no row at this stage yet, or pivot 0: fpgivs is skipped) runs the
+// rotation with cs = 1, sn = 0, which returns its finite inputs unchanged — so the step has no per-element selects.
+struct GivLane {
+  double a1, a2, a3, a4, z1, z2;       // the band row this lane owns
+  int j;                                // its index (0 = none yet)
+  double o_piv, o_r0, o_r1, o_x1, o_x2; // data row leaving this lane (rotated to the next lane at the next step)
+  double fp;                            // fp as accumulated by the stage-4 lane of the current run (uniform between runs)
+  int l;                                // knot interval of the current run (0 = no run)
+  int stage;                            // this lane's stage (1..4) in the current run
+  int t;                                // steps of the current run so far
+  int fed;                              // rows fed into the current run so far
+  int bad;                              // FAST division met an operand outside the safe exponent band
 };
 
-// per-lane pipeline state of one observation pass (carried across its chunks)
-struct GivState {
-  GivItem out;      // item leaving this lane, rotated to the next lane at the next step
-  GivRow row;
-  double fpl;       // fp token value (valid in the lane that has it)
-  int has;          // this lane holds the fp token
-  int tau;          // step counter
-  int t_base;       // step after the last injection
-  int l_prev;       // knot interval of the last injected row
-  int last_finish;  // step at which the last injected row leaves the pipeline
-  int first;        // no row injected yet
-};
-
-__device__ __forceinline__ void giv_init(GivState& st) {
-  st.out.piv = st.out.r0 = st.out.r1 = st.out.r2 = st.out.x1 = st.out.x2 = st.out.fpc = 0.0;
-  st.out.j = 0;
-  st.out.info = 0;
-  st.row.j = 0;
-  st.row.a1 = st.row.a2 = st.row.a3 = st.row.a4 = st.row.z1 = st.row.z2 = 0.0;
-  st.fpl = 0.0;
-  st.has = 0;
-  st.tau = 0;
-  st.t_base = 0;
-  st.l_prev = 0;
-  st.last_finish = -1;
-  st.first = 1;
+__device__ __forceinline__ void giv_init(GivLane& st) {
+  st.a1 = st.a2 = st.a3 = st.a4 = st.z1 = st.z2 = 0.0;
+  st.j = 0;
+  st.o_piv = st.o_r0 = st.o_r1 = st.o_x1 = st.o_x2 = 0.0;
+  st.fp = 0.0;
+  st.l = 0;
+  st.stage = 1;
+  st.t = 0;
+  st.fed = 0;
+  st.bad = 0;
 }
 
-template <int G>
-__device__ __forceinline__ void giv_flush(SplineWS<G>& ws, const GivRow& r, int n) {
-  if (r.j > 0) {
-    ws.A(r.j, 1) = r.a1;
-    ws.A(r.j, 2) = r.a2;
-    ws.A(r.j, 3) = r.a3;
-    ws.A(r.j, 4) = r.a4;
-    ws.z[r.j] = r.z1;
-    ws.z[r.j + n] = r.z2;
+template <class WS>
+__device__ __forceinline__ void giv_flush(WS& ws, const GivLane& st, int lane, int n) {
+  if (lane < 4 && st.j > 0) {
+    ws.A(st.j, 1) = st.a1;
+    ws.A(st.j, 2) = st.a2;
+    ws.A(st.j, 3) = st.a3;
+    ws.A(st.j, 4) = st.a4;
+    ws.z[st.j] = st.z1;
+    ws.z[st.j + n] = st.z2;
   }
 }
 
-// one stage of one data row on this lane: rotate against the owned band row, hand the row on (or retire it)
-template <int G>
-__device__ __forceinline__ void giv_process(SplineWS<G>& ws, GivState& st, const GivItem& in, int lane, int n) {
-  const int stage = in.info & 0xff;
-  const bool active = stage > 0;
-  if (active && st.row.j != in.j) {
-    // this lane moves on to its next band row (j + 4): the old one is complete, the new one has not been touched yet
-    // in this pass (rows arrive in increasing interval order), i.e. it is still all zero
-    giv_flush<G>(ws, st.row, n);
-    st.row.j = in.j;
-    st.row.a1 = st.row.a2 = st.row.a3 = st.row.a4 = st.row.z1 = st.row.z2 = 0.0;
-  }
-  // fp token: leaves with the first row that exits elsewhere, arrives with a row at its exit stage
-  const int exit_lane = (in.j + 4 - stage) & 3;
-  const bool tok_in = (in.info & GIV_TOK) != 0;
-  const bool arrive = active && tok_in && stage == 4;
-  const bool leave = active && st.has != 0 && exit_lane != lane;
-  const double fpc_out = leave ? st.fpl : in.fpc;
-  const bool tok_out = (tok_in && !arrive) || leave;
-  st.fpl = arrive ? in.fpc : st.fpl;
-  st.has = ((st.has != 0 && !leave) || arrive) ? 1 : 0;
+__device__ __forceinline__ double quad_prev(double d) {  // value of the previous lane of the quad (lane 0 <- lane 3)
+#ifdef FSDP_EMU
+  int l = emu::B->cur;
+  return emu::gexchange(d, (l & ~3) | ((l + 3) & 3), 4);
+#else
+  int lo = __double2loint(d), hi = __double2hiint(d);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x93, 0xf, 0xf, true);  // quad_perm:[3,0,1,2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x93, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+#endif
+}
 
-  double piv = in.piv, r0 = in.r0, r1 = in.r1, r2 = in.r2, x1 = in.x1, x2 = in.x2;
-  const bool rot = active && piv != 0.0;
-  {
-    // fpgivs.f: dd = |piv| * sqrt(1 + (ww/piv)^2) if |piv| >= ww else ww * sqrt(1 + (piv/ww)^2) — written with selects so
-    // that one division and one square root are issued (same operations, same operands, same bits); every lane runs
-    // the arithmetic, the results are kept where `rot` holds
-    const double ww = st.row.a1;
-    const double store = fabs(piv);
-    const bool big = store >= ww;
-    const double num = big ? ww : piv, den = big ? piv : ww, scale = big ? store : ww;
+// One pipeline step on every lane.  feed: the stage-1 lane takes the data row (h0..h3, x, y); otherwise nothing enters.
+template <bool FAST>
+__device__ __forceinline__ void giv_step(GivLane& st, bool feed, double h0, double h1, double h2, double h3, double dx, double dy) {
+  double piv = quad_prev(st.o_piv), r0 = quad_prev(st.o_r0), r1 = quad_prev(st.o_r1), x1 = quad_prev(st.o_x1),
+         x2 = quad_prev(st.o_x2);
+  double r2 = 0.0;
+  const bool s1 = st.stage == 1;
+  if (s1 && feed) {
+    piv = h0;
+    r0 = h1;
+    r1 = h2;
+    r2 = h3;
+    x1 = dx;
+    x2 = dy;
+  }
+  const int idx = st.t - (st.stage - 1);
+  const bool valid = idx >= 0 && idx < st.fed;
+  const bool rot = valid && piv != 0.0;
+  // fpgivs.f: dd = |piv| * sqrt(1 + (ww/piv)^2) if |piv| >= ww else ww * sqrt(1 + (piv/ww)^2) — written with selects so
+  // that one division and one square root are issued (same operations, same operands, same bits)
+  const double ww = st.a1;
+  const double store = fabs(piv);
+  const bool big = store >= ww;
+  const double num = big ? ww : piv, den = big ? piv : ww, scale = big ? store : ww;
+  double dd, cs, sn;
+  if constexpr (FAST) {
+    st.bad |= (int)(rot & !(div_safe(piv) & ((ww == 0.0) | div_safe(ww))));
+    const double rq = rcp_refined(den);
+    const double q = div_rcp(num, den, rq);
+    dd = scale * sqrt_1_2(1.0 + q * q);
+    const double rd = rcp_refined(dd);
+    cs = div_rcp(ww, dd, rd);
+    sn = div_rcp(piv, dd, rd);
+  } else {
     const double q = num / den;
-    const double dd = scale * sqrt_1_2(1.0 + q * q);
-    const double cs = ww / dd;
-    const double sn = piv / dd;
-    const double nz1 = cs * st.row.z1 + sn * x1, nx1 = cs * x1 - sn * st.row.z1;
-    const double nz2 = cs * st.row.z2 + sn * x2, nx2 = cs * x2 - sn * st.row.z2;
-    const double na2 = cs * st.row.a2 + sn * r0, nr0 = cs * r0 - sn * st.row.a2;
-    const double na3 = cs * st.row.a3 + sn * r1, nr1 = cs * r1 - sn * st.row.a3;
-    const double na4 = cs * st.row.a4 + sn * r2, nr2 = cs * r2 - sn * st.row.a4;
-    st.row.a1 = rot ? dd : st.row.a1;
-    st.row.z1 = rot ? nz1 : st.row.z1;
-    x1 = rot ? nx1 : x1;
-    st.row.z2 = rot ? nz2 : st.row.z2;
-    x2 = rot ? nx2 : x2;
-    const bool c3 = rot && stage <= 3, c2 = rot && stage <= 2, c1 = rot && stage <= 1;
-    st.row.a2 = c3 ? na2 : st.row.a2;
-    r0 = c3 ? nr0 : r0;
-    st.row.a3 = c2 ? na3 : st.row.a3;
-    r1 = c2 ? nr1 : r1;
-    st.row.a4 = c1 ? na4 : st.row.a4;
-    r2 = c1 ? nr2 : r2;
+    dd = scale * sqrt(1.0 + q * q);
+    cs = ww / dd;
+    sn = piv / dd;
   }
-  // retire: the rotated-out right-hand sides enter fp in data order
-  const bool retire = active && stage == 4;
+  cs = rot ? cs : 1.0;
+  sn = rot ? sn : 0.0;
+  st.a1 = rot ? dd : st.a1;
+  // fprota on the right-hand sides and the rest of the band row
+  const double nz1 = cs * st.z1 + sn * x1, nx1 = cs * x1 - sn * st.z1;
+  const double nz2 = cs * st.z2 + sn * x2, nx2 = cs * x2 - sn * st.z2;
+  const double na2 = cs * st.a2 + sn * r0, nr0 = cs * r0 - sn * st.a2;
+  const double na3 = cs * st.a3 + sn * r1, nr1 = cs * r1 - sn * st.a3;
+  const double na4 = cs * st.a4 + sn * r2, nr2 = cs * r2 - sn * st.a4;
+  st.z1 = nz1;
+  st.z2 = nz2;
+  st.a2 = na2;
+  st.a3 = na3;
+  st.a4 = na4;
+  // retire at stage 4: the rotated-out right-hand sides enter fp in data order
   {
-    double f = st.fpl + x1 * x1;
-    f = f + x2 * x2;
-    st.fpl = retire ? f : st.fpl;
+    double f = st.fp + nx1 * nx1;
+    f = f + nx2 * nx2;
+    st.fp = (valid && st.stage == 4) ? f : st.fp;
   }
-  const bool fwd = active && stage < 4;
-  st.out.piv = r0;
-  st.out.r0 = r1;
-  st.out.r1 = r2;
-  st.out.r2 = 0.0;
-  st.out.x1 = x1;
-  st.out.x2 = x2;
-  st.out.fpc = fpc_out;
-  st.out.j = in.j + 1;
-  st.out.info = fwd ? ((stage + 1) | (tok_out ? GIV_TOK : 0)) : 0;
+  st.o_piv = nr0;
+  st.o_r0 = nr1;
+  st.o_r1 = nr2;
+  st.o_x1 = nx1;
+  st.o_x2 = nx2;
+  st.t++;
 }
 
-// one chunk of `cnt` data rows (basis values / interval / data in ws.hq, ws.lq, ws.xq, ws.yq) into the pipeline; rows
-// still in flight at the end stay in `st` (the next chunk, or giv_drain, moves them on).  All lanes of the group call.
-template <int G>
-__device__ __forceinline__ void givens_chunk_pipelined(SplineWS<G>& ws, int cnt, int n, GivState& st) {
-  const int lane = Grp<G>::lane();
-  constexpr int k1 = 4;
-  int next_r = 0;
-  // the next row to inject is staged in registers one step ahead (group-uniform LDS reads), off the critical path
-  double p0 = 0, p1 = 0, p2 = 0, p3 = 0, px = 0, py = 0;
-  int pl = 0;
-  auto stage_row = [&](int r) {
-    p0 = ws.hq[r][0];
-    p1 = ws.hq[r][1];
-    p2 = ws.hq[r][2];
-    p3 = ws.hq[r][3];
-    px = ws.xq[r];
-    py = ws.yq[r];
-    pl = ws.lq[r];
-  };
-  if (cnt > 0) stage_row(0);
-  // a row enters one step after its predecessor, later by the number of intervals it skipped (its first band row must
-  // have seen the predecessor).  The test for the next step is evaluated after this step's arithmetic, so the staged
-  // row's interval (an LDS read issued at the previous injection) is consumed late.
-  bool inject = st.first != 0 || st.tau >= st.t_base + (pl - st.l_prev);
-  while (next_r < cnt) {
-    GivItem in = quad_rot_prev<G>(st.out);
-    if (inject) {
-      const int j0 = pl - k1 + 1;
-      if (lane == (j0 & 3)) {
-        in.piv = p0;
-        in.r0 = p1;
-        in.r1 = p2;
-        in.r2 = p3;
-        in.x1 = px;
-        in.x2 = py;
-        in.fpc = 0.0;
-        in.j = j0;
-        in.info = 1 | (st.first != 0 ? GIV_TOK : 0);
-      }
-      st.first = 0;
-      st.last_finish = st.tau + k1 - 1;
-      st.l_prev = pl;
-      st.t_base = st.tau + 1;
-      next_r++;
-      if (next_r < cnt) stage_row(next_r);
-    }
-    giv_process<G>(ws, st, in, lane, n);
-    st.tau++;
-    inject = st.tau >= st.t_base + (pl - st.l_prev);
-  }
+// drain the rows in flight and close the run: fp becomes uniform in the group again
+template <int G, bool FAST>
+__device__ __forceinline__ void giv_end_run(GivLane& st) {
+  if (st.l == 0) return;
+  for (int q = 0; q < 3; q++) giv_step<FAST>(st, false, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
+  st.fp = Grp<G>::bcast(st.fp, st.l & 3);  // the stage-4 lane of interval l: band row l, lane l mod 4
+  st.l = 0;
 }
 
-// empty the pipeline at the end of an observation pass and return fp (group-uniform)
-template <int G>
-__device__ __forceinline__ double giv_drain(SplineWS<G>& ws, int n, GivState& st) {
-  const int lane = Grp<G>::lane();
-  while (st.tau <= st.last_finish) {
-    GivItem in = quad_rot_prev<G>(st.out);
-    giv_process<G>(ws, st, in, lane, n);
-    st.tau++;
+// open the run of knot interval l: stages follow from the lane, the lane whose band row left the window moves on
+template <class WS>
+__device__ __forceinline__ void giv_begin_run(WS& ws, GivLane& st, int l, int lane, int n) {
+  const int j0 = l - 3;
+  st.stage = ((lane - j0) & 3) + 1;
+  const int my_j = j0 + st.stage - 1;
+  if (st.j != my_j) {
+    // the old band row is complete; the new one has not been touched yet in this pass (rows arrive in increasing
+    // interval order), i.e. it is still all zero
+    giv_flush(ws, st, lane, n);
+    st.j = my_j;
+    st.a1 = st.a2 = st.a3 = st.a4 = st.z1 = st.z2 = 0.0;
   }
-  if (lane < 4) giv_flush<G>(ws, st.row, n);
-  // the token rests in the exit lane of the last row (interval l_prev)
-  return Grp<G>::bcast(st.fpl, st.l_prev & 3);
+  st.l = l;
+  st.t = 0;
+  st.fed = 0;
+}
+
+// rows [r0, r1) of the chunk buffers (all of the run's interval) into the pipeline; rows still in flight at the end stay
+// in `st`.  The next row is read (group-uniform LDS reads) one step ahead of its use.
+template <bool FAST, class WS>
+__device__ __forceinline__ void giv_feed(WS& ws, GivLane& st, int r0, int r1) {
+  st.fed += r1 - r0;
+  double h0 = ws.hq[r0][0], h1 = ws.hq[r0][1], h2 = ws.hq[r0][2], h3 = ws.hq[r0][3], dx = ws.xq[r0], dy = ws.yq[r0];
+  for (int r = r0; r < r1; r++) {
+    const double c0 = h0, c1 = h1, c2 = h2, c3 = h3, cx = dx, cy = dy;
+    const int rn = (r + 1 < r1) ? r + 1 : r;
+    h0 = ws.hq[rn][0];
+    h1 = ws.hq[rn][1];
+    h2 = ws.hq[rn][2];
+    h3 = ws.hq[rn][3];
+    dx = ws.xq[rn];
+    dy = ws.yq[rn];
+    giv_step<FAST>(st, true, c0, c1, c2, c3, cx, cy);
+  }
 }
 
 // Residual terms sum_d (s_d(u_i) - x_d,i)^2 of one "super-chunk" of points [base, base + cnt) (cnt <= 4 * CH), one point
@@ -485,7 +478,8 @@ struct ResidualBatch {
     }
   }
 
-  __device__ __forceinline__ void compute(SplineWS<G>& ws, int cnt, int n, double* tbuf, int32_t* fbuf) const {
+  template <class WS>
+  __device__ __forceinline__ void compute(WS& ws, int cnt, int n, double* tbuf, int32_t* fbuf) const {
     const int lane = Grp<G>::lane();
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
@@ -514,11 +508,12 @@ struct ResidualBatch {
 
 // parcur/fppara for idim=2, w=1, iopt=0.  Data (0-based arrays U = parameter, X, Y; m points) in LDS or HBM.
 // All lanes of the group call; result (t, c) left in ws; returns the group-uniform SplineFit.
-template <int K, int G>
-__device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCache& bc, const double* U, const double* X, const double* Y,
+template <int K, bool FAST, class WS>
+__device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, const double* U, const double* X, const double* Y,
                                          int m, double s) {
+  constexpr int G = WS::GRP;
   using GR = Grp<G>;
-  constexpr int CH = SplineWS<G>::CH;
+  constexpr int CH = WS::CH;
   constexpr int SC = ResidualBatch<K, G, false>::ROUNDS * G;  // points per residual half "super-chunk"
   constexpr int HALVES = (2 * SC <= 4 * CH) ? 2 : 1;             // the chunk's basis buffer holds 4 * CH terms
   constexpr int k = K;
@@ -532,7 +527,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
   constexpr int k1 = K + 1, k2 = K + 2;
   constexpr int nmin = 2 * k1;
   int nest = m + 2 * k;
-  constexpr int NK = SplineWS<G>::NK;
+  constexpr int NK = WS::NK;
   if (nest > NK) nest = NK;
   if (m < k1 || nest < nmin) {
     R.status = 1;
@@ -592,8 +587,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
         for (int j = 1; j <= k1; j++) ws.A(i, j) = 0.0;
       GR::sync();
       fp = 0.0;
-      GivState gst;
+      GivLane gst;
       giv_init(gst);
+      int lvq[CH / G] = {};  // knot intervals of this lane's rows of the current chunk
       int lres = k1;  // this lane's previous knot interval (data are increasing: the search resumes there)
       // ---- observation rows: basis values per lane, Givens rotations group-uniform in data order ----
       // the chunk's points (parameter, x, y) are fetched one chunk ahead: the scratch round trip of chunk c + 1 hides
@@ -632,6 +628,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
                 bc.h[j][it] = h[j + 1];
               }
               ws.lq[r] = l;
+              lvq[q] = l;
               bc.l[it] = l;
               ws.xq[r] = pxv[q];
               ws.yq[r] = pyv[q];
@@ -642,7 +639,20 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
         }
         if constexpr (K == 3) {
           PROF(11);
-          givens_chunk_pipelined<G>(ws, cnt, n, gst);
+          // the chunk's rows, one run per knot interval (rows are sorted by interval: a run is contiguous)
+          int r = 0;
+          while (r < cnt) {
+            const int l = ws.lq[r];
+            int same = 0;
+#pragma unroll
+            for (int q = 0; q < NRC; q++) same += __popcll(GR::ballot(q * G + lane < cnt && lvq[q] == l));
+            if (l != gst.l) {
+              giv_end_run<G, FAST>(gst);
+              giv_begin_run(ws, gst, l, lane, n);
+            }
+            giv_feed<FAST>(ws, gst, r, r + same);
+            r += same;
+          }
           PROF_COUNT(20, G, cnt);
         } else {
           if (lane == 0) {  // serial section: rows enter the triangle in data order (single writer of a / z)
@@ -688,7 +698,10 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
       }
       if constexpr (K == 3) {
         PROF(12);
-        fp = giv_drain<G>(ws, n, gst);
+        giv_end_run<G, FAST>(gst);
+        giv_flush(ws, gst, lane, n);
+        fp = gst.fp;
+        if (GR::ballot(gst.bad != 0) != 0ull) R.status = ST_RETRY;
         GR::sync();
       }
       if (lane == 0) {
@@ -1030,20 +1043,21 @@ __device__ __forceinline__ SplineFit spline_fit_k(SplineWS<G>& ws, const BasisCa
   return R;
 }
 
-template <int G>
-__device__ __forceinline__ SplineFit spline_fit(SplineWS<G>& ws, const BasisCache& bc, const double* U, const double* X, const double* Y,
+template <bool FAST, class WS>
+__device__ __forceinline__ SplineFit spline_fit(WS& ws, const BasisCache& bc, const double* U, const double* X, const double* Y,
                                        int m, int k, double s) {
-  if (k == 3) return spline_fit_k<3, G>(ws, bc, U, X, Y, m, s);
-  if (k == 2) return spline_fit_k<2, G>(ws, bc, U, X, Y, m, s);
-  return spline_fit_k<1, G>(ws, bc, U, X, Y, m, s);
+  if (k == 3) return spline_fit_k<3, FAST>(ws, bc, U, X, Y, m, s);
+  if (k == 2) return spline_fit_k<2, FAST>(ws, bc, U, X, Y, m, s);
+  return spline_fit_k<1, FAST>(ws, bc, U, X, Y, m, s);
 }
 
 // splev (der = 0, ext = 0) at arg = i * step for i in [0, count): one evaluation point per lane.
 // Outputs to OX/OY (LDS or global), optional parameter values to OU.  Reads only t / c, so the outputs may alias the
 // rest of the fit workspace (the dense samples of the final spline do).
-template <int K, int G>
-__device__ __forceinline__ void spline_eval_k(const SplineWS<G>& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+template <int K, class WS>
+__device__ __forceinline__ void spline_eval_k(const WS& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
                                      double* OU) {
+  constexpr int G = WS::GRP;
   const int lane = Grp<G>::lane();
   const int n = f.n;
   constexpr int k1 = K + 1;
@@ -1068,15 +1082,15 @@ __device__ __forceinline__ void spline_eval_k(const SplineWS<G>& ws, const Splin
   Grp<G>::sync();
 }
 
-template <int G>
-__device__ __forceinline__ void spline_eval(const SplineWS<G>& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
+template <class WS>
+__device__ __forceinline__ void spline_eval(const WS& ws, const SplineFit& f, double step, int count, double* OX, double* OY,
                                    double* OU) {
   if (f.k == 3)
-    spline_eval_k<3, G>(ws, f, step, count, OX, OY, OU);
+    spline_eval_k<3>(ws, f, step, count, OX, OY, OU);
   else if (f.k == 2)
-    spline_eval_k<2, G>(ws, f, step, count, OX, OY, OU);
+    spline_eval_k<2>(ws, f, step, count, OX, OY, OU);
   else
-    spline_eval_k<1, G>(ws, f, step, count, OX, OY, OU);
+    spline_eval_k<1>(ws, f, step, count, OX, OY, OU);
 }
 
 }  // namespace fsdp

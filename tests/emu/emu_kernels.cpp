@@ -35,7 +35,7 @@ __global__ void fit_test_kernel(const double* xy, int m, double smoothing, doubl
   __syncthreads();
   SplineFit f;
   double max_u;
-  int rc = fit_polyline<WAVE>(S, A, 0, m, smoothing, f, max_u);
+  int rc = fit_polyline<WAVE, true>(S, A, 0, m, smoothing, f, max_u);
   if (lane == 0) {
     info[0] = rc;
     info[1] = f.n;

@@ -45,8 +45,10 @@ struct Block {
   int n_lanes = WAVE;
   int cur = 0;
   int live = 0;
-  int garrived[WAVE] = {0};
-  unsigned ggen[WAVE] = {0};
+  // rendezvous state per group size (index log2 G) and group: groups of different sizes may be in flight at once
+  // (a quad exchange inside a 16-lane group), so they must not share counters
+  int garrived[7][WAVE] = {{0}};
+  unsigned ggen[7][WAVE] = {{0}};
   Dim3 bid, bdim, gdim;
   uint64_t slots[WAVE];
   std::function<void()> body;
@@ -78,13 +80,14 @@ inline int group_live(Block* b, int first, int G) {
 inline void gbarrier(int G) {
   Block* b = B;
   int first = b->cur & ~(G - 1);
-  unsigned g = b->ggen[first];
-  if (++b->garrived[first] >= group_live(b, first, G)) {
-    b->garrived[first] = 0;
-    b->ggen[first]++;
+  const int lg = __builtin_ctz((unsigned)G);
+  unsigned g = b->ggen[lg][first];
+  if (++b->garrived[lg][first] >= group_live(b, first, G)) {
+    b->garrived[lg][first] = 0;
+    b->ggen[lg][first]++;
     return;
   }
-  while (b->ggen[first] == g) yield_lane();
+  while (b->ggen[lg][first] == g) yield_lane();
 }
 inline void barrier() { gbarrier(WAVE); }
 
@@ -115,10 +118,11 @@ void launch(unsigned grid, unsigned block, F&& f) {
     B = b;
     b->n_lanes = (int)block;
     b->live = (int)block;
-    for (int i = 0; i < WAVE; i++) {
-      b->garrived[i] = 0;
-      b->ggen[i] = 0;
-    }
+    for (int q = 0; q < 7; q++)
+      for (int i = 0; i < WAVE; i++) {
+        b->garrived[q][i] = 0;
+        b->ggen[q][i] = 0;
+      }
     b->bid.x = bx;
     b->bdim.x = block;
     b->gdim.x = grid;
