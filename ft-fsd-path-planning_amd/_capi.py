@@ -16,6 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "lib" / "libfsdp_hip.so"
 
 MAX_LEN, MAX_MATCH, PATH_POINTS, MAX_CONES = 12, 24, 40, 256
+MAX_STAGES = 8  # FSDP_MAX_STAGES
 
 # numpy mirror of fsdp_frame_result (include/fsdp.h)
 RESULT_DTYPE = np.dtype(
@@ -217,9 +218,10 @@ class Context:
 
     def time_runs(self, iters: int):
         tot = ctypes.c_float()
-        st = (ctypes.c_float * 3)()
+        st = (ctypes.c_float * MAX_STAGES)()
         self._check(self._lib.fsdp_time_runs(self._h, int(iters), ctypes.byref(tot), st), "fsdp_time_runs")
-        return float(tot.value), [float(x) for x in st]
+        n = len(self.stage_names())
+        return float(tot.value), [float(x) for x in st][:n]
 
     def stage_names(self):
         """Kernel names behind the per-stage times of the most recent time_runs (the path kernel's lane-group

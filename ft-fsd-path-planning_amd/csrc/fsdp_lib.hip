@@ -46,7 +46,8 @@ struct fsdp_ctx {
   PathOut* d_path = nullptr;
   double* d_default_path = nullptr;  // (40,4)
   double* d_arena = nullptr;         // per-frame working polyline + basis cache (ARENA_DOUBLES doubles), HBM/L2 scratch
-  int* d_retry = nullptr;            // retry list of the packed path kernels (n_frames + 1 ints)
+  int* d_retry = nullptr;            // [0] counter + frames for the exact re-plan kernel (n_frames + 1 ints)
+  PathMid* d_mid = nullptr;          // hand-over records of the three-kernel path stage
   double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
   double* d_prev = nullptr;          // optional per-frame previous paths (n_frames,40,4) for sequential replays
   bool use_prev = false;
@@ -54,8 +55,9 @@ struct fsdp_ctx {
   int n_gpath = 0;
   // further sets of intermediates + streams (fsdp_set_overlap): consecutive fsdp_run passes rotate through the sets, so
   // the next passes start while the slowest wavefronts of the previous ones are still finishing
-  int last_path_g = 0;        // lanes per frame of the most recent path-kernel launch
-  int force_path_g = 0;       // 0 = automatic; 8 / 16 / 64 = test / tuning override (FSDP_PATH_G environment variable)
+  int force_path_mode = 0;    // 0 = by batch size; 1 = one kernel (64 lanes per frame); 2 = three kernels (FSDP_PATH_MODE=mono|split)
+  int fit_g = 8;              // lanes per frame of fit_kernel (FSDP_FIT_G=4|8)
+  std::string stage_names;    // kernels of the most recent pass, comma-separated
   bool profile_sort = false;  // profiling build: which kernel fsdp_profile_path runs
   int overlap = 1;
   unsigned turn = 0;
@@ -67,6 +69,7 @@ struct fsdp_ctx {
     PathOut* d_path = nullptr;
     double* d_arena = nullptr;
     int* d_retry = nullptr;
+    PathMid* d_mid = nullptr;
     int cap_frames = 0;
   } extra[FSDP_MAX_OVERLAP - 1];
   std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
@@ -119,6 +122,8 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->d_retry) (void)hipFree(c->d_retry);
     c->d_retry = nullptr;
+    if (c->d_mid) (void)hipFree(c->d_mid);
+    c->d_mid = nullptr;
     if (c->d_prev) (void)hipFree(c->d_prev);
     c->d_prev = nullptr;
     c->use_prev = false;
@@ -136,6 +141,7 @@ static int ensure_capacity(fsdp_ctx* c, int n_frames, size_t n_cones) {
     HIP_TRY(c, hipMalloc(&c->d_path, sizeof(PathOut) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_arena, sizeof(double) * ARENA_DOUBLES * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_retry, sizeof(int) * ((size_t)n_frames + 1)));
+    HIP_TRY(c, hipMalloc(&c->d_mid, sizeof(PathMid) * (size_t)n_frames));
     HIP_TRY(c, hipMalloc(&c->d_prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n_frames));
     c->cap_frames = n_frames;
   }
@@ -178,12 +184,13 @@ struct Slot {
   MatchOut* d_match;
   PathOut* d_path;
   double* d_arena;
-  int* d_retry;  // [0] counter + frames the packed path kernel could not finish (knot capacity)
+  int* d_retry;  // [0] counter + frames handed to the exact re-plan kernel
+  PathMid* d_mid;
 };
 static Slot slot_of(fsdp_ctx* c, int i) {
-  if (i == 0) return Slot{0, c->stream, c->d_sort, c->d_match, c->d_path, c->d_arena, c->d_retry};
+  if (i == 0) return Slot{0, c->stream, c->d_sort, c->d_match, c->d_path, c->d_arena, c->d_retry, c->d_mid};
   const fsdp_ctx::Extra& x = c->extra[i - 1];
-  return Slot{i, x.stream, x.d_sort, x.d_match, x.d_path, x.d_arena, x.d_retry};
+  return Slot{i, x.stream, x.d_sort, x.d_match, x.d_path, x.d_arena, x.d_retry, x.d_mid};
 }
 
 static int ensure_extra_slots(fsdp_ctx* c) {
@@ -197,6 +204,8 @@ static int ensure_extra_slots(fsdp_ctx* c) {
     if (x.d_arena) (void)hipFree(x.d_arena);
     if (x.d_retry) (void)hipFree(x.d_retry);
     x.d_retry = nullptr;
+    if (x.d_mid) (void)hipFree(x.d_mid);
+    x.d_mid = nullptr;
     x.d_sort = nullptr;
     x.d_match = nullptr;
     x.d_path = nullptr;
@@ -208,6 +217,7 @@ static int ensure_extra_slots(fsdp_ctx* c) {
     HIP_TRY(c, hipMalloc(&x.d_path, sizeof(PathOut) * n));
     HIP_TRY(c, hipMalloc(&x.d_arena, sizeof(double) * ARENA_DOUBLES * n));
     HIP_TRY(c, hipMalloc(&x.d_retry, sizeof(int) * (n + 1)));
+    HIP_TRY(c, hipMalloc(&x.d_mid, sizeof(PathMid) * n));
     x.cap_frames = c->cap_frames;
   }
   return 0;
@@ -229,58 +239,73 @@ static void launch_match(fsdp_ctx* c, const Slot& q) {
   hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
                      q.d_sort, q.d_match);
 }
-template <int G>
-static void launch_path_g(fsdp_ctx* c, const Slot& q, int* retry) {
-  const double* prev = c->use_prev ? c->d_prev : nullptr;
-  c->slot_prev[q.index] = prev;  // finish_knot_overflow re-plans with the previous paths this launch saw
-  hipLaunchKernelGGL(path_kernel<G>, dim3((c->n_frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, c->n_frames,
-                     c->d_poses, q.d_match, c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, retry);
-}
-// lanes per frame: see path_kernel.h (results do not depend on the choice)
-static void launch_path(fsdp_ctx* c, const Slot& q) {
-  int g = c->force_path_g;
-  if (g == 0) {
-    if (c->overlap > 1 || c->n_frames > PATH_LATENCY_BATCH)
-      g = PATH_G_THROUGHPUT;  // more wavefronts than SIMDs in flight: throughput regime
-    else if (c->n_frames <= PATH_SMALL_BATCH)
-      g = PATH_G_SMALL;
-    else
-      g = PATH_G_LATENCY;
-  }
-  c->last_path_g = g;
-  if (g == PATH_G_SMALL) {
-    launch_path_g<PATH_G_SMALL>(c, q, nullptr);
-    return;
-  }
-  // The packed kernels keep 32 knots per fit in LDS; a frame that needs more (long polylines with sharp corners, e.g.
-  // the acceleration mission's known path) ends with status 204.  Such frames are rare and results are only visible
-  // after a download, so they are finished there (finish_knot_overflow) instead of stalling every pass with a second
-  // launch that needs whole SIMDs.
-  if (g == PATH_G_THROUGHPUT)
-    launch_path_g<PATH_G_THROUGHPUT>(c, q, nullptr);
-  else
-    launch_path_g<PATH_G_LATENCY>(c, q, nullptr);
+// ---- the path stage of one pass ------------------------------------------------------------------------------------------
+// Small batches (<= PATH_SMALL_BATCH frames: single-frame calls, latency): one kernel, one frame per wavefront.
+// Large batches: three kernels (path_kernel.h: path_prep_kernel -> fit_kernel -> path_finish_kernel).  Either way the
+// frames the fast kernels hand on (retry list on the device) are planned by the exact kernel in the same stream, so a
+// pass is complete when its stream is idle and results do not depend on the route.
+constexpr int MAX_STAGES = FSDP_MAX_STAGES;
+struct StageEvents {  // optional timing: ev[k] is recorded before stage k, ev[n_stages] after the last
+  hipEvent_t* ev = nullptr;
+  int n = 0;
+};
+static void mark(const Slot& q, StageEvents* t) {
+  if (t && t->ev) (void)hipEventRecord(t->ev[t->n++], q.stream);
 }
 
-// After the path records of slot q are on the host (h_path): frames the packed path kernels left at ST_OVERFLOW_KNOTS are
-// planned again by the one-frame-per-wavefront instantiation (64 knots) and their records fetched again.
-static int finish_knot_overflow(fsdp_ctx* c, const Slot& q) {
-  std::vector<int> list(1, 0);
-  for (int i = 0; i < c->n_frames; i++)
-    if (c->h_path[i].status == ST_OVERFLOW_KNOTS || c->h_path[i].status == ST_RETRY) list.push_back(i);
-  list[0] = (int)list.size() - 1;
-  if (list[0] == 0) return 0;
-  HIP_TRY(c, hipMemcpyAsync(q.d_retry, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, q.stream));
-  const int blocks = list[0] < 1024 ? list[0] : 1024;
-  hipLaunchKernelGGL(path_retry_kernel, dim3(blocks), dim3(WAVE), 0, q.stream, c->d_poses, q.d_match, c->d_default_path,
-                     c->slot_prev[q.index], c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry);
-  HIP_TRY(c, hipMemcpyAsync(c->h_path, q.d_path, sizeof(PathOut) * (size_t)c->n_frames, hipMemcpyDeviceToHost, q.stream));
-  HIP_TRY(c, hipStreamSynchronize(q.stream));
-  return 0;
+template <int GF>
+static void launch_fit(fsdp_ctx* c, const Slot& q) {
+  hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((c->n_frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, q.stream, c->n_frames,
+                     q.d_arena, q.d_mid, q.d_retry);
+}
+
+static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
+  const double* prev = c->use_prev ? c->d_prev : nullptr;
+  const int n = c->n_frames;
+  const bool split = c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH;
+  c->stage_names = "sort_kernel,match_kernel,";
+  mark(q, t);
+  (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
+  if (!split) {
+    hipLaunchKernelGGL(path_kernel<PATH_G_SMALL>, dim3(n), dim3(WAVE), 0, q.stream, n, c->d_poses, q.d_match, c->d_default_path, prev,
+                       c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry);
+    c->stage_names += "path_kernel<64>,";
+  } else {
+    constexpr int G = PATH_G_SPLIT;
+    const int blocks = (n + WAVE / G - 1) / (WAVE / G);
+    hipLaunchKernelGGL(path_prep_kernel<G>, dim3(blocks), dim3(WAVE), 0, q.stream, n, c->d_poses, q.d_match, c->d_default_path, prev,
+                       c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry);
+    mark(q, t);
+    if (c->fit_g == 4)
+      launch_fit<4>(c, q);
+    else
+      launch_fit<8>(c, q);
+    mark(q, t);
+    hipLaunchKernelGGL(path_finish_kernel<G>, dim3(blocks), dim3(WAVE), 0, q.stream, n, q.d_arena, q.d_mid, q.d_path, q.d_retry);
+    c->stage_names += std::string("path_prep_kernel<8>,fit_kernel<") + (c->fit_g == 4 ? "4" : "8") + ">,path_finish_kernel<8>,";
+  }
+  mark(q, t);
+  const int rb = n < 128 ? n : 128;
+  hipLaunchKernelGGL(path_retry_kernel, dim3(rb), dim3(WAVE), 0, q.stream, c->d_poses, q.d_match, c->d_default_path, prev, c->d_gpath,
+                     c->n_gpath, q.d_arena, q.d_path, q.d_retry);
+  c->stage_names += "path_retry_kernel";
+  mark(q, t);
+}
+
+// sorting -> matching -> path stage of the resident batch on slot q
+static void launch_pass(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
+  mark(q, t);
+  launch_sort(c, q);
+  mark(q, t);
+  launch_match(c, q);
+  if (t && t->ev) {
+    launch_path(c, q, t);
+  } else {
+    launch_path(c, q);
+  }
 }
 static void launch_sort(fsdp_ctx* c) { launch_sort(c, slot_of(c, 0)); }
 static void launch_match(fsdp_ctx* c) { launch_match(c, slot_of(c, 0)); }
-static void launch_path(fsdp_ctx* c) { launch_path(c, slot_of(c, 0)); }
 
 static void assemble(const SortOut* s, const MatchOut* m, const PathOut* p, fsdp_frame_result* r) {
   // r may already hold fields from earlier stages when only part of the pipeline ran
@@ -345,10 +370,8 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
   fsdp_ctx* c = new fsdp_ctx();
   c->device = device;
   c->mission = mission;
-  if (const char* e = getenv("FSDP_PATH_G")) {
-    int g = atoi(e);
-    if (g == 8 || g == 16 || g == 64) c->force_path_g = g;
-  }
+  if (const char* e = getenv("FSDP_PATH_MODE")) c->force_path_mode = !strcmp(e, "mono") ? 1 : (!strcmp(e, "split") ? 2 : 0);
+  if (const char* e = getenv("FSDP_FIT_G")) c->fit_g = atoi(e) == 4 ? 4 : 8;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
@@ -396,6 +419,7 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_path);
   (void)hipFree(c->d_arena);
   (void)hipFree(c->d_retry);
+  (void)hipFree(c->d_mid);
   (void)hipFree(c->d_prev);
   (void)hipFree(c->d_gpath);
   (void)hipFree(c->d_chord);
@@ -418,6 +442,7 @@ void fsdp_destroy(fsdp_ctx* c) {
     (void)hipFree(x.d_path);
     (void)hipFree(x.d_arena);
     (void)hipFree(x.d_retry);
+    (void)hipFree(x.d_mid);
     if (x.stream) (void)hipStreamDestroy(x.stream);
   }
   for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
@@ -483,9 +508,7 @@ int fsdp_run(fsdp_ctx* c) {
   const int si = (c->overlap > 1) ? (int)(c->turn++ % (unsigned)c->overlap) : 0;
   const Slot q = slot_of(c, si);
   c->last_slot = si;
-  launch_sort(c, q);
-  launch_match(c, q);
-  launch_path(c, q);
+  launch_pass(c, q);
   HIP_TRY(c, hipGetLastError());
   return 0;
 }
@@ -510,8 +533,6 @@ int fsdp_download(fsdp_ctx* c, fsdp_frame_result* results) {
   HIP_TRY(c, hipMemcpyAsync(c->h_match, q.d_match, sizeof(MatchOut) * n, hipMemcpyDeviceToHost, q.stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_path, q.d_path, sizeof(PathOut) * n, hipMemcpyDeviceToHost, q.stream));
   int rc = sync_all(c);
-  if (rc) return rc;
-  rc = finish_knot_overflow(c, q);
   if (rc) return rc;
   for (int i = 0; i < n; i++) {
     memset(&results[i], 0, sizeof(fsdp_frame_result));
@@ -578,9 +599,10 @@ int fsdp_plan_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double*
 
 int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
   if (!c || iters <= 0) return 1;
+  if (ms_stage)
+    for (int k = 0; k < MAX_STAGES; k++) ms_stage[k] = 0;
   if (c->n_frames == 0) {
     if (ms_total) *ms_total = 0;
-    if (ms_stage) ms_stage[0] = ms_stage[1] = ms_stage[2] = 0;
     return 0;
   }
   if (!c->resident) {
@@ -590,9 +612,10 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
   HIP_TRY(c, hipSetDevice(c->device));
   int rc = sync_all(c);
   if (rc) return rc;
-  // 4 events per pass (before sort | match | path | after); passes alternate between the slots when overlap is on and are
-  // NOT synchronised with the host in between
-  const size_t need = 4 * (size_t)iters + 2;
+  // MAX_STAGES + 1 events per pass (before every kernel, after the last); passes rotate through the slots when overlap is
+  // on and are NOT synchronised with the host in between
+  constexpr int EPP = MAX_STAGES + 1;
+  const size_t need = (size_t)EPP * (size_t)iters + 2;
   while (c->tev.size() < need) {
     hipEvent_t e;
     HIP_TRY(c, hipEventCreate(&e));
@@ -606,52 +629,43 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
     last_of_slot[i] = -1;
     started[i] = false;
   }
+  int n_stages = 0;
   for (int it = 0; it < iters; it++) {
     const int si = (c->overlap > 1) ? (int)(c->turn++ % (unsigned)c->overlap) : 0;
     const Slot q = slot_of(c, si);
     c->last_slot = si;
-    hipEvent_t* e = &c->tev[4 * (size_t)it];
     if (!started[si] && si != 0) HIP_TRY(c, hipStreamWaitEvent(q.stream, ev_begin, 0));
     started[si] = true;
-    HIP_TRY(c, hipEventRecord(e[0], q.stream));
-    launch_sort(c, q);
-    HIP_TRY(c, hipEventRecord(e[1], q.stream));
-    launch_match(c, q);
-    HIP_TRY(c, hipEventRecord(e[2], q.stream));
-    launch_path(c, q);
-    HIP_TRY(c, hipEventRecord(e[3], q.stream));
+    StageEvents t;
+    t.ev = &c->tev[(size_t)EPP * (size_t)it];
+    launch_pass(c, q, &t);
+    n_stages = t.n - 1;
     last_of_slot[si] = it;
   }
-  // the end event follows the last pass of both slots
+  // the end event follows the last pass of every slot
   for (int i = 1; i < FSDP_MAX_OVERLAP; i++)
-    if (last_of_slot[i] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->tev[4 * (size_t)last_of_slot[i] + 3], 0));
+    if (last_of_slot[i] >= 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->tev[(size_t)EPP * (size_t)last_of_slot[i] + n_stages], 0));
   HIP_TRY(c, hipEventRecord(ev_end, c->stream));
   HIP_TRY(c, hipEventSynchronize(ev_end));
   rc = sync_all(c);
   if (rc) return rc;
   HIP_TRY(c, hipGetLastError());
-  float acc[3] = {0, 0, 0};
   float total = 0;
   HIP_TRY(c, hipEventElapsedTime(&total, ev_begin, ev_end));
-  for (int it = 0; it < iters; it++) {
-    float t;
-    for (int st = 0; st < 3; st++) {
-      HIP_TRY(c, hipEventElapsedTime(&t, c->tev[4 * (size_t)it + st], c->tev[4 * (size_t)it + st + 1]));
-      acc[st] += t;
-    }
-  }
+  if (ms_stage)
+    for (int it = 0; it < iters; it++)
+      for (int st = 0; st < n_stages; st++) {
+        float t;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->tev[(size_t)EPP * (size_t)it + st], c->tev[(size_t)EPP * (size_t)it + st + 1]));
+        ms_stage[st] += t;
+      }
   if (ms_total) *ms_total = total;
-  if (ms_stage) {
-    ms_stage[0] = acc[0];
-    ms_stage[1] = acc[1];
-    ms_stage[2] = acc[2];
-  }
   return 0;
 }
 
 int fsdp_stage_names(fsdp_ctx* c, char* out, int cap) {
   if (!c || !out || cap < 64) return 1;
-  snprintf(out, (size_t)cap, "sort_kernel,match_kernel,path_kernel<%d>", c->last_path_g);
+  snprintf(out, (size_t)cap, "%s", c->stage_names.c_str());
   return 0;
 }
 
@@ -750,13 +764,11 @@ int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, const double
     HIP_TRY(c, hipMemcpyAsync(c->d_prev, prev_paths, sizeof(double) * PATH_POINTS * 4 * (size_t)n_frames, hipMemcpyHostToDevice,
                               c->stream));
   c->use_prev = prev_paths != nullptr;
-  launch_path(c);
+  launch_path(c, slot_of(c, 0));
   c->use_prev = false;  // resident previous paths belonged to the batch this call replaced
   if (int rcs = ensure_staging(c, n_frames)) return rcs;
   HIP_TRY(c, hipMemcpyAsync(c->h_path, c->d_path, sizeof(PathOut) * n_frames, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  rc = finish_knot_overflow(c, slot_of(c, 0));
-  if (rc) return rc;
   for (int i = 0; i < n_frames; i++) {
     results[i].status = 0;
     assemble(nullptr, nullptr, &c->h_path[i], &results[i]);
@@ -781,7 +793,7 @@ int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
   if (c->profile_sort)
     launch_sort(c);
   else
-    launch_path(c);
+    launch_path(c, slot_of(c, 0));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, copy_sync(c, out32_per_frame, d, bytes, hipMemcpyDeviceToHost));
   long long* z = nullptr;

@@ -32,13 +32,29 @@ constexpr int SEG_CAP = 3 * DENSE_CAP;  // segment-length scratch in LDS (the de
 
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
 constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
-constexpr int ARENA_DOUBLES = 7 * PATH_CAP + PATH_CAP / 2 + ARENA_B + DENSE_CAP;
+constexpr int FITREC_DOUBLES = 112;  // >= sizeof(FitRec) / 8
+constexpr int ARENA_DOUBLES = 3 * PATH_CAP + 8 * PATH_CAP + ARENA_B + DENSE_CAP + FITREC_DOUBLES;  // x | y | u | records | ...
+// knots / coefficients of the refit (fit #2) on their way from fit_kernel to path_finish_kernel
+struct FitRec {
+  int32_t n, ier, status, pad;
+  double fp;
+  double t[34];
+  double c[68];  // x coefficients [0, n), y coefficients [n, 2n)
+};
+static_assert(sizeof(FitRec) <= FITREC_DOUBLES * 8, "FitRec does not fit its arena region");
+// what path_prep_kernel hands on: the polyline [off, off + n) of the arena is to be refitted (status 0), or the frame is
+// finished / handed to the exact kernel (status != 0)
+struct PathMid {
+  int32_t status, fallback, off, n;
+};
+static_assert(ARENA_DOUBLES % 8 == 0 && (3 * PATH_CAP) % 8 == 0, "basis records must stay 64-byte aligned");
 struct Arena {
   double* x;
   double* y;
   double* u;
   BasisCache bc;
   double* filt;  // filtered curvature of the dense samples
+  FitRec* fit;
 };
 
 // Per-frame LDS = the spline workspace; while no fit is running the path stage uses its bytes for segment lengths (before
@@ -475,10 +491,13 @@ __device__ __forceinline__ double cumulative_length(PathShared<G>& S, const Aren
 }
 
 // core_calculate_path.py:380-417 do_all_mpc_parameter_calculations on the polyline [1, 1+n) of the arena
-// (slot 0 is reserved for the point connect_path_to_car may prepend).  rc as parameterize_path.
-template <int G, bool FAST>
-__device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
-                                 double (*out)[4], int* fallback, int* n_dense) {
+// (slot 0 is reserved for the point connect_path_to_car may prepend), in three steps so that the refit can run in its
+// own kernel: mpc_prepare (connect to the car, extend, trim behind the car -> polyline [off, off+n) to refit),
+// the refit (utils/spline_fit.py, smoothing 0.2), mpc_finish (predict 30 m, cut at 20 m, parameterize).
+// rc as parameterize_path.
+template <int G>
+__device__ __forceinline__ int mpc_prepare(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
+                                           int* fallback, int* off_out, int* n_out) {
   using GR = Grp<G>;
   const int lane = GR::lane();
   if (n <= 0) return ST_REF_UNDEFINED_PATH;
@@ -597,19 +616,20 @@ __device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int 
     n -= bi;
   }
   GR::sync();
-  // refit_path_for_mpc_with_safety_factor :239-259 (predict to 1.5 * 20 m), then cut at 20 m :467-499
+  *off_out = off;
+  *n_out = n;
+  return 0;
+}
+
+// after refit_path_for_mpc_with_safety_factor's fit :239-259 (knots / coefficients in S.ws, `fitted` false when the
+// polyline had fewer than 2 points): predict to 1.5 * 20 m, cut at 20 m :467-499, parameterize
+template <int G, bool FAST>
+__device__ __forceinline__ int mpc_finish(PathShared<G>& S, const Arena& A, bool fitted, const SplineFit& f, double (*out)[4],
+                                          int* n_dense) {
   int n5;
   {
     int n4 = 0;
-    SplineFit f;
-    if (n >= 2) {
-      double max_u;
-      int rc;
-      {
-        PROF(4);
-        rc = fit_polyline<G, FAST>(S, A, off, n, 0.2, f, max_u);
-      }
-      if (rc) return rc;
+    if (fitted) {
       PROF(5);
       n4 = arange_len(20.0 * 1.5, 0.1);
       spline_eval(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
@@ -623,6 +643,53 @@ __device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int 
   return parameterize_path<G, FAST>(S, A, 0, n5, out, n_dense);
 }
 
+template <int G, bool FAST>
+__device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
+                                 double (*out)[4], int* fallback, int* n_dense) {
+  int off = 0;
+  int rc = mpc_prepare<G>(S, A, n, px, py, dx, dy, fallback, &off, &n);
+  if (rc) return rc;
+  SplineFit f;
+  f.k = 3;
+  f.n = 0;
+  const bool fitted = n >= 2;
+  if (fitted) {
+    double max_u;
+    PROF(4);
+    rc = fit_polyline<G, FAST>(S, A, off, n, 0.2, f, max_u);
+    if (rc) return rc;
+  }
+  return mpc_finish<G, FAST>(S, A, fitted, f, out, n_dense);
+}
+
+// overwrite_path_if_it_is_too_far_away :225-237 on the dense path update [1, 1+n1) of the arena; returns the new n1
+template <int G>
+__device__ __forceinline__ int overwrite_if_too_far(const Arena& A, int n1, double px, double py, const double* prev, int* fallback) {
+  using GR = Grp<G>;
+  const int lane = GR::lane();
+  double bv = 0.0;
+  int bi = -1;
+  for (int i = lane; i < n1; i += G) {
+    double d = norm_axis(px - A.x[1 + i], py - A.y[1 + i]);
+    if (bi < 0 || d < bv) {
+      bv = d;
+      bi = i;
+    }
+  }
+  GR::argmin(bv, bi);
+  if (bv > 5.0) {
+    *fallback |= 4;
+    GR::sync();
+    for (int i = lane; i < PATH_POINTS; i += G) {
+      A.x[1 + i] = prev[4 * i + 1];
+      A.y[1 + i] = prev[4 * i + 2];
+    }
+    n1 = PATH_POINTS;
+    GR::sync();
+  }
+  return n1;
+}
+
 // core_calculate_path.py:555-575: too-far check + MPC step with its ValueError retry, on the dense path update stored
 // in the arena at [1, 1+n1); prev = previous path (40,4) rows [s, x, y, curvature].  Returns the frame status.
 template <int G, bool FAST>
@@ -631,29 +698,7 @@ __device__ __forceinline__ int finish_path(PathShared<G>& S, const Arena& A, int
   using GR = Grp<G>;
   const int lane = GR::lane();
   if (n1 == 0) return ST_REF_UNDEFINED_PATH;  // min() of an empty array
-  // overwrite_path_if_it_is_too_far_away :225-237
-  {
-    double bv = 0.0;
-    int bi = -1;
-    for (int i = lane; i < n1; i += G) {
-      double d = norm_axis(px - A.x[1 + i], py - A.y[1 + i]);
-      if (bi < 0 || d < bv) {
-        bv = d;
-        bi = i;
-      }
-    }
-    GR::argmin(bv, bi);
-    if (bv > 5.0) {
-      *fallback |= 4;
-      GR::sync();
-      for (int i = lane; i < PATH_POINTS; i += G) {
-        A.x[1 + i] = prev[4 * i + 1];
-        A.y[1 + i] = prev[4 * i + 2];
-      }
-      n1 = PATH_POINTS;
-      GR::sync();
-    }
-  }
+  n1 = overwrite_if_too_far<G>(A, n1, px, py, prev, fallback);
   // one call site (the stage is inlined into the kernel so that every LDS access is a DS instruction): the second
   // round of the loop is the ValueError retry with the previous path (:564-570)
   int rc = 1;
@@ -696,10 +741,10 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame) {
   A.x = b;
   A.y = b + PATH_CAP;
   A.u = b + 2 * PATH_CAP;
-  for (int j = 0; j < 4; j++) A.bc.h[j] = b + (3 + j) * PATH_CAP;
-  A.bc.l = (int32_t*)(b + 7 * PATH_CAP);
-  A.bc.b = b + 7 * PATH_CAP + PATH_CAP / 2;
+  A.bc.rec = (BRec*)(b + 3 * PATH_CAP);  // 64-byte aligned: ARENA_DOUBLES and 3 * PATH_CAP are multiples of 8
+  A.bc.b = b + 11 * PATH_CAP;
   A.filt = A.bc.b + ARENA_B;
+  A.fit = (FitRec*)(A.filt + DENSE_CAP);
   return A;
 }
 
@@ -739,25 +784,20 @@ constexpr int PATH_G_THROUGHPUT = 8;
 constexpr int PATH_G_LATENCY = 16;
 constexpr int PATH_G_SMALL = 64;
 constexpr int PATH_SMALL_BATCH = 1024;    // frames at or below which every frame gets its own wavefront
+constexpr int PATH_G_SPLIT = 8;           // lanes per frame of path_prep_kernel / path_finish_kernel (three-kernel path stage)
+constexpr int FIT_KNOTS = 16;             // knots fit_kernel keeps per frame in LDS (more: exact kernel, 64)
 constexpr int PATH_LATENCY_BATCH = 4096;  // largest single pass that G = 16 serves with one wavefront per SIMD
 
+// First half of run_path_calculation (core_calculate_path.py:514-553): centre points (or the global path window), fit #1
+// and its dense evaluation.  Leaves the dense path update in the arena [1, 1 + *n1_out); returns the frame status.
 template <int G, bool FAST>
-__device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
-                                  const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
-                                  const double* __restrict__ prev_paths, const double* __restrict__ gpath, int n_gpath,
-                                  double* __restrict__ arena, PathOut* __restrict__ out) {
+__device__ __forceinline__ int path_front(PathShared<G>& S, const Arena& A, const MatchOut* mo, double px, double py,
+                                          const double* prev, const double* __restrict__ gpath, int n_gpath, int* fallback_out,
+                                          int* n1_out) {
   using GR = Grp<G>;
-  PROF(0);
   const int lane = GR::lane();
-  const Arena A = frame_arena(arena, frame);
-  const MatchOut* mo = &matched[frame];
-  PathOut* o = &out[frame];
-  const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
   int status = mo->status;
-  int fallback = 0, n_dense = 0;
-  // previous_paths[-1]: the constant initial path (fresh planner) or, for sequential replays, the caller-supplied
-  // previous output of this planner (core_calculate_path.py:572-573)
-  const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
+  int fallback = 0;
   const int nl = mo->n_left_v, nr = mo->n_right_v;
   int nc = 0;  // centre points, written to the arena polyline [0, nc)
   if (status == ST_OK && gpath != nullptr) {
@@ -899,7 +939,15 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
       GR::sync();
     }
   }
-  if (status == ST_OK) status = finish_path<G, FAST>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
+  *fallback_out = fallback;
+  *n1_out = n1;
+  return status;
+}
+
+template <int G>
+__device__ __forceinline__ void write_path_status(PathOut* o, int status, int fallback, int n_dense) {
+  using GR = Grp<G>;
+  const int lane = GR::lane();
   GR::sync();
   if (status != ST_OK)
     for (int i = lane; i < PATH_POINTS; i += G)
@@ -909,6 +957,142 @@ __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const do
     o->fallback = fallback;
     o->n_dense = n_dense;
     o->pad = 0;
+  }
+}
+
+// the whole path stage of one frame on one lane group
+template <int G, bool FAST>
+__device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
+                                  const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
+                                  const double* __restrict__ prev_paths, const double* __restrict__ gpath, int n_gpath,
+                                  double* __restrict__ arena, PathOut* __restrict__ out) {
+  PROF(0);
+  const Arena A = frame_arena(arena, frame);
+  PathOut* o = &out[frame];
+  const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
+  // previous_paths[-1]: the constant initial path (fresh planner) or, for sequential replays, the caller-supplied
+  // previous output of this planner (core_calculate_path.py:572-573)
+  const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
+  int fallback = 0, n_dense = 0, n1 = 0;
+  int status = path_front<G, FAST>(S, A, &matched[frame], px, py, prev, gpath, n_gpath, &fallback, &n1);
+  if (status == ST_OK) status = finish_path<G, FAST>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
+  write_path_status<G>(o, status, fallback, n_dense);
+}
+
+// ---- the path stage as three kernels (large batches) --------------------------------------------------------------------
+// 72 % of the one-kernel stage is the refit of the dense path update (fit #2: 450-500 points, ~10 knots, 2-5 observation
+// passes, 3-19 smoothing iterations).  Split off, it becomes a kernel that holds nothing but one degree-3 fit — few enough
+// registers and LDS for two wavefronts per SIMD, 16 fits per SIMD in flight — while the lane-parallel rest runs before
+// (path_prep_kernel) and after it (path_finish_kernel).  Whatever is not the plain case (a fit that raises, fewer than 4
+// points, a knot set beyond the packed capacity, an operand outside the fast division's exponent band, the ValueError
+// retry of core_calculate_path.py:564-570) is appended to the retry list and planned from scratch by the exact
+// one-frame-per-wavefront kernel (path_retry_kernel), so results do not depend on the route a frame took.
+__device__ __forceinline__ void push_retry(int* retry, int frame) { retry[1 + atomicAdd(&retry[0], 1)] = frame; }
+
+template <int G>
+__global__ void __launch_bounds__(64) path_prep_kernel(int n_frames, const double* __restrict__ poses, const MatchOut* __restrict__ matched,
+                                                       const double* __restrict__ default_path, const double* __restrict__ prev_paths,
+                                                       const double* __restrict__ gpath, int n_gpath, double* __restrict__ arena,
+                                                       PathOut* __restrict__ out, PathMid* __restrict__ mid, int* __restrict__ retry) {
+  using GR = Grp<G>;
+  __shared__ PathShared<G> S_all[WAVE / G];
+  const int frame = blockIdx.x * (WAVE / G) + GR::index();
+  if (frame >= n_frames) return;
+  PathShared<G>& S = S_all[GR::index()];
+  const Arena A = frame_arena(arena, frame);
+  const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
+  const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
+  int fallback = 0, n1 = 0, off = 0, n = 0;
+  int status = path_front<G, true>(S, A, &matched[frame], px, py, prev, gpath, n_gpath, &fallback, &n1);
+  bool plain = false;
+  if (status == ST_OK && n1 > 0) {
+    n1 = overwrite_if_too_far<G>(A, n1, px, py, prev, &fallback);
+    const int rc = mpc_prepare<G>(S, A, n1, px, py, dx, dy, &fallback, &off, &n);
+    plain = rc == 0 && n >= 4;  // degree 3 needs 4 points; everything else takes the exact route
+    if (plain) build_parameter<G>(S, A, off, n);
+  }
+  const bool final_status = status != ST_OK && status != ST_RETRY && status != ST_OVERFLOW_KNOTS;
+  if (final_status) write_path_status<G>(&out[frame], status, fallback, 0);  // sorting / matching / fit #1 decided the frame
+  if (GR::lane() == 0) {
+    PathMid m;
+    m.status = plain ? ST_OK : (final_status ? status : ST_RETRY);
+    m.fallback = fallback;
+    m.off = off;
+    m.n = n;
+    mid[frame] = m;
+    if (!plain && !final_status) push_retry(retry, frame);
+  }
+}
+
+// the refit: utils/spline_fit.py:95-128 (splprep, k = 3, s = 0.2) of the arena polyline [off, off + n), G lanes per frame
+template <int G, int NKC>
+__global__ void __launch_bounds__(64, (G >= 8 ? 2 : 1)) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
+                                                 int* __restrict__ retry) {
+  using GR = Grp<G>;
+  using WS = SplineWS<G, NKC, 1>;
+  __shared__ WS ws_all[WAVE / G];
+  const int frame = blockIdx.x * (WAVE / G) + GR::index();
+  PROF_INIT();
+  if (frame < n_frames && mid[frame].status == ST_OK) {
+    PROF(0);
+    WS& ws = ws_all[GR::index()];
+    const Arena A = frame_arena(arena, frame);
+    const int off = mid[frame].off, m = mid[frame].n;
+    const SplineFit f = spline_fit_k<3, true>(ws, A.bc, A.u + off, A.x + off, A.y + off, m, 0.2);
+    const int lane = GR::lane();
+    if (f.status != 0) {
+      if (lane == 0) {
+        mid[frame].status = ST_RETRY;
+        push_retry(retry, frame);
+      }
+    } else {
+      FitRec* fr = A.fit;
+      for (int i = lane; i < f.n; i += G) {
+        fr->t[i] = ws.t[1 + i];
+        fr->c[i] = ws.c[1 + i];
+        fr->c[f.n + i] = ws.c[1 + f.n + i];
+      }
+      if (lane == 0) {
+        fr->n = f.n;
+        fr->ier = f.ier;
+        fr->status = 0;
+        fr->fp = f.fp;
+      }
+    }
+  }
+  PROF_FLUSH();
+}
+
+template <int G>
+__global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
+                                                         PathOut* __restrict__ out, int* __restrict__ retry) {
+  using GR = Grp<G>;
+  __shared__ PathShared<G> S_all[WAVE / G];
+  const int frame = blockIdx.x * (WAVE / G) + GR::index();
+  if (frame >= n_frames || mid[frame].status != ST_OK) return;
+  PathShared<G>& S = S_all[GR::index()];
+  const Arena A = frame_arena(arena, frame);
+  const int lane = GR::lane();
+  const FitRec* fr = A.fit;
+  SplineFit f;
+  f.k = 3;
+  f.n = fr->n;
+  f.ier = fr->ier;
+  f.fp = fr->fp;
+  f.status = 0;
+  for (int i = lane; i < f.n; i += G) {
+    S.ws.t[1 + i] = fr->t[i];
+    S.ws.c[1 + i] = fr->c[i];
+    S.ws.c[1 + f.n + i] = fr->c[f.n + i];
+  }
+  GR::sync();
+  int n_dense = 0;
+  const int rc = mpc_finish<G, true>(S, A, true, f, out[frame].path, &n_dense);
+  if (rc == 0) {
+    write_path_status<G>(&out[frame], ST_OK, mid[frame].fallback, n_dense);
+  } else if (lane == 0) {
+    mid[frame].status = ST_RETRY;
+    push_retry(retry, frame);
   }
 }
 

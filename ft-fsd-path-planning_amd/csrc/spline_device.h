@@ -34,7 +34,7 @@ constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121
 // right-hand sides), what only its observation / residual passes need (chunk buffers, knot bookkeeping), what only the
 // smoothing iteration needs (the extended triangle g; the f(p) term buffer overlays it while it is dead), and — when no
 // fit is running — the path stage's dense samples.  The rows of the smoothness matrix b live in the frame's scratch.
-template <int G, int NKC = knot_capacity<G>()>
+template <int G, int NKC = knot_capacity<G>(), int DCAP = DENSE_CAP>  // DCAP = 1: a fit-only workspace (fit_kernel)
 struct SplineWS {
   static constexpr int GRP = G;
   static constexpr int NK = NKC;
@@ -58,8 +58,8 @@ struct SplineWS {
       };
     };
     struct {  // ---- no fit running (path stage) ----
-      double curv[DENSE_CAP];      // raw curvature; overlays t | c: written only after the last spline evaluation
-      double dxyu[3 * DENSE_CAP];  // dense samples x | y | u of the final spline; before fit #3 the segment lengths
+      double curv[DCAP];      // raw curvature; overlays t | c: written only after the last spline evaluation
+      double dxyu[3 * DCAP];  // dense samples x | y | u of the final spline; before fit #3 the segment lengths
                                    // (<= 3 * DENSE_CAP), in the extension the tail points of the polyline
     };
   };
@@ -67,13 +67,23 @@ struct SplineWS {
   __device__ __forceinline__ double& Gm(int i, int j) { return g_[i][j - 1]; }
 };
 
-// Per-point basis cache in the frame's HBM/L2 scratch: the K+1 non-zero B-spline values and the knot interval of every
-// data point, written by the observation pass of the current knot set and re-read by the residual pass and by every
-// f(p) evaluation of the smoothing iteration (same knots => same values; saves the interval search and the de Boor
-// recursion with its six divisions per point and pass).
+// Per-point basis cache in the frame's HBM/L2 scratch: one 64-byte record per data point — the K+1 non-zero B-spline
+// values, the point itself and its knot interval — written by the observation pass of the current knot set and re-read
+// by the residual pass and by every f(p) evaluation of the smoothing iteration (same knots => same values; saves the
+// interval search and the de Boor recursion with its six divisions per point and pass).  A record is a cache line half:
+// a lane moves it with four 16-byte accesses, the lanes of a group touch consecutive records.
+struct alignas(16) D2 {
+  double a, b;
+};
+struct alignas(64) BRec {
+  D2 h01, h23;  // basis values h[0..3] (unused entries of lower degrees are 0)
+  D2 xy;        // the data point
+  int32_t l;    // knot interval
+  int32_t pad[3];
+};
+static_assert(sizeof(BRec) == 64, "basis record is one 64-byte line");
 struct BasisCache {
-  double* h[4];
-  int32_t* l;
+  BRec* rec;
   double* b;  // (NK + 2) x 5 rows of the smoothness matrix (fpdisc) of the running fit, row-major, element (i, j) at 5 i + j - 1
 };
 
@@ -459,22 +469,29 @@ struct ResidualBatch {
   double hv[ROUNDS][K + 1], xv[ROUNDS], yv[ROUNDS];
   int lv[ROUNDS], lpv[ROUNDS];
 
-  __device__ __forceinline__ void load(const BasisCache& bc, const double* X, const double* Y, int base, int cnt) {
+  // Loads are unconditional (rows past the end re-read the last record, index clamped) so that all of a super-chunk's
+  // loads sit in one basic block and fly together; only the stores of compute() are predicated.
+  __device__ __forceinline__ void load(const BasisCache& bc, int base, int cnt, int m) {
+    (void)cnt;
     const int lane = Grp<G>::lane();
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
-      const int r = q * G + lane;
-      const int it = base + r;
-      if (r < cnt) {
+      int it = base + q * G + lane;
+      it = it < m ? it : m - 1;
+      const BRec* p = &bc.rec[it];
+      const D2 a = p->h01, b = p->h23, c = p->xy;
+      const double hh[4] = {a.a, a.b, b.a, b.b};
 #pragma unroll
-        for (int j = 0; j < k1; j++) hv[q][j] = bc.h[j][it];
-        // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
-        // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point
-        lv[q] = bc.l[it] + 1;
-        if constexpr (FLAGS) lpv[q] = it > 0 ? bc.l[it - 1] + 1 : k2;
-        xv[q] = X[it];
-        yv[q] = Y[it];
+      for (int j = 0; j < k1; j++) hv[q][j] = hh[j];
+      // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
+      // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point
+      lv[q] = p->l + 1;
+      if constexpr (FLAGS) {
+        const int lp = bc.rec[it > 0 ? it - 1 : 0].l + 1;
+        lpv[q] = it > 0 ? lp : k2;
       }
+      xv[q] = c.a;
+      yv[q] = c.b;
     }
   }
 
@@ -484,21 +501,21 @@ struct ResidualBatch {
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
       const int r = q * G + lane;
-      if (r < cnt) {
-        const int l0 = lv[q] - k2;
-        double term = 0.0;
+      const int l0 = lv[q] - k2;
+      double term = 0.0;
 #pragma unroll
-        for (int d = 0; d < 2; d++) {
-          double fac = 0.0;
-          int j1 = l0 + d * n;
+      for (int d = 0; d < 2; d++) {
+        double fac = 0.0;
+        int j1 = l0 + d * n;
 #pragma unroll
-          for (int j = 1; j <= k1; j++) {
-            j1++;
-            fac = fac + ws.c[j1] * hv[q][j - 1];
-          }
-          double dv = 1.0 * (fac - (d == 0 ? xv[q] : yv[q]));  // w = 1
-          term = term + dv * dv;
+        for (int j = 1; j <= k1; j++) {
+          j1++;
+          fac = fac + ws.c[j1] * hv[q][j - 1];
         }
+        double dv = 1.0 * (fac - (d == 0 ? xv[q] : yv[q]));  // w = 1
+        term = term + dv * dv;
+      }
+      if (r < cnt) {
         tbuf[r] = term;
         if constexpr (FLAGS) fbuf[r] = (lv[q] > lpv[q]) ? 1 : 0;
       }
@@ -599,12 +616,11 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       auto fetch_chunk = [&](int base) {
 #pragma unroll
         for (int q = 0; q < NRC; q++) {
-          const int it = base + q * G + lane;
-          if (it < m) {
-            pu[q] = U[it];
-            pxv[q] = X[it];
-            pyv[q] = Y[it];
-          }
+          int it = base + q * G + lane;  // unconditional loads (index clamped): the chunk's fetches fly together
+          it = it < m ? it : m - 1;
+          pu[q] = U[it];
+          pxv[q] = X[it];
+          pyv[q] = Y[it];
         }
       };
       fetch_chunk(0);
@@ -622,16 +638,21 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
               lres = l;
               double h[K + 2];
               fpbspl<K>(ws.t, ui, l, h);
+              double hf[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
               for (int j = 0; j < k1; j++) {
                 ws.hq[r][j] = h[j + 1];
-                bc.h[j][it] = h[j + 1];
+                hf[j] = h[j + 1];
               }
               ws.lq[r] = l;
               lvq[q] = l;
-              bc.l[it] = l;
               ws.xq[r] = pxv[q];
               ws.yq[r] = pyv[q];
+              BRec* p = &bc.rec[it];
+              p->h01 = D2{hf[0], hf[1]};
+              p->h23 = D2{hf[2], hf[3]};
+              p->xy = D2{pxv[q], pyv[q]};
+              p->l = l;
             }
           }
           GR::sync();
@@ -760,15 +781,15 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         int32_t* const fbuf = (int32_t*)ws.xq;  // xq | yq: 4 * CH flags
         ResidualBatch<K, G, true> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
         auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
-        ra.load(bc, X, Y, 0, clampc(m));
+        ra.load(bc, 0, clampc(m), m);
         for (int base = 0; base < m; base += HALVES * SC) {
           const int cnt_a = clampc(m - base);
           const int cnt_b = (HALVES == 2) ? clampc(m - base - SC) : 0;
           const int cnt = cnt_a + cnt_b;
-          if (cnt_b > 0) rb.load(bc, X, Y, base + SC, cnt_b);
+          if constexpr (HALVES == 2) rb.load(bc, base + SC, cnt_b, m);
           ra.compute(ws, cnt_a, n, tbuf, fbuf);
-          if (base + HALVES * SC < m) ra.load(bc, X, Y, base + HALVES * SC, clampc(m - base - HALVES * SC));
-          if (cnt_b > 0) rb.compute(ws, cnt_b, n, tbuf + SC, fbuf + SC);
+          ra.load(bc, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
+          if constexpr (HALVES == 2) rb.compute(ws, cnt_b, n, tbuf + SC, fbuf + SC);
           GR::sync();
           for (int r0 = 0; r0 < cnt; r0 += 8) {  // operands eight at a time (one LDS round trip), order kept
             double tv[8];
@@ -961,16 +982,16 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         double* const tbuf = &ws.hq[0][0];  // 4 * CH terms
         ResidualBatch<K, G, false> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
         auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
-        ra.load(bc, X, Y, 0, clampc(m));
+        ra.load(bc, 0, clampc(m), m);
         for (int base = 0; base < m; base += HALVES * SC) {
           const int cnt_a = clampc(m - base);
           const int cnt_b = (HALVES == 2) ? clampc(m - base - SC) : 0;
           {
             PROF(28);
-            if (cnt_b > 0) rb.load(bc, X, Y, base + SC, cnt_b);
+            if constexpr (HALVES == 2) rb.load(bc, base + SC, cnt_b, m);
             ra.compute(ws, cnt_a, n, tbuf, nullptr);
-            if (base + HALVES * SC < m) ra.load(bc, X, Y, base + HALVES * SC, clampc(m - base - HALVES * SC));
-            if (cnt_b > 0) rb.compute(ws, cnt_b, n, tbuf + SC, nullptr);
+            ra.load(bc, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
+            if constexpr (HALVES == 2) rb.compute(ws, cnt_b, n, tbuf + SC, nullptr);
             GR::sync();
           }
           PROF(29);

@@ -49,7 +49,7 @@ enum {
   FSDP_OVERFLOW_CONES = 201,
   FSDP_OVERFLOW_ENDS = 202,
   FSDP_OVERFLOW_PATH = 203,
-  FSDP_OVERFLOW_KNOTS = 204, /* more than 64 knots (fits beyond 32 are re-planned by the one-frame-per-wavefront kernel) */
+  FSDP_OVERFLOW_KNOTS = 204, /* more than 64 knots (fits beyond the packed kernels' capacity are re-planned by the one-frame-per-wavefront kernel) */
   FSDP_OVERFLOW_CLUSTERS = 205 /* skidpad relocalization: more than 64 centre clusters */
 };
 
@@ -136,13 +136,15 @@ int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
 #define FSDP_MAX_OVERLAP 4
 int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
 
-/* Enqueue `iters` back-to-back passes over the resident batch (alternating slots when overlap is 2; no host
+/* Enqueue `iters` back-to-back passes over the resident batch (rotating through the slots when passes overlap; no host
  * synchronisation in between) and time them with HIP events recorded on the streams the kernels run on.
- * ms_total: whole region; ms_stage[3]: summed durations of the sorting / matching / path kernel launches (events around
- * each launch; with overlap these include the time a launch shares the chip with the other slot's kernels).
- * Either pointer may be NULL. */
+ * ms_total: whole region; ms_stage[FSDP_MAX_STAGES]: summed durations of every kernel of a pass, in launch order (events
+ * around each launch; with overlap these include the time a launch shares the chip with the other slots' kernels);
+ * unused entries are 0 and fsdp_stage_names names the used ones.  Either pointer may be NULL. */
+#define FSDP_MAX_STAGES 8
 int fsdp_time_runs(fsdp_ctx* ctx, int iters, float* ms_total, float* ms_stage);
-/* comma-separated kernel names behind ms_stage of the most recent launches, e.g. "sort_kernel,match_kernel,path_kernel<8>" */
+/* comma-separated kernel names behind ms_stage of the most recent pass, e.g.
+ * "sort_kernel,match_kernel,path_prep_kernel<8>,fit_kernel<8>,path_finish_kernel<8>,path_retry_kernel" */
 int fsdp_stage_names(fsdp_ctx* ctx, char* out, int cap);
 
 /* Stage-level entry points (README "parts of the pipeline are also available as individual classes"). */

@@ -10,15 +10,24 @@
 #include <mutex>
 #include <vector>
 
+// 64-byte aligned scratch like hipMalloc's (the basis records of the arena are alignas(64))
+struct AlignedArena {
+  double* p;
+  explicit AlignedArena(size_t n) : p((double*)aligned_alloc(64, ((n * sizeof(double) + 63) / 64) * 64)) { memset(p, 0, n * sizeof(double)); }
+  ~AlignedArena() { free(p); }
+  double* data() { return p; }
+};
+
 static double g_default_path[fsdp::PATH_POINTS * 4];
 static const double* g_prev_paths = nullptr;
 static const double* g_gpath = nullptr;
 static int g_n_gpath = 0;
 static std::once_flag g_once;
+static int g_last_retries = 0;
 static void build_default() {
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
-  std::vector<double> arena(fsdp::ARENA_DOUBLES);
+  AlignedArena arena(fsdp::ARENA_DOUBLES);
   emu::launch(1, 64, [&]() { fsdp::default_path_kernel(&chord[0][0], arena.data(), g_default_path); });
 }
 
@@ -55,7 +64,7 @@ __global__ void fit_test_kernel(const double* xy, int m, double smoothing, doubl
 
 template <int G>
 static void emu_path_launch(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
-  std::vector<double> arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
+  AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
   const unsigned per = 64 / G;
   std::vector<int> retry((size_t)n_frames + 1, 0);
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() {
@@ -68,9 +77,30 @@ static void emu_path_launch(int n_frames, const double* poses, const fsdp::Match
     });
 }
 
+// the path stage as the library launches it for large batches: prep -> fit -> finish -> exact re-plan of the retry list
+template <int GF, int NKC>
+static void emu_path_split_launch(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
+  constexpr int G = fsdp::PATH_G_SPLIT;
+  AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
+  std::vector<fsdp::PathMid> mid(n_frames);
+  std::vector<int> retry((size_t)n_frames + 1, 0);
+  const unsigned per = 64 / G, perf = 64 / GF;
+  emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() {
+    fsdp::path_prep_kernel<G>(n_frames, poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out,
+                              mid.data(), retry.data());
+  });
+  emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data()); });
+  emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G>(n_frames, arena.data(), mid.data(), out, retry.data()); });
+  g_last_retries = retry[0];
+  emu::launch(8, 64, [&]() {
+    fsdp::path_retry_kernel(poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out, retry.data());
+  });
+}
+
 extern "C" {
+int emu_last_retries() { return g_last_retries; }
 void emu_fit(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
-  std::vector<double> arena(fsdp::ARENA_DOUBLES);
+  AlignedArena arena(fsdp::ARENA_DOUBLES);
   emu::launch(1, 64, [&]() { fsdp::fit_test_kernel(xy, m, smoothing, arena.data(), t_out, c_out, info, fp_out); });
 }
 int emu_sizeof_sort_out() { return (int)sizeof(fsdp::SortOut); }
@@ -104,7 +134,7 @@ void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, c
   T.mean_distance = mean_distance;
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
-  std::vector<double> arena((size_t)fsdp::ARENA_DOUBLES * n_inst);
+  AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_inst);
   std::vector<int32_t> status(n_inst, 0);
   emu::launch((unsigned)n_inst, 64, [&]() { fsdp::skid_reloc_kernel(n_inst, offsets, cones, poses, states, T, arena.data(), status.data()); });
   emu::launch((unsigned)n_inst, 64, [&]() {
@@ -137,6 +167,10 @@ int emu_path_g(int G, int n_frames, const double* poses, const fsdp::MatchOut* m
     emu_path_launch<16>(n_frames, poses, matched, out);
   else if (G == 64)
     emu_path_launch<64>(n_frames, poses, matched, out);
+  else if (G == 1004)  // split pipeline, fit kernel with 4 lanes per frame
+    emu_path_split_launch<4, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
+  else if (G == 1008)
+    emu_path_split_launch<8, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
   else
     return 1;
   return 0;

@@ -76,7 +76,14 @@ def match(offsets, cones, poses, sorted_out):
     return out
 
 
-PATH_GROUP_SIZES = (8, 16, 64)  # lanes per frame of the three path-kernel instantiations the library launches
+# lanes per frame of the one-kernel path stage (8 / 16 / 64), and the three-kernel path stage the library launches for
+# large batches with 4 or 8 lanes per frame in its fit kernel (1004 / 1008)
+PATH_GROUP_SIZES = (8, 16, 64, 1004, 1008)
+
+
+def last_retries():
+    """Frames the last split-pipeline launch handed to the exact re-plan kernel."""
+    return int(lib().emu_last_retries())
 
 
 def path(poses, matched, group=8):

@@ -15,7 +15,7 @@ PKG = ROOT / "ft-fsd-path-planning_amd"
 so = ROOT / "gpurun_out" / "libfsdp_prof.so"
 so.parent.mkdir(exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                "-DFSDP_PROFILE", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so)], check=True, capture_output=True)
+                "-DFSDP_PROFILE", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so), "-ldl"], check=True, capture_output=True)
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 pkg._capi.LIB_PATH = so
 ctx = pkg.Context(device=0)
@@ -31,7 +31,8 @@ assert rc == 0
 # frames: 16): one row per wavefront (group 0's lane 0 keeps the clock; the groups run in lock-step, so its sections span
 # the wavefront's time in them)
 import os
-G = int(os.environ.get("FSDP_PATH_G", "16" if N > 1024 else "64"))
+# large batches run the three-kernel path stage: the profile below is fit_kernel's (FSDP_FIT_G lanes per frame)
+G = int(os.environ.get("FSDP_FIT_G", "8")) if N > 1024 else 64
 FPW = 64 // G
 out = out[: (N + FPW - 1) // FPW]
 tot = out[:, 0]
