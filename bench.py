@@ -22,9 +22,9 @@ from __future__ import annotations
 
 import os
 
-# four passes in flight = four HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+# several passes in flight = one HIP stream each; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
 # RCCL / the null stream take queues too — must be set before the HIP runtime starts in this process
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 import argparse
 import importlib
@@ -46,7 +46,7 @@ CFG4_FRAMES, CFG4_CONES_PER_SIDE = 65536, 100  # config 4 (global batch)
 def algo_bytes_per_frame(cones_per_frame: int) -> int:
     """read N*24 + 32 (cones, pose) + write 1280 + 96 + 8: 4488 at N = 128, 6216 at N = 200."""
     return cones_per_frame * 24 + 32 + 1280 + 96 + 8
-PASS_OVERLAP = 4  # passes in flight in the timed region (fsdp_set_overlap); measured best of 1..8 (profiles/README.md)
+PASS_OVERLAP = 6  # passes in flight in the timed region (fsdp_set_overlap); measured 3..8 with tools/ab_variants.py (profiles/README.md)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="(always measured at N = 1; kept for compatibility)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
-    ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..4)")
+    ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..8)")
     args = ap.parse_args()
 
     pkg = importlib.import_module("ft-fsd-path-planning_amd")

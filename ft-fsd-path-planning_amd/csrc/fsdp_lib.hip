@@ -56,7 +56,8 @@ struct fsdp_ctx {
   // further sets of intermediates + streams (fsdp_set_overlap): consecutive fsdp_run passes rotate through the sets, so
   // the next passes start while the slowest wavefronts of the previous ones are still finishing
   int force_path_mode = 0;    // 0 = by batch size; 1 = one kernel (64 lanes per frame); 2 = three kernels (FSDP_PATH_MODE=mono|split)
-  int fit_g = 8;              // lanes per frame of fit_kernel (FSDP_FIT_G=4|8)
+  int fit_g = 8;              // lanes per frame of fit_kernel when frames are packed (FSDP_FIT_G=4|8; measured: tools/ab_variants.py)
+  int force_pack = 0;         // 0 = by frames in flight; 1 = 4 frames per wavefront; 2 = packed (FSDP_PACK=0|1)
   std::string stage_names;    // kernels of the most recent pass, comma-separated
   bool profile_sort = false;  // profiling build: which kernel fsdp_profile_path runs
   int overlap = 1;
@@ -258,6 +259,24 @@ static void launch_fit(fsdp_ctx* c, const Slot& q) {
   hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((c->n_frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, q.stream, c->n_frames,
                      q.d_arena, q.d_mid, q.d_retry);
 }
+template <int G>
+static void launch_prep(fsdp_ctx* c, const Slot& q, const double* prev) {
+  const int n = c->n_frames;
+  hipLaunchKernelGGL(path_prep_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, n, c->d_poses, q.d_match,
+                     c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry);
+}
+template <int G>
+static void launch_finish(fsdp_ctx* c, const Slot& q) {
+  const int n = c->n_frames;
+  hipLaunchKernelGGL(path_finish_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, n, q.d_arena, q.d_mid, q.d_path,
+                     q.d_retry);
+}
+
+// Lanes per frame: a serial instruction costs its issue cycles whatever the number of active lanes, so the more frames
+// share a wavefront the cheaper a frame gets — as long as there are enough wavefronts for every SIMD.  With at least
+// PACK_FRAMES frames in flight (batch size x passes overlapped) the fit kernel packs 16 frames into a wavefront (4 lanes
+// each: exactly the Givens quad) and the kernels around it 8; below that, 4 frames per wavefront everywhere.
+constexpr int PACK_FRAMES = 12288;
 
 static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
   const double* prev = c->use_prev ? c->d_prev : nullptr;
@@ -271,18 +290,26 @@ static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
                        c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry);
     c->stage_names += "path_kernel<64>,";
   } else {
-    constexpr int G = PATH_G_SPLIT;
-    const int blocks = (n + WAVE / G - 1) / (WAVE / G);
-    hipLaunchKernelGGL(path_prep_kernel<G>, dim3(blocks), dim3(WAVE), 0, q.stream, n, c->d_poses, q.d_match, c->d_default_path, prev,
-                       c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry);
-    mark(q, t);
-    if (c->fit_g == 4)
-      launch_fit<4>(c, q);
+    const bool packed = c->force_pack ? c->force_pack == 2 : (long long)n * c->overlap >= PACK_FRAMES;
+    const int gf = packed ? c->fit_g : 16;
+    if (packed)
+      launch_prep<8>(c, q, prev);
     else
-      launch_fit<8>(c, q);
+      launch_prep<16>(c, q, prev);
     mark(q, t);
-    hipLaunchKernelGGL(path_finish_kernel<G>, dim3(blocks), dim3(WAVE), 0, q.stream, n, q.d_arena, q.d_mid, q.d_path, q.d_retry);
-    c->stage_names += std::string("path_prep_kernel<8>,fit_kernel<") + (c->fit_g == 4 ? "4" : "8") + ">,path_finish_kernel<8>,";
+    if (gf == 4)
+      launch_fit<4>(c, q);
+    else if (gf == 8)
+      launch_fit<8>(c, q);
+    else
+      launch_fit<16>(c, q);
+    mark(q, t);
+    if (packed)
+      launch_finish<8>(c, q);
+    else
+      launch_finish<16>(c, q);
+    const std::string g = packed ? "8" : "16";
+    c->stage_names += "path_prep_kernel<" + g + ">,fit_kernel<" + std::to_string(gf) + ">,path_finish_kernel<" + g + ">,";
   }
   mark(q, t);
   const int rb = n < 128 ? n : 128;
@@ -372,6 +399,7 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
   c->mission = mission;
   if (const char* e = getenv("FSDP_PATH_MODE")) c->force_path_mode = !strcmp(e, "mono") ? 1 : (!strcmp(e, "split") ? 2 : 0);
   if (const char* e = getenv("FSDP_FIT_G")) c->fit_g = atoi(e) == 4 ? 4 : 8;
+  if (const char* e = getenv("FSDP_PACK")) c->force_pack = atoi(e) ? 2 : 1;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);

@@ -33,7 +33,8 @@ constexpr int SEG_CAP = 3 * DENSE_CAP;  // segment-length scratch in LDS (the de
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
 constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
 constexpr int FITREC_DOUBLES = 112;  // >= sizeof(FitRec) / 8
-constexpr int ARENA_DOUBLES = 3 * PATH_CAP + 8 * PATH_CAP + ARENA_B + DENSE_CAP + FITREC_DOUBLES;  // x | y | u | records | ...
+constexpr int BAND_DOUBLES = 112;    // >= 6 * (FIT_KNOTS + 2): band triangle + right-hand sides of fit_kernel's fit
+constexpr int ARENA_DOUBLES = 3 * PATH_CAP + 8 * PATH_CAP + ARENA_B + DENSE_CAP + FITREC_DOUBLES + BAND_DOUBLES;  // x | y | u | records | ...
 // knots / coefficients of the refit (fit #2) on their way from fit_kernel to path_finish_kernel
 struct FitRec {
   int32_t n, ier, status, pad;
@@ -55,6 +56,7 @@ struct Arena {
   BasisCache bc;
   double* filt;  // filtered curvature of the dense samples
   FitRec* fit;
+  double* band;  // fit_kernel's band triangle between observation passes (FitWS)
 };
 
 // Per-frame LDS = the spline workspace; while no fit is running the path stage uses its bytes for segment lengths (before
@@ -285,14 +287,29 @@ __device__ __forceinline__ double build_parameter(PathShared<G>& S, const Arena&
 }
 
 // utils/spline_fit.py:95-128 on the arena polyline [off, off+m).  rc: 0 ok, 1 ValueError, >=200 overflow
-template <int G, bool FAST>
+// CUBIC (the kernels of the three-kernel path stage): only the degree-3 fit is compiled in; a polyline of fewer than
+// four points sends the frame to the exact kernel (ST_RETRY).
+template <int G, bool FAST, bool CUBIC = false>
 __device__ __forceinline__ int fit_polyline(PathShared<G>& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
                                    double& max_u) {
   int k = m - 1;
   k = k < 1 ? 1 : (k > 3 ? 3 : k);
-  max_u = build_parameter<G>(S, A, off, m);
-  f = spline_fit<FAST>(S.ws, A.bc, A.u + off, A.x + off, A.y + off, m, k, smoothing);
+  if constexpr (CUBIC) {
+    if (k < 3) return ST_RETRY;
+    max_u = build_parameter<G>(S, A, off, m);
+    f = spline_fit_k<3, FAST>(S.ws, A.bc, A.u + off, A.x + off, A.y + off, m, smoothing);
+  } else {
+    max_u = build_parameter<G>(S, A, off, m);
+    f = spline_fit<FAST>(S.ws, A.bc, A.u + off, A.x + off, A.y + off, m, k, smoothing);
+  }
   return f.status;
+}
+template <bool CUBIC, class WS>
+__device__ __forceinline__ void eval_spline(const WS& ws, const SplineFit& f, double step, int count, double* OX, double* OY, double* OU) {
+  if constexpr (CUBIC)
+    spline_eval_k<3>(ws, f, step, count, OX, OY, OU);
+  else
+    spline_eval(ws, f, step, count, OX, OY, OU);
 }
 
 __device__ __forceinline__ int arange_len(double stop, double step) {
@@ -303,7 +320,7 @@ __device__ __forceinline__ int arange_len(double stop, double step) {
 
 // calculate_path/path_parameterization.py:297-328 on the arena polyline [off, off+n).
 // rc: 0 ok (out filled), 1 ValueError, ST_* otherwise.
-template <int G, bool FAST>
+template <int G, bool FAST, bool CUBIC = false>
 __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
   using GR = Grp<G>;
   const int lane = GR::lane();
@@ -355,7 +372,7 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
   int rc;
   {
     PROF(7);
-    rc = fit_polyline<G, FAST>(S, A, off, ns, 0.01, f, max_u);
+    rc = fit_polyline<G, FAST, CUBIC>(S, A, off, ns, 0.01, f, max_u);
   }
   if (rc) return rc;
   // _calculate_path_curvature :163-193 — dense samples into LDS
@@ -367,7 +384,7 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
   double* const DU = S.du();
   {
     PROF(8);
-    spline_eval(S.ws, f, predict_every, L, DX, DY, DU);
+    eval_spline<CUBIC>(S.ws, f, predict_every, L, DX, DY, DU);
   }
   double* curv = S.curv();
   double* filt = A.filt;
@@ -623,7 +640,7 @@ __device__ __forceinline__ int mpc_prepare(PathShared<G>& S, const Arena& A, int
 
 // after refit_path_for_mpc_with_safety_factor's fit :239-259 (knots / coefficients in S.ws, `fitted` false when the
 // polyline had fewer than 2 points): predict to 1.5 * 20 m, cut at 20 m :467-499, parameterize
-template <int G, bool FAST>
+template <int G, bool FAST, bool CUBIC = false>
 __device__ __forceinline__ int mpc_finish(PathShared<G>& S, const Arena& A, bool fitted, const SplineFit& f, double (*out)[4],
                                           int* n_dense) {
   int n5;
@@ -632,7 +649,7 @@ __device__ __forceinline__ int mpc_finish(PathShared<G>& S, const Arena& A, bool
     if (fitted) {
       PROF(5);
       n4 = arange_len(20.0 * 1.5, 0.1);
-      spline_eval(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
+      eval_spline<CUBIC>(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
     }
     int nseg = n4 - 1;
     if (nseg <= 1) return 1;  // previous (40,4) array handed on -> LinAlgError (a ValueError) downstream
@@ -640,7 +657,7 @@ __device__ __forceinline__ int mpc_finish(PathShared<G>& S, const Arena& A, bool
     cumulative_length<G>(S, A, 0, n4, 20.0, &first);
     n5 = first;
   }
-  return parameterize_path<G, FAST>(S, A, 0, n5, out, n_dense);
+  return parameterize_path<G, FAST, CUBIC>(S, A, 0, n5, out, n_dense);
 }
 
 template <int G, bool FAST>
@@ -745,6 +762,7 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame) {
   A.bc.b = b + 11 * PATH_CAP;
   A.filt = A.bc.b + ARENA_B;
   A.fit = (FitRec*)(A.filt + DENSE_CAP);
+  A.band = A.filt + DENSE_CAP + FITREC_DOUBLES;
   return A;
 }
 
@@ -790,7 +808,7 @@ constexpr int PATH_LATENCY_BATCH = 4096;  // largest single pass that G = 16 ser
 
 // First half of run_path_calculation (core_calculate_path.py:514-553): centre points (or the global path window), fit #1
 // and its dense evaluation.  Leaves the dense path update in the arena [1, 1 + *n1_out); returns the frame status.
-template <int G, bool FAST>
+template <int G, bool FAST, bool CUBIC = false>
 __device__ __forceinline__ int path_front(PathShared<G>& S, const Arena& A, const MatchOut* mo, double px, double py,
                                           const double* prev, const double* __restrict__ gpath, int n_gpath, int* fallback_out,
                                           int* n1_out) {
@@ -912,13 +930,13 @@ __device__ __forceinline__ int path_front(PathShared<G>& S, const Arena& A, cons
       SplineFit f;
       double max_u;
       PROF(1);
-      int rc = fit_polyline<G, FAST>(S, A, 0, nc, 0.2, f, max_u);
+      int rc = fit_polyline<G, FAST, CUBIC>(S, A, 0, nc, 0.2, f, max_u);
       if (rc == 0) {
         n1 = arange_len(max_u, 0.1);
         if (n1 + 1 + 50 > PATH_CAP) {
           status = ST_OVERFLOW_PATH;
         } else {
-          spline_eval(S.ws, f, 0.1, n1, A.x + 1, A.y + 1, nullptr);
+          eval_spline<CUBIC>(S.ws, f, 0.1, n1, A.x + 1, A.y + 1, nullptr);
         }
         break;
       }
@@ -1003,7 +1021,7 @@ __global__ void __launch_bounds__(64) path_prep_kernel(int n_frames, const doubl
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
   const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
   int fallback = 0, n1 = 0, off = 0, n = 0;
-  int status = path_front<G, true>(S, A, &matched[frame], px, py, prev, gpath, n_gpath, &fallback, &n1);
+  int status = path_front<G, true, true>(S, A, &matched[frame], px, py, prev, gpath, n_gpath, &fallback, &n1);
   bool plain = false;
   if (status == ST_OK && n1 > 0) {
     n1 = overwrite_if_too_far<G>(A, n1, px, py, prev, &fallback);
@@ -1026,10 +1044,11 @@ __global__ void __launch_bounds__(64) path_prep_kernel(int n_frames, const doubl
 
 // the refit: utils/spline_fit.py:95-128 (splprep, k = 3, s = 0.2) of the arena polyline [off, off + n), G lanes per frame
 template <int G, int NKC>
-__global__ void __launch_bounds__(64, (G >= 8 ? 2 : 1)) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
+__global__ void __launch_bounds__(64, 2) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                  int* __restrict__ retry) {
   using GR = Grp<G>;
-  using WS = SplineWS<G, NKC, 1>;
+  using WS = FitWS<G, NKC>;
+  static_assert(6 * (NKC + 2) <= BAND_DOUBLES, "band region of the arena");
   __shared__ WS ws_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
   PROF_INIT();
@@ -1037,6 +1056,8 @@ __global__ void __launch_bounds__(64, (G >= 8 ? 2 : 1)) fit_kernel(int n_frames,
     PROF(0);
     WS& ws = ws_all[GR::index()];
     const Arena A = frame_arena(arena, frame);
+    if (GR::lane() == 0) ws.band = A.band;
+    GR::sync();
     const int off = mid[frame].off, m = mid[frame].n;
     const SplineFit f = spline_fit_k<3, true>(ws, A.bc, A.u + off, A.x + off, A.y + off, m, 0.2);
     const int lane = GR::lane();
@@ -1087,7 +1108,7 @@ __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* _
   }
   GR::sync();
   int n_dense = 0;
-  const int rc = mpc_finish<G, true>(S, A, true, f, out[frame].path, &n_dense);
+  const int rc = mpc_finish<G, true, true>(S, A, true, f, out[frame].path, &n_dense);
   if (rc == 0) {
     write_path_status<G>(&out[frame], ST_OK, mid[frame].fallback, n_dense);
   } else if (lane == 0) {

@@ -63,7 +63,37 @@ struct SplineWS {
                                    // (<= 3 * DENSE_CAP), in the extension the tail points of the polyline
     };
   };
+  static constexpr bool BAND_GLOBAL = false;
   __device__ __forceinline__ double& A(int i, int j) { return a_[i][j - 1]; }
+  __device__ __forceinline__ double& Z(int i) { return z[i]; }
+  __device__ __forceinline__ double& Gm(int i, int j) { return g_[i][j - 1]; }
+};
+
+// The fit-only workspace of fit_kernel: 1160 bytes at 16 knots, so that sixteen frames of a wavefront take 18.6 KB and two
+// wavefronts fit a SIMD's share of the LDS.  The band triangle and its right-hand sides are not here: during an
+// observation pass they live in the registers of the Givens quad, between passes in the frame's scratch (`band`:
+// (NK + 2) x 4 rows, then 2 (NK + 2) right-hand sides), where back-substitution and the smoothing iteration fetch them.
+template <int G, int NKC>
+struct FitWS {
+  static constexpr int GRP = G;
+  static constexpr int NK = NKC;
+  static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : (G >= 8 ? 16 : 8));
+  static constexpr bool BAND_GLOBAL = true;
+  double t[NK + 2];
+  double c[2 * (NK + 2)];
+  double* band;
+  union {
+    struct {
+      double hq[CH][4];
+      double xq[CH], yq[CH];
+      int32_t lq[CH];
+      double fpint[NK + 2];
+      int32_t nrdata[NK + 2];
+    };
+    double g_[NK + 2][5];
+  };
+  __device__ __forceinline__ double& A(int i, int j) { return band[4 * i + j - 1]; }
+  __device__ __forceinline__ double& Z(int i) { return band[4 * (NK + 2) + i]; }
   __device__ __forceinline__ double& Gm(int i, int j) { return g_[i][j - 1]; }
 };
 
@@ -275,6 +305,81 @@ __device__ __forceinline__ double sqrt_1_2(double x) {
 #endif
 }
 
+// fpbspl for degree 3 as straight-line code: the six knots around the interval are fetched together (one LDS round
+// trip instead of a dependent read per term), coincident knots are handled by selects (the quotient of the skipped
+// branch is computed and dropped), and with FAST the six divisions use the exact scaled-free sequence above (operands
+// outside its exponent band set `bad`).  Same operations on the same operands as fpbspl<3>: same bits.
+template <bool FAST>
+__device__ __forceinline__ void fpbspl3(const double* t, double x, int l, double* h /*[0..3]*/, int& bad) {
+  const double tm2 = t[l - 2], tm1 = t[l - 1], t0 = t[l], tp1 = t[l + 1], tp2 = t[l + 2], tp3 = t[l + 3];
+  auto quot = [&](double num, double den) {
+    if constexpr (FAST) {
+      bad |= (int)((den != 0.0) & !(div_safe(den) & ((num == 0.0) | div_safe(num))));
+      return div_rcp(num, den, rcp_refined(den));
+    } else {
+      return num / den;
+    }
+  };
+  // level 1
+  double h1, h2, h3, h4;
+  {
+    const double den = tp1 - t0;
+    const bool same = tp1 == t0;
+    const double f = quot(1.0, den);
+    h1 = same ? 0.0 : 0.0 + f * (tp1 - x);
+    h2 = same ? 0.0 : f * (x - t0);
+  }
+  // level 2
+  {
+    const double a1 = h1, a2 = h2;
+    h1 = 0.0;
+    {
+      const double den = tp1 - tm1;
+      const bool same = tp1 == tm1;
+      const double f = quot(a1, den);
+      h1 = same ? h1 : h1 + f * (tp1 - x);
+      h2 = same ? 0.0 : f * (x - tm1);
+    }
+    {
+      const double den = tp2 - t0;
+      const bool same = tp2 == t0;
+      const double f = quot(a2, den);
+      h2 = same ? h2 : h2 + f * (tp2 - x);
+      h3 = same ? 0.0 : f * (x - t0);
+    }
+  }
+  // level 3
+  {
+    const double a1 = h1, a2 = h2, a3 = h3;
+    h1 = 0.0;
+    {
+      const double den = tp1 - tm2;
+      const bool same = tp1 == tm2;
+      const double f = quot(a1, den);
+      h1 = same ? h1 : h1 + f * (tp1 - x);
+      h2 = same ? 0.0 : f * (x - tm2);
+    }
+    {
+      const double den = tp2 - tm1;
+      const bool same = tp2 == tm1;
+      const double f = quot(a2, den);
+      h2 = same ? h2 : h2 + f * (tp2 - x);
+      h3 = same ? 0.0 : f * (x - tm1);
+    }
+    {
+      const double den = tp3 - t0;
+      const bool same = tp3 == t0;
+      const double f = quot(a3, den);
+      h3 = same ? h3 : h3 + f * (tp3 - x);
+      h4 = same ? 0.0 : f * (x - t0);
+    }
+  }
+  h[0] = h1;
+  h[1] = h2;
+  h[2] = h3;
+  h[3] = h4;
+}
+
 // ---- 4-stage systolic Givens pipeline (degree 3) ------------------------------------------------------
 // A data row of knot interval l touches the 4 consecutive band rows l-3..l, one rotation each, in that order;
 // consecutive data rows fall (almost always) into the same interval.  Lane p of the group's first quad owns the band
@@ -324,8 +429,8 @@ __device__ __forceinline__ void giv_flush(WS& ws, const GivLane& st, int lane, i
     ws.A(st.j, 2) = st.a2;
     ws.A(st.j, 3) = st.a3;
     ws.A(st.j, 4) = st.a4;
-    ws.z[st.j] = st.z1;
-    ws.z[st.j + n] = st.z2;
+    ws.Z(st.j) = st.z1;
+    ws.Z(st.j + n) = st.z2;
   }
 }
 
@@ -462,9 +567,9 @@ __device__ __forceinline__ void giv_feed(WS& ws, GivLane& st, int r0, int r1) {
 #ifndef RB_MAX_ROUNDS
 #define RB_MAX_ROUNDS 4  // rounds of a residual super-chunk held in registers
 #endif
-template <int K, int G, bool FLAGS>
+template <int K, int G, bool FLAGS, int CHV>
 struct ResidualBatch {
-  static constexpr int ROUNDS = (4 * SplineWS<G>::CH / G > RB_MAX_ROUNDS) ? RB_MAX_ROUNDS : 4 * SplineWS<G>::CH / G;
+  static constexpr int ROUNDS = (4 * CHV / G > RB_MAX_ROUNDS) ? RB_MAX_ROUNDS : 4 * CHV / G;
   static constexpr int k1 = K + 1, k2 = K + 2;
   double hv[ROUNDS][K + 1], xv[ROUNDS], yv[ROUNDS];
   int lv[ROUNDS], lpv[ROUNDS];
@@ -531,7 +636,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
   constexpr int G = WS::GRP;
   using GR = Grp<G>;
   constexpr int CH = WS::CH;
-  constexpr int SC = ResidualBatch<K, G, false>::ROUNDS * G;  // points per residual half "super-chunk"
+  constexpr int SC = ResidualBatch<K, G, false, CH>::ROUNDS * G;  // points per residual half "super-chunk"
   constexpr int HALVES = (2 * SC <= 4 * CH) ? 2 : 1;             // the chunk's basis buffer holds 4 * CH terms
   constexpr int k = K;
   const int lane = GR::lane();
@@ -599,7 +704,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         ws.t[1 + lane] = ub;
         ws.t[n - lane] = ue;
       }
-      for (int i = 1 + lane; i <= 2 * (NK + 1); i += G) ws.z[i] = 0.0;
+      for (int i = 1 + lane; i <= 2 * (NK + 1); i += G) ws.Z(i) = 0.0;
       for (int i = 1 + lane; i <= nk1; i += G)
         for (int j = 1; j <= k1; j++) ws.A(i, j) = 0.0;
       GR::sync();
@@ -637,7 +742,10 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
               int l = find_interval_from(ws.t, lres, nk1, ui);
               lres = l;
               double h[K + 2];
-              fpbspl<K>(ws.t, ui, l, h);
+              if constexpr (K == 3)
+                fpbspl3<FAST>(ws.t, ui, l, &h[1], gst.bad);
+              else
+                fpbspl<K>(ws.t, ui, l, h);
               double hf[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
               for (int j = 0; j < k1; j++) {
@@ -693,11 +801,11 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
                 double ww = ws.A(j, 1);
                 fpgivs(piv, ww, cs, sn);
                 ws.A(j, 1) = ww;
-                double z1 = ws.z[j], z2 = ws.z[j + n];
+                double z1 = ws.Z(j), z2 = ws.Z(j + n);
                 fprota(cs, sn, xi1, z1);
                 fprota(cs, sn, xi2, z2);
-                ws.z[j] = z1;
-                ws.z[j + n] = z2;
+                ws.Z(j) = z1;
+                ws.Z(j + n) = z2;
                 if (i == k1) break;
                 int i2 = 1;
 #pragma unroll
@@ -725,12 +833,42 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         if (GR::ballot(gst.bad != 0) != 0ull) R.status = ST_RETRY;
         GR::sync();
       }
-      if (lane == 0) {
+      if constexpr (WS::BAND_GLOBAL) {
+        GR::sync();  // the quad's band rows are in the scratch
+        if (lane == 0) {
+          PROF(13);
+          // fpback for both coordinates in one sweep over the band rows (scratch), the next row fetched while the
+          // current one is solved; per coordinate the operations and their order are fpback's
+          double a1 = ws.A(nk1, 1), a2 = ws.A(nk1, 2), a3 = ws.A(nk1, 3), a4 = ws.A(nk1, 4), z1 = ws.Z(nk1), z2 = ws.Z(nk1 + n);
+          for (int i = nk1; i >= 1; i--) {
+            const double b1 = a1, b2 = a2, b3 = a3, b4 = a4, y1 = z1, y2 = z2;
+            if (i > 1) {
+              a1 = ws.A(i - 1, 1);
+              a2 = ws.A(i - 1, 2);
+              a3 = ws.A(i - 1, 3);
+              a4 = ws.A(i - 1, 4);
+              z1 = ws.Z(i - 1);
+              z2 = ws.Z(i - 1 + n);
+            }
+            const int i1 = (nk1 - i) < (k1 - 1) ? (nk1 - i) : (k1 - 1);
+            double s1 = y1, s2 = y2;
+            const double bl[3] = {b2, b3, b4};
+#pragma unroll
+            for (int l = 1; l <= 3; l++)
+              if (l <= i1) {
+                s1 = s1 - ws.c[i + l] * bl[l - 1];
+                s2 = s2 - ws.c[n + i + l] * bl[l - 1];
+              }
+            ws.c[i] = s1 / b1;
+            ws.c[n + i] = s2 / b1;
+          }
+        }
+      } else if (lane == 0) {
         PROF(13);
         // back substitution (both coordinates)
         auto ael = [&](int i, int j) { return ws.A(i, j); };
-        fpback(ael, &ws.z[0], nk1, k1, &ws.c[0]);
-        fpback(ael, &ws.z[n], nk1, k1, &ws.c[n]);
+        fpback(ael, &ws.Z(0), nk1, k1, &ws.c[0]);
+        fpback(ael, &ws.Z(n), nk1, k1, &ws.c[n]);
       }
       GR::sync();
       if (ier == -2) fp0 = fp;
@@ -779,7 +917,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         int ii = 1;
         double* const tbuf = &ws.hq[0][0];     // 4 * CH terms
         int32_t* const fbuf = (int32_t*)ws.xq;  // xq | yq: 4 * CH flags
-        ResidualBatch<K, G, true> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
+        ResidualBatch<K, G, true, CH> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
         auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
         ra.load(bc, 0, clampc(m), m);
         for (int base = 0; base < m; base += HALVES * SC) {
@@ -921,7 +1059,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       double pinv = one / p;
       PROF_COUNT(24, G, 1);
       GR::sync();
-      for (int i = 1 + lane; i <= 2 * n; i += G) ws.c[i] = ws.z[i];
+      for (int i = 1 + lane; i <= 2 * n; i += G) ws.c[i] = ws.Z(i);
       for (int i = 1 + lane; i <= nk1; i += G) {
         ws.Gm(i, k2) = 0.;
         for (int j = 1; j <= k1; j++) ws.Gm(i, j) = ws.A(i, j);
@@ -980,7 +1118,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       fp = 0.;
       {
         double* const tbuf = &ws.hq[0][0];  // 4 * CH terms
-        ResidualBatch<K, G, false> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
+        ResidualBatch<K, G, false, CH> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
         auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
         ra.load(bc, 0, clampc(m), m);
         for (int base = 0; base < m; base += HALVES * SC) {
@@ -1083,11 +1221,18 @@ __device__ __forceinline__ void spline_eval_k(const WS& ws, const SplineFit& f, 
   const int n = f.n;
   constexpr int k1 = K + 1;
   const int nk1 = n - k1;
+  int lcur = k1;  // a lane's evaluation points increase: the interval search resumes where the previous one ended
   for (int i = lane; i < count; i += G) {
     double arg = (double)i * step;
-    int l = find_interval(ws.t, k1, nk1, arg);
+    int l = find_interval_from(ws.t, lcur, nk1, arg);
+    lcur = l;
     double h[K + 2];
-    fpbspl<K>(ws.t, arg, l, h);
+    if constexpr (K == 3) {
+      int unused = 0;
+      fpbspl3<false>(ws.t, arg, l, &h[1], unused);
+    } else {
+      fpbspl<K>(ws.t, arg, l, h);
+    }
     double sx = 0., sy = 0.;
     int ll = l - k1;
 #pragma unroll

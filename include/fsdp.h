@@ -133,7 +133,7 @@ int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
  * other.  Every stream takes one of the HIP runtime's hardware queues (environment variable GPU_MAX_HW_QUEUES, default 4):
  * with depth 4 and any other stream in the process (the null stream, RCCL) two passes share a queue and serialize —
  * raise GPU_MAX_HW_QUEUES (bench.py sets 8) or use depth 3. */
-#define FSDP_MAX_OVERLAP 4
+#define FSDP_MAX_OVERLAP 8
 int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
 
 /* Enqueue `iters` back-to-back passes over the resident batch (rotating through the slots when passes overlap; no host
