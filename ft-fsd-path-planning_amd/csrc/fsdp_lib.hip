@@ -21,7 +21,7 @@
 using namespace fsdp;
 
 static_assert(FSDP_MAX_LEN == MAX_LEN && FSDP_MAX_MATCH == MAX_MATCH && FSDP_PATH_POINTS == PATH_POINTS &&
-                  FSDP_MAX_CONES == MAX_CONES,
+                  FSDP_MAX_CONES == BIG_CONES,
               "header/device constant mismatch");
 
 static thread_local std::string g_create_error;
@@ -48,6 +48,7 @@ struct fsdp_ctx {
   double* d_arena = nullptr;         // per-frame working polyline + basis cache (ARENA_DOUBLES doubles), HBM/L2 scratch
   int* d_retry = nullptr;            // [0] counter + frames for the exact re-plan kernel (n_frames + 1 ints)
   PathMid* d_mid = nullptr;          // hand-over records of the three-kernel path stage
+  SortSharedBig* d_sort_big = nullptr;  // frame states of sort_big_kernel (SORT_BIG_BLOCKS per slot)
   double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
   double* d_prev = nullptr;          // optional per-frame previous paths (n_frames,40,4) for sequential replays
   bool use_prev = false;
@@ -232,9 +233,15 @@ static int sync_all(fsdp_ctx* c) {
   return 0;
 }
 
+// Sorting: the LDS kernel for every frame, then the frames beyond its capacities (more than 255 cones, more than 64 raw
+// end configurations per side; list on the device) once more with the frame state in global memory.
+constexpr int SORT_BIG_BLOCKS = 32;
 static void launch_sort(fsdp_ctx* c, const Slot& q) {
+  (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
   hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
-                     q.d_sort);
+                     q.d_sort, q.d_retry);
+  hipLaunchKernelGGL(sort_big_kernel, dim3(SORT_BIG_BLOCKS), dim3(WAVE), 0, q.stream, c->d_off, c->d_cones, c->d_poses, q.d_sort,
+                     q.d_retry, c->d_sort_big + (size_t)q.index * SORT_BIG_BLOCKS);
 }
 static void launch_match(fsdp_ctx* c, const Slot& q) {
   hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
@@ -404,6 +411,7 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
   if (e == hipSuccess) e = hipMalloc(&c->d_default_path, sizeof(double) * PATH_POINTS * 4);
+  if (e == hipSuccess) e = hipMalloc(&c->d_sort_big, sizeof(SortSharedBig) * SORT_BIG_BLOCKS * FSDP_MAX_OVERLAP);
   if (e != hipSuccess) {
     g_create_error = std::string("fsdp_create: ") + hipGetErrorString(e);
     delete c;
@@ -458,6 +466,7 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_skid_info);
   (void)hipFree(c->d_skid_status);
   (void)hipFree(c->d_default_path);
+  (void)hipFree(c->d_sort_big);
   if (c->h_sort) (void)hipHostFree(c->h_sort);
   if (c->h_match) (void)hipHostFree(c->h_match);
   if (c->h_path) (void)hipHostFree(c->h_path);

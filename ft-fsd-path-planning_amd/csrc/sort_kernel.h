@@ -38,22 +38,33 @@ namespace fsdp {
 #define PROF_MARK_DECL(k)
 #endif
 
-struct SortShared {
-  double x[MAX_CONES];
-  double y[MAX_CONES];
-  double dist[MAX_CONES];          // distance car->cone (start-cone selection)
-  uint8_t type[MAX_CONES];
-  uint8_t flags[MAX_CONES];        // bit0 in ellipse, bit1 angle>0, bit2 angle<0, bit3 angle window, bit4 "in front" (skip for 2nd cone)
-  uint8_t knn[MAX_CONES][KNN];     // k nearest (index), 255 = none
-  uint8_t knn_ok[MAX_CONES];       // bit q: knn[q] within max_dist
-  uint8_t nbr[2][MAX_CONES][KNN];  // mutual neighbours, ascending — one adjacency per side (both DFS run together)
-  uint8_t nbr_cnt[2][MAX_CONES];
-  uint8_t vis[MAX_CONES];
-  int16_t ends[2][MAX_ENDS][MAX_LEN];  // raw / filtered end configurations per side, -1 padded
-  uint8_t keep[MAX_ENDS];
-  double cost[MAX_ENDS];
-  int32_t good[MAX_ENDS];
-  int32_t bad[MAX_ENDS];
+// The frame state of the sorting stage.  Two instantiations: the product kernel keeps it in LDS (up to 255 cones with
+// one-byte indices, 64 raw end configurations per side); frames beyond either capacity are planned again by
+// sort_big_kernel with the same code over a state in global memory (1024 cones, 4096 raw end configurations) — the
+// reference's own buffers grow without bound (adjacency_matrix.py:21-31, end_configurations.py:74-105,346-348).
+template <int CAP_, class IDX_, int ENDS_>
+struct SortSharedT {
+  static constexpr int CAP = CAP_;      // cones per frame
+  static constexpr int ENDS = ENDS_;    // raw end configurations per side
+  using idx_t = IDX_;                   // cone index in the neighbour lists
+  static constexpr int NONE = (sizeof(IDX_) == 1) ? 255 : 32767;  // "no neighbour" (sorts last)
+  static constexpr int MAX_N = (sizeof(IDX_) == 1) ? 255 : CAP_;  // largest frame (index NONE is reserved)
+  double x[CAP];
+  double y[CAP];
+  double dist[CAP];          // distance car->cone (start-cone selection)
+  uint8_t type[CAP];
+  uint8_t flags[CAP];        // bit0 in ellipse, bit1 angle>0, bit2 angle<0, bit3 angle window, bit4 "in front" (skip for 2nd cone)
+  idx_t knn[CAP][KNN];       // k nearest (index), NONE = none
+  uint8_t knn_ok[CAP];       // bit q: knn[q] within max_dist
+  idx_t nbr[2][CAP][KNN];    // mutual neighbours, ascending — one adjacency per side (both DFS run together)
+  uint8_t nbr_cnt[2][CAP];
+  uint8_t vis[CAP];
+  int16_t ends[2][ENDS][MAX_LEN];  // raw / filtered end configurations per side, -1 padded
+  uint8_t keep[ENDS];
+  uint8_t keep2[ENDS];
+  double cost[ENDS];
+  int32_t good[ENDS];
+  int32_t bad[ENDS];
   int16_t stack[2][MAX_STACK][2];
   double stack_ang[2][MAX_STACK];  // direction (atan2) of the edge parent -> stacked cone
   int16_t attempt[2][MAX_LEN];
@@ -64,10 +75,10 @@ struct SortShared {
     int32_t adj;                   // which adjacency the DFS walks (0 for both sides of a colourless frame)
     int32_t n_ends, status;
   } ctl[2];
-  int16_t all_list[MAX_ENDS * MAX_LEN > MAX_CONES ? MAX_CONES : MAX_ENDS * MAX_LEN];
-  unsigned long long all_mask[MAX_CONES / 64];
-  unsigned long long near_mask[MAX_CONES / 64];
-  unsigned long long close_mask[MAX_CONES / 64];
+  int16_t all_list[ENDS * MAX_LEN > CAP ? CAP : ENDS * MAX_LEN];
+  unsigned long long all_mask[CAP / 64];
+  unsigned long long near_mask[CAP / 64];
+  unsigned long long close_mask[CAP / 64];
   int16_t best[2][MAX_LEN];        // best configuration per side (0 = left, 1 = right)
   int32_t best_len[2];
   int32_t n_configs[2];
@@ -75,6 +86,9 @@ struct SortShared {
   int32_t first_k[2][2];
   int32_t adj_built;               // the mutual-kNN lists below have been built for this frame
 };
+using SortShared = SortSharedT<MAX_CONES, uint8_t, MAX_ENDS>;          // LDS, product kernel
+constexpr int BIG_CONES = 1024, BIG_ENDS = 4096;
+using SortSharedBig = SortSharedT<BIG_CONES, int16_t, BIG_ENDS>;        // global memory, sort_big_kernel
 
 // ---- trace_sorter/line_segment_intersection.py:136-200 (epsilon 1e-6) ----
 __device__ inline bool segments_intersect(double a0x, double a0y, double a1x, double a1y, double b0x, double b0y, double b1x,
@@ -133,7 +147,8 @@ __device__ inline bool inside_ellipse(double px, double py, double cx, double cy
 
 // end_configurations.py:108-223 for ONE candidate neighbour `cand` of the popped node.
 // check_if_neighbor_lies_between_last_in_attempt_and_candidate (:226-257) for one (candidate, neighbour) pair
-__device__ __forceinline__ bool neighbour_lies_between(const SortShared& S, int node, int cand, int nb) {  // (cone indices only)
+template <class SH>
+__device__ __forceinline__ bool neighbour_lies_between(const SH& S, int node, int cand, int nb) {  // (cone indices only)
   if (nb == cand) return false;
   const double lx = S.x[node], ly = S.y[node];
   const double cx = S.x[cand], cy = S.y[cand];
@@ -148,7 +163,8 @@ __device__ __forceinline__ bool neighbour_lies_between(const SortShared& S, int 
 // two edges of the attempt (ang_sl: attempt[pos-1] -> node, ang_tl: attempt[pos-2] -> attempt[pos-1]) are the atan2
 // values computed when those cones were candidates themselves (same operands, same bits); ang_cand returns the direction
 // of the edge node -> candidate for the candidate's own children.
-__device__ inline bool candidate_can_be_added(const SortShared& S, int side, int cone_type, int pos, int node, int cand, bool between,
+template <class SH>
+__device__ inline bool candidate_can_be_added(const SH& S, int side, int cone_type, int pos, int node, int cand, bool between,
                                               double px, double py, double dx, double dy, double dnx, double dny, double a_car,
                                               double ang_sl, double ang_tl, double& ang_cand) {
   const double lx = S.x[node], ly = S.y[node];
@@ -221,7 +237,8 @@ __device__ __forceinline__ double np_sum_reg(const double (&a)[MAX_LEN], int n) 
 // Phase 1 of a side (S4-S7): start cones, mutual-kNN adjacency, reachability -> S.ctl[side].
 // reuse_adjacency: the mutual-kNN lists were built by the other side's call and no cone of the frame carries a side
 // colour, so they are the same for this side (no-colour mode builds them once per frame).
-__device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, int side, double px, double py, double dx,
+template <class SH>
+__device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, double px, double py, double dx,
                                          double dy, bool reuse_adjacency) {
   const int lane = lane_id();
   const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
@@ -312,7 +329,7 @@ __device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, in
 #pragma unroll
       for (int q = 0; q < KNN; q++) {
         bd[q] = INFINITY;
-        bj[q] = 255;
+        bj[q] = SH::NONE;
       }
       const double xi = S.x[i], yi = S.y[i];
       const bool row_inf = (S.type[i] == other_type);
@@ -333,11 +350,15 @@ __device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, in
             if (j >= n || j == i || tj8[e] == other_type) continue;
             double d = cdist_sq(xi, yi, xj[e], yj[e]);
             if (d < bd[KNN - 1]) {
-              // sorted insertion through registers; strict '<' keeps the earlier index first on ties
+              // sorted insertion through registers: strict '<' finds the slot (the earlier index stays first on an exact
+              // tie), from there on every element moves down one slot — a stable order, lowest index first.  (The
+              // reference's np.argsort is unstable: on exact ties its pick depends on the NumPy build)
               int cj = j;
+              bool ins = false;
 #pragma unroll
               for (int q = 0; q < KNN; q++) {
-                bool lt = d < bd[q];
+                bool lt = ins || d < bd[q];
+                ins = lt;
                 double td = lt ? bd[q] : d;
                 int tj = lt ? bj[q] : cj;
                 bd[q] = lt ? d : bd[q];
@@ -352,8 +373,8 @@ __device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, in
       int okm = 0;
 #pragma unroll
       for (int q = 0; q < KNN; q++) {
-        bool in_k = (q < k_nn) && (bj[q] != 255);
-        S.knn[i][q] = in_k ? (uint8_t)bj[q] : (uint8_t)255;
+        bool in_k = (q < k_nn) && (bj[q] != SH::NONE);
+        S.knn[i][q] = in_k ? (typename SH::idx_t)bj[q] : (typename SH::idx_t)SH::NONE;
         if (in_k && !(bd[q] > 6.5 * 6.5)) okm |= (1 << q);
       }
       S.knn_ok[i] = (uint8_t)okm;
@@ -363,19 +384,19 @@ __device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, in
       int cnt = 0;
       int lst[KNN];
 #pragma unroll
-      for (int q = 0; q < KNN; q++) lst[q] = 255;
+      for (int q = 0; q < KNN; q++) lst[q] = SH::NONE;
       int okm = S.knn_ok[i];
 #pragma unroll
       for (int q = 0; q < KNN; q++) {
         int j = S.knn[i][q];
-        if (j == 255 || !(okm & (1 << q))) continue;
+        if (j == SH::NONE || !(okm & (1 << q))) continue;
         int okj = S.knn_ok[j];
         bool mutual = false;
 #pragma unroll
         for (int r = 0; r < KNN; r++)
           if (S.knn[j][r] == i && (okj & (1 << r))) mutual = true;
         if (mutual) {
-          // ascending insertion (255 = empty sorts last)
+          // ascending insertion (NONE = empty sorts last)
           int v = j;
 #pragma unroll
           for (int p = 0; p < KNN; p++) {
@@ -388,7 +409,7 @@ __device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, in
         }
       }
 #pragma unroll
-      for (int q = 0; q < KNN; q++) S.nbr[adj][i][q] = (uint8_t)lst[q];
+      for (int q = 0; q < KNN; q++) S.nbr[adj][i][q] = (typename SH::idx_t)lst[q];
       S.nbr_cnt[adj][i] = (uint8_t)cnt;
     }
     __syncthreads();
@@ -398,9 +419,9 @@ __device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, in
   __syncthreads();
   // BFS reachability from start_idx (common.py:36-67); only min(len, 12) is consumed
   int reach = 1;
-  for (int it = 0; it < MAX_CONES && reach < MAX_LEN; it++) {
+  for (int it = 0; it < SH::CAP && reach < MAX_LEN; it++) {
     int add = 0;
-    unsigned long long newbits[MAX_CONES / WAVE];
+    unsigned long long newbits[SH::CAP / WAVE];
     for (int w = 0; w * WAVE < n; w++) {
       int i = w * WAVE + lane;
       bool nv = false;
@@ -437,7 +458,8 @@ __device__ inline void sort_side_prepare(SortShared& S, int n, int cone_type, in
 // Phase 2 (S8): DFS over the cost tree (end_configurations.py:320-431) of BOTH sides at once, one half-wavefront per
 // side.  A pop keeps at most 5 candidate lanes and 25 (candidate, neighbour) lanes busy, so the two independent searches
 // share every instruction; the loop runs until both stacks are empty.
-__device__ inline void sort_dfs_both(SortShared& S, double px, double py, double dx, double dy) {
+template <class SH>
+__device__ inline void sort_dfs_both(SH& S, double px, double py, double dx, double dy) {
   const int lane = lane_id();
   const int side = lane >> 5, sl = lane & 31;
   const int cone_type = (side == 0) ? T_LEFT : T_RIGHT;
@@ -515,7 +537,7 @@ __device__ inline void sort_dfs_both(SortShared& S, double px, double py, double
           S.stack_ang[side][slot] = cand_ang;
         }
         sp += __popc(m);
-      } else if (n_ends >= MAX_ENDS) {
+      } else if (n_ends >= SH::ENDS) {
         status = ST_OVERFLOW_ENDS;
       } else {
         if (sl < MAX_LEN) S.ends[side][n_ends][sl] = (sl < target_length) ? S.attempt[side][sl] : (int16_t)-1;
@@ -533,7 +555,8 @@ __device__ inline void sort_dfs_both(SortShared& S, double px, double py, double
 }
 
 // Phase 3 of a side (S10-S12): post filters, side counting, costs, pick.  Returns the frame status of this side.
-__device__ inline int sort_side_finish(SortShared& S, int n, int cone_type, int side, double px, double py, double dx,
+template <class SH>
+__device__ inline int sort_side_finish(SH& S, int n, int cone_type, int side, double px, double py, double dx,
                                        double dy) {
   const int lane = lane_id();
   const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
@@ -546,81 +569,96 @@ __device__ inline int sort_side_finish(SortShared& S, int n, int cone_type, int 
   (void)py;
   PROF_MARK_DECL(4);
   // ---------------- S10: post filters (end_configurations.py:420-515), lane = raw configuration ----------------
+  // (configurations in chunks of 64: one chunk in the product kernel, more in sort_big_kernel)
   const int L = target_length;
-  bool keep = false;
-  int16_t cfg[MAX_LEN];
-  int len = 0;
-  if (lane < n_ends) {
+  for (int c0 = 0; c0 < n_ends; c0 += WAVE) {
+    const int c = c0 + lane;
+    bool keep = false;
+    if (c < n_ends) {
+      int16_t cfg[MAX_LEN];
+      int len = 0;
 #pragma unroll
-    for (int l = 0; l < MAX_LEN; l++) {
-      cfg[l] = S.ends[side][lane][l];
-      len += (cfg[l] != -1);
-    }
-    keep = len > 2;
-    if (keep && n_first == 2) keep = (cfg[0] == fk0) && (L > 1) && (cfg[1] == fk1);
-    if (keep) {
-      // drop the last cone if it is not of the side's colour (:491-500)
-      int am = 0;
-      bool found = false;
-      for (int l = 0; l < L; l++)
-        if (cfg[l] == -1) {
-          am = l;
-          found = true;
-          break;
-        }
-      if (!found) am = 0;
-      int last_idx = ((am - 1) % L + L) % L;
-      int last_cone = 0;
-#pragma unroll
-      for (int l = 0; l < MAX_LEN; l++)
-        if (l == last_idx) last_cone = cfg[l];
-      if (S.type[last_cone] != cone_type) {
+      for (int l = 0; l < MAX_LEN; l++) {
+        cfg[l] = S.ends[side][c][l];
+        len += (cfg[l] != -1);
+      }
+      keep = len > 2;
+      if (keep && n_first == 2) keep = (cfg[0] == fk0) && (L > 1) && (cfg[1] == fk1);
+      if (keep) {
+        // drop the last cone if it is not of the side's colour (:491-500)
+        int am = 0;
+        bool found = false;
+        for (int l = 0; l < L; l++)
+          if (cfg[l] == -1) {
+            am = l;
+            found = true;
+            break;
+          }
+        if (!found) am = 0;
+        int last_idx = ((am - 1) % L + L) % L;
+        int last_cone = 0;
 #pragma unroll
         for (int l = 0; l < MAX_LEN; l++)
-          if (l == last_idx) cfg[l] = -1;
-        len--;
+          if (l == last_idx) last_cone = cfg[l];
+        if (S.type[last_cone] != cone_type) {
+#pragma unroll
+          for (int l = 0; l < MAX_LEN; l++)
+            if (l == last_idx) cfg[l] = -1;
+          len--;
+        }
+        keep = len >= 3;
       }
-      keep = len >= 3;
+      for (int l = 0; l < MAX_LEN; l++) S.ends[side][c][l] = cfg[l];
+      S.keep[c] = keep ? 1 : 0;
     }
-    for (int l = 0; l < MAX_LEN; l++) S.ends[side][lane][l] = cfg[l];
   }
-  if (lane < MAX_ENDS) S.keep[lane] = keep ? 1 : 0;
   __syncthreads();
   // np.unique(axis=0) + prefix removal (:507-515)
-  if (lane < n_ends && keep) {
-    bool drop = false;
-    for (int o = 0; o < n_ends && !drop; o++) {
-      if (o == lane || !S.keep[o]) continue;
-      bool same = true, prefix = true;
-      for (int l = 0; l < MAX_LEN; l++) {
-        int a = S.ends[side][o][l], b = cfg[l];
-        if (a != b) same = false;
-        if (!(a == b || b == -1)) prefix = false;
+  int C = 0;
+  for (int c0 = 0; c0 < n_ends; c0 += WAVE) {
+    const int c = c0 + lane;
+    bool keep = c < n_ends && S.keep[c] != 0;
+    if (keep) {
+      int16_t cfg[MAX_LEN];
+#pragma unroll
+      for (int l = 0; l < MAX_LEN; l++) cfg[l] = S.ends[side][c][l];
+      bool drop = false;
+      for (int o = 0; o < n_ends && !drop; o++) {
+        if (o == c || !S.keep[o]) continue;
+        bool same = true, prefix = true;
+        for (int l = 0; l < MAX_LEN; l++) {
+          int a = S.ends[side][o][l], b = cfg[l];
+          if (a != b) same = false;
+          if (!(a == b || b == -1)) prefix = false;
+        }
+        if (same && o < c) drop = true;       // duplicate of an earlier row
+        if (!same && prefix) drop = true;     // strict prefix of another row
       }
-      if (same && o < lane) drop = true;       // duplicate of an earlier row
-      if (!same && prefix) drop = true;        // strict prefix of another row
+      keep = !drop;
     }
-    keep = !drop;
+    if (c < n_ends) S.keep2[c] = keep ? 1 : 0;
+    C += __popcll(__ballot(keep));
   }
   __syncthreads();
-  if (lane < MAX_ENDS) S.keep[lane] = keep ? 1 : 0;
+  for (int c = lane; c < n_ends; c += WAVE) S.keep[c] = S.keep2[c];
   __syncthreads();
-  unsigned long long keepm = __ballot(keep);
-  const int C = __popcll(keepm);
   if (lane == 0) S.n_configs[side] = C;
   if (C == 0) return ST_OK;  // NoPathError -> side has no result
 
   // ---------------- S12: cones on either side (nearby_cone_search.py:213-297) ----------------
   PROF_MARK(5);
   const int n_words = (n + WAVE - 1) / WAVE;
-  if (lane < MAX_CONES / WAVE) {
+  if (lane < SH::CAP / WAVE) {
     S.all_mask[lane] = 0ull;
   }
   __syncthreads();
-  if (keep) {
-    for (int l = 0; l < MAX_LEN; l++)
-      if (cfg[l] != -1) atomicOr(&S.all_mask[cfg[l] >> 6], 1ull << (cfg[l] & 63));
-  }
+  for (int c = lane; c < n_ends; c += WAVE)
+    if (S.keep[c]) {
+      for (int l = 0; l < MAX_LEN; l++) {
+        const int v = S.ends[side][c][l];
+        if (v != -1) atomicOr(&S.all_mask[v >> 6], 1ull << (v & 63));
+      }
+    }
   __syncthreads();
   // all_list: ascending indices of all_mask (wave-uniform build)
   int n_all = 0;
@@ -675,15 +713,15 @@ __device__ inline int sort_side_finish(SortShared& S, int n, int cone_type, int 
   // counts per kept configuration: lane = (configuration, position in it); every lane walks the candidate cones of
   // its pair ("other" = close ∪ (all \ configuration), a few dozen bits) and tests the few that lie within 6 m.
   // (Integer counts of order-independent predicates: same values as the reference's per-cone loops.)
-  if (lane < MAX_ENDS) {
-    S.good[lane] = 0;
-    S.bad[lane] = 0;
+  for (int c = lane; c < n_ends; c += WAVE) {
+    S.good[c] = 0;
+    S.bad[c] = 0;
   }
   __syncthreads();
   for (int p0 = 0; p0 < n_ends * MAX_LEN; p0 += WAVE) {
     const int p = p0 + lane;
     const int c = p / MAX_LEN, j = p - c * MAX_LEN;
-    if (c < n_ends && ((keepm >> c) & 1ull)) {
+    if (c < n_ends && S.keep[c]) {
       const int16_t* e = S.ends[side][c];
       int clen = 0;
       for (int l = 0; l < MAX_LEN; l++) clen += (e[l] != -1);
@@ -730,16 +768,18 @@ __device__ inline int sort_side_finish(SortShared& S, int n, int cone_type, int 
   __syncthreads();
   int mval = 0x7fffffff;
   for (int c = 0; c < n_ends; c++)
-    if ((keepm >> c) & 1ull) {
+    if (S.keep[c]) {
       int d = S.good[c] - S.bad[c];
       mval = d < mval ? d : mval;
     }
 
   // ---------------- S11: cost per configuration (cost_function.py:213-304), lane = configuration ----------------
   PROF_MARK(6);
+  for (int c0 = 0; c0 < n_ends; c0 += WAVE) {
+  const int cme = c0 + lane;
   double my_cost = 0.0;
-  if (keep) {
-    const int16_t* ccfg = S.ends[side][lane];  // this lane's configuration (LDS; dynamic indexing stays out of registers)
+  if (cme < n_ends && S.keep[cme]) {
+    const int16_t* ccfg = S.ends[side][cme];  // this lane's configuration (LDS; dynamic indexing stays out of registers)
     auto PX = [&](int l) -> double {
       int idx = ccfg[l];
       if (idx < 0) idx = n + idx;  // NumPy wrap-around of -1
@@ -792,7 +832,7 @@ __device__ inline int sort_side_finish(SortShared& S, int n, int cone_type, int 
     double init_cost = angle_between(PX(1) - PX(0), PY(1) - PY(0), dx, dy);
     double either_cost;
     {
-      int d = S.good[lane] - S.bad[lane];
+      int d = S.good[cme] - S.bad[cme];
       d += (mval < 0 ? -mval : mval) + 1;
       either_cost = 1.0 / (double)d;
     }
@@ -830,14 +870,15 @@ __device__ inline int sort_side_finish(SortShared& S, int n, int cone_type, int 
     my_cost += either_cost * f3;
     my_cost += wrong_cost * f3;
   }
+  if (cme < n_ends) S.cost[cme] = my_cost;
+  }
   // argmin with np.unique's lexicographic row order as tie-break (argsort is stable for the short arrays here)
   {
     int best = -1;
     double bc = 0.0;
-    if (lane < MAX_ENDS) S.cost[lane] = my_cost;
     __syncthreads();
     for (int c = 0; c < n_ends; c++) {
-      if (!((keepm >> c) & 1ull)) continue;
+      if (!S.keep[c]) continue;
       double cc = S.cost[c];
       bool take = best < 0 || cc < bc;
       if (!take && cc == bc) {
@@ -871,7 +912,8 @@ __device__ inline int sort_side_finish(SortShared& S, int n, int cone_type, int 
 }
 
 // combine_traces.py:115-275 (wave-uniform; every lane computes the same scalars)
-__device__ inline void combine_sides(SortShared& S, int& nl, int& nr) {
+template <class SH>
+__device__ inline void combine_sides(SH& S, int& nl, int& nr) {
   nl = S.best_len[0];
   nr = S.best_len[1];
   if (nl == 0 || nr == 0) return;
@@ -968,25 +1010,21 @@ __device__ inline void combine_sides(SortShared& S, int& nl, int& nr) {
   nr = rs;
 }
 
-// One workgroup (= one wavefront) per frame.
-__global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
-                                                  const double* __restrict__ cones_xyt, const double* __restrict__ poses,
-                                                  SortOut* __restrict__ out) {
-  __shared__ SortShared S;
-  const int frame = blockIdx.x;
-  if (frame >= n_frames) return;
-  PROF_INIT();
+// The sorting stage of one frame on one wavefront; S = the frame state (LDS or global memory).
+template <class SH>
+__device__ inline void sort_frame(SH& S, int frame, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
+                                  const double* __restrict__ poses, SortOut* __restrict__ out) {
   const int lane = lane_id();
   const int off = cone_offsets[frame];
   int n = cone_offsets[frame + 1] - off;
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
   SortOut* o = &out[frame];
   int status = ST_OK;
-  if (n > MAX_CONES) {
+  if (n > SH::MAX_N) {
     status = ST_OVERFLOW_CONES;
     n = 0;
   }
-  // stage the frame's cones in LDS: coalesced loads of the (n,3) row-major block (lane = consecutive doubles)
+  // stage the frame's cones: coalesced loads of the (n,3) row-major block (lane = consecutive doubles)
   {
     const double* src = cones_xyt + 3 * (size_t)off;
     for (int e = lane; e < 3 * n; e += WAVE) {
@@ -1057,7 +1095,34 @@ __global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames,
     o->left_idx[lane] = (status == ST_OK && lane < nl) ? (int32_t)S.best[0][lane] : -1;
     o->right_idx[lane] = (status == ST_OK && lane < nr) ? (int32_t)S.best[1][lane] : -1;
   }
+  __syncthreads();
+}
+
+// One workgroup (= one wavefront) per frame, frame state in LDS.  big (optional): [0] = counter, [1..] = frames beyond
+// the LDS capacities (more than 255 cones, more than 64 raw end configurations), planned again by sort_big_kernel.
+__global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
+                                                  const double* __restrict__ cones_xyt, const double* __restrict__ poses,
+                                                  SortOut* __restrict__ out, int* __restrict__ big) {
+  __shared__ SortShared S;
+  const int frame = blockIdx.x;
+  if (frame >= n_frames) return;
+  PROF_INIT();
+  sort_frame(S, frame, cone_offsets, cones_xyt, poses, out);
+  if (big != nullptr && lane_id() == 0 && (out[frame].status == ST_OVERFLOW_CONES || out[frame].status == ST_OVERFLOW_ENDS))
+    big[1 + atomicAdd(&big[0], 1)] = frame;
   PROF_FLUSH();
+}
+
+// The frames sort_kernel could not hold in LDS, with the frame state in global memory (one SortSharedBig per block).
+__global__ void __launch_bounds__(64) sort_big_kernel(const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
+                                                      const double* __restrict__ poses, SortOut* __restrict__ out,
+                                                      const int* __restrict__ big, SortSharedBig* __restrict__ state) {
+  const int n = big[0];
+  SortSharedBig& S = state[blockIdx.x];
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    sort_frame(S, big[1 + i], cone_offsets, cones_xyt, poses, out);
+    __syncthreads();
+  }
 }
 
 }  // namespace fsdp

@@ -24,6 +24,7 @@ static const double* g_gpath = nullptr;
 static int g_n_gpath = 0;
 static std::once_flag g_once;
 static int g_last_retries = 0;
+static int g_last_big = 0;
 static void build_default() {
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
@@ -99,6 +100,7 @@ static void emu_path_split_launch(int n_frames, const double* poses, const fsdp:
 
 extern "C" {
 int emu_last_retries() { return g_last_retries; }
+int emu_last_big() { return g_last_big; }
 void emu_fit(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
   AlignedArena arena(fsdp::ARENA_DOUBLES);
   emu::launch(1, 64, [&]() { fsdp::fit_test_kernel(xy, m, smoothing, arena.data(), t_out, c_out, info, fp_out); });
@@ -108,7 +110,13 @@ int emu_sizeof_match_out() { return (int)sizeof(fsdp::MatchOut); }
 int emu_sizeof_path_out() { return (int)sizeof(fsdp::PathOut); }
 
 void emu_sort(int n_frames, const int32_t* offsets, const double* cones, const double* poses, fsdp::SortOut* out) {
-  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel(n_frames, offsets, cones, poses, out); });
+  std::vector<int> big((size_t)n_frames + 1, 0);
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel(n_frames, offsets, cones, poses, out, big.data()); });
+  g_last_big = big[0];
+  if (big[0] > 0) {
+    std::vector<fsdp::SortSharedBig> state(2);
+    emu::launch(2, 64, [&]() { fsdp::sort_big_kernel(offsets, cones, poses, out, big.data(), state.data()); });
+  }
 }
 void emu_match(int n_frames, const int32_t* offsets, const double* cones, const double* poses, const fsdp::SortOut* sorted,
                fsdp::MatchOut* out) {

@@ -52,6 +52,16 @@ def capture(offsets, cones, poses, frames=None):
         l2r=np.full((F, MAX_MATCH), -1, np.int32),
         r2l=np.full((F, MAX_MATCH), -1, np.int32),
         path=np.full((F, 40, 4), np.nan),
+        # per-stage intermediates: start cones per side (select_first_k_starting_cones), number of end
+        # configurations per side after the post-filters and the cost of the best one (cost_configurations)
+        first_k_left=np.full((F, 2), -1, np.int32),
+        first_k_right=np.full((F, 2), -1, np.int32),
+        first_k_tie=np.zeros((F, 2), bool),  # [left, right]: exact distance tie of the closest start candidates (unstable argsort)
+        knn_tie=np.zeros(F, bool),  # exact tie among a cone's nearest neighbours (unstable argsort decides the adjacency)
+        n_configs_left=np.zeros(F, np.int32),
+        n_configs_right=np.zeros(F, np.int32),
+        best_cost_left=np.zeros(F),
+        best_cost_right=np.zeros(F),
     )
     sub_cones, sub_off = [], [0]
     for k, f in enumerate(frames):
@@ -59,6 +69,16 @@ def capture(offsets, cones, poses, frames=None):
         sub_cones.append(xyt)
         sub_off.append(sub_off[-1] + len(xyt))
         r = refharness.run_frame(xyt, poses[f])
+        for side, t in (("left", 2), ("right", 1)):
+            out["first_k_tie"][k, 0 if side == "left" else 1] = bool((r.get("first_k_tie") or {}).get(t, False))
+            fk = (r.get("first_k") or {}).get(t)
+            if fk is not None:
+                out[f"first_k_{side}"][k, : len(fk)] = fk
+            costs = r.get(f"{side}_costs")
+            if costs is not None and len(costs):
+                out[f"n_configs_{side}"][k] = len(costs)
+                out[f"best_cost_{side}"][k] = costs[0]
+        out["knn_tie"][k] = refharness.knn_boundary_tie(xyt)
         if r["status"] != "ok":
             out["exc"][k] = r["status"]
             continue
@@ -202,6 +222,61 @@ def spline_fixtures(seed=0, n=90):
         items[f"ev_{i}"] = ev
     items["n"] = np.array(n)
     return items
+
+
+def lattice_frames(seed=7, trials=400, want=24):
+    """Colourless staggered lattices (2-4.5 m spacing): the depth-first search of the sorter finds up to ~200 raw end
+    configurations per side on them — the frames that exceed the 64 the product kernel holds in LDS (sort_big_kernel)."""
+    rng = np.random.default_rng(seed)
+    frames = []
+    for trial in range(trials):
+        sp = rng.uniform(2.0, 4.5)
+        nx, ny = int(rng.integers(6, 14)), int(rng.integers(3, 8))
+        gx, gy = np.meshgrid(np.arange(nx) * sp, (np.arange(ny) - (ny - 1) / 2) * sp * rng.uniform(0.6, 1.0))
+        if trial % 2:
+            gx = gx + (np.arange(ny)[:, None] % 2) * sp / 2
+        xy = np.column_stack([gx.ravel() + rng.uniform(-1, 3), gy.ravel()]) + rng.normal(0, rng.uniform(0, 0.3), (nx * ny, 2))
+        pose = np.array([0.0, rng.uniform(-1, 1), 1.0, 0.0])
+        if trial in (7, 33, 43, 143, 145, 181, 197, 203, 207, 221, 231, 265, 269, 275, 293, 301, 305, 317, 327, 331, 2, 4, 6, 8):
+            frames.append((np.column_stack([xy, np.zeros(len(xy))]), pose))
+    frames = frames[:want]
+    off = np.concatenate([[0], np.cumsum([len(f[0]) for f in frames])]).astype(np.int32)
+    return off, np.concatenate([f[0] for f in frames]), np.array([f[1] for f in frames])
+
+
+def capacity_golden():
+    """Frames beyond the product kernels' LDS capacities: 300 and 600 cones (coloured and colourless; a whole SLAM map
+    handed in every frame, demo/json_demo.py:255-275) and lattices with more than 64 raw end configurations."""
+    refharness.load()
+    sets = {}
+    parts = []
+    for n_side, seed in ((150, 21), (300, 22)):
+        for color in (True, False):
+            parts.append(synth.make_replay_batch(4, n_side, 0.15, seed=seed, color=color, random_pose=True))
+    off = np.concatenate([[0]] + [p[0][1:] + sum(int(q[0][-1]) for q in parts[:i]) for i, p in enumerate(parts)]).astype(np.int32)
+    sets["big_frames"] = capture(off, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
+    sets["lattice"] = capture(*lattice_frames())
+    for name, d in sets.items():
+        np.savez_compressed(HERE / f"{name}.npz", **d)
+        print(name, "frames", len(d["ok"]), "ok", int(d["ok"].sum()), "exc", sorted(set(d["exc"].tolist()) - {""}),
+              "cones", np.diff(d["offsets"]).tolist()[:20], "configs", d["n_configs_left"].tolist(), d["n_configs_right"].tolist())
+
+
+def add_intermediates():
+    """Re-run the reference on the committed frame sets and add the per-stage intermediates; every field the files already
+    hold must come out identical."""
+    refharness.load()
+    for name in ("scenarios", "cfg2_color", "cfg3_nocolor", "cfg4_200cones", "cfg4_noisy_nocolor", "fuzz"):
+        old = dict(np.load(HERE / f"{name}.npz"))
+        new = capture(old["offsets"], old["cones"], old["poses"])
+        for k, v in old.items():
+            if k in new:
+                assert np.array_equal(v, new[k], equal_nan=v.dtype.kind == "f"), (name, k)
+            else:
+                new[k] = v
+        np.savez_compressed(HERE / f"{name}.npz", **new)
+        print(name, "frames", len(new["ok"]), "first_k", int((new["first_k_left"][:, 0] >= 0).sum()), "max configs",
+              int(new["n_configs_left"].max()), int(new["n_configs_right"].max()))
 
 
 def main():
@@ -387,6 +462,10 @@ def global_path_golden():
 
 if __name__ == "__main__" and "--global-path-only" in sys.argv:
     global_path_golden()
+if __name__ == "__main__" and "--capacity-only" in sys.argv:
+    capacity_golden()
+if __name__ == "__main__" and "--intermediates-only" in sys.argv:
+    add_intermediates()
 
 
 if __name__ == "__main__" and not any(a.endswith("-only") for a in sys.argv[1:]):

@@ -38,6 +38,24 @@ def split_by_type(xyt):
     return [np.ascontiguousarray(xyt[xyt[:, 2] == t, :2]) for t in range(5)]
 
 
+def knn_boundary_tie(xyt: np.ndarray) -> bool:
+    """True when some cone has an EXACT tie among its 8 smallest squared distances (the reference's own expansion-form
+    matrix, utils/math_utils.py:120-150): create_adjacency_matrix takes the 5 nearest with a full unstable np.argsort
+    (adjacency_matrix.py:55), so which of the tied cones is a neighbour depends on the NumPy build.  Only the
+    mirror-symmetric demo scenarios do this; the parity tests skip the end-configuration counts on such frames (the final
+    configurations agree anyway)."""
+    from fsd_path_planning.utils.math_utils import my_cdist_sq_euclidean
+
+    xy = np.ascontiguousarray(xyt[:, :2], dtype=float)
+    if len(xy) < 3:
+        return False
+    d = my_cdist_sq_euclidean(xy, xy).copy()
+    np.fill_diagonal(d, np.inf)
+    d.sort(axis=1)
+    head = d[:, : min(8, d.shape[1])]
+    return bool((np.diff(head, axis=1) == 0).any())
+
+
 def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True):
     """Fresh PathPlanner (trackdrive) on one frame.  Returns dict with status 'ok' or the
     exception class name.  The frame is handed over as the pre-flattened (N,3) array
@@ -58,6 +76,23 @@ def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True):
         return out
 
     cts.calc_final_configs_for_left_and_right = wrapper
+    # first_k per side: TraceSorter.select_first_k_starting_cones (core_trace_sorter.py:409-465), called once per side
+    orig_fk = cts.TraceSorter.select_first_k_starting_cones
+    captured["first_k"] = {}
+    captured["first_k_tie"] = {}
+
+    def fk_wrapper(self, car_position, car_direction, cones, cone_type):
+        out = orig_fk(self, car_position, car_direction, cones, cone_type)
+        captured["first_k"][int(cone_type)] = None if out is None else np.array(out, dtype=np.int64)
+        # select_starting_cone orders the candidates with np.argsort (unstable): on an EXACT distance tie of the two
+        # closest candidates the pick depends on the NumPy build (AVX-512 argsort here) — recorded so that the parity
+        # tests can skip the start-cone comparison on such frames (mirror-symmetric demo scenarios)
+        dist, valid = self.mask_cone_can_be_first_in_config(car_position, car_direction, cones, cone_type)
+        d = np.where(valid, dist, np.inf)
+        captured["first_k_tie"][int(cone_type)] = bool(np.isfinite(d).any() and (d == d.min()).sum() > 1)
+        return out
+
+    cts.TraceSorter.select_first_k_starting_cones = fk_wrapper
     try:
         pp = m["PathPlanner"](m["MissionTypes"].trackdrive)
         cones = np.ascontiguousarray(xyt, dtype=float) if flattened else split_by_type(xyt)
@@ -67,7 +102,9 @@ def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True):
             return dict(status=type(e).__name__, msg=str(e), **captured)
     finally:
         cts.calc_final_configs_for_left_and_right = orig
+        cts.TraceSorter.select_first_k_starting_cones = orig_fk
     path, sl, sr, lv, rv, l2r, r2l = out
+    captured["knn_tie"] = knn_boundary_tie(xyt)
     lc = captured["left_config"]
     rc = captured["right_config"]
     return dict(
@@ -83,4 +120,7 @@ def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True):
         right_costs=captured["right_costs"],
         left_configs=captured["left_configs"],
         right_configs=captured["right_configs"],
+        first_k=captured["first_k"],
+        first_k_tie=captured["first_k_tie"],
+        knn_tie=captured["knn_tie"],
     )

@@ -35,6 +35,22 @@ def compare_frame(res, g, k, require_exact_match=True):
         np.array_equal(res["left_idx"][:nl], g["left_idx"][k][:nl]) and np.array_equal(res["right_idx"][:nr], g["right_idx"][k][:nr])
     ):
         return "IDX", f"{res['left_idx']} vs {g['left_idx'][k]} | {res['right_idx']} vs {g['right_idx'][k]}"
+    # per-stage intermediates (fixtures generated with them): start cones, number of end configurations after the
+    # post-filters and the cost of the best one, per side — a compensating error between stages would show here
+    if "first_k_left" in g and "first_k_left" in res.dtype.names:
+        for si, side in enumerate(("left", "right")):
+            if g["first_k_tie"][k, si]:
+                continue  # exact tie of the two closest start candidates: the reference's pick is its argsort's (unstable)
+            if not np.array_equal(res[f"first_k_{side}"], g[f"first_k_{side}"][k]):
+                return "IDX", f"first_k_{side}: {res[f'first_k_{side}']} vs {g[f'first_k_{side}'][k]}"
+            if g["knn_tie"][k]:
+                continue  # exact tie among nearest neighbours: the reference's adjacency is its argsort's (unstable)
+            if int(res[f"n_configs_{side}"]) != int(g[f"n_configs_{side}"][k]):
+                return "IDX", f"n_configs_{side}: {res[f'n_configs_{side}']} vs {g[f'n_configs_{side}'][k]}"
+            if int(g[f"n_configs_{side}"][k]) > 0:
+                a_, b_ = float(res[f"best_cost_{side}"]), float(g[f"best_cost_{side}"][k])
+                if not abs(a_ - b_) <= 1e-9 * max(1.0, abs(b_)):
+                    return "IDX", f"best_cost_{side}: {a_} vs {b_}"
     ml, mr = int(g["n_left_v"][k]), int(g["n_right_v"][k])
     if int(res["n_left_v"]) != ml or int(res["n_right_v"]) != mr:
         return "MATCH", "virtual cone counts differ"
@@ -62,3 +78,16 @@ def is_sample_count_flip(p, q):
     sp, sq = p[-1, 0], q[-1, 0]
     step = max(np.diff(p[:, 0]).min(), 1e-9) / 2.0
     return abs(sp - sq) < 2.5 * step * 2 and abs(sp - sq) > 1e-5
+
+
+def assert_intermediates_equal(res, ref, ok, cost_rtol=0.0):
+    """Device (or emulated kernels) against the oracle: per-stage intermediates of the sorting stage — start cones per
+    side and number of end configurations after the post-filters exactly, cost of the best one (where a side has
+    configurations at all) bit for bit under the emulator (same libm) and within cost_rtol on the GPU (the costs hold
+    atan2 / acos values of the device's libm; no discrete decision depends on their last bit in these sets)."""
+    for f in ("first_k_left", "first_k_right", "n_configs_left", "n_configs_right"):
+        assert np.array_equal(res[f][ok], ref[f][ok]), f
+    for side in ("left", "right"):
+        has = ok & (ref[f"n_configs_{side}"] > 0)
+        a_, b_ = res[f"best_cost_{side}"][has], ref[f"best_cost_{side}"][has]
+        assert (np.abs(a_ - b_) <= cost_rtol * np.maximum(1.0, np.abs(b_))).all(), f"best_cost_{side}"

@@ -7,10 +7,11 @@ import pytest
 
 import emu_lib
 import oracle_lib
+import parity
 
 
 @pytest.mark.parametrize("name,stride", [("scenarios", 1), ("cfg2_color", 4), ("cfg3_nocolor", 8), ("cfg4_200cones", 8),
-                                          ("cfg4_noisy_nocolor", 6), ("fuzz", 5)])
+                                          ("cfg4_noisy_nocolor", 6), ("fuzz", 5), ("big_frames", 4), ("lattice", 2)])
 @pytest.mark.parametrize("group", emu_lib.PATH_GROUP_SIZES)
 def test_emulated_kernels_equal_oracle(golden_dir, name, stride, group):
     g = np.load(golden_dir / f"{name}.npz")
@@ -27,6 +28,9 @@ def test_emulated_kernels_equal_oracle(golden_dir, name, stride, group):
     ok = ref["status"] == 0
     for f in ("left_idx", "right_idx", "n_left_v", "n_right_v", "l2r", "r2l", "left_v", "right_v", "path_fallback"):
         assert np.array_equal(res[f][ok], ref[f][ok]), f
+    parity.assert_intermediates_equal(res, ref, ok)
+    if name in ("big_frames", "lattice") and group == 8:
+        assert emu_lib.lib().emu_last_big() > 0  # the sorting stage took the global-memory route for some frames
     # no libm value enters the float chain -> bit-identical
     assert np.array_equal(res["path"][ok], ref["path"][ok])
 

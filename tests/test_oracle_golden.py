@@ -8,7 +8,9 @@ import pytest
 import oracle_lib
 import parity
 
-SETS = ["scenarios", "cfg2_color", "cfg3_nocolor", "cfg4_200cones", "cfg4_noisy_nocolor", "fuzz"]
+# big_frames: 300 / 600 cones per frame; lattice: up to 190 end configurations per side (beyond the LDS capacities of
+# the product sorting kernel: planned by sort_big_kernel)
+SETS = ["scenarios", "cfg2_color", "cfg3_nocolor", "cfg4_200cones", "cfg4_noisy_nocolor", "fuzz", "big_frames", "lattice"]
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["libm", "detmath"])
