@@ -50,6 +50,39 @@ class FsdpError(RuntimeError):
     pass
 
 
+class Params(ctypes.Structure):
+    """fsdp_params (include/fsdp.h): the kwargs of the reference's ConeSorting / ConeMatching / CalculatePath
+    (defaults: fsd_path_planning/config.py:28-163, filled by fsdp_default_params)."""
+
+    _fields_ = [
+        ("max_n_neighbors", ctypes.c_int32), ("max_dist", ctypes.c_double), ("max_dist_to_first", ctypes.c_double),
+        ("max_length", ctypes.c_int32), ("threshold_directional_angle", ctypes.c_double), ("threshold_absolute_angle", ctypes.c_double),
+        ("use_unknown_cones", ctypes.c_int32),
+        ("smoothing", ctypes.c_double), ("predict_every", ctypes.c_double), ("max_deg", ctypes.c_int32),
+        ("maximal_distance_for_valid_path", ctypes.c_double), ("mpc_path_length", ctypes.c_double), ("mpc_prediction_horizon", ctypes.c_int32),
+        ("min_track_width", ctypes.c_double), ("max_search_range", ctypes.c_double), ("max_search_angle", ctypes.c_double),
+        ("matches_should_be_monotonic", ctypes.c_int32),
+    ]
+
+
+PARAM_NAMES = [f[0] for f in Params._fields_]
+
+
+def make_params(overrides=None) -> Params:
+    """Defaults from the library, then `overrides` (a dict of the reference's kwarg names); unknown names raise."""
+    p = Params()
+    load().fsdp_default_params(ctypes.byref(p))
+    for k, v in (overrides or {}).items():
+        if k == "experimental_performance_improvements":
+            if v:
+                raise NotImplementedError("the experimental sorting cache is out of scope (SURVEY.md section 2 row 15)")
+            continue
+        if k not in PARAM_NAMES:
+            raise TypeError(f"unknown parameter {k!r}")
+        setattr(p, k, type(getattr(p, k))(v))
+    return p
+
+
 _lib = None
 
 
@@ -67,7 +100,7 @@ def load() -> ctypes.CDLL:
     lib.fsdp_version.restype = ctypes.c_char_p
     lib.fsdp_last_error.restype = ctypes.c_char_p
     lib.fsdp_last_error.argtypes = [ctypes.c_void_p]
-    lib.fsdp_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.fsdp_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     lib.fsdp_destroy.argtypes = [ctypes.c_void_p]
     lib.fsdp_resident_frames.argtypes = [ctypes.c_void_p]
     lib.fsdp_stage_names.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
@@ -84,7 +117,7 @@ def load() -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
+    "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_default_params", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
     "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_stage_names", "fsdp_resident_frames",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
@@ -105,12 +138,14 @@ def _ip(a):
 class Context:
     """One GPU context (= fsdp_ctx): device buffers + one HIP stream."""
 
-    def __init__(self, device: int | None = None, mission: int = 4):
+    def __init__(self, device: int | None = None, mission: int = 4, params: dict | None = None):
+        """params: overrides of the reference's configuration constants by their kwarg names (None = defaults)."""
         lib = load()
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) % max(lib.fsdp_device_count(), 1)
         h = ctypes.c_void_p()
-        rc = lib.fsdp_create(int(device), int(mission), ctypes.byref(h))
+        self.params = make_params(params)
+        rc = lib.fsdp_create(int(device), int(mission), ctypes.byref(self.params), ctypes.byref(h))
         if rc != 0:
             raise FsdpError(f"fsdp_create failed ({rc}): {lib.fsdp_last_error(None).decode()}")
         self._lib, self._h, self.device, self.n_frames = lib, h, device, 0

@@ -43,6 +43,20 @@ constexpr int ST_OVERFLOW_PATH = 203;
 constexpr int ST_OVERFLOW_KNOTS = 204;
 constexpr int ST_RETRY = 299;  // internal: the fast kernels hand the frame to the exact one-frame-per-wavefront kernel (never leaves the library)
 
+// The reference's configuration constants (fsd_path_planning/config.py:33-41,48,55-59,124-129), one device copy per
+// context (fsdp_create): the kernels read them with scalar loads.  Structural ones are bounded by the compiled capacities
+// (max_n_neighbors <= KNN, max_length <= MAX_LEN); mpc_prediction_horizon = 40, max_deg = 3, use_unknown_cones = True and
+// matches_should_be_monotonic = False (the pipeline's choice, full_pipeline.py:65) are fixed.
+struct Params {
+  // sorting_cones (config.py:33-41)
+  int32_t max_n_neighbors, max_length;
+  double max_dist, max_dist_to_first, threshold_directional_angle, threshold_absolute_angle;
+  // cone_matching (config.py:124-129)
+  double min_track_width, max_search_range, max_search_angle;
+  // calculate_path (config.py:48,55-59)
+  double smoothing, predict_every, maximal_distance_for_valid_path, mpc_path_length;
+};
+
 #define FSDP_PI 3.14159265358979323846
 #define FSDP_DEG (FSDP_PI / 180.0)
 

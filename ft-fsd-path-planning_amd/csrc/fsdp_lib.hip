@@ -49,6 +49,8 @@ struct fsdp_ctx {
   int* d_retry = nullptr;            // [0] counter + frames for the exact re-plan kernel (n_frames + 1 ints)
   PathMid* d_mid = nullptr;          // hand-over records of the three-kernel path stage
   SortSharedBig* d_sort_big = nullptr;  // frame states of sort_big_kernel (SORT_BIG_BLOCKS per slot)
+  Params params;                        // configuration constants (fsdp_params) ...
+  Params* d_params = nullptr;           // ... and their device copy, read by every kernel
   double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
   double* d_prev = nullptr;          // optional per-frame previous paths (n_frames,40,4) for sequential replays
   bool use_prev = false;
@@ -239,13 +241,13 @@ constexpr int SORT_BIG_BLOCKS = 32;
 static void launch_sort(fsdp_ctx* c, const Slot& q) {
   (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
   hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
-                     q.d_sort, q.d_retry);
+                     q.d_sort, q.d_retry, c->d_params);
   hipLaunchKernelGGL(sort_big_kernel, dim3(SORT_BIG_BLOCKS), dim3(WAVE), 0, q.stream, c->d_off, c->d_cones, c->d_poses, q.d_sort,
-                     q.d_retry, c->d_sort_big + (size_t)q.index * SORT_BIG_BLOCKS);
+                     q.d_retry, c->d_sort_big + (size_t)q.index * SORT_BIG_BLOCKS, c->d_params);
 }
 static void launch_match(fsdp_ctx* c, const Slot& q) {
   hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
-                     q.d_sort, q.d_match);
+                     q.d_sort, q.d_match, c->d_params);
 }
 // ---- the path stage of one pass ------------------------------------------------------------------------------------------
 // Small batches (<= PATH_SMALL_BATCH frames: single-frame calls, latency): one kernel, one frame per wavefront.
@@ -264,19 +266,19 @@ static void mark(const Slot& q, StageEvents* t) {
 template <int GF>
 static void launch_fit(fsdp_ctx* c, const Slot& q) {
   hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((c->n_frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, q.stream, c->n_frames,
-                     q.d_arena, q.d_mid, q.d_retry);
+                     q.d_arena, q.d_mid, q.d_retry, c->d_params);
 }
 template <int G>
 static void launch_prep(fsdp_ctx* c, const Slot& q, const double* prev) {
   const int n = c->n_frames;
   hipLaunchKernelGGL(path_prep_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, n, c->d_poses, q.d_match,
-                     c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry);
+                     c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry, c->d_params);
 }
 template <int G>
 static void launch_finish(fsdp_ctx* c, const Slot& q) {
   const int n = c->n_frames;
   hipLaunchKernelGGL(path_finish_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, n, q.d_arena, q.d_mid, q.d_path,
-                     q.d_retry);
+                     q.d_retry, c->d_params);
 }
 
 // Lanes per frame: a serial instruction costs its issue cycles whatever the number of active lanes, so the more frames
@@ -294,7 +296,7 @@ static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
   (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
   if (!split) {
     hipLaunchKernelGGL(path_kernel<PATH_G_SMALL>, dim3(n), dim3(WAVE), 0, q.stream, n, c->d_poses, q.d_match, c->d_default_path, prev,
-                       c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry);
+                       c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
     c->stage_names += "path_kernel<64>,";
   } else {
     const bool packed = c->force_pack ? c->force_pack == 2 : (long long)n * c->overlap >= PACK_FRAMES;
@@ -321,7 +323,7 @@ static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
   mark(q, t);
   const int rb = n < 128 ? n : 128;
   hipLaunchKernelGGL(path_retry_kernel, dim3(rb), dim3(WAVE), 0, q.stream, c->d_poses, q.d_match, c->d_default_path, prev, c->d_gpath,
-                     c->n_gpath, q.d_arena, q.d_path, q.d_retry);
+                     c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
   c->stage_names += "path_retry_kernel";
   mark(q, t);
 }
@@ -386,8 +388,54 @@ int fsdp_device_count(void) {
 
 const char* fsdp_last_error(const fsdp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int fsdp_create(int device, int mission, fsdp_ctx** out) {
+void fsdp_default_params(fsdp_params* p) {
+  if (!p) return;
+  // fsd_path_planning/config.py:33-41 (sorting), :48 (fitting), :55-59 (path), :124-129 + full_pipeline.py:65 (matching)
+  p->max_n_neighbors = 5;
+  p->max_dist = 6.5;
+  p->max_dist_to_first = 6.0;
+  p->max_length = 12;
+  p->threshold_directional_angle = 40 * FSDP_DEG;  // np.deg2rad(40)
+  p->threshold_absolute_angle = 65 * FSDP_DEG;
+  p->use_unknown_cones = 1;
+  p->smoothing = 0.2;
+  p->predict_every = 0.1;
+  p->max_deg = 3;
+  p->maximal_distance_for_valid_path = 5;
+  p->mpc_path_length = 20;
+  p->mpc_prediction_horizon = 40;
+  p->min_track_width = 3;
+  p->max_search_range = 5;
+  p->max_search_angle = 50 * FSDP_DEG;
+  p->matches_should_be_monotonic = 0;
+}
+
+// what the kernels can take: structural parameters within the compiled capacities, the fixed ones at their values
+static const char* check_params(const fsdp_params& p) {
+  if (p.max_n_neighbors < 1 || p.max_n_neighbors > KNN) return "max_n_neighbors must be in 1..5";
+  if (p.max_length < 3 || p.max_length > MAX_LEN) return "max_length must be in 3..12";
+  if (!(p.max_dist > 0) || !(p.max_dist_to_first > 0)) return "max_dist / max_dist_to_first must be positive";
+  if (!(p.smoothing > 0) || !(p.predict_every > 0)) return "smoothing / predict_every must be positive";
+  if (!(p.mpc_path_length > 0) || !(p.maximal_distance_for_valid_path >= 0)) return "mpc_path_length must be positive";
+  if (!(p.min_track_width > 0) || !(p.max_search_range > 0)) return "min_track_width / max_search_range must be positive";
+  if (p.max_deg != 3) return "max_deg is fixed at 3";
+  if (p.mpc_prediction_horizon != FSDP_PATH_POINTS) return "mpc_prediction_horizon is fixed at 40 (the shape of the result)";
+  if (!p.use_unknown_cones) return "use_unknown_cones = False is not supported";
+  if (p.matches_should_be_monotonic) return "matches_should_be_monotonic = True is not supported (the pipeline uses False, full_pipeline.py:65)";
+  // the dense path update (fit #1 evaluated every predict_every over <= ~80 m) must fit the working polyline
+  if (p.predict_every < 0.05) return "predict_every below 0.05 exceeds the working polyline capacity";
+  return nullptr;
+}
+
+int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** out) {
   *out = nullptr;
+  fsdp_params pp;
+  fsdp_default_params(&pp);
+  if (params) pp = *params;
+  if (const char* why = check_params(pp)) {
+    g_create_error = std::string("fsdp_create: ") + why;
+    return 1;
+  }
   int n = fsdp_device_count();
   if (n <= 0) {
     g_create_error = "no HIP device visible (libfsdp_hip.so has no CPU fallback)";
@@ -410,6 +458,21 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+  c->params.max_n_neighbors = pp.max_n_neighbors;
+  c->params.max_length = pp.max_length;
+  c->params.max_dist = pp.max_dist;
+  c->params.max_dist_to_first = pp.max_dist_to_first;
+  c->params.threshold_directional_angle = pp.threshold_directional_angle;
+  c->params.threshold_absolute_angle = pp.threshold_absolute_angle;
+  c->params.min_track_width = pp.min_track_width;
+  c->params.max_search_range = pp.max_search_range;
+  c->params.max_search_angle = pp.max_search_angle;
+  c->params.smoothing = pp.smoothing;
+  c->params.predict_every = pp.predict_every;
+  c->params.maximal_distance_for_valid_path = pp.maximal_distance_for_valid_path;
+  c->params.mpc_path_length = pp.mpc_path_length;
+  if (e == hipSuccess) e = hipMalloc(&c->d_params, sizeof(Params));
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_params, &c->params, sizeof(Params), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMalloc(&c->d_default_path, sizeof(double) * PATH_POINTS * 4);
   if (e == hipSuccess) e = hipMalloc(&c->d_sort_big, sizeof(SortSharedBig) * SORT_BIG_BLOCKS * FSDP_MAX_OVERLAP);
   if (e != hipSuccess) {
@@ -428,7 +491,7 @@ int fsdp_create(int device, int mission, fsdp_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&d_arena0, sizeof(double) * ARENA_DOUBLES);
     if (e == hipSuccess) e = hipMemcpyAsync(d_chord, chord, sizeof(chord), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(default_path_kernel, dim3(1), dim3(WAVE), 0, c->stream, d_chord, d_arena0, c->d_default_path);
+      hipLaunchKernelGGL(default_path_kernel, dim3(1), dim3(WAVE), 0, c->stream, d_chord, d_arena0, c->d_default_path, c->d_params);
       e = hipStreamSynchronize(c->stream);
     }
     if (d_arena0) (void)hipFree(d_arena0);
@@ -467,6 +530,7 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_skid_status);
   (void)hipFree(c->d_default_path);
   (void)hipFree(c->d_sort_big);
+  (void)hipFree(c->d_params);
   if (c->h_sort) (void)hipHostFree(c->h_sort);
   if (c->h_match) (void)hipHostFree(c->h_match);
   if (c->h_path) (void)hipHostFree(c->h_path);
@@ -881,6 +945,7 @@ int fsdp_skidpad_set_tables(fsdp_ctx* c, const double* table_xy, int n_table, co
   c->tables.ref_left[0] = c->skid_consts[2];
   c->tables.ref_left[1] = c->skid_consts[3];
   c->tables.mean_distance = c->skid_consts[4];
+  c->tables.prm = c->d_params;
   c->have_tables = true;
   return 0;
 }

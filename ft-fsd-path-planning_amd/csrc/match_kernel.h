@@ -52,7 +52,7 @@ __device__ inline void match_dirs(const double* px, const double* py, int n, int
 }
 
 // functional_cone_matching.py:340-384 (+ :73-175).  Result in S.match[0..n).  own dirs left in S.d1.
-__device__ inline void matches_for_side(MatchShared& S, const double* px, const double* py, int n, int cone_type,
+__device__ inline void matches_for_side(MatchShared& S, const Params& P, const double* px, const double* py, int n, int cone_type,
                                         const double* qx, const double* qy, int m) {
   const int lane = lane_id();
   if (lane < MAX_MATCH) S.match[lane] = -1;
@@ -76,13 +76,16 @@ __device__ inline void matches_for_side(MatchShared& S, const double* px, const 
     const int i = p / m, j = p - i * m;
     const double sx = px[i], sy = py[i];
     const Rot2 rot{S.rc[i], S.rs[i]};
-    const double r0 = (5 * 1.5) * (5 * 1.5), r1 = 3.0 * 3.0;
+    // radii_square = [major_radius, minor_radius] ** 2 with major = max_search_range * 1.5, minor = min_track_width
+    // (core_cone_matching.py:101-102)
+    const double rmaj = P.max_search_range * 1.5, rmin = P.min_track_width;
+    const double r0 = rmaj * rmaj, r1 = rmin * rmin;
     double vx, vy;
     rot_apply(rot, qx[j] - sx, qy[j] - sy, vx, vy);
     double sc = (vx * vx) / r0 + (vy * vy) / r1;
     bool ok = sc < 1;
     double a = atan2(vy, vx);
-    if (fabs(a / 2) > 50 * FSDP_DEG) ok = false;
+    if (fabs(a / 2) > P.max_search_angle) ok = false;
     if (m > 1) {  // with a single other-side cone the reference's direction mask is empty
       double dd = angle_between(S.d1x[i], S.d1y[i], S.d2x[j], S.d2y[j]);
       if (dd < FSDP_PI / 2) ok = false;
@@ -216,18 +219,18 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
 }
 
 // functional_cone_matching.py:387-440: result written to (ox, oy), returns its length
-__device__ inline int cones_for_other_side(MatchShared& S, const double* px, const double* py, int n, int cone_type,
+__device__ inline int cones_for_other_side(MatchShared& S, const Params& P, const double* px, const double* py, int n, int cone_type,
                                            const double* qx, const double* qy, int m, double carx, double cary, double* ox,
                                            double* oy) {
   const int lane = lane_id();
-  matches_for_side(S, px, py, n, cone_type, qx, qy, m);
+  matches_for_side(S, P, px, py, n, cone_type, qx, qy, m);
   bool unmatched = lane < n && S.match[lane] == -1;
   unsigned long long um = __ballot(unmatched);
   const int nv = __popcll(um);
   double vx = 0, vy = 0;
   if (unmatched) {
-    vx = px[lane] + S.d1x[lane] * 3.0;
-    vy = py[lane] + S.d1y[lane] * 3.0;
+    vx = px[lane] + S.d1x[lane] * P.min_track_width;
+    vy = py[lane] + S.d1y[lane] * P.min_track_width;
   }
   int no;
   __syncthreads();
@@ -286,8 +289,10 @@ __device__ inline int cones_for_other_side(MatchShared& S, const double* px, con
 
 __global__ void __launch_bounds__(64) match_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
                                                    const double* __restrict__ cones_xyt, const double* __restrict__ poses,
-                                                   const SortOut* __restrict__ sorted, MatchOut* __restrict__ out) {
+                                                   const SortOut* __restrict__ sorted, MatchOut* __restrict__ out,
+                                                   const Params* __restrict__ prm) {
   __shared__ MatchShared S;
+  const Params& P = *prm;
   const int frame = blockIdx.x;
   if (frame >= n_frames) return;
   const int lane = lane_id();
@@ -325,7 +330,7 @@ __global__ void __launch_bounds__(64) match_kernel(int n_frames, const int32_t* 
     }
     // right cones with virtual: driven by the left side
     if (nl >= 2) {
-      nb = cones_for_other_side(S, S.lx, S.ly, nl, T_LEFT, S.rx, S.ry, nr, carx, cary, S.bx, S.by);
+      nb = cones_for_other_side(S, P, S.lx, S.ly, nl, T_LEFT, S.rx, S.ry, nr, carx, cary, S.bx, S.by);
     } else {
       if (lane < nr) {
         S.bx[lane] = S.rx[lane];
@@ -335,7 +340,7 @@ __global__ void __launch_bounds__(64) match_kernel(int n_frames, const int32_t* 
     }
     __syncthreads();
     if (nr >= 2) {
-      na = cones_for_other_side(S, S.rx, S.ry, nr, T_RIGHT, S.lx, S.ly, nl, carx, cary, S.ax, S.ay);
+      na = cones_for_other_side(S, P, S.rx, S.ry, nr, T_RIGHT, S.lx, S.ly, nl, carx, cary, S.ax, S.ay);
     } else {
       if (lane < nl) {
         S.ax[lane] = S.lx[lane];
@@ -346,14 +351,14 @@ __global__ void __launch_bounds__(64) match_kernel(int n_frames, const int32_t* 
     __syncthreads();
   }
   // final matching on the lists with virtual cones (:443-476)
-  matches_for_side(S, S.ax, S.ay, na, T_LEFT, S.bx, S.by, nb);
+  matches_for_side(S, P, S.ax, S.ay, na, T_LEFT, S.bx, S.by, nb);
   if (lane < MAX_MATCH) {
     o->l2r[lane] = (lane < na) ? S.match[lane] : -1;
     o->left_v[lane][0] = (lane < na) ? S.ax[lane] : 0.0;
     o->left_v[lane][1] = (lane < na) ? S.ay[lane] : 0.0;
   }
   __syncthreads();
-  matches_for_side(S, S.bx, S.by, nb, T_RIGHT, S.ax, S.ay, na);
+  matches_for_side(S, P, S.bx, S.by, nb, T_RIGHT, S.ax, S.ay, na);
   if (lane < MAX_MATCH) {
     o->r2l[lane] = (lane < nb) ? S.match[lane] : -1;
     o->right_v[lane][0] = (lane < nb) ? S.bx[lane] : 0.0;

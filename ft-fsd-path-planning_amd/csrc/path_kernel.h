@@ -57,6 +57,7 @@ struct Arena {
   double* filt;  // filtered curvature of the dense samples
   FitRec* fit;
   double* band;  // fit_kernel's band triangle between observation passes (FitWS)
+  const Params* prm;  // the context's configuration constants
 };
 
 // Per-frame LDS = the spline workspace; while no fit is running the path stage uses its bytes for segment lengths (before
@@ -557,7 +558,7 @@ __device__ __forceinline__ int mpc_prepare(PathShared<G>& S, const Arena& A, int
       if (nin < 2) return ST_REF_UNDEFINED_PATH;  // cumsum([])[-1] -> IndexError
       // path length in front of the car: np.cumsum of the segment lengths (sequential)
       double plen = cumulative_length<G>(S, A, off + f0, nin, INFINITY, nullptr);
-      if (!(plen > 20.0)) {
+      if (!(plen > A.prm->mpc_path_length)) {
         int nrel = nin < 20 ? nin : 20;
         int r0 = off + n - nrel;
         // the last <= 20 points through LDS for the circle fit
@@ -648,13 +649,13 @@ __device__ __forceinline__ int mpc_finish(PathShared<G>& S, const Arena& A, bool
     int n4 = 0;
     if (fitted) {
       PROF(5);
-      n4 = arange_len(20.0 * 1.5, 0.1);
-      eval_spline<CUBIC>(S.ws, f, 0.1, n4, A.x, A.y, nullptr);
+      n4 = arange_len(A.prm->mpc_path_length * 1.5, A.prm->predict_every);
+      eval_spline<CUBIC>(S.ws, f, A.prm->predict_every, n4, A.x, A.y, nullptr);
     }
     int nseg = n4 - 1;
     if (nseg <= 1) return 1;  // previous (40,4) array handed on -> LinAlgError (a ValueError) downstream
     int first = nseg;
-    cumulative_length<G>(S, A, 0, n4, 20.0, &first);
+    cumulative_length<G>(S, A, 0, n4, A.prm->mpc_path_length, &first);
     n5 = first;
   }
   return parameterize_path<G, FAST, CUBIC>(S, A, 0, n5, out, n_dense);
@@ -673,7 +674,7 @@ __device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int 
   if (fitted) {
     double max_u;
     PROF(4);
-    rc = fit_polyline<G, FAST>(S, A, off, n, 0.2, f, max_u);
+    rc = fit_polyline<G, FAST>(S, A, off, n, A.prm->smoothing, f, max_u);
     if (rc) return rc;
   }
   return mpc_finish<G, FAST>(S, A, fitted, f, out, n_dense);
@@ -694,7 +695,7 @@ __device__ __forceinline__ int overwrite_if_too_far(const Arena& A, int n1, doub
     }
   }
   GR::argmin(bv, bi);
-  if (bv > 5.0) {
+  if (bv > A.prm->maximal_distance_for_valid_path) {
     *fallback |= 4;
     GR::sync();
     for (int i = lane; i < PATH_POINTS; i += G) {
@@ -752,7 +753,7 @@ inline void default_chord_points(double (*chord)[2]) {
   }
 }
 
-__device__ __forceinline__ Arena frame_arena(double* arena, int frame) {
+__device__ __forceinline__ Arena frame_arena(double* arena, int frame, const Params* prm) {
   double* b = arena + (size_t)frame * ARENA_DOUBLES;
   Arena A;
   A.x = b;
@@ -763,16 +764,17 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame) {
   A.filt = A.bc.b + ARENA_B;
   A.fit = (FitRec*)(A.filt + DENSE_CAP);
   A.band = A.filt + DENSE_CAP + FITREC_DOUBLES;
+  A.prm = prm;
   return A;
 }
 
 // core_calculate_path.py:103-121: previous_paths[0] = parameterize_path(fit(chord).predict())
 __global__ void __launch_bounds__(64) default_path_kernel(const double* __restrict__ chord, double* __restrict__ arena,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, const Params* __restrict__ prm) {
   constexpr int G = WAVE;
   __shared__ PathShared<G> S;
   const int lane = lane_id();
-  const Arena A = frame_arena(arena, 0);
+  const Arena A = frame_arena(arena, 0, prm);
   if (lane < PATH_POINTS) {
     A.x[lane] = chord[2 * lane];
     A.y[lane] = chord[2 * lane + 1];
@@ -781,10 +783,10 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
   SplineFit f;
   double max_u;
   constexpr bool FAST = false;  // one-off per context: plain divisions
-  int rc = fit_polyline<G, FAST>(S, A, 0, PATH_POINTS, 0.2, f, max_u);
-  int n1 = arange_len(max_u, 0.1);
+  int rc = fit_polyline<G, FAST>(S, A, 0, PATH_POINTS, A.prm->smoothing, f, max_u);
+  int n1 = arange_len(max_u, A.prm->predict_every);
   if (rc == 0 && n1 <= PATH_CAP) {
-    spline_eval(S.ws, f, 0.1, n1, A.x, A.y, nullptr);
+    spline_eval(S.ws, f, A.prm->predict_every, n1, A.x, A.y, nullptr);
     int nd = 0;
     double(*o)[4] = (double(*)[4])out;
     rc = parameterize_path<G, FAST>(S, A, 0, n1, o, &nd);
@@ -930,13 +932,13 @@ __device__ __forceinline__ int path_front(PathShared<G>& S, const Arena& A, cons
       SplineFit f;
       double max_u;
       PROF(1);
-      int rc = fit_polyline<G, FAST, CUBIC>(S, A, 0, nc, 0.2, f, max_u);
+      int rc = fit_polyline<G, FAST, CUBIC>(S, A, 0, nc, A.prm->smoothing, f, max_u);
       if (rc == 0) {
-        n1 = arange_len(max_u, 0.1);
+        n1 = arange_len(max_u, A.prm->predict_every);
         if (n1 + 1 + 50 > PATH_CAP) {
           status = ST_OVERFLOW_PATH;
         } else {
-          eval_spline<CUBIC>(S.ws, f, 0.1, n1, A.x + 1, A.y + 1, nullptr);
+          eval_spline<CUBIC>(S.ws, f, A.prm->predict_every, n1, A.x + 1, A.y + 1, nullptr);
         }
         break;
       }
@@ -983,9 +985,9 @@ template <int G, bool FAST>
 __device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
                                   const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
                                   const double* __restrict__ prev_paths, const double* __restrict__ gpath, int n_gpath,
-                                  double* __restrict__ arena, PathOut* __restrict__ out) {
+                                  double* __restrict__ arena, PathOut* __restrict__ out, const Params* __restrict__ prm) {
   PROF(0);
-  const Arena A = frame_arena(arena, frame);
+  const Arena A = frame_arena(arena, frame, prm);
   PathOut* o = &out[frame];
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
   // previous_paths[-1]: the constant initial path (fresh planner) or, for sequential replays, the caller-supplied
@@ -1011,13 +1013,14 @@ template <int G>
 __global__ void __launch_bounds__(64) path_prep_kernel(int n_frames, const double* __restrict__ poses, const MatchOut* __restrict__ matched,
                                                        const double* __restrict__ default_path, const double* __restrict__ prev_paths,
                                                        const double* __restrict__ gpath, int n_gpath, double* __restrict__ arena,
-                                                       PathOut* __restrict__ out, PathMid* __restrict__ mid, int* __restrict__ retry) {
+                                                       PathOut* __restrict__ out, PathMid* __restrict__ mid, int* __restrict__ retry,
+                                                       const Params* __restrict__ prm) {
   using GR = Grp<G>;
   __shared__ PathShared<G> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
   if (frame >= n_frames) return;
   PathShared<G>& S = S_all[GR::index()];
-  const Arena A = frame_arena(arena, frame);
+  const Arena A = frame_arena(arena, frame, prm);
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
   const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
   int fallback = 0, n1 = 0, off = 0, n = 0;
@@ -1045,7 +1048,7 @@ __global__ void __launch_bounds__(64) path_prep_kernel(int n_frames, const doubl
 // the refit: utils/spline_fit.py:95-128 (splprep, k = 3, s = 0.2) of the arena polyline [off, off + n), G lanes per frame
 template <int G, int NKC>
 __global__ void __launch_bounds__(64, 2) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
-                                                 int* __restrict__ retry) {
+                                                 int* __restrict__ retry, const Params* __restrict__ prm) {
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;
   static_assert(6 * (NKC + 2) <= BAND_DOUBLES, "band region of the arena");
@@ -1055,11 +1058,11 @@ __global__ void __launch_bounds__(64, 2) fit_kernel(int n_frames, double* __rest
   if (frame < n_frames && mid[frame].status == ST_OK) {
     PROF(0);
     WS& ws = ws_all[GR::index()];
-    const Arena A = frame_arena(arena, frame);
+    const Arena A = frame_arena(arena, frame, prm);
     if (GR::lane() == 0) ws.band = A.band;
     GR::sync();
     const int off = mid[frame].off, m = mid[frame].n;
-    const SplineFit f = spline_fit_k<3, true>(ws, A.bc, A.u + off, A.x + off, A.y + off, m, 0.2);
+    const SplineFit f = spline_fit_k<3, true>(ws, A.bc, A.u + off, A.x + off, A.y + off, m, A.prm->smoothing);
     const int lane = GR::lane();
     if (f.status != 0) {
       if (lane == 0) {
@@ -1086,13 +1089,14 @@ __global__ void __launch_bounds__(64, 2) fit_kernel(int n_frames, double* __rest
 
 template <int G>
 __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
-                                                         PathOut* __restrict__ out, int* __restrict__ retry) {
+                                                         PathOut* __restrict__ out, int* __restrict__ retry,
+                                                         const Params* __restrict__ prm) {
   using GR = Grp<G>;
   __shared__ PathShared<G> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
   if (frame >= n_frames || mid[frame].status != ST_OK) return;
   PathShared<G>& S = S_all[GR::index()];
-  const Arena A = frame_arena(arena, frame);
+  const Arena A = frame_arena(arena, frame, prm);
   const int lane = GR::lane();
   const FitRec* fr = A.fit;
   SplineFit f;
@@ -1130,12 +1134,12 @@ __global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames,
                                                      const double* __restrict__ prev_paths,
                                                      const double* __restrict__ gpath, int n_gpath,
                                                      double* __restrict__ arena, PathOut* __restrict__ out,
-                                                     int* __restrict__ retry) {
+                                                     int* __restrict__ retry, const Params* __restrict__ prm) {
   __shared__ PathShared<G> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
   PROF_INIT();
   if (frame < n_frames) {
-    path_frame<G, true>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out);
+    path_frame<G, true>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out, prm);
     if (retry != nullptr && Grp<G>::lane() == 0 && (out[frame].status == ST_OVERFLOW_KNOTS || out[frame].status == ST_RETRY))
       retry[1 + atomicAdd(&retry[0], 1)] = frame;
   }  // (retry list on the device: used by the emulator harness; the library collects the list on the host)
@@ -1148,11 +1152,11 @@ __global__ void __launch_bounds__(64, 1) path_retry_kernel(const double* __restr
                                                            const double* __restrict__ prev_paths,
                                                            const double* __restrict__ gpath, int n_gpath,
                                                            double* __restrict__ arena, PathOut* __restrict__ out,
-                                                           const int* __restrict__ retry) {
+                                                           const int* __restrict__ retry, const Params* __restrict__ prm) {
   __shared__ PathShared<WAVE> S;
   const int n = retry[0];
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    path_frame<WAVE, false>(S, retry[1 + i], poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out);
+    path_frame<WAVE, false>(S, retry[1 + i], poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out, prm);
     __syncthreads();
   }
 }

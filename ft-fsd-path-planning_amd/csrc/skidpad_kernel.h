@@ -39,6 +39,7 @@ struct SkidTables {
   int n_noise;
   double ref_right[2], ref_left[2];  // calculate_reference_centers_for_skidpad_path
   double mean_distance;              // mean of the first 9 segment lengths of the known path (NumPy mean)
+  const Params* prm;                 // the context's configuration constants
 };
 
 struct SkidInfo {  // what RelocalizationInformation / the planner state expose (relocalization_information.py:12-35)
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(64) skid_reloc_kernel(int n_inst, const int32_
   const int off = cone_offsets[inst];
   const int n = cone_offsets[inst + 1] - off;
   const double* cones = cones_xyt + 3 * (size_t)off;
-  const Arena A = frame_arena(arena, inst);
+  const Arena A = frame_arena(arena, inst, T.prm);
   // ---- 20 closest cones, in argsort order (stable) ----
   const int m = n < SKID_NEAR ? n : SKID_NEAR;
   {
@@ -437,7 +438,7 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
   const int inst = blockIdx.x;
   if (inst >= n_inst) return;
   const int lane = lane_id();
-  const Arena A = frame_arena(arena, inst);
+  const Arena A = frame_arena(arena, inst, T.prm);
   SkidState* st = &states[inst];
   PathOut* o = &out[inst];
   double px = poses[4 * inst + 0], py = poses[4 * inst + 1], dx = poses[4 * inst + 2], dy = poses[4 * inst + 3];

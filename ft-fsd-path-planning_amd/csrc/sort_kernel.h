@@ -164,7 +164,7 @@ __device__ __forceinline__ bool neighbour_lies_between(const SH& S, int node, in
 // values computed when those cones were candidates themselves (same operands, same bits); ang_cand returns the direction
 // of the edge node -> candidate for the candidate's own children.
 template <class SH>
-__device__ inline bool candidate_can_be_added(const SH& S, int side, int cone_type, int pos, int node, int cand, bool between,
+__device__ inline bool candidate_can_be_added(const SH& S, const Params& P, int side, int cone_type, int pos, int node, int cand, bool between,
                                               double px, double py, double dx, double dy, double dnx, double dny, double a_car,
                                               double ang_sl, double ang_tl, double& ang_cand) {
   const double lx = S.x[node], ly = S.y[node];
@@ -190,12 +190,12 @@ __device__ inline bool candidate_can_be_added(const SH& S, int side, int cone_ty
     double angle_2 = ang_cand;
     double difference = angle_difference(angle_2, angle_1);
     double len = norm_blas(l2cx, l2cy);
-    if (fabs(difference) > 65 * FSDP_DEG)
+    if (fabs(difference) > P.threshold_absolute_angle)
       can = false;
     else if (cone_type == T_LEFT)
-      can = (difference < 40 * FSDP_DEG) || (len < 4.0);
+      can = (difference < P.threshold_directional_angle) || (len < 4.0);
     else
-      can = (difference > -(40 * FSDP_DEG)) || (len < 4.0);
+      can = (difference > -P.threshold_directional_angle) || (len < 4.0);
     if (pos >= 2) {
       double angle_3 = ang_tl;
       double difference_2 = angle_difference(angle_1, angle_3);
@@ -238,7 +238,7 @@ __device__ __forceinline__ double np_sum_reg(const double (&a)[MAX_LEN], int n) 
 // reuse_adjacency: the mutual-kNN lists were built by the other side's call and no cone of the frame carries a side
 // colour, so they are the same for this side (no-colour mode builds them once per frame).
 template <class SH>
-__device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, double px, double py, double dx,
+__device__ inline void sort_side_prepare(SH& S, const Params& P, int n, int cone_type, int side, double px, double py, double dx,
                                          double dy, bool reuse_adjacency) {
   const int lane = lane_id();
   const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
@@ -272,7 +272,7 @@ __device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, 
   }
   wave_argmin(bv, bi);
   int index_1 = bi;
-  if (index_1 >= 0 && bv > 6.0) index_1 = -1;
+  if (index_1 >= 0 && bv > P.max_dist_to_first) index_1 = -1;
   if (index_1 < 0) return;  // no start cone -> side has no result
   bv = 0.0;
   bi = -1;
@@ -288,7 +288,7 @@ __device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, 
   }
   wave_argmin(bv, bi);
   int index_2 = bi;
-  if (index_2 >= 0 && bv > 6.0) index_2 = -1;
+  if (index_2 >= 0 && bv > P.max_dist_to_first) index_2 = -1;
   int fk0, fk1 = -1, n_first = 1;
   if (index_2 < 0) {
     fk0 = index_1;
@@ -304,7 +304,7 @@ __device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, 
       index_2 = t;
     }
     double dist = norm_blas(d1x, d1y);
-    if (dist > 6.5 * 1.1 || dist < 1.4) {
+    if (dist > P.max_dist * 1.1 || dist < 1.4) {
       fk0 = index_1;
     } else {
       fk0 = index_2;
@@ -322,7 +322,7 @@ __device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, 
   PROF_MARK(2);
   const int adj = reuse_adjacency ? 0 : side;
   if (!reuse_adjacency) {
-    const int k_nn = (n - 1 < KNN) ? (n - 1) : KNN;
+    const int k_nn = (n - 1 < P.max_n_neighbors) ? (n - 1) : P.max_n_neighbors;
     for (int i = lane; i < n; i += WAVE) {
       double bd[KNN];
       int bj[KNN];
@@ -375,7 +375,7 @@ __device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, 
       for (int q = 0; q < KNN; q++) {
         bool in_k = (q < k_nn) && (bj[q] != SH::NONE);
         S.knn[i][q] = in_k ? (typename SH::idx_t)bj[q] : (typename SH::idx_t)SH::NONE;
-        if (in_k && !(bd[q] > 6.5 * 6.5)) okm |= (1 << q);
+        if (in_k && !(bd[q] > P.max_dist * P.max_dist)) okm |= (1 << q);
       }
       S.knn_ok[i] = (uint8_t)okm;
     }
@@ -419,7 +419,7 @@ __device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, 
   __syncthreads();
   // BFS reachability from start_idx (common.py:36-67); only min(len, 12) is consumed
   int reach = 1;
-  for (int it = 0; it < SH::CAP && reach < MAX_LEN; it++) {
+  for (int it = 0; it < SH::CAP && reach < P.max_length; it++) {
     int add = 0;
     unsigned long long newbits[SH::CAP / WAVE];
     for (int w = 0; w * WAVE < n; w++) {
@@ -442,7 +442,7 @@ __device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, 
     __syncthreads();
     reach += add;
   }
-  const int target_length = reach < MAX_LEN ? reach : MAX_LEN;
+  const int target_length = reach < P.max_length ? reach : P.max_length;
   PROF_MARK(7);  // closes section 2
   if (lane == 0) {
     S.ctl[side].active = 1;
@@ -459,7 +459,7 @@ __device__ inline void sort_side_prepare(SH& S, int n, int cone_type, int side, 
 // side.  A pop keeps at most 5 candidate lanes and 25 (candidate, neighbour) lanes busy, so the two independent searches
 // share every instruction; the loop runs until both stacks are empty.
 template <class SH>
-__device__ inline void sort_dfs_both(SH& S, double px, double py, double dx, double dy) {
+__device__ inline void sort_dfs_both(SH& S, const Params& P, double px, double py, double dx, double dy) {
   const int lane = lane_id();
   const int side = lane >> 5, sl = lane & 31;
   const int cone_type = (side == 0) ? T_LEFT : T_RIGHT;
@@ -523,7 +523,7 @@ __device__ inline void sort_dfs_both(SH& S, double px, double py, double dx, dou
     if (sl < n_nb) {
       const bool between = ((bm >> (sl * n_nb)) & ((1u << n_nb) - 1u)) != 0u;
       const double ang_tl = (pos >= 2) ? S.attempt_ang[side][pos - 1] : 0.0;
-      can = candidate_can_be_added(S, side, cone_type, pos, node, S.nbr[adj][node][sl], between, px, py, dx, dy, dnx, dny, a_car,
+      can = candidate_can_be_added(S, P, side, cone_type, pos, node, S.nbr[adj][node][sl], between, px, py, dx, dy, dnx, dny, a_car,
                                    node_ang, ang_tl, cand_ang);
     }
     const unsigned m = (unsigned)(__ballot(can) >> (32 * side));
@@ -1012,7 +1012,7 @@ __device__ inline void combine_sides(SH& S, int& nl, int& nr) {
 
 // The sorting stage of one frame on one wavefront; S = the frame state (LDS or global memory).
 template <class SH>
-__device__ inline void sort_frame(SH& S, int frame, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
+__device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
                                   const double* __restrict__ poses, SortOut* __restrict__ out) {
   const int lane = lane_id();
   const int off = cone_offsets[frame];
@@ -1048,7 +1048,9 @@ __device__ inline void sort_frame(SH& S, int frame, const int32_t* __restrict__ 
       rot_apply(r, S.x[i] - px, S.y[i] - py, rx, ry);
       double ang = atan2(ry, rx);
       S.dist[i] = sqrt(rx * rx + ry * ry);
-      double crit = (rx * rx) / (9.0 * 9.0) + (ry * ry) / (4.0 * 4.0);
+      // points_inside_ellipse(major = max_dist_to_first * 1.5, minor = max_dist_to_first / 1.5) — core_trace_sorter.py:388-394
+      const double emaj = P.max_dist_to_first * 1.5, emin = P.max_dist_to_first / 1.5;
+      double crit = (rx * rx) / (emaj * emaj) + (ry * ry) / (emin * emin);
       int f = 0;
       if (crit < 1) f |= 1;
       if (ang > 0) f |= 2;
@@ -1066,11 +1068,11 @@ __device__ inline void sort_frame(SH& S, int frame, const int32_t* __restrict__ 
   for (int i = lane; i < n; i += WAVE) coloured = coloured || S.type[i] == T_LEFT || S.type[i] == T_RIGHT;
   const bool colourless = __ballot(coloured) == 0ull;
   if (status == ST_OK) {
-    sort_side_prepare(S, n, T_LEFT, 0, px, py, dx, dy, false);
+    sort_side_prepare(S, P, n, T_LEFT, 0, px, py, dx, dy, false);
     // (the left call returns before building the adjacency when it finds no start cone or n < 3)
     const bool left_built = S.adj_built != 0;
-    sort_side_prepare(S, n, T_RIGHT, 1, px, py, dx, dy, colourless && left_built);
-    sort_dfs_both(S, px, py, dx, dy);
+    sort_side_prepare(S, P, n, T_RIGHT, 1, px, py, dx, dy, colourless && left_built);
+    sort_dfs_both(S, P, px, py, dx, dy);
     status = sort_side_finish(S, n, T_LEFT, 0, px, py, dx, dy);
     __syncthreads();
     if (status == ST_OK) status = sort_side_finish(S, n, T_RIGHT, 1, px, py, dx, dy);
@@ -1102,12 +1104,12 @@ __device__ inline void sort_frame(SH& S, int frame, const int32_t* __restrict__ 
 // the LDS capacities (more than 255 cones, more than 64 raw end configurations), planned again by sort_big_kernel.
 __global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
                                                   const double* __restrict__ cones_xyt, const double* __restrict__ poses,
-                                                  SortOut* __restrict__ out, int* __restrict__ big) {
+                                                  SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
   __shared__ SortShared S;
   const int frame = blockIdx.x;
   if (frame >= n_frames) return;
   PROF_INIT();
-  sort_frame(S, frame, cone_offsets, cones_xyt, poses, out);
+  sort_frame(S, *prm, frame, cone_offsets, cones_xyt, poses, out);
   if (big != nullptr && lane_id() == 0 && (out[frame].status == ST_OVERFLOW_CONES || out[frame].status == ST_OVERFLOW_ENDS))
     big[1 + atomicAdd(&big[0], 1)] = frame;
   PROF_FLUSH();
@@ -1116,11 +1118,12 @@ __global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames,
 // The frames sort_kernel could not hold in LDS, with the frame state in global memory (one SortSharedBig per block).
 __global__ void __launch_bounds__(64) sort_big_kernel(const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
                                                       const double* __restrict__ poses, SortOut* __restrict__ out,
-                                                      const int* __restrict__ big, SortSharedBig* __restrict__ state) {
+                                                      const int* __restrict__ big, SortSharedBig* __restrict__ state,
+                                                      const Params* __restrict__ prm) {
   const int n = big[0];
   SortSharedBig& S = state[blockIdx.x];
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    sort_frame(S, big[1 + i], cone_offsets, cones_xyt, poses, out);
+    sort_frame(S, *prm, big[1 + i], cone_offsets, cones_xyt, poses, out);
     __syncthreads();
   }
 }

@@ -941,13 +941,14 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
             for (int q = 0; q < 8; q++) {
               if (r0 + q < cnt) {
                 double term = tv[q];
+                // fppara.f: fpart = fpart+term; on a new interval: store = term*half; fpint(i) = fpart-store; fpart = store
+                // ((fpart + term) - term/2 rounds differently from fpart + term/2, and fpknot compares these sums)
+                fpart = fpart + term;
                 if (fl[q]) {
                   double store = term * half;
-                  if (lane == 0) ws.fpint[ii] = fpart + store;
+                  if (lane == 0) ws.fpint[ii] = fpart - store;
                   ii++;
                   fpart = store;
-                } else {
-                  fpart = fpart + term;
                 }
               }
             }

@@ -122,7 +122,7 @@ class PathPlanner:
     """
 
     def __init__(self, mission: MissionTypes, experimental_performance_improvements: bool = False, device: int | None = None,
-                 stateful: bool = True, relocalization_seed: int | None = 0):
+                 stateful: bool = True, relocalization_seed: int | None = 0, params: dict | None = None):
         if experimental_performance_improvements:
             # reference README.md:24-27: off by default, changes results, meaningless for independent frames
             raise NotImplementedError("the experimental sorting cache is out of scope (SURVEY.md §2 row 15)")
@@ -142,10 +142,12 @@ class PathPlanner:
         if self.mission == MissionTypes.skidpad:
             from .skidpad import SkidpadBatch
 
-            self._skid = SkidpadBatch(1, device=device)  # stateful, like the reference's skidpad planner
+            self._skid = SkidpadBatch(1, device=device, params=params)  # stateful, like the reference's skidpad planner
             self._ctx = self._skid._ctx
         else:
-            self._ctx = _capi.Context(device=device, mission=int(self.mission))
+            # params: overrides of the configuration constants by the reference's kwarg names (config.py), e.g.
+            # dict(max_dist=5.5, max_length=10, smoothing=0.1); None = the reference's defaults
+            self._ctx = _capi.Context(device=device, mission=int(self.mission), params=params)
 
     @property
     def relocalization_info(self):

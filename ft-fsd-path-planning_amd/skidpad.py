@@ -44,8 +44,8 @@ class RelocalizationInformation:
 class SkidpadBatch:
     """n independent skidpad planners advanced in lock-step (one frame of every instance per step)."""
 
-    def __init__(self, n_instances: int = 1, device: int | None = None, table: np.ndarray | None = None):
-        self._ctx = _capi.Context(device=device, mission=2)
+    def __init__(self, n_instances: int = 1, device: int | None = None, table: np.ndarray | None = None, params: dict | None = None):
+        self._ctx = _capi.Context(device=device, mission=2, params=params)
         self.n = int(n_instances)
         table, noise = load_tables(table)
         self.tables = (table, noise)

@@ -6,7 +6,10 @@ points (fsdp_sort_batch / fsdp_match_batch / fsdp_path_batch):
   ConeMatching  cone_matching/core_cone_matching.py:26-124
   CalculatePath calculate_path/core_calculate_path.py:36-60,514-575   (fresh-planner semantics)
 
-Only the reference's default parameters (config.py) are compiled into the kernels; other values are rejected.
+The constructors take the reference's kwargs (defaults = the factories of config.py); they travel to the kernels as the
+context's parameter block (include/fsdp.h fsdp_params).  Values outside what the kernels can take (max_n_neighbors > 5,
+max_length > 12, max_deg != 3, mpc_prediction_horizon != 40, use_unknown_cones = False, monotonic matching) make the
+library refuse the context: nothing is silently substituted.
 """
 from __future__ import annotations
 
@@ -21,11 +24,25 @@ from .planner import ConeTypes, flatten_cones_by_type_array, raise_for_status
 _shared_ctx = {}
 
 
-def _ctx(device=None):
-    key = device
+def _ctx(device=None, params=None):
+    """One context per (device, parameter set)."""
+    key = (device, tuple(sorted((params or {}).items())))
     if key not in _shared_ctx:
-        _shared_ctx[key] = _capi.Context(device=device, mission=4)
+        _shared_ctx[key] = _capi.Context(device=device, mission=4, params=params)
     return _shared_ctx[key]
+
+
+def _overrides(defaults, kwargs):
+    out = {}
+    for k, v in kwargs.items():
+        if k == "experimental_performance_improvements":
+            if v:
+                raise NotImplementedError("the experimental sorting cache is out of scope (SURVEY.md section 2 row 15)")
+            continue
+        if k not in defaults:
+            raise TypeError(f"unexpected keyword argument {k!r}")
+        out[k] = float(v) if isinstance(defaults[k], float) or isinstance(v, float) else v
+    return out
 
 
 _check = raise_for_status
@@ -46,11 +63,7 @@ class ConeSorting:
                     threshold_directional_angle=np.deg2rad(40), threshold_absolute_angle=np.deg2rad(65), use_unknown_cones=True)
 
     def __init__(self, device=None, **kwargs):
-        for k, v in kwargs.items():
-            if k == "experimental_performance_improvements" and not v:
-                continue
-            if k not in self.DEFAULTS or self.DEFAULTS[k] != v:
-                raise NotImplementedError(f"only the reference defaults are compiled into the kernel ({k}={v!r})")
+        self._params = _overrides(self.DEFAULTS, kwargs)
         self.input = ConeSortingInput()
         self._device = device
 
@@ -60,7 +73,7 @@ class ConeSorting:
     def run_cone_sorting(self) -> Tuple[np.ndarray, np.ndarray]:
         xyt = flatten_cones_by_type_array(self.input.slam_cones)
         pose = np.concatenate([np.asarray(self.input.slam_position, float).reshape(2), np.asarray(self.input.slam_direction, float).reshape(2)])
-        r = _ctx(self._device).sort_batch(np.array([0, len(xyt)], np.int32), xyt, pose[None])[0]
+        r = _ctx(self._device, self._params).sort_batch(np.array([0, len(xyt)], np.int32), xyt, pose[None])[0]
         _check(r["status"])
         self.last_result = r
         return xyt[r["left_idx"][: r["n_left"]], :2], xyt[r["right_idx"][: r["n_right"]], :2]
@@ -80,9 +93,7 @@ class ConeMatching:
     DEFAULTS = dict(min_track_width=3, max_search_range=5, max_search_angle=np.deg2rad(50), matches_should_be_monotonic=False)
 
     def __init__(self, device=None, **kwargs):
-        for k, v in kwargs.items():
-            if k not in self.DEFAULTS or self.DEFAULTS[k] != v:
-                raise NotImplementedError(f"only the pipeline's defaults are compiled into the kernel ({k}={v!r})")
+        self._params = _overrides(self.DEFAULTS, kwargs)
         self.input = ConeMatchingInput()
         self._device = device
 
@@ -97,7 +108,7 @@ class ConeMatching:
         sl, sr = np.zeros((1, 12, 2)), np.zeros((1, 12, 2))
         sl[0, : len(left)], sr[0, : len(right)] = left, right
         pose = np.concatenate([np.asarray(self.input.slam_position, float).reshape(2), np.asarray(self.input.slam_direction, float).reshape(2)])
-        r = _ctx(self._device).match_batch(sl, [len(left)], sr, [len(right)], pose[None])[0]
+        r = _ctx(self._device, self._params).match_batch(sl, [len(left)], sr, [len(right)], pose[None])[0]
         _check(r["status"])
         self.last_result = r
         ml, mr = int(r["n_left_v"]), int(r["n_right_v"])
@@ -123,9 +134,7 @@ class CalculatePath:
     DEFAULTS = dict(smoothing=0.2, predict_every=0.1, max_deg=3, maximal_distance_for_valid_path=5, mpc_path_length=20, mpc_prediction_horizon=40)
 
     def __init__(self, device=None, stateful: bool = True, **kwargs):
-        for k, v in kwargs.items():
-            if k not in self.DEFAULTS or self.DEFAULTS[k] != v:
-                raise NotImplementedError(f"only the reference defaults are compiled into the kernel ({k}={v!r})")
+        self._params = _overrides(self.DEFAULTS, kwargs)
         self.input = PathCalculationInput()
         self._device = device
         self.stateful = stateful
@@ -145,7 +154,7 @@ class CalculatePath:
         res["l2r"][0, : len(lv)] = np.asarray(i.left_to_right_matches, dtype=np.int32)
         res["r2l"][0, : len(rv)] = np.asarray(i.right_to_left_matches, dtype=np.int32)
         pose = np.concatenate([np.asarray(i.position_global, float).reshape(2), np.asarray(i.direction_global, float).reshape(2)])
-        ctx = _ctx(self._device)
+        ctx = _ctx(self._device, self._params)
         if i.global_path is not None:  # core_calculate_path.py:514-529: the path is drawn from the global path
             ctx.set_global_path(i.global_path)
         try:

@@ -85,6 +85,38 @@ typedef struct {
 
 typedef struct fsdp_ctx fsdp_ctx;
 
+/* The reference's configuration constants — the kwargs of ConeSorting (sorting_cones/core_cone_sorting.py:49-100), ConeMatching
+ * (cone_matching/core_cone_matching.py:50-71) and CalculatePath (calculate_path/core_calculate_path.py:69-110), whose defaults
+ * are the factories of fsd_path_planning/config.py:28-163.  fsdp_default_params fills those defaults.  A context keeps its own
+ * copy on the device.  Structural parameters are bounded by the compiled capacities (max_n_neighbors <= 5, max_length <= 12);
+ * max_deg (3), mpc_prediction_horizon (40: the shape of the result), use_unknown_cones (True) and
+ * matches_should_be_monotonic (False, the pipeline's choice: full_pipeline.py:65) are accepted only at these values
+ * (fsdp_create fails otherwise: no silent substitution). */
+typedef struct {
+  /* config.py:33-41 get_cone_sorting_config */
+  int32_t max_n_neighbors;
+  double max_dist;
+  double max_dist_to_first;
+  int32_t max_length;
+  double threshold_directional_angle; /* radians */
+  double threshold_absolute_angle;    /* radians */
+  int32_t use_unknown_cones;
+  /* config.py:48 get_cone_fitting_config */
+  double smoothing;
+  double predict_every;
+  int32_t max_deg;
+  /* config.py:55-59 get_path_calculation_config */
+  double maximal_distance_for_valid_path;
+  double mpc_path_length;
+  int32_t mpc_prediction_horizon;
+  /* config.py:124-129 get_default_matching_kwargs */
+  double min_track_width;
+  double max_search_range;
+  double max_search_angle; /* radians */
+  int32_t matches_should_be_monotonic;
+} fsdp_params;
+void fsdp_default_params(fsdp_params* out);
+
 const char* fsdp_version(void);
 int fsdp_result_size(void);                 /* sizeof(fsdp_frame_result), for binding sanity checks */
 int fsdp_device_count(void);                /* number of visible HIP devices (0 if none)            */
@@ -93,7 +125,7 @@ int fsdp_device_count(void);                /* number of visible HIP devices (0 
  * stream, the constant initial previous path of core_calculate_path.py:103-107 computed on device).
  * mission = a value of utils/mission_types.py; 2 (skidpad) makes the context a set of stateful planner instances
  * (fsdp_skidpad_*), every other mission runs the batch entry points below. */
-int fsdp_create(int device, int mission, fsdp_ctx** out);
+int fsdp_create(int device, int mission, const fsdp_params* params /* NULL = the reference's defaults */, fsdp_ctx** out);
 void fsdp_destroy(fsdp_ctx* ctx);
 const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creation error */
 

@@ -379,14 +379,16 @@ bool parcur_fit(const double* u0, const double* x0, const double* y0, int m, int
           term = term + d * d;
           l0 += n;
         }
+        // fppara.f: fpart = fpart+term; if(new.eq.0) go to 180; store = term*half; fpint(i) = fpart-store; ... —
+        // (fpart + term) - term/2, not fpart + term/2: the two round differently, and the knot selection compares
+        // these sums (pinned by tests/golden/params_path.npz frame 119 and splines.npz)
+        fpart = fpart + term;
         if (nw != 0) {
           double store = term * half;
-          fpint[i] = fpart + store;
+          fpint[i] = fpart - store;
           i++;
           fpart = store;
           nw = 0;
-        } else {
-          fpart = fpart + term;
         }
       }
       fpint[nrint] = fpart;

@@ -11,7 +11,10 @@
 namespace fsdo {
 
 static const int T_RIGHT = 1, T_LEFT = 2;
-static const double MIN_TRACK_WIDTH = 3.0, MAJOR_RADIUS = 5 * 1.5, MINOR_RADIUS = 3.0;
+// core_cone_matching.py:101-102: major_radius = max_search_range * 1.5, minor_radius = min_track_width
+#define MIN_TRACK_WIDTH (g_prm.min_track_width)
+#define MAJOR_RADIUS (g_prm.max_search_range * 1.5)
+#define MINOR_RADIUS (g_prm.min_track_width)
 
 // match_directions.py:23-44 calculate_match_search_direction
 static Pts match_search_directions(const Pts& c, int cone_type) {
@@ -29,7 +32,7 @@ static std::vector<char> has_potential_match(const Pts& start, const Pts& dirs, 
   const int M = (int)start.size(), N = (int)other.size();
   std::vector<char> any(M, 0);
   if (M == 0 || N == 0) return any;
-  const double max_search_angle = deg2rad(50);
+  const double max_search_angle = g_prm.max_search_angle;
   const double r0 = MAJOR_RADIUS * MAJOR_RADIUS, r1 = MINOR_RADIUS * MINOR_RADIUS;
   for (int i = 0; i < M; i++) {
     double ang = std::atan2(dirs[i].y, dirs[i].x);

@@ -214,5 +214,27 @@ int fsdo_side_configs(const double* xyt, int n, const double* pose, int cone_typ
 int fsdo_result_size(void) { return (int)sizeof(fsdo_frame_result); }
 
 void fsdo_set_math_mode(int mode) { fsdo::g_math_mode = mode; }
+// 13 values in the order of OParams (ints as doubles); NULL restores the reference's defaults.  Not thread-safe: call
+// between batches.
+void fsdo_set_params(const double* v) {
+  fsdo::OParams p;
+  if (v) {
+    p.max_n_neighbors = (int)v[0];
+    p.max_length = (int)v[1];
+    p.max_dist = v[2];
+    p.max_dist_to_first = v[3];
+    p.threshold_directional_angle = v[4];
+    p.threshold_absolute_angle = v[5];
+    p.min_track_width = v[6];
+    p.max_search_range = v[7];
+    p.max_search_angle = v[8];
+    p.smoothing = v[9];
+    p.predict_every = v[10];
+    p.maximal_distance_for_valid_path = v[11];
+    p.mpc_path_length = v[12];
+  }
+  fsdo::g_prm = p;
+  fsdo::rebuild_default_previous_path();
+}
 int fsdo_get_math_mode(void) { return fsdo::g_math_mode; }
 }

@@ -8,6 +8,18 @@
 
 namespace fsdo {
 
+// The reference's configuration constants (fsd_path_planning/config.py:33-41,48,55-59,124-129); defaults = the factories'
+// values.  One process-wide set (fsdo_set_params), read-only while frames are planned.
+struct OParams {
+  int max_n_neighbors = 5, max_length = 12;
+  double max_dist = 6.5, max_dist_to_first = 6.0, threshold_directional_angle = 40 * (PI / 180.0),
+         threshold_absolute_angle = 65 * (PI / 180.0);
+  double min_track_width = 3.0, max_search_range = 5.0, max_search_angle = 50 * (PI / 180.0);
+  double smoothing = 0.2, predict_every = 0.1, maximal_distance_for_valid_path = 5.0, mpc_path_length = 20.0;
+};
+extern OParams g_prm;
+void rebuild_default_previous_path();
+
 struct Frame {
   int n = 0;
   std::vector<double> x, y;

@@ -22,9 +22,13 @@ double m_atan2(double y, double x) { return g_math_mode ? detm::det_atan2(y, x) 
 double m_cos(double a) { return g_math_mode ? detm::det_cos(a) : std::cos(a); }
 double m_sin(double a) { return g_math_mode ? detm::det_sin(a) : std::sin(a); }
 
-static const double SMOOTHING = 0.2, PREDICT_EVERY = 0.1;  // config.py:48
+// config.py:48 / :55-59, overridable (fsdo_set_params)
+#define SMOOTHING (g_prm.smoothing)
+#define PREDICT_EVERY (g_prm.predict_every)
+#define MAX_DIST_VALID_PATH (g_prm.maximal_distance_for_valid_path)
+#define MPC_PATH_LENGTH (g_prm.mpc_path_length)
+OParams g_prm;
 static const int MAX_DEG = 3;
-static const double MAX_DIST_VALID_PATH = 5.0, MPC_PATH_LENGTH = 20.0;  // config.py:55-59
 static const int HORIZON = FSDO_PATH_POINTS;
 
 // utils/math_utils.py:579-646 circle_fit (hyper fit); returns (cx, cy, r)
@@ -379,6 +383,11 @@ static void build_default() {
 const double (*default_previous_path())[4] {
   std::call_once(g_default_once, build_default);
   return g_default;
+}
+// after fsdo_set_params: the constant initial previous path depends on smoothing / predict_every
+void rebuild_default_previous_path() {
+  std::call_once(g_default_once, build_default);
+  build_default();
 }
 
 // core_calculate_path.py:514-575 run_path_calculation (global_path is None)

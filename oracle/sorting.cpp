@@ -37,7 +37,7 @@ static void mask_first(const Frame& f, int cone_type, std::vector<double>& dist,
   valid.assign(n, 0);
   double car_ang = std::atan2(f.dy, f.dx);
   Rot r(-car_ang);
-  const double max_dist_to_first = 6.0;
+  const double max_dist_to_first = g_prm.max_dist_to_first;
   for (int i = 0; i < n; i++) {
     Vec2 rel = r.apply(f.x[i] - f.px, f.y[i] - f.py);
     double ang = std::atan2(rel.y, rel.x);
@@ -74,7 +74,7 @@ static int select_starting_cone(const Frame& f, int cone_type, const std::vector
     }
   }
   if (best < 0) return -1;
-  if (dist[best] > 6.0) return -1;
+  if (dist[best] > g_prm.max_dist_to_first) return -1;
   return best;
 }
 
@@ -96,7 +96,7 @@ static std::vector<int> select_first_k(const Frame& f, int cone_type) {
   double angle_2 = vec_angle_between(d2x, d2y, f.dx, f.dy);
   if (angle_1 > angle_2) std::swap(index_1, index_2);
   double dist = norm2(d1x, d1y);
-  const double max_dist = 6.5;
+  const double max_dist = g_prm.max_dist;
   if (dist > max_dist * 1.1 || dist < 1.4) return {index_1};
   return {index_2, index_1};
 }
@@ -106,7 +106,7 @@ static std::vector<int> select_first_k(const Frame& f, int cone_type) {
 static void create_adjacency(const Frame& f, int n_neighbors, int start_idx, int cone_type,
                              std::vector<std::vector<int>>& nbrs, int& n_reachable) {
   const int n = f.n;
-  const double max_dist = 6.5;
+  const double max_dist = g_prm.max_dist;
   const int other = invert_cone_type(cone_type);
   // thread-local scratch: an N x N double matrix is 128 KB at N = 128 — above glibc's mmap threshold, so a fresh
   // std::vector per call would mmap/munmap on every frame and serialise many host threads in the kernel
@@ -206,7 +206,7 @@ bool segments_intersect(Vec2 a0, Vec2 a1, Vec2 b0, Vec2 b1) {
 // ---- S9: trace_sorter/end_configurations.py:108-223 ----------------------------------------
 static void neighbor_mask(const Frame& f, int cone_type, const std::vector<int>& attempt, int pos,
                           const std::vector<int>& neighbors, std::vector<char>& can) {
-  const double thr_dir = deg2rad(40), thr_abs = deg2rad(65), car_size = 2.1;
+  const double thr_dir = g_prm.threshold_directional_angle, thr_abs = g_prm.threshold_absolute_angle, car_size = 2.1;
   const int m = (int)neighbors.size();
   can.assign(m, 0);
   double nrm = norm2(f.dx, f.dy);
@@ -605,11 +605,11 @@ SideResult configs_for_one_side(const Frame& f, int cone_type) {
   for (size_t i = 0; i < first_k.size(); i++) res.first_k[i] = first_k[i];
   int start_idx = first_k[0];
   std::vector<int> must = (first_k.size() > 1) ? first_k : std::vector<int>{};
-  int n_neighbors = std::min(5, f.n - 1);
+  int n_neighbors = std::min(g_prm.max_n_neighbors, f.n - 1);
   std::vector<std::vector<int>> nbrs;
   int n_reach = 0;
   create_adjacency(f, n_neighbors, start_idx, cone_type, nbrs, n_reach);
-  int target_length = std::min(n_reach, 12);
+  int target_length = std::min(n_reach, g_prm.max_length);
   std::vector<Config> configs = find_all_end_configurations(f, cone_type, start_idx, nbrs, target_length, must);
   if (configs.empty()) return res;  // NoPathError
   std::vector<double> costs = cost_configurations(f, configs, cone_type);

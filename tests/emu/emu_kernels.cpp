@@ -18,6 +18,8 @@ struct AlignedArena {
   double* data() { return p; }
 };
 
+// configuration constants handed to the kernels (emu_set_params; defaults = fsd_path_planning/config.py)
+static fsdp::Params g_prm = {5, 12, 6.5, 6.0, 40 * FSDP_DEG, 65 * FSDP_DEG, 3.0, 5.0, 50 * FSDP_DEG, 0.2, 0.1, 5.0, 20.0};
 static double g_default_path[fsdp::PATH_POINTS * 4];
 static const double* g_prev_paths = nullptr;
 static const double* g_gpath = nullptr;
@@ -29,7 +31,7 @@ static void build_default() {
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
   AlignedArena arena(fsdp::ARENA_DOUBLES);
-  emu::launch(1, 64, [&]() { fsdp::default_path_kernel(&chord[0][0], arena.data(), g_default_path); });
+  emu::launch(1, 64, [&]() { fsdp::default_path_kernel(&chord[0][0], arena.data(), g_default_path, &g_prm); });
 }
 
 namespace fsdp {
@@ -37,7 +39,7 @@ namespace fsdp {
 __global__ void fit_test_kernel(const double* xy, int m, double smoothing, double* arena, double* t_out, double* c_out, int* info, double* fp_out) {
   __shared__ PathShared<WAVE> S;
   const int lane = lane_id();
-  const Arena A = frame_arena(arena, 0);
+  const Arena A = frame_arena(arena, 0, &g_prm);
   for (int i = lane; i < m; i += WAVE) {
     A.x[i] = xy[2 * i];
     A.y[i] = xy[2 * i + 1];
@@ -70,11 +72,11 @@ static void emu_path_launch(int n_frames, const double* poses, const fsdp::Match
   std::vector<int> retry((size_t)n_frames + 1, 0);
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() {
     fsdp::path_kernel<G>(n_frames, poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out,
-                         G != 64 ? retry.data() : nullptr);
+                         G != 64 ? retry.data() : nullptr, &g_prm);
   });
   if (G != 64)  // like fsdp_lib.hip launch_path: frames beyond the packed kernels' knot capacity go through the G = 64 code
     emu::launch(8, 64, [&]() {
-      fsdp::path_retry_kernel(poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out, retry.data());
+      fsdp::path_retry_kernel(poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out, retry.data(), &g_prm);
     });
 }
 
@@ -88,13 +90,13 @@ static void emu_path_split_launch(int n_frames, const double* poses, const fsdp:
   const unsigned per = 64 / G, perf = 64 / GF;
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() {
     fsdp::path_prep_kernel<G>(n_frames, poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out,
-                              mid.data(), retry.data());
+                              mid.data(), retry.data(), &g_prm);
   });
-  emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data()); });
-  emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G>(n_frames, arena.data(), mid.data(), out, retry.data()); });
+  emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data(), &g_prm); });
+  emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G>(n_frames, arena.data(), mid.data(), out, retry.data(), &g_prm); });
   g_last_retries = retry[0];
   emu::launch(8, 64, [&]() {
-    fsdp::path_retry_kernel(poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out, retry.data());
+    fsdp::path_retry_kernel(poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out, retry.data(), &g_prm);
   });
 }
 
@@ -111,16 +113,16 @@ int emu_sizeof_path_out() { return (int)sizeof(fsdp::PathOut); }
 
 void emu_sort(int n_frames, const int32_t* offsets, const double* cones, const double* poses, fsdp::SortOut* out) {
   std::vector<int> big((size_t)n_frames + 1, 0);
-  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel(n_frames, offsets, cones, poses, out, big.data()); });
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel(n_frames, offsets, cones, poses, out, big.data(), &g_prm); });
   g_last_big = big[0];
   if (big[0] > 0) {
     std::vector<fsdp::SortSharedBig> state(2);
-    emu::launch(2, 64, [&]() { fsdp::sort_big_kernel(offsets, cones, poses, out, big.data(), state.data()); });
+    emu::launch(2, 64, [&]() { fsdp::sort_big_kernel(offsets, cones, poses, out, big.data(), state.data(), &g_prm); });
   }
 }
 void emu_match(int n_frames, const int32_t* offsets, const double* cones, const double* poses, const fsdp::SortOut* sorted,
                fsdp::MatchOut* out) {
-  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::match_kernel(n_frames, offsets, cones, poses, sorted, out); });
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::match_kernel(n_frames, offsets, cones, poses, sorted, out, &g_prm); });
 }
 int emu_sizeof_skid_state() { return (int)sizeof(fsdp::SkidState); }
 int emu_sizeof_skid_info() { return (int)sizeof(fsdp::SkidInfo); }
@@ -140,6 +142,7 @@ void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, c
   T.ref_left[0] = ref4[2];
   T.ref_left[1] = ref4[3];
   T.mean_distance = mean_distance;
+  T.prm = &g_prm;
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
   AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_inst);
@@ -156,6 +159,11 @@ void emu_skidpad_constants(const double* table_xy, int n_table, double* out5) {
   emu::launch(1, 64, [&]() { fsdp::skid_centers_kernel(table_xy, n_table, scratch.data(), out5); });
 }
 
+// 13 values in the order of fsdp::Params (ints as doubles); resets the cached default path
+void emu_set_params(const double* v) {
+  g_prm = fsdp::Params{(int32_t)v[0], (int32_t)v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]};
+  build_default();
+}
 void emu_set_prev_paths(const double* p) { g_prev_paths = p; }
 void emu_set_global_path(const double* xy, int n) {
   g_gpath = xy;

@@ -166,3 +166,19 @@ class SkidpadEmu:
             _p(self.half), ctypes.c_int(len(self.half)), _p(self.noise), ctypes.c_int(len(self.noise)), _p(self.ref),
             ctypes.c_double(self.md), ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(info.ctypes.data))
         return out, info
+
+
+class params:
+    """with emu_lib.params(dict(max_dist=5.5)): ... — the kernel sources with non-default configuration constants."""
+
+    def __init__(self, overrides):
+        import oracle_lib
+
+        self.v = oracle_lib.param_vector(overrides)
+        self.d = oracle_lib.param_vector(None)
+
+    def __enter__(self):
+        lib().emu_set_params(_p(self.v))
+
+    def __exit__(self, *a):
+        lib().emu_set_params(_p(self.d))

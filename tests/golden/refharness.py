@@ -56,7 +56,37 @@ def knn_boundary_tie(xyt: np.ndarray) -> bool:
     return bool((np.diff(head, axis=1) == 0).any())
 
 
-def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True):
+def planner_with_params(m, params):
+    """A reference PathPlanner whose three stage objects are built with `params` (the kwargs of config.py's factories,
+    overridden by name) — exactly what a user of the stage classes would construct by hand."""
+    pp = m["PathPlanner"](m["MissionTypes"].trackdrive)
+    if not params:
+        return pp
+    from fsd_path_planning import config as cfg
+    from fsd_path_planning.calculate_path.core_calculate_path import CalculatePath
+    from fsd_path_planning.cone_matching.core_cone_matching import ConeMatching
+    from fsd_path_planning.sorting_cones.core_cone_sorting import ConeSorting
+
+    mission = m["MissionTypes"].trackdrive
+    sk = cfg.get_cone_sorting_config(mission)
+    sk["experimental_performance_improvements"] = False
+    mk = cfg.get_default_matching_kwargs(mission)
+    mk["matches_should_be_monotonic"] = False  # the pipeline's choice (full_pipeline.py:65)
+    pk = {**cfg.get_path_calculation_config(mission), **cfg.get_cone_fitting_config(mission)}
+    for k, v in params.items():
+        hit = False
+        for d in (sk, mk, pk):
+            if k in d:
+                d[k] = v
+                hit = True
+        assert hit, k
+    pp.cone_sorting = ConeSorting(**sk)
+    pp.cone_matching = ConeMatching(**mk)
+    pp.pathing = CalculatePath(**pk)
+    return pp
+
+
+def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True, params=None):
     """Fresh PathPlanner (trackdrive) on one frame.  Returns dict with status 'ok' or the
     exception class name.  The frame is handed over as the pre-flattened (N,3) array
     (accepted by the sorter, core_trace_sorter.py:40-41) so that index spaces coincide."""
@@ -94,7 +124,7 @@ def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True):
 
     cts.TraceSorter.select_first_k_starting_cones = fk_wrapper
     try:
-        pp = m["PathPlanner"](m["MissionTypes"].trackdrive)
+        pp = planner_with_params(m, params)
         cones = np.ascontiguousarray(xyt, dtype=float) if flattened else split_by_type(xyt)
         try:
             out = pp.calculate_path_in_global_frame(cones, pose[:2].copy(), pose[2:].copy(), return_intermediate_results=True)

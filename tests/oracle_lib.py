@@ -229,3 +229,30 @@ class SkidpadPlanner:
             lib().fsdo_skidpad_destroy(self._h)
         except Exception:
             pass
+
+
+PARAM_ORDER = ["max_n_neighbors", "max_length", "max_dist", "max_dist_to_first", "threshold_directional_angle",
+               "threshold_absolute_angle", "min_track_width", "max_search_range", "max_search_angle", "smoothing", "predict_every",
+               "maximal_distance_for_valid_path", "mpc_path_length"]
+PARAM_DEFAULTS = [5, 12, 6.5, 6.0, float(np.deg2rad(40)), float(np.deg2rad(65)), 3.0, 5.0, float(np.deg2rad(50)), 0.2, 0.1, 5.0, 20.0]
+
+
+def param_vector(overrides=None):
+    v = dict(zip(PARAM_ORDER, PARAM_DEFAULTS))
+    for k, val in (overrides or {}).items():
+        assert k in v, k
+        v[k] = float(val)
+    return np.array([v[k] for k in PARAM_ORDER], dtype=np.float64)
+
+
+class params:
+    """with oracle_lib.params(dict(max_dist=5.5)): ... — the oracle with non-default configuration constants."""
+
+    def __init__(self, overrides):
+        self.v = param_vector(overrides)
+
+    def __enter__(self):
+        lib().fsdo_set_params(_p(self.v))
+
+    def __exit__(self, *a):
+        lib().fsdo_set_params(None)

@@ -225,8 +225,15 @@ def test_stage_classes_mirror_reference_protocol(pkg, golden_dir):
         cp.set_new_input(pkg.PathCalculationInput(lv, rv, l2r, r2l, pose[:2], pose[2:]))
         path, _ = cp.run_path_calculation()
         assert np.abs(path - g["path"][k]).max() < 1e-5 or parity.is_sample_count_flip(path, g["path"][k])
-    with pytest.raises(NotImplementedError):
-        pkg.ConeSorting(max_dist=7.0)
+    # other values travel to the kernels as the context's parameter block (test_non_default_parameters); what the
+    # kernels cannot take is refused when the context is created
+    pkg.ConeSorting(max_dist=7.0)
+    with pytest.raises(TypeError):
+        pkg.ConeSorting(no_such_kwarg=1)
+    with pytest.raises(pkg.FsdpError):
+        cs = pkg.ConeSorting(max_n_neighbors=7)
+        cs.set_new_input(pkg.ConeSortingInput(xyt, pose[:2], pose[2:]))
+        cs.run_cone_sorting()
 
 
 def test_replay_cli_roundtrip(pkg, golden_dir, tmp_path):
@@ -336,3 +343,57 @@ def test_two_contexts_interleaved_from_one_thread(pkg):
     assert np.array_equal(sa["left_idx"], ref_a["left_idx"]) and len(rb) == 160 and len(ra) == 96
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("name", ["params_sort", "params_path"])
+def test_non_default_parameters(pkg, golden_dir, name):
+    """fsdp_create with a parameter block: the reference's stage classes constructed with non-default kwargs (goldens:
+    make_golden.py params_golden) — indices bit-equal, paths within 1e-5 of the reference, bit-equal to the oracle."""
+    g = np.load(golden_dir / f"{name}.npz")
+    prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist()))
+    c = pkg.Context(device=0, mission=4, params=prm)
+    res = c.plan_batch(g["offsets"], g["cones"], g["poses"])
+    rows = _as_oracle_rows(res)
+    cats = collections.Counter()
+    for k in range(len(rows)):
+        cat, detail = parity.compare_frame(rows[k], g, k)
+        cats[cat] += 1
+        assert cat in ("ok", "ref_undefined", "flip"), (k, cat, detail)
+    assert cats["flip"] <= 3, cats
+    with oracle_lib.params(prm), oracle_lib.math_mode(1):
+        ref = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=os.cpu_count() or 1)
+    _assert_equal_to_oracle(res, ref)
+    # a second context with the defaults is unaffected
+    d = np.load(golden_dir / "cfg2_color.npz")
+    c0 = pkg.Context(device=0, mission=4)
+    r0 = c0.plan_batch(d["offsets"], d["cones"], d["poses"])
+    assert np.array_equal(r0["left_idx"], d["left_idx"]) and np.array_equal(c.plan_batch(d["offsets"], d["cones"], d["poses"])["status"] >= 0, np.ones(len(r0), bool))
+    c.close()
+    c0.close()
+
+
+def test_parameters_outside_the_kernels_capacities_are_refused(pkg):
+    for bad in (dict(max_n_neighbors=6), dict(max_length=13), dict(max_deg=2), dict(mpc_prediction_horizon=50),
+                dict(use_unknown_cones=False), dict(matches_should_be_monotonic=True)):
+        with pytest.raises(pkg.FsdpError):
+            pkg.Context(device=0, mission=4, params=bad)
+    with pytest.raises(TypeError):
+        pkg.Context(device=0, mission=4, params=dict(no_such_parameter=1))
+
+
+def test_stage_classes_take_the_reference_kwargs(pkg, golden_dir):
+    """ConeSorting(**kwargs) as the reference constructs it (core_cone_sorting.py:49-100), with a non-default max_length."""
+    g = np.load(golden_dir / "params_sort.npz")
+    prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist()))
+    sk = {k: prm[k] for k in ("max_n_neighbors", "max_dist", "max_dist_to_first", "max_length", "threshold_directional_angle",
+                              "threshold_absolute_angle")}
+    sk["max_n_neighbors"], sk["max_length"] = int(sk["max_n_neighbors"]), int(sk["max_length"])
+    cs = pkg.ConeSorting(device=0, use_unknown_cones=True, experimental_performance_improvements=False, **sk)
+    for k in range(0, 40, 7):
+        if not g["ok"][k]:
+            continue
+        xyt = g["cones"][g["offsets"][k] : g["offsets"][k + 1]]
+        cs.set_new_input(pkg.ConeSortingInput(xyt, g["poses"][k][:2], g["poses"][k][2:]))
+        left, right = cs.run_cone_sorting()
+        assert np.array_equal(left, xyt[g["left_idx"][k][: g["n_left"][k]], :2])
+        assert np.array_equal(right, xyt[g["right_idx"][k][: g["n_right"][k]], :2])

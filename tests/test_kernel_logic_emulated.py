@@ -38,3 +38,28 @@ def test_emulated_kernels_equal_oracle(golden_dir, name, stride, group):
 def test_emulated_default_path_equals_reference(golden_dir):
     ref = np.load(golden_dir / "default_path.npz")["path"]
     assert np.abs(emu_lib.default_path() - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["params_sort", "params_path"])
+def test_emulated_kernels_with_non_default_parameters(golden_dir, name):
+    """The parameter block (include/fsdp.h fsdp_params) through the kernel sources: non-default constructor kwargs of the
+    reference's stage classes, kernels == oracle bit for bit, and both == the reference's goldens."""
+    g = np.load(golden_dir / f"{name}.npz")
+    prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist()))
+    idx = np.arange(0, len(g["ok"]), 3)
+    off = np.concatenate([[0], np.cumsum([g["offsets"][i + 1] - g["offsets"][i] for i in idx])]).astype(np.int32)
+    cones = np.concatenate([g["cones"][g["offsets"][i] : g["offsets"][i + 1]] for i in idx])
+    poses = g["poses"][idx]
+    with emu_lib.params(prm):
+        res, _ = emu_lib.plan(off, cones, poses, 1008)
+    with oracle_lib.params(prm), oracle_lib.math_mode(1):
+        ref = oracle_lib.plan_batch(off, cones, poses)
+    assert np.array_equal(res["status"], ref["status"])
+    ok = ref["status"] == 0
+    for f in ("left_idx", "right_idx", "n_left_v", "n_right_v", "l2r", "r2l", "left_v", "right_v", "path_fallback"):
+        assert np.array_equal(res[f][ok], ref[f][ok]), f
+    parity.assert_intermediates_equal(res, ref, ok)
+    assert np.array_equal(res["path"][ok], ref["path"][ok])
+    for j, k in enumerate(idx):
+        cat, detail = parity.compare_frame(res[j], g, int(k))
+        assert cat in ("ok", "ref_undefined", "flip"), (k, cat, detail)

@@ -49,3 +49,26 @@ def test_empty_and_tiny_frames():
         assert r["status"] == 0 and r["n_left"] == 0 and r["n_right"] == 0
         assert r["path_fallback"] & 1
         assert np.isfinite(r["path"]).all()
+
+
+@pytest.mark.parametrize("name", ["params_sort", "params_path"])
+def test_oracle_with_non_default_parameters(golden_dir, name):
+    """The reference's stage classes constructed with non-default kwargs (fixtures: make_golden.py params_golden): the
+    oracle with the same constants (fsdo_set_params) reproduces indices, matches and paths."""
+    g = np.load(golden_dir / f"{name}.npz")
+    prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist()))
+    with oracle_lib.params(prm):
+        res = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=4)
+    cats = collections.Counter()
+    bad = []
+    for k in range(len(res)):
+        cat, detail = parity.compare_frame(res[k], g, k)
+        cats[cat] += 1
+        if cat in ("IDX", "MATCH", "PATH", "STATUS"):
+            bad.append((k, cat, detail))
+    assert not bad, bad[:5]
+    assert cats["flip"] <= 3, cats
+    # and the defaults are back afterwards
+    d = np.load(golden_dir / "cfg2_color.npz")
+    r = oracle_lib.plan_batch(d["offsets"][:3], d["cones"][: d["offsets"][2]], d["poses"][:2])
+    assert np.array_equal(r["left_idx"], d["left_idx"][:2])
