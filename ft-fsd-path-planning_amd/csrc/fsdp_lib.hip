@@ -1041,6 +1041,46 @@ int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
   return 0;
 }
 
+// ---- device arithmetic self-test ------------------------------------------------------------------------------------------
+// The hand-rolled sequences of spline_device.h against the compiler's IEEE operations, element-wise on the device:
+// out[0][i] = sqrt_1_2(x[i]), out[1][i] = sqrt(x[i]) (x in [1, 2]); out[2][i] = div_rcp(a[i], b[i], rcp_refined(b[i])),
+// out[3][i] = a[i] / b[i]; out[4][i] = div_safe(a[i]) && div_safe(b[i]).
+__global__ void math_selftest_kernel(int n, const double* __restrict__ x, const double* __restrict__ a, const double* __restrict__ b,
+                                     double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = sqrt_1_2(x[i]);
+  out[(size_t)n + i] = sqrt(x[i]);
+  out[2 * (size_t)n + i] = div_rcp(a[i], b[i], rcp_refined(b[i]));
+  out[3 * (size_t)n + i] = a[i] / b[i];
+  out[4 * (size_t)n + i] = (div_safe(a[i]) && div_safe(b[i])) ? 1.0 : 0.0;
+}
+
+extern "C" int fsdp_selftest_math(fsdp_ctx* c, int n, const double* x, const double* a, const double* b, double* out5n) {
+  if (!c || n <= 0 || !x || !a || !b || !out5n) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *dx = nullptr, *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  HIP_TRY(c, hipMalloc(&dx, bytes));
+  HIP_TRY(c, hipMalloc(&da, bytes));
+  HIP_TRY(c, hipMalloc(&db, bytes));
+  HIP_TRY(c, hipMalloc(&dout, 5 * bytes));
+  hipError_t e = hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(math_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dx, da, db, dout);
+    e = hipMemcpyAsync(out5n, dout, 5 * bytes, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dx);
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  HIP_TRY(c, e);
+  return 0;
+}
+
 // ---- multi-GPU: RCCL over xGMI (see fsdp_comm.h) ----------------------------------------------------------------------
 #define NCCL_TRY(ctx, call)                                                                                    \
   do {                                                                                                         \

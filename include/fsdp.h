@@ -240,6 +240,11 @@ int fsdp_comm_allreduce(fsdp_ctx* ctx, double* values, int n, int op);          
 int fsdp_comm_barrier(fsdp_ctx* ctx);        /* waits for this rank's passes in flight, then an all-reduce rendezvous */
 int fsdp_comm_destroy(fsdp_ctx* ctx);        /* also done by fsdp_destroy */
 
+/* Self-test of the device's hand-rolled FP64 sequences against the compiler's IEEE operations (n elements each; out5n =
+ * [sqrt_1_2(x) | sqrt(x) | fast quotient a/b | IEEE a/b | operands inside the fast division's exponent band]): the spline
+ * kernels replace sqrt on [1, 2] and divisions of safe-band operands by shorter sequences that must return the same bits. */
+int fsdp_selftest_math(fsdp_ctx* ctx, int n, const double* x, const double* a, const double* b, double* out5n);
+
 /* The constant initial previous path (core_calculate_path.py:103-107), (40,4), as computed on the device. */
 int fsdp_default_path(fsdp_ctx* ctx, double* out40x4);
 

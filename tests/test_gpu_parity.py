@@ -397,3 +397,27 @@ def test_stage_classes_take_the_reference_kwargs(pkg, golden_dir):
         left, right = cs.run_cone_sorting()
         assert np.array_equal(left, xyt[g["left_idx"][k][: g["n_left"][k]], :2])
         assert np.array_equal(right, xyt[g["right_idx"][k][: g["n_right"][k]], :2])
+
+
+def test_device_math_helpers(ctx):
+    """sqrt_1_2 == sqrt on [1, 2] and the scaling-free quotient == the IEEE division for operands in its exponent band,
+    bit for bit, on 10^6 arguments each (incl. the band's edges, exact quotients, tiny / huge ratios inside the band)."""
+    rng = np.random.default_rng(0)
+    n = 1_000_000
+    x = np.concatenate([rng.uniform(1.0, 2.0, n - 6), [1.0, 2.0, np.nextafter(1.0, 2.0), np.nextafter(2.0, 1.0), 1.5, 1.25]])
+    mant = rng.uniform(1.0, 2.0, (2, n))
+    ea, eb = rng.integers(-250, 250, n), rng.integers(-250, 250, n)
+    a = np.ldexp(mant[0], ea) * rng.choice([-1.0, 1.0], n)
+    b = np.ldexp(mant[1], eb) * rng.choice([-1.0, 1.0], n)
+    a[:1000] = 0.0                      # zero numerators (fresh band rows)
+    a[1000:2000] = b[1000:2000] * 3.0   # exact quotients
+    out = ctx.selftest_math(x, a, b)
+    assert np.array_equal(out[0].view(np.uint64), out[1].view(np.uint64)), int((out[0] != out[1]).sum())
+    assert np.array_equal(out[1], np.sqrt(x))
+    safe = (out[4] == 1.0) | (a == 0.0)
+    assert safe.mean() > 0.99
+    assert np.array_equal(out[2][safe].view(np.uint64), out[3][safe].view(np.uint64)), int((out[2][safe] != out[3][safe]).sum())
+    assert np.array_equal(out[3], a / b)
+    # outside the band the guard reports it (such operands send a frame to the exact kernel)
+    o2 = ctx.selftest_math(np.full(4, 1.5), np.array([1e-300, 1e300, 1.0, 1.0]), np.array([1.0, 1.0, 1e-300, 1e300]))
+    assert (o2[4] == 0.0).all()

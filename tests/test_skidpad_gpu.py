@@ -75,3 +75,54 @@ def test_reset_gives_fresh_planners(pkg, golden_dir):
         else:
             assert all(np.array_equal(a, b) for a, b in zip(first, outs))
         batch.reset()
+
+
+def test_full_size_config5(pkg, golden_dir):
+    """BASELINE config 5 at its full size: 1024 planner instances (rigidly perturbed starts) x all 341 frames of the
+    recording.  Properties on every instance (relocalization, window index, finite paths), instance 0 (the unperturbed
+    recording) against the reference's golden sequence, and 12 sampled instances against stateful oracle planners."""
+    g = sk.load_sequence(golden_dir)
+    n, T = 1024, len(g["poses"])
+    tf = sk.perturbed_instances(g, n)
+    batch = pkg.SkidpadBatch(n, device=0)
+    table, noise = batch.tables
+    sample = [0, 1, 2, 3, 100, 257, 511, 512, 700, 901, 1000, 1023]
+    # vectorised form of skidpad_support.batch_for_step (every instance sees the same cones under its own rigid transform)
+    R = np.stack([r for r, _ in tf])
+    tr = np.stack([t for _, t in tf])
+    reloc_frame = np.full(n, -1)
+    last_idx = np.zeros(n, np.int64)
+    flips0 = 0
+    with oracle_lib.math_mode(1):
+        ops = {i: oracle_lib.SkidpadPlanner(table, noise) for i in sample}
+        for t in range(T):
+            xyt, pose = sk.frame(g, t)
+            m = len(xyt)
+            cones = np.empty((n, m, 3))
+            cones[:, :, :2] = np.einsum("nij,mj->nmi", R, xyt[:, :2]) + tr[:, None, :]
+            cones[:, :, 2] = xyt[:, 2]
+            poses = np.concatenate([np.einsum("nij,j->ni", R, pose[:2]) + tr, np.einsum("nij,j->ni", R, pose[2:])], axis=1)
+            off = (np.arange(n + 1) * m).astype(np.int32)
+            res, info = batch.step(off, cones.reshape(-1, 3), poses)
+            assert (res["status"] == 0).all(), (t, np.unique(res["status"]))
+            assert np.isfinite(res["path"]).all()
+            newly = (info["relocalized"] != 0) & (reloc_frame < 0)
+            reloc_frame[newly] = t
+            rel = info["relocalized"] != 0
+            # the window index never runs backwards by more than the search radius and stays inside the table
+            assert (info["index_along_path"][rel] >= 0).all() and (info["index_along_path"][rel] < len(table) // 2 + 1).all()
+            last_idx[rel] = info["index_along_path"][rel]
+            # instance 0 = the reference's recording
+            e = np.abs(res["path"][0] - g["path"][t]).max()
+            assert bool(info["relocalized"][0]) == bool(g["relocalized"][t])
+            if e > 1e-5:
+                assert 0.1 < e < 0.2, (t, e)
+                flips0 += 1
+            for i, op in ops.items():
+                r, oi = op.step(cones[i], poses[i])
+                assert int(res[i]["status"]) == int(r["status"]) and int(info[i]["relocalized"]) == int(oi[0]), (t, i)
+                assert int(info[i]["index_along_path"]) == int(oi[4]), (t, i)
+                assert np.abs(res[i]["path"] - r["path"]).max() <= 1e-9, (t, i)
+    assert flips0 <= 0.03 * T
+    assert (reloc_frame >= 0).mean() > 0.95, float((reloc_frame >= 0).mean())   # relocalization success count
+    assert np.median(reloc_frame[reloc_frame >= 0]) <= 40
