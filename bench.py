@@ -46,7 +46,7 @@ CFG4_FRAMES, CFG4_CONES_PER_SIDE = 65536, 100  # config 4 (global batch)
 def algo_bytes_per_frame(cones_per_frame: int) -> int:
     """read N*24 + 32 (cones, pose) + write 1280 + 96 + 8: 4488 at N = 128, 6216 at N = 200."""
     return cones_per_frame * 24 + 32 + 1280 + 96 + 8
-PASS_OVERLAP = 6  # passes in flight in the timed region (fsdp_set_overlap); measured 3..8 with tools/ab_variants.py (profiles/README.md)
+PASS_OVERLAP = 8  # passes in flight in the timed region (fsdp_set_overlap); measured 3..8 with tools/ab_variants.py (profiles/README.md)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override the frame count (per GPU for config 2, global for config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="(always measured at N = 1; kept for compatibility)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency loop and the golden flip count (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
     ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..8)")
     args = ap.parse_args()
@@ -268,7 +269,7 @@ def main():
             "arc_extension_frames": arc_frames,
             "lib_sha256_16": _lib_hash(pkg),
         }
-        if world == 1:
+        if world == 1 and not args.no_latency:
             # sample-count flips against the reference, measured on the committed golden fuzz set
             out["flip_count"] = golden_flip_count(pkg, ctx)
             # BASELINE metric, second half: p50 single-frame latency (batch = 1, host buffers, PCIe-inclusive)

@@ -323,7 +323,25 @@ __device__ inline void sort_side_prepare(SH& S, const Params& P, int n, int cone
   const int adj = reuse_adjacency ? 0 : side;
   if (!reuse_adjacency) {
     const int k_nn = (n - 1 < P.max_n_neighbors) ? (n - 1) : P.max_n_neighbors;
-    for (int i = lane; i < n; i += WAVE) {
+    // Cones of the other side's colour neither have neighbours nor are neighbours (their rows and columns of the distance
+    // matrix are inf, adjacency_matrix.py:93-99): the rows and columns that count are compacted first (ascending, in
+    // S.all_list, free until S12), so a coloured frame searches half the matrix.
+    int ncand = 0;
+    for (int w = 0; w * WAVE < n; w++) {
+      const int i = w * WAVE + lane;
+      const bool c = i < n && S.type[i] != other_type;
+      const unsigned long long cm = __ballot(c);
+      if (c) S.all_list[ncand + __popcll(cm & ((1ull << lane) - 1ull))] = (int16_t)i;
+      if (i < n) {
+#pragma unroll
+        for (int q = 0; q < KNN; q++) S.knn[i][q] = (typename SH::idx_t)SH::NONE;
+        S.knn_ok[i] = 0;
+      }
+      ncand += __popcll(cm);
+    }
+    __syncthreads();
+    for (int ci = lane; ci < ncand; ci += WAVE) {
+      const int i = S.all_list[ci];
       double bd[KNN];
       int bj[KNN];
 #pragma unroll
@@ -332,40 +350,36 @@ __device__ inline void sort_side_prepare(SH& S, const Params& P, int n, int cone
         bj[q] = SH::NONE;
       }
       const double xi = S.x[i], yi = S.y[i];
-      const bool row_inf = (S.type[i] == other_type);
-      if (!row_inf) {
-        for (int j0 = 0; j0 < n; j0 += 8) {  // operands eight at a time (group-uniform LDS reads, one round trip)
-          double xj[8], yj[8];
-          int tj8[8];
+      for (int j0 = 0; j0 < ncand; j0 += 8) {  // operands eight at a time (group-uniform LDS reads, one round trip)
+        double xj[8], yj[8];
+        int jj[8];
 #pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const int j = (j0 + e < n) ? j0 + e : n - 1;
-            xj[e] = S.x[j];
-            yj[e] = S.y[j];
-            tj8[e] = S.type[j];
-          }
+        for (int e = 0; e < 8; e++) {
+          jj[e] = S.all_list[(j0 + e < ncand) ? j0 + e : ncand - 1];
+          xj[e] = S.x[jj[e]];
+          yj[e] = S.y[jj[e]];
+        }
 #pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const int j = j0 + e;
-            if (j >= n || j == i || tj8[e] == other_type) continue;
-            double d = cdist_sq(xi, yi, xj[e], yj[e]);
-            if (d < bd[KNN - 1]) {
-              // sorted insertion through registers: strict '<' finds the slot (the earlier index stays first on an exact
-              // tie), from there on every element moves down one slot — a stable order, lowest index first.  (The
-              // reference's np.argsort is unstable: on exact ties its pick depends on the NumPy build)
-              int cj = j;
-              bool ins = false;
+        for (int e = 0; e < 8; e++) {
+          const int j = jj[e];
+          if (j0 + e >= ncand || j == i) continue;
+          double d = cdist_sq(xi, yi, xj[e], yj[e]);
+          if (d < bd[KNN - 1]) {
+            // sorted insertion through registers: strict '<' finds the slot (the earlier index stays first on an exact
+            // tie), from there on every element moves down one slot — a stable order, lowest index first.  (The
+            // reference's np.argsort is unstable: on exact ties its pick depends on the NumPy build)
+            int cj = j;
+            bool ins = false;
 #pragma unroll
-              for (int q = 0; q < KNN; q++) {
-                bool lt = ins || d < bd[q];
-                ins = lt;
-                double td = lt ? bd[q] : d;
-                int tj = lt ? bj[q] : cj;
-                bd[q] = lt ? d : bd[q];
-                bj[q] = lt ? cj : bj[q];
-                d = td;
-                cj = tj;
-              }
+            for (int q = 0; q < KNN; q++) {
+              bool lt = ins || d < bd[q];
+              ins = lt;
+              double td = lt ? bd[q] : d;
+              int tj = lt ? bj[q] : cj;
+              bd[q] = lt ? d : bd[q];
+              bj[q] = lt ? cj : bj[q];
+              d = td;
+              cj = tj;
             }
           }
         }

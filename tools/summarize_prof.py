@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 (rocpd sqlite) outputs — kernel stats + separate PMC passes — into a short text
-summary that is committed under profiles/.  Usage: summarize_prof.py <gpurun_out/prof_TAG>"""
+"""Condense rocprofv3 (rocpd sqlite) outputs — kernel stats + separate PMC passes + the counter calibration — into a
+short text summary that is committed under profiles/, and into pmc_traffic.json (read by bench.py, keyed by the library's
+hash).  Usage: summarize_prof.py <gpurun_out/prof_TAG> [pmc_traffic.json]"""
 import glob
+import hashlib
 import json
+import re
 import sqlite3
 import sys
+from pathlib import Path
 
 out = sys.argv[1]
 json_out = sys.argv[2] if len(sys.argv) > 2 else None
-traffic = {}
+ROOT = Path(__file__).resolve().parent.parent
 FRAMES = 4096
 ALGO_BYTES = 4488  # SURVEY.md 8d, N = 128
+SIMDS, CLOCK_GHZ = 1024, 2.4  # MI355X: 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
 
 
 def db(sub):
@@ -18,49 +23,99 @@ def db(sub):
     return sqlite3.connect(files[0]) if files else None
 
 
-for sub, label in (("trace", "python bench.py --steps 5 --warmup 1 --no-cpu-baseline  [passes overlap 4 deep, as the bench runs]"),
-                   ("trace_serial", "same command with --no-overlap  [one pass after the other]")):
-  con = db(sub)
-  print(f"== rocprofv3 --kernel-trace --stats ({label}) ==")
-  if con:
-      print(f"{'kernel':<28}{'calls':>6}{'avg_us':>12}{'total_ms':>11}{'pct':>7}")
-      for name, calls, tot, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-          print(f"{name.split('(')[0]:<28}{calls:>6}{avg:>12.1f}{tot / 1e3:>11.2f}{pct:>7.2f}")
-      print("-- per-kernel resources --")
-      seen = set()
-      for r in con.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x, duration from kernels"):
-          if r[0] in seen:
-              continue
-          seen.add(r[0])
-          print(f"{r[0].split('(')[0]:<28} vgpr={r[1]} agpr={r[2]} sgpr={r[3]} lds={r[4]}B scratch={r[5]}B/lane wg={r[6]} grid={r[7]}")
-      for name, avg in con.execute("select name, avg(duration) from kernels group by name"):
-          if "fsdp::" in name and "default" not in name:
-              gbs = ALGO_BYTES * FRAMES / (avg * 1e-9) / 1e9
-              print(f"roofline[{name.split('(')[0]}]: avg {avg / 1e3:.1f} us -> algorithmic {gbs:.3f} GB/s = {gbs / 8000:.2e} of 8 TB/s HBM peak")
+def short(name):
+    """'void fsdp::fit_kernel<8, 16>(int, ...)' -> 'fit_kernel<8>' (the names bench.py / fsdp_stage_names use)"""
+    s = name.split("(")[0].replace("void ", "").split("::")[-1].strip()
+    return re.sub(r"<(\d+), \d+>", r"<\1>", s)
 
+
+durations = {}
+for sub, label in (("trace", "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-latency  [passes overlapped, as the bench runs]"),
+                   ("trace_serial", "same command with --no-overlap  [one pass after the other]")):
+    con = db(sub)
+    print(f"== rocprofv3 --kernel-trace --stats ({label}) ==")
+    if con:
+        print(f"{'kernel':<30}{'calls':>6}{'avg_us':>12}{'total_ms':>11}{'pct':>7}")
+        for name, calls, tot, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+            print(f"{short(name):<30}{calls:>6}{avg:>12.1f}{tot / 1e3:>11.2f}{pct:>7.2f}")
+        print("-- per-kernel resources (4096-frame launches) --")
+        seen = set()
+        for r in con.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x from kernels order by grid_x desc"):
+            if r[0] in seen:
+                continue
+            seen.add(r[0])
+            print(f"{short(r[0]):<30} vgpr={r[1]} agpr={r[2]} sgpr={r[3]} lds={r[4]}B scratch={r[5]}B/lane wg={r[6]} grid={r[7]}")
+        for name, avg, cnt in con.execute("select name, avg(duration), count(*) from kernels where grid_x >= 4096 group by name"):
+            if "fsdp::" in name and "default" not in name:
+                gbs = ALGO_BYTES * FRAMES / (avg * 1e-9) / 1e9
+                durations.setdefault(sub, {})[short(name)] = avg
+                print(f"roofline[{short(name)}]: avg {avg / 1e3:.1f} us over {cnt} launches -> algorithmic {gbs:.3f} GB/s = {gbs / 8000:.2e} of 8 TB/s HBM peak")
+
+# counter calibration: 1 GiB moved per kernel
+calib = {}
+for sub, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+    con = db(sub)
+    if not con:
+        continue
+    print(f"== counter calibration ({ctr}, kernels that move exactly 1 048 576 KB; tools/ubench/fetch_calib.hip) ==")
+    for k, c, v, n in con.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name"):
+        if c != ctr:
+            continue
+        kn = short(k)
+        if (ctr == "FETCH_SIZE") == kn.startswith("read"):
+            calib[kn] = 1048576.0 / v if v else None
+            print(f"{kn:<14}{c:<12}{v:>14.1f} KB reported  -> true/reported = {calib[kn]:.3f}")
+
+pmc = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     con = db(sub)
     if not con:
         continue
-    print(f"== rocprofv3 --pmc pass: {sub} (per-dispatch averages) ==")
-    q = "select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name"
-    for k, c, v, n in con.execute(q):
-        if "fsdp::" not in k or "default" in k:
+    print(f"== rocprofv3 --pmc pass: {sub} (per-dispatch averages of the 4096-frame launches) ==")
+    # (dispatches of other sizes — the default-path kernel, flip-count frames — are excluded by their grid size)
+    q = ("select c.kernel_name, c.counter_name, avg(c.value), count(*) from counters_collection c "
+         "where c.grid_size >= 4096 * 8 group by c.kernel_name, c.counter_name")
+    try:
+        rows = list(con.execute(q))
+    except sqlite3.OperationalError:
+        rows = list(con.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name"))
+    for k, c, v, n in rows:
+        if "fsdp::" not in k or "default" in k or "selftest" in k:
             continue
-        extra = ""
-        if c == "FETCH_SIZE":
-            extra = f"  (KB; x2 gfx950 correction for wide coalesced reads -> <= {2 * v / 1024:.2f} MB/launch; algorithmic read {FRAMES * (128 * 24 + 32) / 1e6:.2f} MB)"
-        if c == "WRITE_SIZE":
-            extra = f"  (KB -> {v / 1024:.2f} MB/launch; algorithmic write {FRAMES * 1384 / 1e6:.2f} MB)"
-        print(f"{k.split('(')[0]:<28}{c:<22}{v:>16.1f}  n={n}{extra}")
-        if c in ("FETCH_SIZE", "WRITE_SIZE"):
-            short = k.split("(")[0].replace("void ", "").split("::")[-1]
-            traffic.setdefault(short, {})[c + "_KB"] = round(v, 1)
+        kn = short(k)
+        print(f"{kn:<30}{c:<22}{v:>16.1f}  n={n}")
+        pmc.setdefault(kn, {})[c] = v
 
-if json_out and traffic:
-    for k, d in traffic.items():
-        # HBM bytes per launch: FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE
-        d["hbm_bytes_per_launch"] = int(1024 * (2 * d.get("FETCH_SIZE_KB", 0.0) + d.get("WRITE_SIZE_KB", 0.0)))
-    doc = {"source": f"{out} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per-dispatch averages; "
-                     "tools/profile_gpu.sh)", **traffic}
+if json_out and pmc:
+    f8 = calib.get("read_b64") or 1.0
+    f16 = calib.get("read_rec64") or calib.get("read_b128") or 1.0
+    fw = calib.get("write_b64") or 1.0
+    doc = {"source": f"{out}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes, per-dispatch averages of the "
+                     "4096-frame launches; tools/profile_gpu.sh)",
+           "lib_sha256_16": hashlib.sha256((ROOT / "ft-fsd-path-planning_amd" / "lib" / "libfsdp_hip.so").read_bytes()).hexdigest()[:16],
+           "calibration_true_over_reported": calib,
+           "note": "hbm_bytes_per_launch = FETCH_SIZE x calibration factor + WRITE_SIZE x factor.  The fit / prep / finish kernels "
+                   "read their scratch mostly as 64-byte records (16 B per lane: factor of read_rec64), the sorting and "
+                   "matching kernels read 8 B per lane (factor of read_b64)."}
+    for kn, d in pmc.items():
+        ff = f16 if ("fit" in kn or "prep" in kn or "finish" in kn or "path" in kn) else f8
+        e = {}
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            e["FETCH_SIZE_KB"] = round(d.get("FETCH_SIZE", 0.0), 1)
+            e["WRITE_SIZE_KB"] = round(d.get("WRITE_SIZE", 0.0), 1)
+            e["fetch_factor"] = ff
+            e["hbm_bytes_per_launch"] = int(1024 * (ff * d.get("FETCH_SIZE", 0.0) + fw * d.get("WRITE_SIZE", 0.0)))
+        if "SQ_INSTS_VALU" in d:
+            e["valu_insts_per_frame"] = round(d["SQ_INSTS_VALU"] / FRAMES, 1)
+            dur = durations.get("trace_serial", {}).get(kn)
+            if dur:
+                # share of the chip's VALU issue slots the kernel's wave-instructions fill while it runs alone
+                # (one wave64 FP64/VALU instruction = 4 issue cycles of one SIMD)
+                e["valu_issue_util"] = round(d["SQ_INSTS_VALU"] * 4 / (dur * CLOCK_GHZ * SIMDS), 4)
+            if d.get("SQ_WAVE_CYCLES"):
+                e["valu_active_share_of_wave_cycles"] = round(d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_WAVE_CYCLES"], 3)
+                e["wait_share_of_wave_cycles"] = round(d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"], 3)
+        doc[kn] = e
     json.dump(doc, open(json_out, "w"), indent=1)
+    print("== pmc_traffic.json ==")
+    print(json.dumps(doc, indent=1))
