@@ -541,22 +541,27 @@ __device__ __forceinline__ void giv_begin_run(WS& ws, GivLane& st, int l, int la
 }
 
 // rows [r0, r1) of the chunk buffers (all of the run's interval) into the pipeline; rows still in flight at the end stay
-// in `st`.  The next row is read (group-uniform LDS reads) one step ahead of its use.
+// in `st`.  Two rows per loop trip: a row's registers are refilled (group-uniform LDS reads) right after the step that
+// consumed them, so the read flies during the other row's step and the loop carries no register copies.
 template <bool FAST, class WS>
 __device__ __forceinline__ void giv_feed(WS& ws, GivLane& st, int r0, int r1) {
   st.fed += r1 - r0;
-  double h0 = ws.hq[r0][0], h1 = ws.hq[r0][1], h2 = ws.hq[r0][2], h3 = ws.hq[r0][3], dx = ws.xq[r0], dy = ws.yq[r0];
-  for (int r = r0; r < r1; r++) {
-    const double c0 = h0, c1 = h1, c2 = h2, c3 = h3, cx = dx, cy = dy;
-    const int rn = (r + 1 < r1) ? r + 1 : r;
-    h0 = ws.hq[rn][0];
-    h1 = ws.hq[rn][1];
-    h2 = ws.hq[rn][2];
-    h3 = ws.hq[rn][3];
-    dx = ws.xq[rn];
-    dy = ws.yq[rn];
-    giv_step<FAST>(st, true, c0, c1, c2, c3, cx, cy);
+  struct Row {
+    double h0, h1, h2, h3, x, y;
+  };
+  auto load = [&](int r) {
+    const int q = r < r1 ? r : r1 - 1;
+    return Row{ws.hq[q][0], ws.hq[q][1], ws.hq[q][2], ws.hq[q][3], ws.xq[q], ws.yq[q]};
+  };
+  Row a = load(r0), b = load(r0 + 1);
+  int r = r0;
+  for (; r + 1 < r1; r += 2) {
+    giv_step<FAST>(st, true, a.h0, a.h1, a.h2, a.h3, a.x, a.y);
+    a = load(r + 2);
+    giv_step<FAST>(st, true, b.h0, b.h1, b.h2, b.h3, b.x, b.y);
+    b = load(r + 3);
   }
+  if (r < r1) giv_step<FAST>(st, true, a.h0, a.h1, a.h2, a.h3, a.x, a.y);
 }
 
 // Residual terms sum_d (s_d(u_i) - x_d,i)^2 of one "super-chunk" of points [base, base + cnt) (cnt <= 4 * CH), one point

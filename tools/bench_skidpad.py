@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
-"""BASELINE config 5: 1024 skidpad planner instances replaying demo/skidpad.json (golden copy) with rigidly perturbed
-starts on one MI355X.  Reports frames/s over the whole stateful sequence, relocalization success, kernel time."""
+"""BASELINE config 5: skidpad planner instances replaying demo/skidpad.json (golden copy) with rigidly perturbed starts.
+Reports frames/s over the whole stateful sequence, relocalization success, kernel time.
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher, like bench.py): the planner instances are
+sharded across the ranks, rank 0 alone loads the constant tables (known skidpad path 5786 x 2 f64 = 92 576 B, fixed-seed noise
+table) and every other rank receives them through the RCCL broadcast of the C ABI (fsdp_comm_broadcast) — the only collective
+besides the timing barrier.   python tools/bench_skidpad.py [n_instances_total]"""
 import importlib
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -15,23 +21,39 @@ sys.path.insert(0, str(ROOT / "tests"))
 import skidpad_support as sk  # noqa: E402
 
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n_total = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+comm_ctx = pkg.Context(device=local_rank, mission=4)  # carries the communicator
+d = pkg.dist.Dist(comm_ctx)
+lo, hi = d.frame_range(n_total)  # contiguous shard of the planner instances
+n = hi - lo
+# the track map travels over RCCL: only rank 0 touches the data file
+table = d.broadcast_array(pkg.skidpad.load_tables()[0] if rank == 0 else None, (5786, 2))
+noise = d.broadcast_array(pkg.skidpad.load_tables()[1] if rank == 0 else None, (1140, 3, 2))
 g = sk.load_sequence(ROOT / "tests" / "golden")
-tf = sk.perturbed_instances(g, n)
+tf = sk.perturbed_instances(g, n_total)[lo:hi]
 T = len(g["poses"])
 batches = [sk.batch_for_step(g, t, tf) for t in range(T)]
-batch = pkg.SkidpadBatch(n, device=0)
+batch = pkg.SkidpadBatch(n, device=local_rank, table=table)
+assert np.array_equal(batch.tables[1], noise)
 for t in range(3):  # warm-up on a throw-away state (reference demo does the same, json_demo.py:89-94)
     batch.step(*batches[t])
 batch.reset()
+d.barrier()
 t0 = time.perf_counter()
 status = np.zeros(n, np.int64)
 for t in range(T):
     res, info = batch.step(*batches[t])
     status += res["status"] != 0
-el = time.perf_counter() - t0
+d.barrier()
+el = d.max_over_ranks(time.perf_counter() - t0)
 kms = batch.time_path(10) / 10
-print(json.dumps({"config": "BASELINE configs[4]: skidpad, batch=%d perturbed starts x %d frames" % (n, T),
-                  "frames_per_s_incl_pcie": n * T / el, "seconds": el, "relocalized": int(info["relocalized"].sum()),
-                  "frames_with_nonzero_status": int(status.sum()), "skid_path_kernel_ms_per_step": kms,
-                  "frames_per_s_kernel_only": n / (kms * 1e-3)}))
+reloc = d.sum_over_ranks(float(info["relocalized"].sum()))
+bad = d.sum_over_ranks(float(status.sum()))
+if rank == 0:
+    print(json.dumps({"config": "BASELINE configs[4]: skidpad, batch=%d perturbed starts x %d frames on %d GPU(s)" % (n_total, T, d.world),
+                      "frames_per_s_incl_pcie": n_total * T / el, "seconds": el, "relocalized": int(reloc),
+                      "frames_with_nonzero_status": int(bad), "skid_path_kernel_ms_per_step": kms,
+                      "frames_per_s_kernel_only_per_gpu": n / (kms * 1e-3),
+                      "tables": "rank 0 loads them, RCCL broadcast to the others" if d._active else "single process"}))
+d.close()
