@@ -17,10 +17,6 @@
 #pragma once
 #include "fsdp_device.h"
 
-#ifndef FSDP_SORT_WAVES
-#define FSDP_SORT_WAVES 3
-#endif
-
 namespace fsdp {
 
 // section accounting of the profiling build: PROF_MARK(k) closes the running section and opens section k
@@ -238,7 +234,7 @@ __device__ __forceinline__ double np_sum_reg(const double (&a)[MAX_LEN], int n) 
 // reuse_adjacency: the mutual-kNN lists were built by the other side's call and no cone of the frame carries a side
 // colour, so they are the same for this side (no-colour mode builds them once per frame).
 template <class SH>
-__device__ inline void sort_side_prepare(SH& S, const Params& P, int n, int cone_type, int side, double px, double py, double dx,
+__device__ __forceinline__ void sort_side_prepare(SH& S, const Params& P, int n, int cone_type, int side, double px, double py, double dx,
                                          double dy, bool reuse_adjacency) {
   const int lane = lane_id();
   const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
@@ -570,7 +566,7 @@ __device__ inline void sort_dfs_both(SH& S, const Params& P, double px, double p
 
 // Phase 3 of a side (S10-S12): post filters, side counting, costs, pick.  Returns the frame status of this side.
 template <class SH>
-__device__ inline int sort_side_finish(SH& S, int n, int cone_type, int side, double px, double py, double dx,
+__device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int side, double px, double py, double dx,
                                        double dy) {
   const int lane = lane_id();
   const int other_type = (cone_type == T_LEFT) ? T_RIGHT : T_LEFT;
@@ -1116,7 +1112,7 @@ __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32
 
 // One workgroup (= one wavefront) per frame, frame state in LDS.  big (optional): [0] = counter, [1..] = frames beyond
 // the LDS capacities (more than 255 cones, more than 64 raw end configurations), planned again by sort_big_kernel.
-__global__ void __launch_bounds__(64, FSDP_SORT_WAVES) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
+__global__ void __launch_bounds__(64) sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
                                                   const double* __restrict__ cones_xyt, const double* __restrict__ poses,
                                                   SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
   __shared__ SortShared S;
