@@ -118,6 +118,21 @@ def _pmc(pkg):
         return None
 
 
+def _all_kernel_insts(pmc, names):
+    """VALU wave-instructions per frame summed over the kernels of a pass, or None when a kernel has no counters."""
+    if not pmc:
+        return None
+    tot = 0.0
+    for n in names:
+        v = (pmc.get(n) or {}).get("valu_insts_per_frame")
+        if v is None:
+            if n in ("path_retry_kernel",):
+                continue
+            return None
+        tot += v
+    return tot
+
+
 def golden_flip_count(pkg, ctx):
     """Sample-count flips (120 <-> 121 dense samples, DESIGN.md "arithmetic contract") against the REFERENCE on the
     committed golden fuzz set (tests/golden/fuzz.npz: reference outputs captured by tests/golden/make_golden.py):
@@ -259,7 +274,11 @@ def main():
                 "ms_per_step_serial": ser_total_ms / n_ser,
                 "traffic_unit": "GB per launch (rocprofv3 PMC passes of this very library build, profiles/pmc_traffic.json; null when the recorded library hash differs)",
                 "valu_insts_per_frame": pk.get("valu_insts_per_frame"),
-                "valu_issue_util": pk.get("valu_issue_util"),
+                # FP64 / VALU issue utilisation of the whole chip over the timed region: wave-instructions of every kernel of
+                # a pass (SQ_INSTS_VALU of the committed PMC passes, same library build) x 4 issue cycles / (SIMDs x clock x time)
+                "valu_insts_per_frame_all_kernels": _all_kernel_insts(pmc, names),
+                "valu_issue_util": (_all_kernel_insts(pmc, names) * n_local * 4 / (elapsed / args.steps * 2.4e9 * 1024)
+                                    if _all_kernel_insts(pmc, names) else None),
                 "note": f"algorithmic bytes/frame = {algo_bytes} (SURVEY 8d) x {n_local} frames / average duration of the dominant "
                         "kernel's launches in the timed region (HIP events on the streams the kernels run on; passes overlap, "
                         "so a launch shares the chip with the other streams' kernels — kernel_ms_serial is the same launch "

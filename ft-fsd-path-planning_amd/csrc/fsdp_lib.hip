@@ -321,7 +321,7 @@ static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
     c->stage_names += "path_prep_kernel<" + g + ">,fit_kernel<" + std::to_string(gf) + ">,path_finish_kernel<" + g + ">,";
   }
   mark(q, t);
-  const int rb = n < 128 ? n : 128;
+  const int rb = n < 1024 ? n : 1024;  // one wavefront per SIMD at most; blocks beyond the list's length return at once
   hipLaunchKernelGGL(path_retry_kernel, dim3(rb), dim3(WAVE), 0, q.stream, c->d_poses, q.d_match, c->d_default_path, prev, c->d_gpath,
                      c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
   c->stage_names += "path_retry_kernel";

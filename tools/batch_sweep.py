@@ -16,5 +16,7 @@ for n in sizes:
     ctx.upload(off[: n + 1], cones[: off[n]], poses[:n])
     ctx.time_runs(2)
     tot, st = ctx.time_runs(10)
-    print(json.dumps({"frames": n, "ms": tot / 10, "sort": st[0] / 10, "match": st[1] / 10, "path": st[2] / 10,
-                      "path_us_per_frame": st[2] / 10 / n * 1e3, "frames_per_s": n / (tot / 10) * 1e3}))
+    names = ctx.stage_names()
+    path = sum(st[2:]) / 10
+    print(json.dumps({"frames": n, "ms": round(tot / 10, 3), "kernel_ms": {k: round(v / 10, 3) for k, v in zip(names, st)},
+                      "path_stage_us_per_frame": round(path / n * 1e3, 3), "frames_per_s": round(n / (tot / 10) * 1e3)}), flush=True)

@@ -16,24 +16,28 @@ pkg = importlib.import_module("ft-fsd-path-planning_amd")
 ctx = pkg.Context(device=0)
 
 
+OVERLAP = 8
+
+
 def run(name, off, cones, poses, steps=10):
     ctx.set_overlap(1)
     ctx.upload(off, cones, poses)
     ctx.time_runs(2)
     tot, st = ctx.time_runs(steps)  # one pass after the other: per-launch kernel durations
-    ctx.set_overlap(4)
-    ctx.time_runs(4)
-    tot2, _ = ctx.time_runs(2 * steps)  # four passes in flight (how bench.py runs)
+    names = ctx.stage_names()
+    ctx.set_overlap(OVERLAP)
+    ctx.time_runs(OVERLAP)
+    tot2, _ = ctx.time_runs(4 * steps)  # passes in flight (how bench.py runs)
     res = ctx.download()
     ctx.set_overlap(1)
     n = len(off) - 1
     hist = {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}
     arc = int(((res["path_fallback"] & 16) != 0).sum())
     print(json.dumps({"config": name, "frames": n, "cones_per_frame": int((off[1:] - off[:-1]).mean()),
-                      "ms_per_batch_serial": tot / steps, "frames_per_s_serial": n / (tot / steps) * 1e3,
-                      "ms_per_batch_overlapped": tot2 / (2 * steps), "frames_per_s_overlapped": n / (tot2 / (2 * steps)) * 1e3,
-                      "kernel_ms": {"sort": st[0] / steps, "match": st[1] / steps, "path": st[2] / steps},
-                      "status_histogram": hist, "arc_extension_frames": arc}))
+                      "ms_per_batch_serial": round(tot / steps, 3), "frames_per_s_serial": round(n / (tot / steps) * 1e3),
+                      "ms_per_batch_overlapped": round(tot2 / (4 * steps), 3), "frames_per_s_overlapped": round(n / (tot2 / (4 * steps)) * 1e3),
+                      "pass_overlap": OVERLAP, "kernel_ms_serial": {k: round(v / steps, 3) for k, v in zip(names, st)},
+                      "status_histogram": hist, "arc_extension_frames": arc}), flush=True)
 
 
 g = np.load(ROOT / "tests" / "golden" / "scenarios.npz")
@@ -49,6 +53,6 @@ print(json.dumps({"config": "cfg1: single Hairpin frame through fsdp_plan_batch 
                   "p50_us": float(np.median(lat) * 1e6), "p99_us": float(np.percentile(lat, 99) * 1e6)}))
 run("cfg2: 4096 replay frames, 128 coloured cones", *pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True))
 run("cfg3: 4096 replay frames, 128 cones, no colour", *pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=False))
-run("cfg4 (per-GPU shard): 8192 frames x 200 cones, sigma 0.1", *pkg.synth.make_replay_batch(8192, 100, 0.0, seed=7, frame_noise=0.1, random_pose=True), steps=5)
+run("cfg4 (per-GPU shard of the 65 536): 8192 frames x 200 cones, sigma 0.1", *pkg.synth.make_config4_shard(0, 8192, 100, 0.1, seed=7), steps=5)
 run("cfg4-robustness: 2048 frames x 200 cones, sigma 0.3, no colour", *pkg.synth.make_replay_batch(2048, 100, 0.0, seed=8, frame_noise=0.3, random_pose=True, color=False), steps=5)
 run("scale: 32768 replay frames, 128 coloured cones", *pkg.synth.make_replay_batch(32768, 64, 0.15, seed=1, color=True), steps=3)

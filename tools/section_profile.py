@@ -16,6 +16,9 @@ so = ROOT / "gpurun_out" / "libfsdp_prof.so"
 so.parent.mkdir(exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                 "-DFSDP_PROFILE", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so), "-ldl"], check=True, capture_output=True)
+import os
+
+os.environ.setdefault("FSDP_PACK", "1")  # the packed kernels the overlapped bench runs (a single pass alone would get 16 lanes per frame)
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 pkg._capi.LIB_PATH = so
 ctx = pkg.Context(device=0)
