@@ -429,9 +429,37 @@ __device__ __forceinline__ void sort_side_prepare(SH& S, const Params& P, int n,
   __syncthreads();
   // BFS reachability from start_idx (common.py:36-67); only min(len, 12) is consumed
   int reach = 1;
+  // this lane's cones keep their neighbour lists in registers for the sweeps (product kernel: <= 4 cones per lane); a
+  // sweep then costs one round of independent LDS reads instead of a dependent chain per neighbour
+  constexpr int NWR = (SH::CAP / WAVE <= 4) ? SH::CAP / WAVE : 1;
+  constexpr bool PRELOAD = SH::CAP / WAVE <= 4;
+  int nbq[NWR][KNN];
+  if constexpr (PRELOAD) {
+#pragma unroll
+    for (int w = 0; w < NWR; w++) {
+      const int i = w * WAVE + lane;
+#pragma unroll
+      for (int q = 0; q < KNN; q++) nbq[w][q] = (i < n && q < S.nbr_cnt[adj][i]) ? (int)S.nbr[adj][i][q] : i < n ? i : 0;
+    }
+  }
   for (int it = 0; it < SH::CAP && reach < P.max_length; it++) {
     int add = 0;
     unsigned long long newbits[SH::CAP / WAVE];
+    if constexpr (PRELOAD) {
+#pragma unroll
+      for (int w = 0; w < NWR; w++) {
+        const int i = w * WAVE + lane;
+        bool nv = false;
+        if (w * WAVE < n) {
+          int any = 0;
+#pragma unroll
+          for (int q = 0; q < KNN; q++) any |= S.vis[nbq[w][q]];  // (padding entries point at the cone itself: not visited)
+          nv = i < n && !S.vis[i] && any != 0;
+        }
+        newbits[w] = __ballot(nv);
+        add += __popcll(newbits[w]);
+      }
+    } else {
     for (int w = 0; w * WAVE < n; w++) {
       int i = w * WAVE + lane;
       bool nv = false;
@@ -442,6 +470,7 @@ __device__ __forceinline__ void sort_side_prepare(SH& S, const Params& P, int n,
       }
       newbits[w] = __ballot(nv);
       add += __popcll(newbits[w]);
+    }
     }
     if (add == 0) break;
     __syncthreads();
@@ -678,47 +707,69 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
     n_all += __popcll(mw);
   }
   __syncthreads();
-  // near_mask[j]: any i in all with D[i][j] < 36 (diag 1e7)
+  // near_mask[j]: any i in all with D[i][j] < 36 (diag 1e7) — the 'all' cones eight at a time (indices, then their
+  // coordinates: two LDS round trips per eight instead of two per cone)
+  constexpr int NW = SH::CAP / WAVE;
+  unsigned long long near_w[NW], close_w[NW];
+#pragma unroll
+  for (int w = 0; w < NW; w++) near_w[w] = 0ull;
   for (int w = 0; w < n_words; w++) {
     int j = w * WAVE + lane;
     bool nr = false;
-    if (j < n) {
-      double xj = S.x[j], yj = S.y[j];
-      for (int a = 0; a < n_all && !nr; a++) {
-        int i = S.all_list[a];
-        if (i == j) continue;
-        if (cdist_sq(S.x[i], S.y[i], xj, yj) < 36.0) nr = true;
+    const int jc = j < n ? j : 0;
+    const double xj = S.x[jc], yj = S.y[jc];
+    for (int a0 = 0; a0 < n_all; a0 += 8) {
+      int ia[8];
+      double xa[8], ya[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) ia[e] = S.all_list[(a0 + e < n_all) ? a0 + e : n_all - 1];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        xa[e] = S.x[ia[e]];
+        ya[e] = S.y[ia[e]];
       }
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+        if (a0 + e < n_all && ia[e] != j && cdist_sq(xa[e], ya[e], xj, yj) < 36.0) nr = true;
     }
-    unsigned long long mw = __ballot(nr);
-    if (lane == 0) {
-      S.near_mask[w] = mw;
-      S.close_mask[w] = mw;
-    }
+    const unsigned long long mw = __ballot(nr && j < n);
+#pragma unroll
+    for (int q = 0; q < NW; q++)
+      if (q == w) near_w[q] = mw;
   }
-  __syncthreads();
-  // sorted_set_diff(near_all, all) with the searchsorted quirk (:88-94) — wave-uniform
+  // sorted_set_diff(near_all, all) with the searchsorted quirk (:88-94) on register-resident words (every lane computes
+  // the same): for every b of `all` in ascending order, drop the first element of near_all that is >= b
   {
+#pragma unroll
+    for (int w = 0; w < NW; w++) close_w[w] = near_w[w];
     bool undefined = false;
-    if (lane == 0) {
-      for (int a = 0; a < n_all; a++) {
-        int b = S.all_list[a];
-        // position = first element of near_all >= b
-        int pos = -1;
-        for (int w = b >> 6; w < n_words && pos < 0; w++) {
-          unsigned long long mw = S.near_mask[w];
-          if (w == (b >> 6)) mw &= ~((1ull << (b & 63)) - 1ull);
-          if (mw) pos = w * WAVE + (__ffsll(mw) - 1);
-        }
-        if (pos < 0)
-          undefined = true;
-        else
-          S.close_mask[pos >> 6] &= ~(1ull << (pos & 63));
+    for (int a = 0; a < n_all; a++) {
+      const int b = S.all_list[a];
+      const int bw = b >> 6;
+      int pos = -1;
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        unsigned long long mw = near_w[w];
+        if (w == bw) mw &= ~((1ull << (b & 63)) - 1ull);
+        if (w >= bw && pos < 0 && mw) pos = w * WAVE + (__ffsll(mw) - 1);
+      }
+      if (pos < 0) {
+        undefined = true;
+      } else {
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+          if (w == (pos >> 6)) close_w[w] &= ~(1ull << (pos & 63));
       }
     }
-    undefined = __ballot(undefined) != 0ull;
-    __syncthreads();
     if (undefined) return ST_REF_UNDEFINED_SET_DIFF;
+    if (lane == 0) {
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        S.near_mask[w] = near_w[w];
+        S.close_mask[w] = close_w[w];
+      }
+    }
+    __syncthreads();
   }
   // counts per kept configuration: lane = (configuration, position in it); every lane walks the candidate cones of
   // its pair ("other" = close ∪ (all \ configuration), a few dozen bits) and tests the few that lie within 6 m.
@@ -790,16 +841,24 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
   double my_cost = 0.0;
   if (cme < n_ends && S.keep[cme]) {
     const int16_t* ccfg = S.ends[side][cme];  // this lane's configuration (LDS; dynamic indexing stays out of registers)
-    auto PX = [&](int l) -> double {
-      int idx = ccfg[l];
-      if (idx < 0) idx = n + idx;  // NumPy wrap-around of -1
-      return S.x[idx];
-    };
-    auto PY = [&](int l) -> double {
-      int idx = ccfg[l];
-      if (idx < 0) idx = n + idx;
-      return S.y[idx];
-    };
+    // the configuration's points into registers once (independent LDS reads; every later use indexes statically)
+    double cfx[MAX_LEN], cfy[MAX_LEN];
+    {
+      int ci[MAX_LEN];
+#pragma unroll
+      for (int l = 0; l < MAX_LEN; l++) {
+        int idx = ccfg[l];
+        if (idx < 0) idx = n + idx;  // NumPy wrap-around of -1
+        ci[l] = idx;
+      }
+#pragma unroll
+      for (int l = 0; l < MAX_LEN; l++) {
+        cfx[l] = S.x[ci[l]];
+        cfy[l] = S.y[ci[l]];
+      }
+    }
+    auto PX = [&](int l) -> double { return cfx[l]; };
+    auto PY = [&](int l) -> double { return cfy[l]; };
     int clen = 0;
     for (int l = 0; l < L; l++) clen += (ccfg[l] != -1);
     double tmp[MAX_LEN];  // static indexing only (fully unrolled loops) so that it stays in registers

@@ -421,3 +421,40 @@ def test_device_math_helpers(ctx):
     # outside the band the guard reports it (such operands send a frame to the exact kernel)
     o2 = ctx.selftest_math(np.full(4, 1.5), np.array([1e-300, 1e300, 1.0, 1.0]), np.array([1.0, 1.0, 1e-300, 1e300]))
     assert (o2[4] == 0.0).all()
+
+
+def test_large_sequential_batch_keeps_previous_paths_on_every_route(pkg, ctx, golden_dir):
+    """A lock-step batch above the small-batch threshold (three-kernel path stage) with a caller-supplied previous path per
+    frame: frames that fall back to their previous path (few cones), frames the fast kernels hand to the exact kernel
+    (2-3 centre points: degree < 3) and ordinary frames all see the caller's previous path, not the default one."""
+    g = np.load(golden_dir / "fuzz.npz")
+    rng = np.random.default_rng(5)
+    n = 1600
+    pick = rng.integers(0, len(g["ok"]), n)
+    off = np.concatenate([[0], np.cumsum([g["offsets"][i + 1] - g["offsets"][i] for i in pick])]).astype(np.int32)
+    cones = np.concatenate([g["cones"][g["offsets"][i] : g["offsets"][i + 1]] for i in pick])
+    poses = g["poses"][pick]
+    # previous paths: the default path rigidly moved per frame (so that using the wrong one is visible)
+    base = ctx.default_path()
+    ang = rng.uniform(-0.3, 0.3, n)
+    sh = rng.uniform(-1.0, 1.0, (n, 2))
+    prev = np.repeat(base[None], n, axis=0)
+    c, s_ = np.cos(ang)[:, None], np.sin(ang)[:, None]
+    prev[:, :, 1] = base[None, :, 1] * c - base[None, :, 2] * s_ + sh[:, :1]
+    prev[:, :, 2] = base[None, :, 1] * s_ + base[None, :, 2] * c + sh[:, 1:]
+    res = ctx.plan_batch_sequential(off, cones, poses, prev)
+    assert "path_prep_kernel" in ",".join(ctx.stage_names())  # the three-kernel route really ran
+    n_prev = 0
+    with oracle_lib.math_mode(1):
+        for k in range(0, n, 3):
+            r = oracle_lib.plan_frame_prev(cones[off[k] : off[k + 1]], poses[k], prev[k])
+            assert int(res[k]["status"]) == int(r["status"]), k
+            if r["status"] == 0:
+                assert np.array_equal(res[k]["left_idx"], r["left_idx"]) and int(res[k]["path_fallback"]) == int(r["path_fallback"]), k
+                assert np.abs(res[k]["path"] - r["path"]).max() <= 1e-9, (k, int(r["path_fallback"]))
+                n_prev += bool(int(r["path_fallback"]) & (1 | 2 | 4 | 8))
+    assert n_prev > 50  # plenty of sampled frames really used their previous path
+    # one-shot: the next plain batch is planned with fresh planners again
+    again = ctx.plan_batch(off[:65], cones[: off[64]], poses[:64])
+    fresh = ctx.plan_batch(off[:65], cones[: off[64]], poses[:64])
+    assert np.array_equal(again["path"], fresh["path"], equal_nan=True)
