@@ -122,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
-    "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math",
+    "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
 ]
 
@@ -264,6 +264,13 @@ class Context:
         buf = ctypes.create_string_buffer(256)
         self._check(self._lib.fsdp_stage_names(self._h, buf, 256), "fsdp_stage_names")
         return buf.value.decode().split(",")
+
+    def debug_refit(self):
+        """(n_knots (n,), knots (n,34), coefficients (n,68)) of the refit of every frame of the most recent pass."""
+        n = int(self._lib.fsdp_resident_frames(self._h))
+        nk, t, c = np.zeros(n, np.int32), np.zeros((n, 34)), np.zeros((n, 68))
+        self._check(self._lib.fsdp_debug_refit(self._h, _ip(nk), _dp(t), _dp(c)), "fsdp_debug_refit")
+        return nk, t, c
 
     def selftest_math(self, x, a, b) -> np.ndarray:
         """(5, n): sqrt_1_2(x), sqrt(x), fast a/b, IEEE a/b, operands in the safe band — all computed on the device."""

@@ -1041,6 +1041,31 @@ int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
   return 0;
 }
 
+// ---- per-stage intermediate of the path stage: the refit's spline ------------------------------------------------------
+extern "C" int fsdp_debug_refit(fsdp_ctx* c, int32_t* n_knots, double* knots34, double* coeffs68) {
+  if (!c || !n_knots || !knots34 || !coeffs68 || c->n_frames <= 0) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = sync_all(c);
+  if (rc) return rc;
+  const Slot q = slot_of(c, c->last_slot);
+  const int n = c->n_frames;
+  std::vector<FitRec> recs((size_t)n);
+  std::vector<PathMid> mids((size_t)n);
+  const size_t fit_off = (size_t)(11 * PATH_CAP + ARENA_B + DENSE_CAP) * sizeof(double);  // frame_arena(): A.fit
+  HIP_TRY(c, hipMemcpy2DAsync(recs.data(), sizeof(FitRec), (const char*)q.d_arena + fit_off, sizeof(double) * ARENA_DOUBLES,
+                              sizeof(FitRec), (size_t)n, hipMemcpyDeviceToHost, q.stream));
+  HIP_TRY(c, hipMemcpyAsync(mids.data(), q.d_mid, sizeof(PathMid) * (size_t)n, hipMemcpyDeviceToHost, q.stream));
+  HIP_TRY(c, hipStreamSynchronize(q.stream));
+  for (int i = 0; i < n; i++) {
+    // only frames that went prep -> fit -> finish hold a record (the others took the exact route or ended earlier)
+    const bool fast = c->stage_names.find("fit_kernel") != std::string::npos && mids[i].status == ST_OK;
+    n_knots[i] = fast ? recs[i].n : -1;
+    memcpy(knots34 + (size_t)i * 34, recs[i].t, sizeof(double) * 34);
+    memcpy(coeffs68 + (size_t)i * 68, recs[i].c, sizeof(double) * 68);
+  }
+  return 0;
+}
+
 // ---- device arithmetic self-test ------------------------------------------------------------------------------------------
 // The hand-rolled sequences of spline_device.h against the compiler's IEEE operations, element-wise on the device:
 // out[0][i] = sqrt_1_2(x[i]), out[1][i] = sqrt(x[i]) (x in [1, 2]); out[2][i] = div_rcp(a[i], b[i], rcp_refined(b[i])),

@@ -240,6 +240,12 @@ int fsdp_comm_allreduce(fsdp_ctx* ctx, double* values, int n, int op);          
 int fsdp_comm_barrier(fsdp_ctx* ctx);        /* waits for this rank's passes in flight, then an all-reduce rendezvous */
 int fsdp_comm_destroy(fsdp_ctx* ctx);        /* also done by fsdp_destroy */
 
+/* Per-stage intermediate of the path stage (tests): the smoothing spline of the refit (fit #2,
+ * core_calculate_path.py:239-259 -> utils/spline_fit.py:117 splprep) of every frame of the most recent pass that went
+ * through the three-kernel path stage: n_knots (n_frames) (-1: the frame took another route), knots (n_frames,34),
+ * coefficients (n_frames,68) = x coefficients [0,n) then y coefficients [n,2n). */
+int fsdp_debug_refit(fsdp_ctx* ctx, int32_t* n_knots, double* knots34, double* coeffs68);
+
 /* Self-test of the device's hand-rolled FP64 sequences against the compiler's IEEE operations (n elements each; out5n =
  * [sqrt_1_2(x) | sqrt(x) | fast quotient a/b | IEEE a/b | operands inside the fast division's exponent band]): the spline
  * kernels replace sqrt on [1, 2] and divisions of safe-band operands by shorter sequences that must return the same bits. */

@@ -73,6 +73,9 @@ int fsdo_side_configs(const double* cones_xyt, int n, const double* pose, int co
                       double* costs_out, int max_configs, int32_t* first_k_out /*2*/);
 
 // math mode for the arc extension: 0 = libm (default; reference pinning), 1 = det_math.h (exact parity with the HIP kernels)
+// fsdo_plan_frame + the smoothing splines the frame fitted (utils/spline_fit.py:117 splprep calls), in call order
+enum { FSDO_FIT_KNOTS = 48, FSDO_FIT_STRIDE = 2 + 3 * 48 };
+int fsdo_plan_frame_capture(const double* cones_xyt, int n, const double* pose, fsdo_frame_result* out, double* fits, int max_fits);
 // configuration constants (config.py): 13 doubles [max_n_neighbors, max_length, max_dist, max_dist_to_first,
 // threshold_directional_angle, threshold_absolute_angle, min_track_width, max_search_range, max_search_angle, smoothing,
 // predict_every, maximal_distance_for_valid_path, mpc_path_length]; NULL = defaults.  Process-wide, set between batches.

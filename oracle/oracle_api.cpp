@@ -213,6 +213,28 @@ int fsdo_side_configs(const double* xyt, int n, const double* pose, int cone_typ
 
 int fsdo_result_size(void) { return (int)sizeof(fsdo_frame_result); }
 
+// plan one frame and hand back the smoothing splines it fitted, in call order (the reference's splprep calls inside
+// calculate_path_in_global_frame): up to max_fits records of FSDO_FIT_STRIDE doubles [k, n, t[0..n), cx[0..n), cy[0..n)]
+// (n <= FSDO_FIT_KNOTS, longer knot vectors are truncated and flagged by n > FSDO_FIT_KNOTS).  Returns the number of fits.
+int fsdo_plan_frame_capture(const double* cones_xyt, int n, const double* pose, fsdo_frame_result* out, double* fits, int max_fits) {
+  std::vector<fsdo::Spline> cap;
+  fsdo::g_fit_capture = &cap;
+  fsdo_plan_frame(cones_xyt, n, pose, out);
+  fsdo::g_fit_capture = nullptr;
+  for (int i = 0; i < (int)cap.size() && i < max_fits; i++) {
+    double* r = fits + (size_t)i * FSDO_FIT_STRIDE;
+    const fsdo::Spline& s = cap[i];
+    r[0] = s.k;
+    r[1] = s.n;
+    const int nn = s.n < FSDO_FIT_KNOTS ? s.n : FSDO_FIT_KNOTS;
+    for (int j = 0; j < nn; j++) {
+      r[2 + j] = s.t[j];
+      r[2 + FSDO_FIT_KNOTS + j] = s.cx[j];
+      r[2 + 2 * FSDO_FIT_KNOTS + j] = s.cy[j];
+    }
+  }
+  return (int)cap.size();
+}
 void fsdo_set_math_mode(int mode) { fsdo::g_math_mode = mode; }
 // 13 values in the order of OParams (ints as doubles); NULL restores the reference's defaults.  Not thread-safe: call
 // between batches.

@@ -18,6 +18,8 @@ struct OParams {
   double smoothing = 0.2, predict_every = 0.1, maximal_distance_for_valid_path = 5.0, mpc_path_length = 20.0;
 };
 extern OParams g_prm;
+struct Spline;
+extern thread_local std::vector<Spline>* g_fit_capture;
 void rebuild_default_previous_path();
 
 struct Frame {

@@ -86,6 +86,9 @@ struct Fitted {
   double predict_every = 0;
 };
 
+// optional capture of every fit of a frame, in call order (fsdo_plan_frame_capture: per-stage intermediates for the tests)
+thread_local std::vector<Spline>* g_fit_capture = nullptr;
+
 static Fitted spline_fit(const Pts& trace, double smoothing, double predict_every) {
   Fitted f;
   f.predict_every = predict_every;
@@ -108,6 +111,7 @@ static Fitted spline_fit(const Pts& trace, double smoothing, double predict_ever
     }
   }
   if (!parcur_fit(u.data(), x.data(), y.data(), m, k, smoothing, f.sp)) throw PyValueError{1};
+  if (g_fit_capture) g_fit_capture->push_back(f.sp);
   f.max_u = u[m - 1];
   return f;
 }

@@ -62,6 +62,14 @@ def capture(offsets, cones, poses, frames=None, params=None):
         n_configs_right=np.zeros(F, np.int32),
         best_cost_left=np.zeros(F),
         best_cost_right=np.zeros(F),
+        # the smoothing splines the frame fitted (scipy splprep inside the call), in call order, up to 6: degree, number
+        # of knots, knots, x / y coefficients (padded to 48)
+        n_fits=np.zeros(F, np.int32),
+        fit_k=np.zeros((F, 6), np.int32),
+        fit_n=np.zeros((F, 6), np.int32),
+        fit_t=np.zeros((F, 6, 48)),
+        fit_cx=np.zeros((F, 6, 48)),
+        fit_cy=np.zeros((F, 6, 48)),
     )
     sub_cones, sub_off = [], [0]
     for k, f in enumerate(frames):
@@ -79,6 +87,14 @@ def capture(offsets, cones, poses, frames=None, params=None):
                 out[f"n_configs_{side}"][k] = len(costs)
                 out[f"best_cost_{side}"][k] = costs[0]
         out["knn_tie"][k] = refharness.knn_boundary_tie(xyt)
+        fits = r.get("fits") or []
+        out["n_fits"][k] = len(fits)
+        for q, (kk, t, cx, cy) in enumerate(fits[:6]):
+            nn = min(len(t), 48)
+            out["fit_k"][k, q], out["fit_n"][k, q] = kk, len(t)
+            out["fit_t"][k, q, :nn] = t[:nn]
+            out["fit_cx"][k, q, : min(len(cx), 48)] = cx[:48]
+            out["fit_cy"][k, q, : min(len(cy), 48)] = cy[:48]
         if r["status"] != "ok":
             out["exc"][k] = r["status"]
             continue

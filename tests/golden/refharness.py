@@ -123,8 +123,25 @@ def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True, params=
         return out
 
     cts.TraceSorter.select_first_k_starting_cones = fk_wrapper
+    # the smoothing splines of the frame: every scipy splprep call inside calculate_path_in_global_frame, in call order
+    # (utils/spline_fit.py:117; the planner's constructor fits its initial path before the wrapper is armed)
+    import fsd_path_planning.utils.spline_fit as sfm
+
+    orig_splprep = sfm.splprep
+    captured["fits"] = []
+    armed = [False]
+
+    def splprep_wrapper(x, **kw):
+        res = orig_splprep(x, **kw)
+        if armed[0]:
+            (t, c, k), _u = res
+            captured["fits"].append((int(k), np.array(t), np.array(c[0]), np.array(c[1])))
+        return res
+
+    sfm.splprep = splprep_wrapper
     try:
         pp = planner_with_params(m, params)
+        armed[0] = True
         cones = np.ascontiguousarray(xyt, dtype=float) if flattened else split_by_type(xyt)
         try:
             out = pp.calculate_path_in_global_frame(cones, pose[:2].copy(), pose[2:].copy(), return_intermediate_results=True)
@@ -133,6 +150,7 @@ def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True, params=
     finally:
         cts.calc_final_configs_for_left_and_right = orig
         cts.TraceSorter.select_first_k_starting_cones = orig_fk
+        sfm.splprep = orig_splprep
     path, sl, sr, lv, rv, l2r, r2l = out
     captured["knn_tie"] = knn_boundary_tie(xyt)
     lc = captured["left_config"]
@@ -153,4 +171,5 @@ def run_frame(xyt: np.ndarray, pose: np.ndarray, flattened: bool = True, params=
         first_k=captured["first_k"],
         first_k_tie=captured["first_k_tie"],
         knn_tie=captured["knn_tie"],
+        fits=captured["fits"],
     )

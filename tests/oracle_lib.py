@@ -256,3 +256,23 @@ class params:
 
     def __exit__(self, *a):
         lib().fsdo_set_params(None)
+
+
+FIT_KNOTS, FIT_STRIDE, MAX_FITS = 48, 2 + 3 * 48, 6
+
+
+def plan_frame_capture(xyt, pose):
+    """(result row, [(k, n, t, cx, cy), ...]): the frame and every smoothing spline it fitted, in call order."""
+    xyt = np.ascontiguousarray(xyt, dtype=np.float64).reshape(-1, 3)
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    out = np.zeros(1, dtype=RESULT_DTYPE)
+    buf = np.zeros((MAX_FITS, FIT_STRIDE))
+    lib().fsdo_plan_frame_capture.restype = ctypes.c_int
+    nf = lib().fsdo_plan_frame_capture(_p(xyt), ctypes.c_int(len(xyt)), _p(pose), ctypes.c_void_p(out.ctypes.data), _p(buf), ctypes.c_int(MAX_FITS))
+    fits = []
+    for i in range(min(nf, MAX_FITS)):
+        k, n = int(buf[i, 0]), int(buf[i, 1])
+        nn = min(n, FIT_KNOTS)
+        fits.append((k, n, buf[i, 2 : 2 + nn].copy(), buf[i, 2 + FIT_KNOTS : 2 + FIT_KNOTS + nn].copy(),
+                     buf[i, 2 + 2 * FIT_KNOTS : 2 + 2 * FIT_KNOTS + nn].copy()))
+    return out[0], nf, fits

@@ -458,3 +458,26 @@ def test_large_sequential_batch_keeps_previous_paths_on_every_route(pkg, ctx, go
     again = ctx.plan_batch(off[:65], cones[: off[64]], poses[:64])
     fresh = ctx.plan_batch(off[:65], cones[: off[64]], poses[:64])
     assert np.array_equal(again["path"], fresh["path"], equal_nan=True)
+
+
+def test_refit_spline_equals_oracle(pkg, ctx):
+    """Per-stage intermediate on the device: knots and coefficients of the refit (fit #2, the kernel the roofline line is
+    about) of every sampled frame of a 2048-frame batch equal the oracle's second spline of that frame bit for bit —
+    and the oracle's splines equal the reference's (tests/test_oracle_golden.py::test_oracle_splines_match_reference_per_frame)."""
+    off, cones, poses = pkg.synth.make_replay_batch(2048, 64, 0.15, seed=1, color=True)
+    res = ctx.plan_batch(off, cones, poses)
+    nk, t, c = ctx.debug_refit()
+    assert (nk > 0).mean() > 0.95  # the fast route
+    checked = 0
+    with oracle_lib.math_mode(1):
+        for k in range(0, 2048, 37):
+            if nk[k] <= 0 or res[k]["status"] != 0:
+                continue
+            r, nf, fits = oracle_lib.plan_frame_capture(cones[off[k] : off[k + 1]], poses[k])
+            assert nf == 3, (k, nf)
+            kk, n, tt, cx, cy = fits[1]
+            assert kk == 3 and n == int(nk[k]), (k, n, int(nk[k]))
+            assert np.array_equal(t[k, :n], tt), k
+            assert np.array_equal(c[k, : n - 4], cx[: n - 4]) and np.array_equal(c[k, n : 2 * n - 4], cy[: n - 4]), k
+            checked += 1
+    assert checked >= 40

@@ -72,3 +72,32 @@ def test_oracle_with_non_default_parameters(golden_dir, name):
     d = np.load(golden_dir / "cfg2_color.npz")
     r = oracle_lib.plan_batch(d["offsets"][:3], d["cones"][: d["offsets"][2]], d["poses"][:2])
     assert np.array_equal(r["left_idx"], d["left_idx"][:2])
+
+
+@pytest.mark.parametrize("name", SETS + ["params_sort", "params_path"])
+def test_oracle_splines_match_reference_per_frame(golden_dir, name):
+    """Per-stage intermediates of the path stage: every smoothing spline a frame fits — fit #1 of the centre
+    points, the refit, the parameterization fit, plus the fallback fits where they happen — captured from the reference's
+    scipy.splprep calls inside calculate_path_in_global_frame; the oracle's FITPACK restatement gives the same degree,
+    the same knots and the same coefficients, bit for bit, in the same call order."""
+    g = np.load(golden_dir / f"{name}.npz")
+    prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist())) if "param_names" in g else None
+    n_frames = n_fits = 0
+    with oracle_lib.params(prm or {}):
+        for k in range(0, len(g["ok"]), 2 if len(g["ok"]) > 100 else 1):
+            if not g["ok"][k]:
+                continue
+            xyt = g["cones"][g["offsets"][k] : g["offsets"][k + 1]]
+            r, nf, fits = oracle_lib.plan_frame_capture(xyt, g["poses"][k])
+            if int(r["path_fallback"]) & parity.ARC_FLAG:
+                continue  # libm values (atan2 / sin / cos) enter the polyline of the refit on these frames
+            assert nf == int(g["n_fits"][k]), (k, nf, int(g["n_fits"][k]))
+            for q, (kk, n, t, cx, cy) in enumerate(fits):
+                assert kk == int(g["fit_k"][k, q]) and n == int(g["fit_n"][k, q]), (k, q)
+                nn = min(n, 48)
+                assert np.array_equal(t, g["fit_t"][k, q, :nn]), (k, q, "knots")
+                nc = n - kk - 1  # meaningful coefficients (the rest of scipy's array is padding)
+                assert np.array_equal(cx[:nc], g["fit_cx"][k, q, :nc]) and np.array_equal(cy[:nc], g["fit_cy"][k, q, :nc]), (k, q, "coefficients")
+                n_fits += 1
+            n_frames += 1
+    assert n_frames > 5 and n_fits >= 3 * n_frames - 3
