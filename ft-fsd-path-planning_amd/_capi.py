@@ -10,6 +10,10 @@ import ctypes
 import os
 from pathlib import Path
 
+# multi-process GPU work (RCCL): the host driver only supports dmabuf IPC; must be in the environment before the HIP
+# runtime starts in this process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
