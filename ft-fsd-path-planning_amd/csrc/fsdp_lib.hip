@@ -238,15 +238,26 @@ static int sync_all(fsdp_ctx* c) {
 // Sorting: the LDS kernel for every frame, then the frames beyond its capacities (more than 255 cones, more than 64 raw
 // end configurations per side; list on the device) once more with the frame state in global memory.
 constexpr int SORT_BIG_BLOCKS = 32;
+#ifdef FSDP_LDS_KNOBS
+// experiment builds only: extra dynamic LDS per workgroup (bytes) from the environment, to probe occupancy sensitivity
+static int lds_knob(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+#define DYN_LDS(name) lds_knob(name)
+#else
+#define DYN_LDS(name) 0
+#endif
+
 static void launch_sort(fsdp_ctx* c, const Slot& q) {
   (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
-  hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
+  hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_SORT"), q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
                      q.d_sort, q.d_retry, c->d_params);
   hipLaunchKernelGGL(sort_big_kernel, dim3(SORT_BIG_BLOCKS), dim3(WAVE), 0, q.stream, c->d_off, c->d_cones, c->d_poses, q.d_sort,
                      q.d_retry, c->d_sort_big + (size_t)q.index * SORT_BIG_BLOCKS, c->d_params);
 }
 static void launch_match(fsdp_ctx* c, const Slot& q) {
-  hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), 0, q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
+  hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_MATCH"), q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
                      q.d_sort, q.d_match, c->d_params);
 }
 // ---- the path stage of one pass ------------------------------------------------------------------------------------------
@@ -265,19 +276,19 @@ static void mark(const Slot& q, StageEvents* t) {
 
 template <int GF>
 static void launch_fit(fsdp_ctx* c, const Slot& q) {
-  hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((c->n_frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, q.stream, c->n_frames,
+  hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((c->n_frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), DYN_LDS("FSDP_LDS_FIT"), q.stream, c->n_frames,
                      q.d_arena, q.d_mid, q.d_retry, c->d_params);
 }
 template <int G>
 static void launch_prep(fsdp_ctx* c, const Slot& q, const double* prev) {
   const int n = c->n_frames;
-  hipLaunchKernelGGL(path_prep_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, n, c->d_poses, q.d_match,
+  hipLaunchKernelGGL(path_prep_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, c->d_poses, q.d_match,
                      c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry, c->d_params);
 }
 template <int G>
 static void launch_finish(fsdp_ctx* c, const Slot& q) {
   const int n = c->n_frames;
-  hipLaunchKernelGGL(path_finish_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, n, q.d_arena, q.d_mid, q.d_path,
+  hipLaunchKernelGGL(path_finish_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, q.d_arena, q.d_mid, q.d_path,
                      q.d_retry, c->d_params);
 }
 

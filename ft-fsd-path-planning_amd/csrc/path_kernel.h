@@ -28,7 +28,8 @@ namespace fsdp {
 
 constexpr int PATH_CAP = 1408;  // points of the working polyline (dense fit-#1 output + extension); the acceleration
                                 // mission reaches ~1300 (outbound + return lane of its known path within 30 m)
-constexpr int SEG_CAP = 3 * DENSE_CAP;  // segment-length scratch in LDS (the dense-sample region of the spline workspace)
+
+constexpr int FIT_KNOTS = 16;  // knots the kernels of the three-kernel path stage keep per fit in LDS (more: exact kernel, 64)
 
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
 constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
@@ -48,6 +49,7 @@ static_assert(sizeof(FitRec) <= FITREC_DOUBLES * 8, "FitRec does not fit its are
 struct PathMid {
   int32_t status, fallback, off, n;
 };
+static_assert(ARENA_B >= DENSE_CAP, "raw curvature of a LEAN workspace lives in the smoothness-matrix rows");
 static_assert(ARENA_DOUBLES % 8 == 0 && (3 * PATH_CAP) % 8 == 0, "basis records must stay 64-byte aligned");
 struct Arena {
   double* x;
@@ -55,21 +57,25 @@ struct Arena {
   double* u;
   BasisCache bc;
   double* filt;  // filtered curvature of the dense samples
+  double* curv;  // raw curvature of the dense samples where the LDS workspace has no room for it (LEAN): the rows of
+                 // the smoothness matrix (bc.b), dead once the last fit is done
   FitRec* fit;
   double* band;  // fit_kernel's band triangle between observation passes (FitWS)
   const Params* prm;  // the context's configuration constants
 };
 
 // Per-frame LDS = the spline workspace; while no fit is running the path stage uses its bytes for segment lengths (before
-// fit #3), the <= 20 tail points of the extension, and after fit #3 the dense samples x | y | u and the raw curvature.
-template <int G>
+// fit #3), the <= 20 tail points of the extension, and after fit #3 the dense samples x | y (and, unless LEAN, the raw
+// curvature; LEAN keeps that in the frame's scratch, Arena::curv).
+template <int G, bool LEAN_ = false>
 struct PathShared {
-  SplineWS<G> ws;
+  static constexpr bool LEAN = LEAN_;
+  using WS = SplineWS<G, LEAN_ ? FIT_KNOTS : knot_capacity<G>(), DENSE_CAP, LEAN_>;
+  static constexpr int SEG_CAP = WS::DENSE_ARRAYS * DENSE_CAP;  // segment-length scratch in LDS
+  WS ws;
   __device__ __forceinline__ double* seg() { return ws.dxyu; }
   __device__ __forceinline__ double* dx() { return ws.dxyu; }
   __device__ __forceinline__ double* dy() { return ws.dxyu + DENSE_CAP; }
-  __device__ __forceinline__ double* du() { return ws.dxyu + 2 * DENSE_CAP; }
-  __device__ __forceinline__ double* curv() { return ws.curv; }
 };
 
 // np.sum of a contiguous run (NumPy pairwise summation) — wave-uniform.  The recursion of
@@ -244,11 +250,11 @@ __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? 
 __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
 
 // chord lengths -> parameter values: A.u[off + i] = cumulative length (np.cumsum: sequential order); returns max_u.
-template <int G>
-__device__ __forceinline__ double build_parameter(PathShared<G>& S, const Arena& A, int off, int m) {
+template <int G, class PS>
+__device__ __forceinline__ double build_parameter(PS& S, const Arena& A, int off, int m) {
   PROF(19);
   using GR = Grp<G>;
-  constexpr int CH = SplineWS<G>::CH;
+  constexpr int CH = PS::WS::CH;
   constexpr int NR = CH / G;
   const int lane = GR::lane();
   double acc = 0.0;
@@ -290,8 +296,8 @@ __device__ __forceinline__ double build_parameter(PathShared<G>& S, const Arena&
 // utils/spline_fit.py:95-128 on the arena polyline [off, off+m).  rc: 0 ok, 1 ValueError, >=200 overflow
 // CUBIC (the kernels of the three-kernel path stage): only the degree-3 fit is compiled in; a polyline of fewer than
 // four points sends the frame to the exact kernel (ST_RETRY).
-template <int G, bool FAST, bool CUBIC = false>
-__device__ __forceinline__ int fit_polyline(PathShared<G>& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
+template <int G, bool FAST, bool CUBIC = false, class PS>
+__device__ __forceinline__ int fit_polyline(PS& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
                                    double& max_u) {
   int k = m - 1;
   k = k < 1 ? 1 : (k > 3 ? 3 : k);
@@ -321,13 +327,13 @@ __device__ __forceinline__ int arange_len(double stop, double step) {
 
 // calculate_path/path_parameterization.py:297-328 on the arena polyline [off, off+n).
 // rc: 0 ok (out filled), 1 ValueError, ST_* otherwise.
-template <int G, bool FAST, bool CUBIC = false>
-__device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
+template <int G, bool FAST, bool CUBIC = false, class PS>
+__device__ __forceinline__ int parameterize_path(PS& S, const Arena& A, int off, int n, double (*out)[4], int* n_dense) {
   using GR = Grp<G>;
   const int lane = GR::lane();
   if (n < 2) return ST_REF_UNDEFINED_PATH;
   // _refit_spline :125-161 — segment lengths (LDS when they fit, else the arena's parameter array)
-  double* seg = (n - 1 <= SEG_CAP) ? S.seg() : (A.u + off);
+  double* seg = (n - 1 <= PS::SEG_CAP) ? S.seg() : (A.u + off);
   for (int i = lane; i < n - 1; i += G) {
     double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
     seg[i] = sqrt(dx * dx + dy * dy);
@@ -382,12 +388,15 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
   if (L == 0) return ST_REF_UNDEFINED_PATH;
   double* const DX = S.dx();
   double* const DY = S.dy();
-  double* const DU = S.du();
   {
     PROF(8);
-    eval_spline<CUBIC>(S.ws, f, predict_every, L, DX, DY, DU);
+    eval_spline<CUBIC>(S.ws, f, predict_every, L, DX, DY, nullptr);
   }
-  double* curv = S.curv();
+  double* curv;
+  if constexpr (PS::LEAN)
+    curv = A.curv;
+  else
+    curv = S.ws.curv;
   double* filt = A.filt;
   int window = (L / 5) < 30 ? (L / 5) : 30;
   if (window % 2 == 0) window += 1;
@@ -425,21 +434,26 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
   }
   PROF(18);
   // scipy.ndimage.uniform_filter1d(size = max(2, window // 2), mode = "nearest"): running sum in index order
-  if (lane == 0) {
-    int size = (window / 2) > 2 ? (window / 2) : 2;
-    int s1 = size / 2, s2 = size - s1 - 1;
+  // (tmp += in[i + s2] - in[i - 1 - s1], filt[i] = tmp / size).  The differences are formed one per lane, the running sum
+  // walks them in index order through the group's registers, and the lane that owns sample i stores filt[i].
+  {
+    const int size = (window / 2) > 2 ? (window / 2) : 2;
+    const int s1 = size / 2, s2 = size - s1 - 1;
+    auto clampi = [&](int q) { return q < 0 ? 0 : (q > L - 1 ? L - 1 : q); };
     double tmp = 0.0;
-    for (int j = -s1; j <= s2; j++) {
-      int q = j < 0 ? 0 : (j > L - 1 ? L - 1 : j);
-      tmp += curv[q];
-    }
-    filt[0] = tmp / size;
-    for (int i = 1; i < L; i++) {
-      int qa = i + s2, qb = i - 1 - s1;
-      qa = qa < 0 ? 0 : (qa > L - 1 ? L - 1 : qa);
-      qb = qb < 0 ? 0 : (qb > L - 1 ? L - 1 : qb);
-      tmp += curv[qa] - curv[qb];
-      filt[i] = tmp / size;
+    for (int j = -s1; j <= s2; j++) tmp += curv[clampi(j)];
+    if (lane == 0) filt[0] = tmp / size;
+    for (int base = 1; base < L; base += G) {
+      const int i = base + lane;
+      double d = 0.0;
+      if (i < L) d = curv[clampi(i + s2)] - curv[clampi(i - 1 - s1)];
+      double mine = 0.0;
+      const int cnt = (L - base) < G ? (L - base) : G;
+      for (int r = 0; r < cnt; r++) {
+        tmp += GR::bcast(d, r);
+        if (lane == r) mine = tmp;
+      }
+      if (i < L) filt[i] = mine / size;
     }
   }
   GR::sync();
@@ -457,7 +471,7 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
     if (GR::ballot(dup) != 0ull) return 1;  // "Indices of resampled path appear twice" (ValueError)
     for (int i = lane; i < PATH_POINTS; i += G) {
       int idx = sample_index(i);
-      out[i][0] = DU[idx];
+      out[i][0] = (double)idx * predict_every;  // np.arange(0, max_u, step)[idx]
       out[i][1] = DX[idx];
       out[i][2] = DY[idx];
       out[i][3] = filt[idx];
@@ -471,10 +485,10 @@ __device__ __forceinline__ int parameterize_path(PathShared<G>& S, const Arena& 
 // sequential sum of segment lengths of the arena polyline [off, off+n) with optional early stop:
 // returns the running total; *first_over = index of the first segment whose cumulative length exceeds
 // `limit` (or n-1 if none).  Chunks of segments are staged in LDS; the additions keep np.cumsum's order.
-template <int G>
-__device__ __forceinline__ double cumulative_length(PathShared<G>& S, const Arena& A, int off, int n, double limit, int* first_over) {
+template <int G, class PS>
+__device__ __forceinline__ double cumulative_length(PS& S, const Arena& A, int off, int n, double limit, int* first_over) {
   using GR = Grp<G>;
-  constexpr int CH = SplineWS<G>::CH;
+  constexpr int CH = PS::WS::CH;
   const int lane = GR::lane();
   double acc = 0.0;
   int first = n - 1;
@@ -513,8 +527,8 @@ __device__ __forceinline__ double cumulative_length(PathShared<G>& S, const Aren
 // own kernel: mpc_prepare (connect to the car, extend, trim behind the car -> polyline [off, off+n) to refit),
 // the refit (utils/spline_fit.py, smoothing 0.2), mpc_finish (predict 30 m, cut at 20 m, parameterize).
 // rc as parameterize_path.
-template <int G>
-__device__ __forceinline__ int mpc_prepare(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
+template <int G, class PS>
+__device__ __forceinline__ int mpc_prepare(PS& S, const Arena& A, int n, double px, double py, double dx, double dy,
                                            int* fallback, int* off_out, int* n_out) {
   using GR = Grp<G>;
   const int lane = GR::lane();
@@ -641,8 +655,8 @@ __device__ __forceinline__ int mpc_prepare(PathShared<G>& S, const Arena& A, int
 
 // after refit_path_for_mpc_with_safety_factor's fit :239-259 (knots / coefficients in S.ws, `fitted` false when the
 // polyline had fewer than 2 points): predict to 1.5 * 20 m, cut at 20 m :467-499, parameterize
-template <int G, bool FAST, bool CUBIC = false>
-__device__ __forceinline__ int mpc_finish(PathShared<G>& S, const Arena& A, bool fitted, const SplineFit& f, double (*out)[4],
+template <int G, bool FAST, bool CUBIC = false, class PS>
+__device__ __forceinline__ int mpc_finish(PS& S, const Arena& A, bool fitted, const SplineFit& f, double (*out)[4],
                                           int* n_dense) {
   int n5;
   {
@@ -661,8 +675,8 @@ __device__ __forceinline__ int mpc_finish(PathShared<G>& S, const Arena& A, bool
   return parameterize_path<G, FAST, CUBIC>(S, A, 0, n5, out, n_dense);
 }
 
-template <int G, bool FAST>
-__device__ __forceinline__ int do_all_mpc(PathShared<G>& S, const Arena& A, int n, double px, double py, double dx, double dy,
+template <int G, bool FAST, class PS>
+__device__ __forceinline__ int do_all_mpc(PS& S, const Arena& A, int n, double px, double py, double dx, double dy,
                                  double (*out)[4], int* fallback, int* n_dense) {
   int off = 0;
   int rc = mpc_prepare<G>(S, A, n, px, py, dx, dy, fallback, &off, &n);
@@ -710,8 +724,8 @@ __device__ __forceinline__ int overwrite_if_too_far(const Arena& A, int n1, doub
 
 // core_calculate_path.py:555-575: too-far check + MPC step with its ValueError retry, on the dense path update stored
 // in the arena at [1, 1+n1); prev = previous path (40,4) rows [s, x, y, curvature].  Returns the frame status.
-template <int G, bool FAST>
-__device__ __forceinline__ int finish_path(PathShared<G>& S, const Arena& A, int n1, double px, double py, double dx, double dy,
+template <int G, bool FAST, class PS>
+__device__ __forceinline__ int finish_path(PS& S, const Arena& A, int n1, double px, double py, double dx, double dy,
                                            const double* prev, double (*out)[4], int* fallback, int* n_dense) {
   using GR = Grp<G>;
   const int lane = GR::lane();
@@ -762,6 +776,7 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame, const Par
   A.bc.rec = (BRec*)(b + 3 * PATH_CAP);  // 64-byte aligned: ARENA_DOUBLES and 3 * PATH_CAP are multiples of 8
   A.bc.b = b + 11 * PATH_CAP;
   A.filt = A.bc.b + ARENA_B;
+  A.curv = A.bc.b;
   A.fit = (FitRec*)(A.filt + DENSE_CAP);
   A.band = A.filt + DENSE_CAP + FITREC_DOUBLES;
   A.prm = prm;
@@ -805,13 +820,12 @@ constexpr int PATH_G_LATENCY = 16;
 constexpr int PATH_G_SMALL = 64;
 constexpr int PATH_SMALL_BATCH = 1024;    // frames at or below which every frame gets its own wavefront
 constexpr int PATH_G_SPLIT = 8;           // lanes per frame of path_prep_kernel / path_finish_kernel (three-kernel path stage)
-constexpr int FIT_KNOTS = 16;             // knots fit_kernel keeps per frame in LDS (more: exact kernel, 64)
 constexpr int PATH_LATENCY_BATCH = 4096;  // largest single pass that G = 16 serves with one wavefront per SIMD
 
 // First half of run_path_calculation (core_calculate_path.py:514-553): centre points (or the global path window), fit #1
 // and its dense evaluation.  Leaves the dense path update in the arena [1, 1 + *n1_out); returns the frame status.
-template <int G, bool FAST, bool CUBIC = false>
-__device__ __forceinline__ int path_front(PathShared<G>& S, const Arena& A, const MatchOut* mo, double px, double py,
+template <int G, bool FAST, bool CUBIC = false, class PS>
+__device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut* mo, double px, double py,
                                           const double* prev, const double* __restrict__ gpath, int n_gpath, int* fallback_out,
                                           int* n1_out) {
   using GR = Grp<G>;
@@ -981,8 +995,8 @@ __device__ __forceinline__ void write_path_status(PathOut* o, int status, int fa
 }
 
 // the whole path stage of one frame on one lane group
-template <int G, bool FAST>
-__device__ __forceinline__ void path_frame(PathShared<G>& S, int frame, const double* __restrict__ poses,
+template <int G, bool FAST, class PS>
+__device__ __forceinline__ void path_frame(PS& S, int frame, const double* __restrict__ poses,
                                   const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
                                   const double* __restrict__ prev_paths, const double* __restrict__ gpath, int n_gpath,
                                   double* __restrict__ arena, PathOut* __restrict__ out, const Params* __restrict__ prm) {
@@ -1016,10 +1030,10 @@ __global__ void __launch_bounds__(64) path_prep_kernel(int n_frames, const doubl
                                                        PathOut* __restrict__ out, PathMid* __restrict__ mid, int* __restrict__ retry,
                                                        const Params* __restrict__ prm) {
   using GR = Grp<G>;
-  __shared__ PathShared<G> S_all[WAVE / G];
+  __shared__ PathShared<G, true> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
   if (frame >= n_frames) return;
-  PathShared<G>& S = S_all[GR::index()];
+  PathShared<G, true>& S = S_all[GR::index()];
   const Arena A = frame_arena(arena, frame, prm);
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
   const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
@@ -1047,7 +1061,7 @@ __global__ void __launch_bounds__(64) path_prep_kernel(int n_frames, const doubl
 
 // the refit: utils/spline_fit.py:95-128 (splprep, k = 3, s = 0.2) of the arena polyline [off, off + n), G lanes per frame
 template <int G, int NKC>
-__global__ void __launch_bounds__(64, 2) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
+__global__ void __launch_bounds__(64) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                  int* __restrict__ retry, const Params* __restrict__ prm) {
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;
@@ -1092,10 +1106,10 @@ __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* _
                                                          PathOut* __restrict__ out, int* __restrict__ retry,
                                                          const Params* __restrict__ prm) {
   using GR = Grp<G>;
-  __shared__ PathShared<G> S_all[WAVE / G];
+  __shared__ PathShared<G, true> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
   if (frame >= n_frames || mid[frame].status != ST_OK) return;
-  PathShared<G>& S = S_all[GR::index()];
+  PathShared<G, true>& S = S_all[GR::index()];
   const Arena A = frame_arena(arena, frame, prm);
   const int lane = GR::lane();
   const FitRec* fr = A.fit;

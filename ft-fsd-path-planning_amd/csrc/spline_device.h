@@ -34,10 +34,16 @@ constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121
 // right-hand sides), what only its observation / residual passes need (chunk buffers, knot bookkeeping), what only the
 // smoothing iteration needs (the extended triangle g; the f(p) term buffer overlays it while it is dead), and — when no
 // fit is running — the path stage's dense samples.  The rows of the smoothness matrix b live in the frame's scratch.
-template <int G, int NKC = knot_capacity<G>(), int DCAP = DENSE_CAP>  // DCAP = 1: a fit-only workspace (fit_kernel)
+//
+// LEAN (the prep / finish kernels of the three-kernel path stage, NKC = 16): the no-fit view is the knots | coefficients of
+// the last fit left untouched, then the dense samples x | y only — the raw curvature goes through the frame's scratch —
+// which makes a frame 2 480 bytes, eight frames of a wavefront 19.4 KB (eight workgroups per CU instead of five).
+template <int G, int NKC = knot_capacity<G>(), int DCAP = DENSE_CAP, bool LEAN_ = false>  // DCAP = 1: a fit-only workspace
 struct SplineWS {
   static constexpr int GRP = G;
   static constexpr int NK = NKC;
+  static constexpr bool LEAN = LEAN_;
+  static constexpr int DENSE_ARRAYS = LEAN_ ? 2 : 3;
   static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : 16);  // data rows staged per chunk
   union {
     struct {  // ---- a fit in progress ----
@@ -58,9 +64,10 @@ struct SplineWS {
       };
     };
     struct {  // ---- no fit running (path stage) ----
-      double curv[DCAP];      // raw curvature; overlays t | c: written only after the last spline evaluation
-      double dxyu[3 * DCAP];  // dense samples x | y | u of the final spline; before fit #3 the segment lengths
-                                   // (<= 3 * DENSE_CAP), in the extension the tail points of the polyline
+      double curv[LEAN_ ? 3 * (NK + 2) : DCAP];  // raw curvature; overlays t | c: written only after the last spline
+                                                 // evaluation (LEAN: never written, the bytes of t | c)
+      double dxyu[DENSE_ARRAYS * DCAP];  // dense samples x | y of the final spline (third array: more room for the segment
+                                         // lengths before fit #3); in the extension the tail points of the polyline
     };
   };
   static constexpr bool BAND_GLOBAL = false;

@@ -194,7 +194,7 @@ int fsdp_path_batch(fsdp_ctx* ctx, int n_frames, const double* poses, const doub
 
 /* ---- skidpad mission (BASELINE config 5): stateful planner instances ------------------------------------------------
  * PathPlanner(MissionTypes.skidpad) keeps state across calls (relocalizer transform, SkidpadCalculatePath.index_along_path,
- * previous path: full_pipeline.py:118-194, relocalization/*, calculate_path/skidpad_calculate_path.py).  A context created
+ * previous path: full_pipeline.py:118-194, relocalization/, calculate_path/skidpad_calculate_path.py).  A context created
  * with mission = 2 holds n_instances independent planners; one fsdp_skidpad_step call = one
  * calculate_path_in_global_frame call of every instance (instance i gets frame i of the batch). */
 typedef struct {
