@@ -112,19 +112,47 @@ __device__ __forceinline__ double cdist_sq(double ax, double ay, double bx, doub
   return acc;
 }
 
-// reference utils/math_utils.py:70-100
-__device__ __forceinline__ double angle_between(double ax, double ay, double bx, double by) {
+// reference utils/math_utils.py:70-100: the clipped cosine, then its arc cosine
+__device__ __forceinline__ double cos_between(double ax, double ay, double bx, double by) {
   double c = ax * bx + ay * by;
   c /= sqrt(ax * ax + ay * ay) * sqrt(bx * bx + by * by);
   if (c < -1) c = -1;
   if (c > 1) c = 1;
-  return acos(c);
+  return c;
 }
+__device__ __forceinline__ double angle_between(double ax, double ay, double bx, double by) { return acos(cos_between(ax, ay, bx, by)); }
+// angle_between(...) < thr and > thr for a constant threshold, from the clipped cosine c: the arc cosine is monotone, so
+// the cosine decides unless it lies within 1e-9 of cos(thr) (nine orders of magnitude above acos' rounding) — only then
+// is the arc cosine itself evaluated and compared, like the reference does.  NaN (a zero vector) compares false everywhere.
+__device__ __forceinline__ bool acos_less(double c, double thr, double cos_thr) {
+  if (c > cos_thr + 1e-9) return true;
+  if (c < cos_thr - 1e-9) return false;
+  return acos(c) < thr;
+}
+__device__ __forceinline__ bool acos_greater(double c, double thr, double cos_thr) {
+  if (c < cos_thr - 1e-9) return true;
+  if (c > cos_thr + 1e-9) return false;
+  return acos(c) > thr;
+}
+constexpr double COS_60DEG = 0.5, COS_85DEG = 0.087155742747658173558, COS_150DEG = -0.86602540378443864676;
 
-// reference utils/math_utils.py:663-676: (a1 - a2 + 3pi) % (2pi) - pi  (NumPy floored modulo)
+// reference utils/math_utils.py:663-676: (a1 - a2 + 3pi) % (2pi) - pi  (NumPy floored modulo).  For arguments in
+// [0, 6 pi) — every difference of two atan2 / acos values — the floating-point remainder is x, x - 2pi or x - 4pi, each an
+// exact subtraction (Sterbenz), i.e. the very value fmod returns; anything else takes fmod.
 __device__ __forceinline__ double angle_difference(double a1, double a2) {
-  double m = fmod(a1 - a2 + 3 * FSDP_PI, 2 * FSDP_PI);
-  if (m != 0.0 && m < 0) m += 2 * FSDP_PI;
+  const double x = a1 - a2 + 3 * FSDP_PI;
+  const double T = 2 * FSDP_PI;
+  double m;
+  if (x >= 0 && x < T) {
+    m = x;
+  } else if (x >= T && x < 2 * T) {
+    m = x - T;
+  } else if (x >= 2 * T && x < 3 * T) {
+    m = x - 2 * T;
+  } else {
+    m = fmod(x, T);
+    if (m != 0.0 && m < 0) m += T;
+  }
   return m - FSDP_PI;
 }
 

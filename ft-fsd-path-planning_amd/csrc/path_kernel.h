@@ -1024,7 +1024,8 @@ __device__ __forceinline__ void path_frame(PS& S, int frame, const double* __res
 __device__ __forceinline__ void push_retry(int* retry, int frame) { retry[1 + atomicAdd(&retry[0], 1)] = frame; }
 
 template <int G>
-__global__ void __launch_bounds__(64) path_prep_kernel(int n_frames, const double* __restrict__ poses, const MatchOut* __restrict__ matched,
+// (two wavefronts per SIMD: 256 registers + 44 bytes of spill instead of 259 registers and one wavefront)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) path_prep_kernel(int n_frames, const double* __restrict__ poses, const MatchOut* __restrict__ matched,
                                                        const double* __restrict__ default_path, const double* __restrict__ prev_paths,
                                                        const double* __restrict__ gpath, int n_gpath, double* __restrict__ arena,
                                                        PathOut* __restrict__ out, PathMid* __restrict__ mid, int* __restrict__ retry,

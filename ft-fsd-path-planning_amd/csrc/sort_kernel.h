@@ -143,10 +143,8 @@ __device__ inline bool segments_intersect(double a0x, double a0y, double a1x, do
          (bb - eps <= py && py <= bt + eps);
 }
 
-__device__ inline bool inside_ellipse(double px, double py, double cx, double cy, double dirx, double diry, double major,
-                                      double minor) {
-  // utils/math_utils.py:493-530
-  double ang = atan2(diry, dirx);
+// utils/math_utils.py:493-530; ang = atan2(diry, dirx) of the ellipse's direction vector
+__device__ inline bool inside_ellipse_at(double px, double py, double cx, double cy, double ang, double major, double minor) {
   Rot2 r = make_rot(-ang);
   double qx, qy;
   rot_apply(r, px - cx, py - cy, qx, qy);
@@ -164,7 +162,7 @@ __device__ __forceinline__ bool neighbour_lies_between(const SH& S, int node, in
   double vlx = lx - S.x[nb], vly = ly - S.y[nb];
   double vcx = cx - S.x[nb], vcy = cy - S.y[nb];
   double dc = norm_blas(vcx, vcy), dl = norm_blas(vlx, vly);
-  return dc < 6.0 && dl < 6.0 && angle_between(vlx, vly, vcx, vcy) > 150 * FSDP_DEG;
+  return dc < 6.0 && dl < 6.0 && acos_greater(cos_between(vlx, vly, vcx, vcy), 150 * FSDP_DEG, COS_150DEG);
 }
 
 // `between` = some neighbour of `node` lies between it and the candidate (evaluated by the caller, one (candidate,
@@ -185,7 +183,8 @@ __device__ inline bool candidate_can_be_added(const SH& S, const Params& P, int 
     if (S.attempt[side][q] == cand) return false;
   int sl = (pos >= 1) ? S.attempt[side][pos - 1] : 0;
   if (pos >= 1) {
-    if (!inside_ellipse(cx, cy, lx, ly, lx - S.x[sl], ly - S.y[sl], 6, 3)) return false;
+    // direction of the ellipse = the edge attempt[pos-1] -> node, whose atan2 is ang_sl (same operands)
+    if (!inside_ellipse_at(cx, cy, lx, ly, ang_sl, 6, 3)) return false;
   }
   if (pos == 0) {
     double a_n = atan2(cy - py, cx - px);
@@ -213,8 +212,7 @@ __device__ inline bool candidate_can_be_added(const SH& S, const Params& P, int 
   }
   if (can && pos == 1) {
     int st = S.attempt[side][0];
-    double off = angle_between(dx, dy, cx - S.x[st], cy - S.y[st]);
-    can = off < FSDP_PI / 2;
+    can = acos_less(cos_between(dx, dy, cx - S.x[st], cy - S.y[st]), FSDP_PI / 2, 0.0);
   }
   if (can) {
     const double car_size = 2.1;
@@ -829,8 +827,11 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
             om &= om - 1ull;
             if (idx < n && cdist_sq(xc, yc, S.x[idx], S.y[idx]) < 36.0) {
               double vx = S.x[idx] - xc, vy = S.y[idx] - yc;
-              good += angle_between(vx, vy, sdx, sdy) < (FSDP_PI / 1.5) / 2;
-              bad += angle_between(vx, vy, -sdx, -sdy) < (FSDP_PI / 1.5) / 2;
+              // the cosine towards -dir is the exact negative of the cosine towards +dir (IEEE negation commutes with
+              // every operation of cos_between)
+              const double cg = cos_between(vx, vy, sdx, sdy);
+              good += acos_less(cg, (FSDP_PI / 1.5) / 2, COS_60DEG);
+              bad += acos_less(-cg, (FSDP_PI / 1.5) / 2, COS_60DEG);
             }
           }
         }
@@ -1138,8 +1139,7 @@ __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32
       if (ang > 0) f |= 2;
       if (ang < 0) f |= 4;
       if (fabs(ang) < FSDP_PI - FSDP_PI / 5 && fabs(ang) > FSDP_PI / 10) f |= 8;
-      double a2c = angle_between(S.x[i] - px, S.y[i] - py, dx, dy);
-      if (fabs(a2c) < FSDP_PI / 2) f |= 16;
+      if (acos_less(cos_between(S.x[i] - px, S.y[i] - py, dx, dy), FSDP_PI / 2, 0.0)) f |= 16;  // |angle to the car| < 90 deg
       S.flags[i] = (uint8_t)f;
     }
   }
