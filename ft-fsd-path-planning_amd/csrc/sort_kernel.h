@@ -848,112 +848,115 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
       mval = d < mval ? d : mval;
     }
 
-  // ---------------- S11: cost per configuration (cost_function.py:213-304), lane = configuration ----------------
+  // ---------------- S11: cost per configuration (cost_function.py:213-304) ----------------
+  // Five kept configurations at a time, lane = (configuration k, position a): every lane evaluates the terms of its
+  // position (one turn angle, one segment length, one segment direction), then the twelve lanes of a configuration fetch
+  // each other's terms and add them up in the reference's order (all twelve redundantly; lane a = 0 stores the cost).
   PROF_MARK(6);
   for (int c0 = 0; c0 < n_ends; c0 += WAVE) {
-  const int cme = c0 + lane;
-  double my_cost = 0.0;
-  if (cme < n_ends && S.keep[cme]) {
-    const int16_t* ccfg = S.ends[side][cme];  // this lane's configuration (LDS; dynamic indexing stays out of registers)
-    // the configuration's points into registers once (independent LDS reads; every later use indexes statically)
-    double cfx[MAX_LEN], cfy[MAX_LEN];
-    {
-      int ci[MAX_LEN];
+    unsigned long long km = __ballot(c0 + lane < n_ends && S.keep[(c0 + lane < n_ends) ? c0 + lane : 0]);
+    while (km) {
+      const int k = lane / MAX_LEN, a = lane - k * MAX_LEN;  // k = 5: lanes 60..63 idle
+      int cid = -1;
 #pragma unroll
-      for (int l = 0; l < MAX_LEN; l++) {
-        int idx = ccfg[l];
-        if (idx < 0) idx = n + idx;  // NumPy wrap-around of -1
-        ci[l] = idx;
-      }
-#pragma unroll
-      for (int l = 0; l < MAX_LEN; l++) {
-        cfx[l] = S.x[ci[l]];
-        cfy[l] = S.y[ci[l]];
-      }
-    }
-    auto PX = [&](int l) -> double { return cfx[l]; };
-    auto PY = [&](int l) -> double { return cfy[l]; };
-    int clen = 0;
-    for (int l = 0; l < L; l++) clen += (ccfg[l] != -1);
-    double tmp[MAX_LEN];  // static indexing only (fully unrolled loops) so that it stays in registers
-    // angle cost :41-79
-    double angle_cost;
-    {
-      int na = L - 2;
-      double cnt = 0.0;
-      int under = 0;
-#pragma unroll
-      for (int a = 0; a < MAX_LEN - 2; a++) {
-        if (a >= na) continue;
-        double n0x = PX(a) - PX(a + 1), n0y = PY(a) - PY(a + 1);
-        if (ccfg[a + 1] == -1) n0x = n0y = 100.0;
-        double n1x = PX(a + 1) - PX(a + 2), n1y = PY(a + 1) - PY(a + 2);
-        if (ccfg[a + 2] == -1) n1x = n1y = 100.0;
-        double ang = angle_between(n1x, n1y, -n0x, -n0y);
-        bool is_part = ccfg[a + 2] != -1;
-        double as_cost = (FSDP_PI - ang) / FSDP_PI;
-        tmp[a] = as_cost * (is_part ? 1.0 : 0.0);
-        cnt += is_part ? 1.0 : 0.0;
-        if (ang < 40 * FSDP_DEG && is_part) under++;
-      }
-      angle_cost = np_sum_reg(tmp, na) / cnt * (double)(under + 1);
-    }
-    // residual distance cost (cone_distance_cost.py:15-32)
-    double dist_cost;
-    {
-#pragma unroll
-      for (int l = 0; l < MAX_LEN - 1; l++) {
-        if (l >= L - 1) continue;
-        double ddx = PX(l + 1) - PX(l), ddy = PY(l + 1) - PY(l);
-        double d = sqrt(ddx * ddx + ddy * ddy);
-        d = d * ((ccfg[l + 1] != -1) ? 1.0 : 0.0);
-        tmp[l] = fmax(0.0, d - 3.0);
-      }
-      dist_cost = np_sum_reg(tmp, L - 1);
-    }
-    double ncones_cost = 1.0 / (double)clen;
-    double init_cost = angle_between(PX(1) - PX(0), PY(1) - PY(0), dx, dy);
-    double either_cost;
-    {
-      int d = S.good[cme] - S.bad[cme];
-      d += (mval < 0 ? -mval : mval) + 1;
-      either_cost = 1.0 / (double)d;
-    }
-    double wrong_cost = 0.0;
-    if (clen != 3) {
-      double unwanted = (cone_type == T_LEFT) ? 1.0 : -1.0;
-      int ns = 0;
-      double prev_ang = atan2(PY(1) - PY(0), PX(1) - PX(0));
-#pragma unroll
-      for (int l = 1; l < MAX_LEN - 1; l++) {
-        if (l >= clen - 1) continue;
-        double a2 = atan2(PY(l + 1) - PY(l), PX(l + 1) - PX(l));
-        double diff = angle_difference(prev_ang, a2);
-        if (sign_of(diff) == unwanted && fabs(diff) > 40 * FSDP_DEG) {
-          // compacting append with static indexing
-#pragma unroll
-          for (int q = 0; q < MAX_LEN - 2; q++)
-            if (q == ns) tmp[q] = diff;
-          ns++;
+      for (int q = 0; q < 5; q++)
+        if (km) {
+          if (q == k) cid = c0 + (__ffsll(km) - 1);
+          km &= km - 1ull;
         }
-        prev_ang = a2;
+      const bool act = cid >= 0;
+      const int base = (k < 5) ? k * MAX_LEN : 0;
+      const int16_t* e = S.ends[side][act ? cid : 0];
+      // this position's cone and the two after it (rows are -1 padded to MAX_LEN; -1 wraps to the last cone like NumPy)
+      const int e0 = e[a], e1 = (a + 1 < MAX_LEN) ? e[a + 1] : -1, e2 = (a + 2 < MAX_LEN) ? e[a + 2] : -1;
+      const int i0 = e0 < 0 ? n + e0 : e0, i1 = e1 < 0 ? n + e1 : e1, i2 = e2 < 0 ? n + e2 : e2;
+      const double x0 = S.x[i0], y0 = S.y[i0], x1 = S.x[i1], y1 = S.y[i1], x2 = S.x[i2], y2 = S.y[i2];
+      const unsigned grp_in = (unsigned)((__ballot(act && a < L && e0 != -1) >> base) & 0xFFFull);
+      const int clen = __popc(grp_in);
+      const int na = L - 2;
+      // angle cost term :41-79
+      double t_ang = 0.0;
+      bool is_part = false, under = false;
+      if (act && a < na) {
+        double n0x = x0 - x1, n0y = y0 - y1;
+        if (e1 == -1) n0x = n0y = 100.0;
+        double n1x = x1 - x2, n1y = y1 - y2;
+        if (e2 == -1) n1x = n1y = 100.0;
+        const double ang = angle_between(n1x, n1y, -n0x, -n0y);
+        is_part = e2 != -1;
+        const double as_cost = (FSDP_PI - ang) / FSDP_PI;
+        t_ang = as_cost * (is_part ? 1.0 : 0.0);
+        under = ang < 40 * FSDP_DEG && is_part;
       }
-      wrong_cost = fabs(np_sum_reg(tmp, ns));
+      // residual distance term (cone_distance_cost.py:15-32)
+      double t_dist = 0.0;
+      if (act && a < L - 1) {
+        const double ddx = x1 - x0, ddy = y1 - y0;
+        double d = sqrt(ddx * ddx + ddy * ddy);
+        d = d * ((e1 != -1) ? 1.0 : 0.0);
+        t_dist = fmax(0.0, d - 3.0);
+      }
+      // direction of the segment a -> a + 1, and the turn at a against the unwanted direction :149-188
+      double seg_ang = 0.0;
+      if (act && a < clen - 1) seg_ang = atan2(y1 - y0, x1 - x0);
+      const double prev_seg = __shfl(seg_ang, (lane + WAVE - 1) & (WAVE - 1));
+      double turn = 0.0;
+      bool wrong = false;
+      if (act && a >= 1 && a < clen - 1) {
+        const double unwanted = (cone_type == T_LEFT) ? 1.0 : -1.0;
+        turn = angle_difference(prev_seg, seg_ang);
+        wrong = sign_of(turn) == unwanted && fabs(turn) > 40 * FSDP_DEG;
+      }
+      double init_cost = 0.0;
+      if (act && a == 0) init_cost = angle_between(x1 - x0, y1 - y0, dx, dy);
+      const unsigned part_bits = (unsigned)((__ballot(is_part) >> base) & 0xFFFull);
+      const unsigned under_bits = (unsigned)((__ballot(under) >> base) & 0xFFFull);
+      const unsigned wrong_bits = (unsigned)((__ballot(wrong) >> base) & 0xFFFull);
+      // the configuration's terms to every one of its lanes, then the sums in the reference's order
+      double tmp[MAX_LEN];  // static indexing only (fully unrolled loops) so that it stays in registers
+#pragma unroll
+      for (int q = 0; q < MAX_LEN; q++) tmp[q] = (q < MAX_LEN - 2) ? __shfl(t_ang, (base + q) & (WAVE - 1)) : 0.0;
+      const double angle_cost = np_sum_reg(tmp, na) / (double)__popc(part_bits) * (double)(__popc(under_bits) + 1);
+#pragma unroll
+      for (int q = 0; q < MAX_LEN; q++) tmp[q] = (q < MAX_LEN - 1) ? __shfl(t_dist, (base + q) & (WAVE - 1)) : 0.0;
+      const double dist_cost = np_sum_reg(tmp, L - 1);
+      const double ncones_cost = 1.0 / (double)clen;
+      double wrong_cost = 0.0;
+      {
+        int ns = 0;
+#pragma unroll
+        for (int l = 1; l < MAX_LEN - 1; l++) {
+          const double tl = __shfl(turn, (base + l) & (WAVE - 1));
+          if ((wrong_bits >> l) & 1u) {
+            // compacting append with static indexing
+#pragma unroll
+            for (int q = 0; q < MAX_LEN - 2; q++)
+              if (q == ns) tmp[q] = tl;
+            ns++;
+          }
+        }
+        if (clen != 3) wrong_cost = fabs(np_sum_reg(tmp, ns));
+      }
+      if (act && a == 0) {
+        double either_cost;
+        {
+          int d = S.good[cid] - S.bad[cid];
+          d += (mval < 0 ? -mval : mval) + 1;
+          either_cost = 1.0 / (double)d;
+        }
+        const double f0 = 1000.0 / 9200.0, f1 = 200.0 / 9200.0, f2 = 5000.0 / 9200.0, f3 = 1000.0 / 9200.0, f4 = 0.0 / 9200.0;
+        // np.sum over the 7 weighted columns (n < 8: sequential from 0); weights [1000,200,5000,1000,0,1000,1000] / 9200
+        double my_cost = 0.0;
+        my_cost += angle_cost * f0;
+        my_cost += dist_cost * f1;
+        my_cost += ncones_cost * f2;
+        my_cost += init_cost * f3;
+        my_cost += 0.0 * f4;
+        my_cost += either_cost * f3;
+        my_cost += wrong_cost * f3;
+        S.cost[cid] = my_cost;
+      }
     }
-    const double fsum = ((1000.0 + 200.0) + (5000.0 + 1000.0)) + ((0.0 + 1000.0) + 1000.0);  // np.sum of 7: sequential
-    double f0 = 1000.0 / 9200.0, f1 = 200.0 / 9200.0, f2 = 5000.0 / 9200.0, f3 = 1000.0 / 9200.0, f4 = 0.0 / 9200.0;
-    (void)fsum;
-    // np.sum over the 7 weighted columns (n < 8: sequential from 0)
-    my_cost = 0.0;
-    my_cost += angle_cost * f0;
-    my_cost += dist_cost * f1;
-    my_cost += ncones_cost * f2;
-    my_cost += init_cost * f3;
-    my_cost += 0.0 * f4;
-    my_cost += either_cost * f3;
-    my_cost += wrong_cost * f3;
-  }
-  if (cme < n_ends) S.cost[cme] = my_cost;
   }
   // argmin with np.unique's lexicographic row order as tie-break (argsort is stable for the short arrays here)
   {
