@@ -347,6 +347,12 @@ __device__ __forceinline__ void sort_side_prepare(SH& S, const Params& P, int n,
       ncand += __popcll(cm);
     }
     __syncthreads();
+    // Only neighbours within max_dist survive the d^2 > max_dist^2 drop (adjacency_matrix.py:105-107), and the k nearest
+    // of a cone that lie within max_dist are the k nearest of its in-range cones: a first sweep over the candidates
+    // marks the in-range ones of every lane's cone (a bit per candidate position), a second one inserts just those — a
+    // handful per cone — into the sorted list.
+    const double md2 = P.max_dist * P.max_dist;
+    constexpr int MW = SH::CAP / WAVE;
     for (int ci = lane; ci < ncand; ci += WAVE) {
       const int i = S.all_list[ci];
       double bd[KNN];
@@ -357,6 +363,9 @@ __device__ __forceinline__ void sort_side_prepare(SH& S, const Params& P, int n,
         bj[q] = SH::NONE;
       }
       const double xi = S.x[i], yi = S.y[i];
+      unsigned long long inr[MW];
+#pragma unroll
+      for (int w = 0; w < MW; w++) inr[w] = 0ull;
       for (int j0 = 0; j0 < ncand; j0 += 8) {  // operands eight at a time (group-uniform LDS reads, one round trip)
         double xj[8], yj[8];
         int jj[8];
@@ -366,28 +375,43 @@ __device__ __forceinline__ void sort_side_prepare(SH& S, const Params& P, int n,
           xj[e] = S.x[jj[e]];
           yj[e] = S.y[jj[e]];
         }
+        unsigned long long bits8 = 0ull;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          const int j = jj[e];
-          if (j0 + e >= ncand || j == i) continue;
-          double d = cdist_sq(xi, yi, xj[e], yj[e]);
-          if (d < bd[KNN - 1]) {
-            // sorted insertion through registers: strict '<' finds the slot (the earlier index stays first on an exact
-            // tie), from there on every element moves down one slot — a stable order, lowest index first.  (The
-            // reference's np.argsort is unstable: on exact ties its pick depends on the NumPy build)
-            int cj = j;
-            bool ins = false;
+          const bool in = j0 + e < ncand && jj[e] != i && cdist_sq(xi, yi, xj[e], yj[e]) <= md2;
+          bits8 |= (unsigned long long)in << e;
+        }
 #pragma unroll
-            for (int q = 0; q < KNN; q++) {
-              bool lt = ins || d < bd[q];
-              ins = lt;
-              double td = lt ? bd[q] : d;
-              int tj = lt ? bj[q] : cj;
-              bd[q] = lt ? d : bd[q];
-              bj[q] = lt ? cj : bj[q];
-              d = td;
-              cj = tj;
-            }
+        for (int w = 0; w < MW; w++)
+          if (w == (j0 >> 6)) inr[w] |= bits8 << (j0 & 63);
+      }
+      for (;;) {
+        int pos = -1;
+#pragma unroll
+        for (int w = 0; w < MW; w++)
+          if (pos < 0 && inr[w] != 0ull) {
+            pos = w * WAVE + (__ffsll(inr[w]) - 1);
+            inr[w] &= inr[w] - 1ull;
+          }
+        if (pos < 0) break;
+        const int j = S.all_list[pos];
+        double d = cdist_sq(xi, yi, S.x[j], S.y[j]);
+        if (d < bd[KNN - 1]) {
+          // sorted insertion through registers: strict '<' finds the slot (the earlier index stays first on an exact
+          // tie), from there on every element moves down one slot — a stable order, lowest index first.  (The
+          // reference's np.argsort is unstable: on exact ties its pick depends on the NumPy build)
+          int cj = j;
+          bool ins = false;
+#pragma unroll
+          for (int q = 0; q < KNN; q++) {
+            bool lt = ins || d < bd[q];
+            ins = lt;
+            double td = lt ? bd[q] : d;
+            int tj = lt ? bj[q] : cj;
+            bd[q] = lt ? d : bd[q];
+            bj[q] = lt ? cj : bj[q];
+            d = td;
+            cj = tj;
           }
         }
       }
@@ -396,7 +420,7 @@ __device__ __forceinline__ void sort_side_prepare(SH& S, const Params& P, int n,
       for (int q = 0; q < KNN; q++) {
         bool in_k = (q < k_nn) && (bj[q] != SH::NONE);
         S.knn[i][q] = in_k ? (typename SH::idx_t)bj[q] : (typename SH::idx_t)SH::NONE;
-        if (in_k && !(bd[q] > P.max_dist * P.max_dist)) okm |= (1 << q);
+        if (in_k) okm |= (1 << q);  // (every listed neighbour lies within max_dist)
       }
       S.knn_ok[i] = (uint8_t)okm;
     }
