@@ -1062,7 +1062,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
 
 // the refit: utils/spline_fit.py:95-128 (splprep, k = 3, s = 0.2) of the arena polyline [off, off + n), G lanes per frame
 template <int G, int NKC>
-__global__ void __launch_bounds__(64) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
+// (three wavefronts per SIMD: 168 registers, measured +2 % frames/s over two)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                  int* __restrict__ retry, const Params* __restrict__ prm) {
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;

@@ -577,7 +577,7 @@ __device__ __forceinline__ void giv_feed(WS& ws, GivLane& st, int r0, int r1) {
 // "a new knot interval starts at this point" flags to fbuf.  The caller issues the next super-chunk's load() before
 // the serial accumulation of the current one, so the scratch round trip hides behind it.
 #ifndef RB_MAX_ROUNDS
-#define RB_MAX_ROUNDS 4  // rounds of a residual super-chunk held in registers
+#define RB_MAX_ROUNDS 2  // rounds of a residual super-chunk held in registers (2: fit_kernel fits three wavefronts per SIMD)
 #endif
 template <int K, int G, bool FLAGS, int CHV>
 struct ResidualBatch {
