@@ -24,7 +24,7 @@ import os
 
 # several passes in flight = one HIP stream each; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
 # RCCL / the null stream take queues too — must be set before the HIP runtime starts in this process
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import argparse
 import importlib
@@ -46,7 +46,8 @@ CFG4_FRAMES, CFG4_CONES_PER_SIDE = 65536, 100  # config 4 (global batch)
 def algo_bytes_per_frame(cones_per_frame: int) -> int:
     """read N*24 + 32 (cones, pose) + write 1280 + 96 + 8: 4488 at N = 128, 6216 at N = 200."""
     return cones_per_frame * 24 + 32 + 1280 + 96 + 8
-PASS_OVERLAP = 8  # passes in flight in the timed region (fsdp_set_overlap); measured 3..8 with tools/ab_variants.py (profiles/README.md)
+PASS_OVERLAP = 10  # passes in flight in the timed region (fsdp_set_overlap); measured 4..20 (profiles/README.md): the steady rate
+# saturates at 8, a 20-pass run is fastest with 10 (two full rounds of passes instead of 8 + 8 + 4)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -167,7 +168,7 @@ def main():
     ap.add_argument("--latency", action="store_true", help="(always measured at N = 1; kept for compatibility)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency loop and the golden flip count (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
-    ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..8)")
+    ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..16)")
     args = ap.parse_args()
 
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
@@ -206,6 +207,8 @@ def main():
     # a replay is a stream of batches: consecutive passes rotate through `overlap` HIP streams / buffer sets so that the
     # next passes fill the compute units the slowest frames of the previous ones no longer occupy (fsdp_set_overlap)
     overlap = 1 if args.no_overlap else args.overlap
+    if n_local * overlap > 131072:  # every pass in flight keeps its own intermediates (~0.13 MB per frame): bound them to ~17 GB
+        overlap = max(2, 131072 // n_local)
     ctx.set_overlap(overlap)
     ctx.upload(off, cones, poses)
 

@@ -249,6 +249,22 @@ struct ProfScope {
 #define PROF_INIT()
 #define PROF_FLUSH()
 #endif
+// which kernel of the three-kernel path stage the profiling build accounts: 1 fit_kernel (default), 2 prep, 3 finish
+#ifndef FSDP_PROFILE_KERNEL
+#define FSDP_PROFILE_KERNEL 1
+#endif
+#define PROF_INIT_K(k)                          \
+  do {                                          \
+    if constexpr (FSDP_PROFILE_KERNEL == (k)) { \
+      PROF_INIT();                              \
+    }                                           \
+  } while (0)
+#define PROF_FLUSH_K(k)                         \
+  do {                                          \
+    if constexpr (FSDP_PROFILE_KERNEL == (k)) { \
+      PROF_FLUSH();                             \
+    }                                           \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------
 // wave primitives

@@ -1033,7 +1033,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
   using GR = Grp<G>;
   __shared__ PathShared<G, true> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
-  if (frame >= n_frames) return;
+  PROF_INIT_K(2);
+  if (frame < n_frames) {
+  PROF(0);
   PathShared<G, true>& S = S_all[GR::index()];
   const Arena A = frame_arena(arena, frame, prm);
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
@@ -1058,6 +1060,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
     mid[frame] = m;
     if (!plain && !final_status) push_retry(retry, frame);
   }
+  }
+  PROF_FLUSH_K(2);
 }
 
 // the refit: utils/spline_fit.py:95-128 (splprep, k = 3, s = 0.2) of the arena polyline [off, off + n), G lanes per frame
@@ -1070,7 +1074,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) fi
   static_assert(6 * (NKC + 2) <= BAND_DOUBLES, "band region of the arena");
   __shared__ WS ws_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
-  PROF_INIT();
+  PROF_INIT_K(1);
   if (frame < n_frames && mid[frame].status == ST_OK) {
     PROF(0);
     WS& ws = ws_all[GR::index()];
@@ -1100,7 +1104,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) fi
       }
     }
   }
-  PROF_FLUSH();
+  PROF_FLUSH_K(1);
 }
 
 template <int G>
@@ -1110,7 +1114,9 @@ __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* _
   using GR = Grp<G>;
   __shared__ PathShared<G, true> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
-  if (frame >= n_frames || mid[frame].status != ST_OK) return;
+  PROF_INIT_K(3);
+  if (frame < n_frames && mid[frame].status == ST_OK) {
+  PROF(0);
   PathShared<G, true>& S = S_all[GR::index()];
   const Arena A = frame_arena(arena, frame, prm);
   const int lane = GR::lane();
@@ -1135,6 +1141,8 @@ __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* _
     mid[frame].status = ST_RETRY;
     push_retry(retry, frame);
   }
+  }
+  PROF_FLUSH_K(3);
 }
 
 // grid = ceil(n_frames / (64 / G)) workgroups of one wavefront; group g of block b plans frame b * (64 / G) + g.

@@ -163,9 +163,11 @@ int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
  * next passes fill the compute units that the slowest frames of the previous ones no longer occupy.  fsdp_sync waits for
  * all passes in flight, fsdp_download returns the most recent one.  depth 1 (default) = strictly one pass after the
  * other.  Every stream takes one of the HIP runtime's hardware queues (environment variable GPU_MAX_HW_QUEUES, default 4):
- * with depth 4 and any other stream in the process (the null stream, RCCL) two passes share a queue and serialize —
- * raise GPU_MAX_HW_QUEUES (bench.py sets 8) or use depth 3. */
-#define FSDP_MAX_OVERLAP 8
+ * with more streams than queues two passes share a queue and serialize — raise GPU_MAX_HW_QUEUES above the depth
+ * (bench.py sets 16 for its depth of 10).  Every extra depth costs one more set of intermediate buffers (~0.13 MB per
+ * frame).  Measured at 4096 frames x 128 cones: the steady rate saturates at depth 8; a run of 20 passes is fastest with
+ * 10 in flight (two full rounds instead of 8 + 8 + 4). */
+#define FSDP_MAX_OVERLAP 16
 int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
 
 /* Enqueue `iters` back-to-back passes over the resident batch (rotating through the slots when passes overlap; no host

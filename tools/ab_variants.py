@@ -10,7 +10,7 @@ libs = sorted((ROOT / "ft-fsd-path-planning_amd" / "lib" / "variants").glob("*.s
 extra_env = [e for e in sys.argv[1:] if "=" in e]
 code = """
 import importlib, sys, json, time, os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, %r)
 from pathlib import Path
 pkg = importlib.import_module('ft-fsd-path-planning_amd')

@@ -14,8 +14,11 @@ sys.path.insert(0, str(ROOT))
 PKG = ROOT / "ft-fsd-path-planning_amd"
 so = ROOT / "gpurun_out" / "libfsdp_prof.so"
 so.parent.mkdir(exist_ok=True)
+KERNELS = {"fit": 1, "prep": 2, "finish": 3}
+which = next((a[len("--kernel="):] for a in sys.argv[1:] if a.startswith("--kernel=")), "fit")
+sys.argv = [a for a in sys.argv if not a.startswith("--kernel=")]
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                "-DFSDP_PROFILE", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so), "-ldl"], check=True, capture_output=True)
+                "-DFSDP_PROFILE", f"-DFSDP_PROFILE_KERNEL={KERNELS[which]}", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so), "-ldl"], check=True, capture_output=True)
 import os
 
 os.environ.setdefault("FSDP_PACK", "1")  # the packed kernels the overlapped bench runs (a single pass alone would get 16 lanes per frame)
@@ -34,8 +37,10 @@ assert rc == 0
 # frames: 16): one row per wavefront (group 0's lane 0 keeps the clock; the groups run in lock-step, so its sections span
 # the wavefront's time in them)
 import os
-# large batches run the three-kernel path stage: the profile below is fit_kernel's (FSDP_FIT_G lanes per frame)
-G = int(os.environ.get("FSDP_FIT_G", "8")) if N > 1024 else 64
+# large batches run the three-kernel path stage: the profile below is the selected kernel's (--kernel=fit|prep|finish;
+# fit_kernel: FSDP_FIT_G lanes per frame, prep / finish: 8)
+G = (int(os.environ.get("FSDP_FIT_G", "8")) if which == "fit" else 8) if N > 1024 else 64
+print(f"== {which} kernel ==")
 FPW = 64 // G
 out = out[: (N + FPW - 1) // FPW]
 tot = out[:, 0]
