@@ -366,6 +366,16 @@ struct Grp {
     return __shfl(v, lane() > 0 ? me - 1 : me, WAVE);
 #endif
   }
+  // value of the next lane of the group (the last lane keeps its own)
+  template <class T>
+  static __device__ __forceinline__ T shfl_down1(T v) {
+#ifdef FSDP_EMU
+    return emu::gexchange(v, lane() < G - 1 ? emu::B->cur + 1 : emu::B->cur, G);
+#else
+    int me = (int)(threadIdx.x & 63);
+    return __shfl(v, lane() < G - 1 ? me + 1 : me, WAVE);
+#endif
+  }
   // argmin over (value, index) pairs with "first smallest" semantics; lanes holding no candidate pass idx = -1
   static __device__ __forceinline__ void argmin(double& v, int& idx) {
     for (int off = G / 2; off >= 1; off >>= 1) {

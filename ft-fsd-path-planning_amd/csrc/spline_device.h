@@ -1078,7 +1078,52 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         for (int j = 1; j <= k1; j++) ws.Gm(i, j) = ws.A(i, j);
       }
       GR::sync();
-      if (lane == 0) {  // serial section (single writer of g / c)
+      if constexpr (G >= K + 4) {
+        // Column-parallel rotations (fppara's smoothing rows b / p into the triangle g): lane q < k2 holds column q + 1 of
+        // the incoming row and, at band row j, the element g(j, q + 1); lanes k2 and k2 + 1 hold the two right-hand
+        // sides.  Every lane derives the rotation (cs, sn) from the pivot (lane 0's element) and g(j, 1), applies it to
+        // its own pair, and the row moves one lane down — the same operations on the same operands as the column loop
+        // of the published algorithm.  (Reads of a step come before its lane exchange, writes after it.)
+        PROF(16);
+        const bool is_rhs = lane == k2 || lane == k2 + 1;
+        double hq = 0.0;
+        double bnext = (lane < k2 && n8 >= 1) ? bc.b[5 * 1 + lane] : 0.0;
+        for (int it = 1; it <= n8; it++) {
+          hq = (lane < k2) ? bnext * pinv : 0.0;  // (right-hand-side lanes: xi = 0)
+          if (it < n8 && lane < k2) bnext = bc.b[5 * (it + 1) + lane];
+          for (int j = it; j <= nk1; j++) {
+            double* const pb = is_rhs ? &ws.c[j + (lane - k2) * n] : &ws.Gm(j, lane < k2 ? lane + 1 : 1);
+            double b = *pb;
+            double ww = ws.Gm(j, 1);
+            const double piv = GR::bcast(hq, 0);
+            double cs, sn;
+            fpgivs(piv, ww, cs, sn);
+            int i2 = k1;
+            if (j > n8) i2 = nk1 - j;
+            const bool col_on = lane >= 1 && lane < k2 && j != nk1 && lane <= i2;  // columns 2 .. i2 + 1
+            double a = hq;
+            fprota(cs, sn, a, b);
+            if (lane == 0)
+              *pb = ww;
+            else if (col_on || is_rhs)
+              *pb = b;
+            if (j == nk1) break;
+            const double mine = (col_on || is_rhs) ? a : hq;
+            const double nxt = GR::shfl_down1(mine);
+            if (lane < k2) {
+              const int col = lane + 1;
+              hq = (col <= i2) ? nxt : (col == i2 + 1 ? 0.0 : mine);
+            } else {
+              hq = mine;
+            }
+          }
+          GR::sync();
+        }
+        if (lane < 2) {  // the two right-hand sides side by side
+          auto gel = [&](int i, int jj) { return ws.Gm(i, jj); };
+          fpback(gel, &ws.c[lane * n], nk1, k2, &ws.c[lane * n]);
+        }
+      } else if (lane == 0) {  // serial section (single writer of g / c): groups of fewer than k2 + 2 lanes
         PROF(16);
         double bn[K + 3];  // next row of b, fetched from scratch one row ahead
 #pragma unroll
