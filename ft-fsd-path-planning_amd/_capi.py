@@ -13,6 +13,9 @@ from pathlib import Path
 # multi-process GPU work (RCCL): the host driver only supports dmabuf IPC; must be in the environment before the HIP
 # runtime starts in this process
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# every pass in flight (Context.set_overlap) runs on its own HIP stream; streams beyond the runtime's hardware queues
+# (default 4) share a queue and serialize — also read when the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 

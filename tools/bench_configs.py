@@ -16,7 +16,7 @@ pkg = importlib.import_module("ft-fsd-path-planning_amd")
 ctx = pkg.Context(device=0)
 
 
-OVERLAP = 8
+OVERLAP = 10
 
 
 def run(name, off, cones, poses, steps=10):
@@ -25,8 +25,9 @@ def run(name, off, cones, poses, steps=10):
     ctx.time_runs(2)
     tot, st = ctx.time_runs(steps)  # one pass after the other: per-launch kernel durations
     names = ctx.stage_names()
-    ctx.set_overlap(OVERLAP)
-    ctx.time_runs(OVERLAP)
+    ov = min(OVERLAP, max(2, 131072 // (len(off) - 1)))  # like bench.py: bound the intermediates of the passes in flight
+    ctx.set_overlap(ov)
+    ctx.time_runs(ov)
     tot2, _ = ctx.time_runs(4 * steps)  # passes in flight (how bench.py runs)
     res = ctx.download()
     ctx.set_overlap(1)
@@ -36,7 +37,7 @@ def run(name, off, cones, poses, steps=10):
     print(json.dumps({"config": name, "frames": n, "cones_per_frame": int((off[1:] - off[:-1]).mean()),
                       "ms_per_batch_serial": round(tot / steps, 3), "frames_per_s_serial": round(n / (tot / steps) * 1e3),
                       "ms_per_batch_overlapped": round(tot2 / (4 * steps), 3), "frames_per_s_overlapped": round(n / (tot2 / (4 * steps)) * 1e3),
-                      "pass_overlap": OVERLAP, "kernel_ms_serial": {k: round(v / steps, 3) for k, v in zip(names, st)},
+                      "pass_overlap": ov, "kernel_ms_serial": {k: round(v / steps, 3) for k, v in zip(names, st)},
                       "status_histogram": hist, "arc_extension_frames": arc}), flush=True)
 
 
