@@ -257,7 +257,7 @@ static void launch_sort(fsdp_ctx* c, const Slot& q) {
                      q.d_retry, c->d_sort_big + (size_t)q.index * SORT_BIG_BLOCKS, c->d_params);
 }
 static void launch_match(fsdp_ctx* c, const Slot& q) {
-  hipLaunchKernelGGL(match_kernel, dim3(c->n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_MATCH"), q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
+  hipLaunchKernelGGL(match_kernel<MATCH_G>, dim3((c->n_frames + WAVE / MATCH_G - 1) / (WAVE / MATCH_G)), dim3(WAVE), DYN_LDS("FSDP_LDS_MATCH"), q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
                      q.d_sort, q.d_match, c->d_params);
 }
 // ---- the path stage of one pass ------------------------------------------------------------------------------------------
@@ -302,7 +302,7 @@ static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
   const double* prev = c->use_prev ? c->d_prev : nullptr;
   const int n = c->n_frames;
   const bool split = c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH;
-  c->stage_names = "sort_kernel,match_kernel,";
+  c->stage_names = "sort_kernel,match_kernel<" + std::to_string(MATCH_G) + ">,";
   mark(q, t);
   (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
   if (!split) {

@@ -1,4 +1,5 @@
-// cone_matching step as a wave-per-frame HIP kernel (gfx950).
+// cone_matching step as a HIP kernel (gfx950): G lanes per frame (a side holds at most 24 cones with its virtual ones, so
+// G = 32 puts two frames into a wavefront and every serial section advances both).
 //
 // Replaces ConeMatching.run_cone_matching -> calculate_virtual_cones_for_both_sides
 // (reference cone_matching/core_cone_matching.py:87-124, functional_cone_matching.py:479-588):
@@ -32,8 +33,9 @@ struct MatchShared {
 };
 
 // match_directions.py:23-44
+template <int G>
 __device__ inline void match_dirs(const double* px, const double* py, int n, int cone_type, double* dx, double* dy) {
-  const int lane = lane_id();
+  const int lane = Grp<G>::lane();
   if (lane < n && n > 1) {
     int a, b;
     if (lane == 0) {
@@ -48,19 +50,20 @@ __device__ inline void match_dirs(const double* px, const double* py, int n, int
     }
     search_direction(px[a], py[a], px[b], py[b], cone_type, dx[lane], dy[lane]);
   }
-  __syncthreads();
+  Grp<G>::sync();
 }
 
 // functional_cone_matching.py:340-384 (+ :73-175).  Result in S.match[0..n).  own dirs left in S.d1.
+template <int G>
 __device__ inline void matches_for_side(MatchShared& S, const Params& P, const double* px, const double* py, int n, int cone_type,
                                         const double* qx, const double* qy, int m) {
-  const int lane = lane_id();
+  const int lane = Grp<G>::lane();
   if (lane < MAX_MATCH) S.match[lane] = -1;
-  __syncthreads();
+  Grp<G>::sync();
   if (n <= 1) return;
-  match_dirs(px, py, n, cone_type, S.d1x, S.d1y);
+  match_dirs<G>(px, py, n, cone_type, S.d1x, S.d1y);
   const int other_type = (cone_type == T_RIGHT) ? T_LEFT : T_RIGHT;
-  if (m > 1) match_dirs(qx, qy, m, other_type, S.d2x, S.d2y);
+  if (m > 1) match_dirs<G>(qx, qy, m, other_type, S.d2x, S.d2y);
   if (m == 0) return;
   // per own cone: rotation into its search frame (:100-104)
   if (lane < n) {
@@ -70,9 +73,9 @@ __device__ inline void matches_for_side(MatchShared& S, const Params& P, const d
     S.rs[lane] = rot.s;
     S.anyok[lane] = 0;
   }
-  __syncthreads();
+  Grp<G>::sync();
   // candidate test, one (own cone, other-side cone) pair per lane: ellipse, search angle, opposing directions
-  for (int p = lane; p < n * m; p += WAVE) {
+  for (int p = lane; p < n * m; p += G) {
     const int i = p / m, j = p - i * m;
     const double sx = px[i], sy = py[i];
     const Rot2 rot{S.rc[i], S.rs[i]};
@@ -91,7 +94,7 @@ __device__ inline void matches_for_side(MatchShared& S, const Params& P, const d
     }
     if (ok) atomicOr(&S.anyok[i], 1);
   }
-  __syncthreads();
+  Grp<G>::sync();
   // nearest other-side cone (first smallest), lane = own cone
   if (lane < n) {
     const double sx = px[lane], sy = py[lane];
@@ -106,12 +109,13 @@ __device__ inline void matches_for_side(MatchShared& S, const Params& P, const d
     }
     S.match[lane] = S.anyok[lane] ? best : -1;
   }
-  __syncthreads();
+  Grp<G>::sync();
 }
 
 // functional_cone_matching.py:195-261; existing/to-insert chosen by the caller.  Result in S.ex/ey, returns count.
+template <int G>
 __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx, double cary) {
-  const int lane = lane_id();
+  const int lane = Grp<G>::lane();
   // order_to_insert = cdist(to_insert, existing).min(axis=1).argsort()
   if (lane < nt) {
     double b = 0.0;
@@ -121,7 +125,7 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
     }
     S.key[lane] = b;
   }
-  __syncthreads();
+  Grp<G>::sync();
   if (lane < nt) {
     int rank = 0;
     double k = S.key[lane];
@@ -131,7 +135,7 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
     }
     S.order[rank] = lane;
   }
-  __syncthreads();
+  Grp<G>::sync();
   for (int r = 0; r < nt; r++) {
     const int ti = S.order[r];
     const double cx = S.tx[ti], cy = S.ty[ti];
@@ -145,7 +149,7 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
     }
     double v1 = v;
     int i1 = idx;
-    wave_argmin(v1, i1);
+    Grp<G>::argmin(v1, i1);
     int index_to_insert = -1;
     if (ne == 1) {
       // calculate_insert_index_for_one_cone :264-282
@@ -155,7 +159,7 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
     } else {
       double v2 = v;
       int i2 = (idx == i1) ? -1 : idx;
-      wave_argmin(v2, i2);
+      Grp<G>::argmin(v2, i2);
       const int closest = i1, second = i2;
       int diff = closest - second;
       if (diff == 1 || diff == -1) {
@@ -175,7 +179,7 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
         mx = S.ex[lane];
         my = S.ey[lane];
       }
-      __syncthreads();
+      Grp<G>::sync();
       if (mv) {
         S.ex[lane + 1] = mx;
         S.ey[lane + 1] = my;
@@ -186,7 +190,7 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
       }
       ne++;
     }
-    __syncthreads();
+    Grp<G>::sync();
   }
   // drop interior cones whose trace angle is < 85 deg (:252-259)
   if (ne >= 3) {
@@ -201,10 +205,10 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
       double qx = -(mx - S.ex[lane - 1]), qy = -(my - S.ey[lane - 1]);
       low = acos_less(cos_between(nx, ny, qx, qy), 85 * FSDP_DEG, COS_85DEG);
     }
-    unsigned long long lowm = __ballot(low);
+    unsigned long long lowm = Grp<G>::ballot(low);
     if (lowm) {
-      unsigned long long keepm = __ballot(lane < ne && !low);
-      __syncthreads();
+      unsigned long long keepm = Grp<G>::ballot(lane < ne && !low);
+      Grp<G>::sync();
       if (lane < ne && !low) {
         int p = __popcll(keepm & ((1ull << lane) - 1ull));
         S.ex[p] = mx;
@@ -212,19 +216,20 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
       }
       ne = __popcll(keepm);
     }
-    __syncthreads();
+    Grp<G>::sync();
   }
   return ne;
 }
 
 // functional_cone_matching.py:387-440: result written to (ox, oy), returns its length
+template <int G>
 __device__ inline int cones_for_other_side(MatchShared& S, const Params& P, const double* px, const double* py, int n, int cone_type,
                                            const double* qx, const double* qy, int m, double carx, double cary, double* ox,
                                            double* oy) {
-  const int lane = lane_id();
-  matches_for_side(S, P, px, py, n, cone_type, qx, qy, m);
+  const int lane = Grp<G>::lane();
+  matches_for_side<G>(S, P, px, py, n, cone_type, qx, qy, m);
   bool unmatched = lane < n && S.match[lane] == -1;
-  unsigned long long um = __ballot(unmatched);
+  unsigned long long um = Grp<G>::ballot(unmatched);
   const int nv = __popcll(um);
   double vx = 0, vy = 0;
   if (unmatched) {
@@ -232,7 +237,7 @@ __device__ inline int cones_for_other_side(MatchShared& S, const Params& P, cons
     vy = py[lane] + S.d1y[lane] * P.min_track_width;
   }
   int no;
-  __syncthreads();
+  Grp<G>::sync();
   if (m == 0) {
     if (unmatched) {
       int p = __popcll(um & ((1ull << lane) - 1ull));
@@ -268,10 +273,10 @@ __device__ inline int cones_for_other_side(MatchShared& S, const Params& P, cons
         S.ty[lane] = qy[lane];
       }
     }
-    __syncthreads();
-    no = insert_virtual(S, other_is_base ? m : nv, other_is_base ? nv : m, carx, cary);
+    Grp<G>::sync();
+    no = insert_virtual<G>(S, other_is_base ? m : nv, other_is_base ? nv : m, carx, cary);
   }
-  __syncthreads();
+  Grp<G>::sync();
   if (no < 2) {  // :436-438 keep the originals
     if (lane < m) {
       ox[lane] = qx[lane];
@@ -282,20 +287,24 @@ __device__ inline int cones_for_other_side(MatchShared& S, const Params& P, cons
     ox[lane] = S.ex[lane];
     oy[lane] = S.ey[lane];
   }
-  __syncthreads();
+  Grp<G>::sync();
   return no;
 }
 
+constexpr int MATCH_G = 32;  // lanes per frame (>= MAX_MATCH + 1: the insertion work list is walked one cone per lane)
+static_assert(MATCH_G > MAX_MATCH, "matching walks its lists one cone per lane");
 // (four wavefronts per SIMD, 126 registers: measured +2 % frames/s over the two the allocator takes unasked)
+template <int G>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) match_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
                                                    const double* __restrict__ cones_xyt, const double* __restrict__ poses,
                                                    const SortOut* __restrict__ sorted, MatchOut* __restrict__ out,
                                                    const Params* __restrict__ prm) {
-  __shared__ MatchShared S;
+  __shared__ MatchShared S_all[WAVE / G];
   const Params& P = *prm;
-  const int frame = blockIdx.x;
+  const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
   if (frame >= n_frames) return;
-  const int lane = lane_id();
+  MatchShared& S = S_all[Grp<G>::index()];
+  const int lane = Grp<G>::lane();
   const SortOut* so = &sorted[frame];
   MatchOut* o = &out[frame];
   const double carx = poses[4 * frame + 0], cary = poses[4 * frame + 1];
@@ -316,7 +325,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) ma
     S.rx[lane] = base[3 * idx];
     S.ry[lane] = base[3 * idx + 1];
   }
-  __syncthreads();
+  Grp<G>::sync();
   int na = 0, nb = 0;
   if (!(nl < 2 && nr < 2)) {
     // discard the shorter side if empty or the length ratio exceeds 2 (:513-520)
@@ -330,7 +339,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) ma
     }
     // right cones with virtual: driven by the left side
     if (nl >= 2) {
-      nb = cones_for_other_side(S, P, S.lx, S.ly, nl, T_LEFT, S.rx, S.ry, nr, carx, cary, S.bx, S.by);
+      nb = cones_for_other_side<G>(S, P, S.lx, S.ly, nl, T_LEFT, S.rx, S.ry, nr, carx, cary, S.bx, S.by);
     } else {
       if (lane < nr) {
         S.bx[lane] = S.rx[lane];
@@ -338,9 +347,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) ma
       }
       nb = nr;
     }
-    __syncthreads();
+    Grp<G>::sync();
     if (nr >= 2) {
-      na = cones_for_other_side(S, P, S.rx, S.ry, nr, T_RIGHT, S.lx, S.ly, nl, carx, cary, S.ax, S.ay);
+      na = cones_for_other_side<G>(S, P, S.rx, S.ry, nr, T_RIGHT, S.lx, S.ly, nl, carx, cary, S.ax, S.ay);
     } else {
       if (lane < nl) {
         S.ax[lane] = S.lx[lane];
@@ -348,17 +357,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) ma
       }
       na = nl;
     }
-    __syncthreads();
+    Grp<G>::sync();
   }
   // final matching on the lists with virtual cones (:443-476)
-  matches_for_side(S, P, S.ax, S.ay, na, T_LEFT, S.bx, S.by, nb);
+  matches_for_side<G>(S, P, S.ax, S.ay, na, T_LEFT, S.bx, S.by, nb);
   if (lane < MAX_MATCH) {
     o->l2r[lane] = (lane < na) ? S.match[lane] : -1;
     o->left_v[lane][0] = (lane < na) ? S.ax[lane] : 0.0;
     o->left_v[lane][1] = (lane < na) ? S.ay[lane] : 0.0;
   }
-  __syncthreads();
-  matches_for_side(S, P, S.bx, S.by, nb, T_RIGHT, S.ax, S.ay, na);
+  Grp<G>::sync();
+  matches_for_side<G>(S, P, S.bx, S.by, nb, T_RIGHT, S.ax, S.ay, na);
   if (lane < MAX_MATCH) {
     o->r2l[lane] = (lane < nb) ? S.match[lane] : -1;
     o->right_v[lane][0] = (lane < nb) ? S.bx[lane] : 0.0;

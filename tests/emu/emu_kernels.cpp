@@ -122,7 +122,8 @@ void emu_sort(int n_frames, const int32_t* offsets, const double* cones, const d
 }
 void emu_match(int n_frames, const int32_t* offsets, const double* cones, const double* poses, const fsdp::SortOut* sorted,
                fsdp::MatchOut* out) {
-  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::match_kernel(n_frames, offsets, cones, poses, sorted, out, &g_prm); });
+  constexpr unsigned per = 64 / fsdp::MATCH_G;
+  emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::match_kernel<fsdp::MATCH_G>(n_frames, offsets, cones, poses, sorted, out, &g_prm); });
 }
 int emu_sizeof_skid_state() { return (int)sizeof(fsdp::SkidState); }
 int emu_sizeof_skid_info() { return (int)sizeof(fsdp::SkidInfo); }
