@@ -111,6 +111,9 @@ def load() -> ctypes.CDLL:
     lib.fsdp_destroy.argtypes = [ctypes.c_void_p]
     lib.fsdp_resident_frames.argtypes = [ctypes.c_void_p]
     lib.fsdp_stage_names.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    lib.fsdp_time_runs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fsdp_time_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.fsdp_time_results.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.fsdp_comm_unique_id.argtypes = [ctypes.c_void_p]
     lib.fsdp_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     lib.fsdp_comm_broadcast.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
@@ -125,7 +128,7 @@ def load() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_default_params", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
-    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_stage_names", "fsdp_resident_frames",
+    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_time_reserve", "fsdp_time_results", "fsdp_stage_names", "fsdp_resident_frames",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
@@ -258,10 +261,27 @@ class Context:
         self._check(self._lib.fsdp_download(self._h, ctypes.c_void_p(out.ctypes.data)), "fsdp_download")
         return out
 
-    def time_runs(self, iters: int):
+    def time_runs(self, iters: int, collect: bool = True):
+        """`iters` back-to-back passes over the resident batch with HIP events around every kernel.  collect=False: only
+        enqueue and wait (for a caller's own wall clock); time_results() reads the events afterwards."""
+        if not collect:
+            self._check(self._lib.fsdp_time_runs(self._h, int(iters), None, None), "fsdp_time_runs")
+            return None
         tot = ctypes.c_float()
         st = (ctypes.c_float * MAX_STAGES)()
         self._check(self._lib.fsdp_time_runs(self._h, int(iters), ctypes.byref(tot), st), "fsdp_time_runs")
+        n = len(self.stage_names())
+        return float(tot.value), [float(x) for x in st][:n]
+
+    def time_reserve(self, iters: int):
+        """Create the events of an `iters`-pass timed region ahead of time."""
+        self._check(self._lib.fsdp_time_reserve(self._h, int(iters)), "fsdp_time_reserve")
+
+    def time_results(self):
+        """(ms of the whole region, summed ms per kernel) of the most recent time_runs."""
+        tot = ctypes.c_float()
+        st = (ctypes.c_float * MAX_STAGES)()
+        self._check(self._lib.fsdp_time_results(self._h, ctypes.byref(tot), st), "fsdp_time_results")
         n = len(self.stage_names())
         return float(tot.value), [float(x) for x in st][:n]
 

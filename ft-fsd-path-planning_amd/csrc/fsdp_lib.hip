@@ -77,6 +77,7 @@ struct fsdp_ctx {
     int cap_frames = 0;
   } extra[FSDP_MAX_OVERLAP - 1];
   std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
+  int timed_iters = 0, timed_stages = 0;  // the most recent fsdp_time_runs (fsdp_time_results reads its events)
   // skidpad mission
   double* d_table = nullptr;
   double* d_noise = nullptr;
@@ -709,14 +710,52 @@ int fsdp_plan_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double*
   return fsdp_download(c, results);
 }
 
+// MAX_STAGES + 1 events per pass (before every kernel, after the last) + begin / end of the region
+constexpr int TIMING_EPP = MAX_STAGES + 1;
+static int reserve_timing(fsdp_ctx* c, int iters) {
+  const size_t need = (size_t)TIMING_EPP * (size_t)iters + 2;
+  while (c->tev.size() < need) {
+    hipEvent_t e;
+    HIP_TRY(c, hipEventCreate(&e));
+    c->tev.push_back(e);
+  }
+  return 0;
+}
+
+int fsdp_time_reserve(fsdp_ctx* c, int iters) {
+  if (!c || iters <= 0) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  return reserve_timing(c, iters);
+}
+
+int fsdp_time_results(fsdp_ctx* c, float* ms_total, float* ms_stage) {
+  if (!c) return 1;
+  if (ms_stage)
+    for (int k = 0; k < MAX_STAGES; k++) ms_stage[k] = 0;
+  if (ms_total) *ms_total = 0;
+  if (c->timed_iters <= 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t need = (size_t)TIMING_EPP * (size_t)c->timed_iters + 2;
+  float total = 0;
+  HIP_TRY(c, hipEventElapsedTime(&total, c->tev[need - 2], c->tev[need - 1]));
+  if (ms_stage)
+    for (int it = 0; it < c->timed_iters; it++)
+      for (int st = 0; st < c->timed_stages; st++) {
+        float t;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->tev[(size_t)TIMING_EPP * (size_t)it + st], c->tev[(size_t)TIMING_EPP * (size_t)it + st + 1]));
+        ms_stage[st] += t;
+      }
+  if (ms_total) *ms_total = total;
+  return 0;
+}
+
 int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
   if (!c || iters <= 0) return 1;
   if (ms_stage)
     for (int k = 0; k < MAX_STAGES; k++) ms_stage[k] = 0;
-  if (c->n_frames == 0) {
-    if (ms_total) *ms_total = 0;
-    return 0;
-  }
+  if (ms_total) *ms_total = 0;
+  c->timed_iters = 0;
+  if (c->n_frames == 0) return 0;
   if (!c->resident) {
     c->err = "fsdp_time_runs: no resident batch";
     return 1;
@@ -724,15 +763,11 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
   HIP_TRY(c, hipSetDevice(c->device));
   int rc = sync_all(c);
   if (rc) return rc;
-  // MAX_STAGES + 1 events per pass (before every kernel, after the last); passes rotate through the slots when overlap is
-  // on and are NOT synchronised with the host in between
-  constexpr int EPP = MAX_STAGES + 1;
+  // passes rotate through the slots when overlap is on and are NOT synchronised with the host in between
+  constexpr int EPP = TIMING_EPP;
   const size_t need = (size_t)EPP * (size_t)iters + 2;
-  while (c->tev.size() < need) {
-    hipEvent_t e;
-    HIP_TRY(c, hipEventCreate(&e));
-    c->tev.push_back(e);
-  }
+  rc = reserve_timing(c, iters);
+  if (rc) return rc;
   hipEvent_t ev_begin = c->tev[need - 2], ev_end = c->tev[need - 1];
   HIP_TRY(c, hipEventRecord(ev_begin, c->stream));
   int last_of_slot[FSDP_MAX_OVERLAP];
@@ -762,16 +797,9 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
   rc = sync_all(c);
   if (rc) return rc;
   HIP_TRY(c, hipGetLastError());
-  float total = 0;
-  HIP_TRY(c, hipEventElapsedTime(&total, ev_begin, ev_end));
-  if (ms_stage)
-    for (int it = 0; it < iters; it++)
-      for (int st = 0; st < n_stages; st++) {
-        float t;
-        HIP_TRY(c, hipEventElapsedTime(&t, c->tev[(size_t)EPP * (size_t)it + st], c->tev[(size_t)EPP * (size_t)it + st + 1]));
-        ms_stage[st] += t;
-      }
-  if (ms_total) *ms_total = total;
+  c->timed_iters = iters;
+  c->timed_stages = n_stages;
+  if (ms_total || ms_stage) return fsdp_time_results(c, ms_total, ms_stage);
   return 0;
 }
 

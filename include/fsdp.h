@@ -177,6 +177,11 @@ int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
  * unused entries are 0 and fsdp_stage_names names the used ones.  Either pointer may be NULL. */
 #define FSDP_MAX_STAGES 8
 int fsdp_time_runs(fsdp_ctx* ctx, int iters, float* ms_total, float* ms_stage);
+/* The same in three steps, for a caller that puts its own wall clock around the passes: fsdp_time_reserve creates the
+ * events of an `iters`-pass region ahead of time, fsdp_time_runs(ctx, iters, NULL, NULL) enqueues the passes and returns
+ * when the last one has finished (no event is read), fsdp_time_results reads the times of that most recent region. */
+int fsdp_time_reserve(fsdp_ctx* ctx, int iters);
+int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
 /* comma-separated kernel names behind ms_stage of the most recent pass, e.g.
  * "sort_kernel,match_kernel,path_prep_kernel<8>,fit_kernel<8>,path_finish_kernel<8>,path_retry_kernel" */
 int fsdp_stage_names(fsdp_ctx* ctx, char* out, int cap);
