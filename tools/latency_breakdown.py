@@ -13,7 +13,6 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 ctx = pkg.Context(device=0)
 off, cones, poses = pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
@@ -33,15 +32,7 @@ for name, k in (("frame 0", 0), ("frame 2048", 2048)):
     out[name] = {"wall_p50_us": float(np.median(lat[100:]) * 1e6), "wall_p10_us": float(np.percentile(lat[100:], 10) * 1e6),
                  "kernels_us": {n: round(v / 100 * 1e3, 1) for n, v in zip(names, st)}, "kernels_sum_us": round(sum(st) / 100 * 1e3, 1),
                  "pass_us_events": round(tot / 100 * 1e3, 1)}
-import oracle_lib  # the CPU restatement, one thread (test infrastructure, here only as the latency baseline)
-
-k = 0
-o1 = np.array([0, off[k + 1] - off[k]], np.int32)
-oracle_lib.plan_batch(o1, cones[off[k] : off[k + 1]], poses[k : k + 1], n_threads=1)
-t0 = time.perf_counter()
-for _ in range(200):
-    oracle_lib.plan_batch(o1, cones[off[k] : off[k + 1]], poses[k : k + 1], n_threads=1)
-out["cpu_oracle_1_thread_us"] = (time.perf_counter() - t0) / 200 * 1e6
+# (the CPU figure to hold against this — the oracle on one core — is in the bench line: cpu_baseline.single_thread_us_per_frame)
 print(json.dumps(out, indent=1))
 print("== section profile of the one-frame path kernel (64 lanes per frame), 256 frames ==")
 sys.stdout.flush()
