@@ -178,7 +178,9 @@ int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
 #define FSDP_MAX_STAGES 8
 int fsdp_time_runs(fsdp_ctx* ctx, int iters, float* ms_total, float* ms_stage);
 /* The same in three steps, for a caller that puts its own wall clock around the passes: fsdp_time_reserve creates the
- * events of an `iters`-pass region ahead of time, fsdp_time_runs(ctx, iters, NULL, NULL) enqueues the passes and returns
+ * events of an `iters`-pass region ahead of time (and runs one pass on every slot of the overlap depth that has not run
+ * one yet: the first launches on a stream pay for its queue and scratch set-up), fsdp_time_runs(ctx, iters, NULL, NULL)
+ * enqueues the passes and returns
  * when the last one has finished (no event is read), fsdp_time_results reads the times of that most recent region. */
 int fsdp_time_reserve(fsdp_ctx* ctx, int iters);
 int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
