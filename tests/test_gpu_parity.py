@@ -272,6 +272,17 @@ def test_overlapped_passes_equal_serial_passes(pkg):
     assert tot > 0 and all(x > 0 for x in st)
     got = ctx.download()
     assert got["path"].tobytes() == ref["path"].tobytes()
+    # the timed region in three steps (events created before, read after: what bench.py puts its wall clock around);
+    # a deeper overlap than passes run so far: fsdp_time_reserve runs one pass on the slots that have not run yet
+    ctx.set_overlap(5)
+    ctx.time_reserve(7)
+    assert ctx.time_runs(7, collect=False) is None
+    tot3, st3 = ctx.time_results()
+    assert tot3 > 0 and len(st3) == len(ctx.stage_names()) and all(x > 0 for x in st3)
+    assert ctx.time_results() == (tot3, st3)  # reading twice is harmless
+    got = ctx.download()
+    assert got["path"].tobytes() == ref["path"].tobytes()
+    ctx.set_overlap(2)
     # a different batch through the same overlapped context
     off2, cones2, poses2 = pkg.synth.make_replay_batch(700, 64, 0.15, seed=12, color=False)
     ref2 = pkg.Context(device=0).plan_batch(off2, cones2, poses2)
