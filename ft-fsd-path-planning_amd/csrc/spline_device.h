@@ -1021,7 +1021,17 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
           restart = true;
           break;
         }
-        if (n == nest) break;
+        if (n == nest) {
+          // FITPACK stops adding knots at nest = m + 2k.  Where nest is this workspace's capacity instead and knots of
+          // this round are still to come, the reference goes on to more knots than fit here: hand the frame on (the
+          // next observation pass would otherwise run — and possibly converge — on a knot set the reference never has).
+          if (lq < nplus && nest == NK && m + 2 * k > NK) {
+            R.status = ST_OVERFLOW_KNOTS;
+            done = true;
+            restart = true;  // leaves the iteration loop
+          }
+          break;
+        }
       }
     }
     if (!restart && !done && !to_part2) to_part2 = true;

@@ -27,6 +27,7 @@ static int g_n_gpath = 0;
 static std::once_flag g_once;
 static int g_last_retries = 0;
 static int g_last_big = 0;
+static std::vector<double> g_refit;  // FitRec per frame of the last three-kernel path launch
 static void build_default() {
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
@@ -81,9 +82,8 @@ static void emu_path_launch(int n_frames, const double* poses, const fsdp::Match
 }
 
 // the path stage as the library launches it for large batches: prep -> fit -> finish -> exact re-plan of the retry list
-template <int GF, int NKC>
+template <int GF, int NKC, int G = fsdp::PATH_G_SPLIT>
 static void emu_path_split_launch(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
-  constexpr int G = fsdp::PATH_G_SPLIT;
   AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
   std::vector<fsdp::PathMid> mid(n_frames);
   std::vector<int> retry((size_t)n_frames + 1, 0);
@@ -95,6 +95,12 @@ static void emu_path_split_launch(int n_frames, const double* poses, const fsdp:
   emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data(), &g_prm); });
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G>(n_frames, arena.data(), mid.data(), out, retry.data(), &g_prm); });
   g_last_retries = retry[0];
+  // the refit records (knots / coefficients fit_kernel handed to path_finish_kernel), kept for emu_last_refit
+  g_refit.assign((size_t)n_frames * fsdp::FITREC_DOUBLES, 0.0);
+  for (int f = 0; f < n_frames; f++) {
+    const fsdp::Arena A = fsdp::frame_arena(arena.data(), f, &g_prm);
+    memcpy(&g_refit[(size_t)f * fsdp::FITREC_DOUBLES], A.fit, sizeof(fsdp::FitRec));
+  }
   emu::launch(8, 64, [&]() {
     fsdp::path_retry_kernel(poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out, retry.data(), &g_prm);
   });
@@ -102,6 +108,14 @@ static void emu_path_split_launch(int n_frames, const double* poses, const fsdp:
 
 extern "C" {
 int emu_last_retries() { return g_last_retries; }
+// refit record of frame f of the last three-kernel launch: n knots, then knots (34), then coefficients (68); returns n
+int emu_last_refit(int f, double* knots34, double* coeffs68) {
+  if ((size_t)(f + 1) * fsdp::FITREC_DOUBLES > g_refit.size()) return -1;
+  const fsdp::FitRec* r = (const fsdp::FitRec*)&g_refit[(size_t)f * fsdp::FITREC_DOUBLES];
+  memcpy(knots34, r->t, sizeof(r->t));
+  memcpy(coeffs68, r->c, sizeof(r->c));
+  return r->n;
+}
 int emu_last_big() { return g_last_big; }
 void emu_fit(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
   AlignedArena arena(fsdp::ARENA_DOUBLES);
@@ -188,6 +202,8 @@ int emu_path_g(int G, int n_frames, const double* poses, const fsdp::MatchOut* m
     emu_path_split_launch<4, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
   else if (G == 1008)
     emu_path_split_launch<8, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
+  else if (G == 1016)  // the three kernels with 16 lanes per frame (one pass of a mid-size batch)
+    emu_path_split_launch<16, fsdp::FIT_KNOTS, 16>(n_frames, poses, matched, out);
   else
     return 1;
   return 0;

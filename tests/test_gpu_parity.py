@@ -84,10 +84,15 @@ def _assert_equal_to_oracle(res, ref):
     assert (err <= 1e-9).all(), (float(err.max()), int((err > 1e-9).sum()))
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
-def test_full_size_batches_against_oracle(pkg, ctx, cfg):
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg2_packed", "cfg3", "cfg4"])
+def test_full_size_batches_against_oracle(pkg, ctx, cfg, monkeypatch):
     """BASELINE configs 2/3 at the full 4096 frames and config 4's per-GPU shard shape (8192 x 200 cones):
-    every frame against the oracle (all host cores)."""
+    every frame against the oracle (all host cores).  cfg2_packed: the 8-lane kernels bench.py's overlapped passes run
+    (a single pass would get the 16-lane ones)."""
+    if cfg == "cfg2_packed":
+        monkeypatch.setenv("FSDP_PACK", "1")
+        ctx = pkg.Context(device=0)
+        cfg = "cfg2"
     if cfg == "cfg2":
         off, cones, poses = pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
     elif cfg == "cfg3":
@@ -292,11 +297,17 @@ def test_overlapped_passes_equal_serial_passes(pkg):
     assert ctx.plan_batch(off, cones, poses)["path"].tobytes() == ref["path"].tobytes()
 
 
-@pytest.mark.parametrize("group", [8, 16, 64])
-def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, group):
-    """The library launches the path kernel with 8, 16 or 64 lanes per frame depending on batch size and pass overlap
-    (path_kernel.h); FSDP_PATH_G pins the choice.  All three must reproduce the oracle bit for bit."""
-    monkeypatch.setenv("FSDP_PATH_G", str(group))
+@pytest.mark.parametrize("mode", ["mono64", "split16", "packed8", "packed8_fit4"])
+def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, mode):
+    """The library picks the path-stage kernels from the batch size and the passes in flight (fsdp_lib.hip launch_path):
+    one kernel with 64 lanes per frame, or prep / fit / finish with 16 lanes per frame, or the packed ones (8 lanes per
+    frame; the fit kernel optionally 4) that bench.py's overlapped passes run.  The environment pins the choice; every
+    instantiation must reproduce the oracle bit for bit."""
+    env = {"mono64": {"FSDP_PATH_MODE": "mono"}, "split16": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "0"},
+           "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1"},
+           "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4"}}[mode]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     ctx = pkg.Context(device=0)
     off, cones, poses = pkg.synth.make_replay_batch(300, 64, 0.15, seed=21, color=True)
     off2, cones2, poses2 = pkg.synth.make_replay_batch(211, 100, 0.0, seed=22, frame_noise=0.3, random_pose=True, color=False)
@@ -305,6 +316,10 @@ def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, group):
         with oracle_lib.math_mode(1):
             ref = oracle_lib.plan_batch(o, c, p, n_threads=os.cpu_count() or 1)
         _assert_equal_to_oracle(res, ref)
+    names = ctx.stage_names()
+    want = {"mono64": "path_kernel<64>", "split16": "fit_kernel<16>", "packed8": "fit_kernel<8>", "packed8_fit4": "fit_kernel<4>"}[mode]
+    assert want in names, names
+    assert ("path_prep_kernel<8>" in names) == mode.startswith("packed"), names
 
 
 def test_rccl_single_rank_communicator(pkg, monkeypatch):
