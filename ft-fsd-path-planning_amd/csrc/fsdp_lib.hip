@@ -76,6 +76,8 @@ struct fsdp_ctx {
     PathMid* d_mid = nullptr;
     int cap_frames = 0;
   } extra[FSDP_MAX_OVERLAP - 1];
+  int max_cones = 0;             // most cones in a frame of the resident batch (picks the sorting kernel's state size)
+  bool no_sort128 = getenv("FSDP_NO_SORT128") != nullptr;  // experiments: always the 255-cone state
   std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
   int timed_iters = 0, timed_stages = 0;  // the most recent fsdp_time_runs (fsdp_time_results reads its events)
   bool primed[FSDP_MAX_OVERLAP] = {};     // slot i has executed a pass of the current packing (its stream / hardware queue is set up)
@@ -253,8 +255,12 @@ static int lds_knob(const char* name) {
 
 static void launch_sort(fsdp_ctx* c, const Slot& q) {
   (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
-  hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_SORT"), q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
-                     q.d_sort, q.d_retry, c->d_params);
+  if (c->max_cones <= SortShared128::MAX_N && !c->no_sort128)
+    hipLaunchKernelGGL(sort_kernel_128, dim3(c->n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_SORT"), q.stream, c->n_frames, c->d_off, c->d_cones,
+                       c->d_poses, q.d_sort, q.d_retry, c->d_params);
+  else
+    hipLaunchKernelGGL(sort_kernel, dim3(c->n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_SORT"), q.stream, c->n_frames, c->d_off, c->d_cones, c->d_poses,
+                       q.d_sort, q.d_retry, c->d_params);
   hipLaunchKernelGGL(sort_big_kernel, dim3(SORT_BIG_BLOCKS), dim3(WAVE), 0, q.stream, c->d_off, c->d_cones, c->d_poses, q.d_sort,
                      q.d_retry, c->d_sort_big + (size_t)q.index * SORT_BIG_BLOCKS, c->d_params);
 }
@@ -304,7 +310,8 @@ static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
   const double* prev = c->use_prev ? c->d_prev : nullptr;
   const int n = c->n_frames;
   const bool split = c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH;
-  c->stage_names = "sort_kernel,match_kernel<" + std::to_string(MATCH_G) + ">,";
+  c->stage_names = std::string((c->max_cones <= SortShared128::MAX_N && !c->no_sort128) ? "sort_kernel_128" : "sort_kernel") + ",match_kernel<" +
+                   std::to_string(MATCH_G) + ">,";
   mark(q, t);
   (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
   if (!split) {
@@ -593,6 +600,8 @@ int fsdp_upload(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
   c->n_frames = n_frames;
   c->resident = true;
   c->last_slot = 0;
+  c->max_cones = 0;
+  for (int i = 0; i < n_frames; i++) c->max_cones = std::max(c->max_cones, (int)(off[i + 1] - off[i]));
   if (n_frames == 0) return 0;
   HIP_TRY(c, hipMemcpyAsync(c->d_off, off, sizeof(int32_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, c->stream));
   if (total) HIP_TRY(c, hipMemcpyAsync(c->d_cones, cones, sizeof(double) * 3 * total, hipMemcpyHostToDevice, c->stream));

@@ -44,7 +44,7 @@ struct SortSharedT {
   static constexpr int ENDS = ENDS_;    // raw end configurations per side
   using idx_t = IDX_;                   // cone index in the neighbour lists
   static constexpr int NONE = (sizeof(IDX_) == 1) ? 255 : 32767;  // "no neighbour" (sorts last)
-  static constexpr int MAX_N = (sizeof(IDX_) == 1) ? 255 : CAP_;  // largest frame (index NONE is reserved)
+  static constexpr int MAX_N = (sizeof(IDX_) == 1 && CAP_ > 255) ? 255 : CAP_;  // largest frame (index NONE is reserved)
   double x[CAP];
   double y[CAP];
   uint8_t type[CAP];
@@ -96,6 +96,7 @@ struct SortSharedT {
   int32_t adj_built;               // the mutual-kNN lists below have been built for this frame
 };
 using SortShared = SortSharedT<MAX_CONES, uint8_t, MAX_ENDS>;          // LDS, product kernel
+using SortShared128 = SortSharedT<128, uint8_t, MAX_ENDS>;             // LDS, batches whose frames hold <= 128 cones
 constexpr int BIG_CONES = 1024, BIG_ENDS = 4096;
 using SortSharedBig = SortSharedT<BIG_CONES, int16_t, BIG_ENDS>;        // global memory, sort_big_kernel
 
@@ -1210,13 +1211,12 @@ __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32
 }
 
 // One workgroup (= one wavefront) per frame, frame state in LDS.  big (optional): [0] = counter, [1..] = frames beyond
-// the LDS capacities (more than 255 cones, more than 64 raw end configurations), planned again by sort_big_kernel.
-// Three wavefronts per SIMD (168 registers, 13.0 KB of LDS per frame): the stage is a chain of short dependent sections, and
-// the third resident wavefront fills issue slots the other two leave open (+8 % frames/s over two; 40 bytes of spill).
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
-sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
-            const double* __restrict__ poses, SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
-  __shared__ SortShared S;
+// the LDS capacities (more cones than the state holds, more than 64 raw end configurations), planned again by
+// sort_big_kernel.
+template <class SH>
+__device__ __forceinline__ void sort_kernel_body(SH& S, int n_frames, const int32_t* __restrict__ cone_offsets,
+                                                 const double* __restrict__ cones_xyt, const double* __restrict__ poses,
+                                                 SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
   const int frame = blockIdx.x;
   if (frame >= n_frames) return;
   PROF_INIT();
@@ -1224,6 +1224,27 @@ sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets, const double
   if (big != nullptr && lane_id() == 0 && (out[frame].status == ST_OVERFLOW_CONES || out[frame].status == ST_OVERFLOW_ENDS))
     big[1 + atomicAdd(&big[0], 1)] = frame;
   PROF_FLUSH();
+}
+// Up to 255 cones per frame.  Three wavefronts per SIMD (168 registers, 13.0 KB of LDS per frame): the stage is a chain of
+// short dependent sections, and the third resident wavefront fills issue slots the other two leave open (+8 % frames/s over
+// two; 40 bytes of spill).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
+sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
+            const double* __restrict__ poses, SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
+  __shared__ SortShared S;
+  sort_kernel_body(S, n_frames, cone_offsets, cones_xyt, poses, out, big, prm);
+}
+// The same code over a state for up to 128 cones (the host launches it when no frame of the batch holds more): the cone
+// arrays, neighbour lists and bit masks are half as long, which makes a frame SORT128_LDS and lets a SIMD hold
+// SORT128_WAVES wavefronts.
+#ifndef SORT128_WAVES
+#define SORT128_WAVES 4
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SORT128_WAVES)))
+sort_kernel_128(int n_frames, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
+                const double* __restrict__ poses, SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
+  __shared__ SortShared128 S;
+  sort_kernel_body(S, n_frames, cone_offsets, cones_xyt, poses, out, big, prm);
 }
 
 // The frames sort_kernel could not hold in LDS, with the frame state in global memory (one SortSharedBig per block).

@@ -267,6 +267,26 @@ __device__ __forceinline__ unsigned hi_word(double v) {
 __device__ __forceinline__ bool div_safe(double v) {  // finite, non-zero, exponent in [-256, 256]
   return (((hi_word(v) >> 20) & 0x7ffu) - 0x2ffu) <= 0x200u;
 }
+// max(|a|, b) / min(|a|, b) of numbers that are never NaN: one v_max_f64 / v_min_f64 each (the absolute value is a source
+// modifier; fmax() would first quiet both operands)
+__device__ __forceinline__ double max_abs_nn(double a, double b) {
+#ifdef FSDP_EMU
+  return fabs(a) >= b ? fabs(a) : b;
+#else
+  double r;
+  asm("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
+}
+__device__ __forceinline__ double min_abs_nn(double a, double b) {
+#ifdef FSDP_EMU
+  return fabs(a) >= b ? b : fabs(a);
+#else
+  double r;
+  asm("v_min_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
+}
 __device__ __forceinline__ double rcp_refined(double d) {
 #ifdef FSDP_EMU
   return d;  // (the emulator divides directly, see div_rcp)
@@ -469,17 +489,19 @@ __device__ __forceinline__ void giv_step(GivLane& st, bool feed, double h0, doub
     x2 = dy;
   }
   const int idx = st.t - (st.stage - 1);
-  const bool valid = idx >= 0 && idx < st.fed;
+  const bool valid = (unsigned)idx < (unsigned)st.fed;  // 0 <= idx < fed
   const bool rot = valid && piv != 0.0;
   // fpgivs.f: dd = |piv| * sqrt(1 + (ww/piv)^2) if |piv| >= ww else ww * sqrt(1 + (piv/ww)^2) — written with selects so
   // that one division and one square root are issued (same operations, same operands, same bits)
+  // The quotient only enters as its square, and |ww / piv| = ww / |piv| bit for bit (IEEE division is sign-symmetric), so
+  // the two branches are den = max(|piv|, ww) = scale, num = min(|piv|, ww) (ww >= 0): two instructions instead of a
+  // compare and six selects.
   const double ww = st.a1;
-  const double store = fabs(piv);
-  const bool big = store >= ww;
-  const double num = big ? ww : piv, den = big ? piv : ww, scale = big ? store : ww;
+  const double den = max_abs_nn(piv, ww), num = min_abs_nn(piv, ww), scale = den;
   double dd, cs, sn;
   if constexpr (FAST) {
-    st.bad |= (int)(rot & !(div_safe(piv) & ((ww == 0.0) | div_safe(ww))));
+    // operands of the scaling-free divisions: den (and dd in [den, sqrt(2) den]) inside the safe band, num inside it or 0
+    st.bad |= (int)(rot & !((den >= 0x1p-255) & (den <= 0x1p+255) & ((num == 0.0) | (num >= 0x1p-255))));
     const double rq = rcp_refined(den);
     const double q = div_rcp(num, den, rq);
     dd = scale * sqrt_1_2(1.0 + q * q);

@@ -127,7 +127,13 @@ int emu_sizeof_path_out() { return (int)sizeof(fsdp::PathOut); }
 
 void emu_sort(int n_frames, const int32_t* offsets, const double* cones, const double* poses, fsdp::SortOut* out) {
   std::vector<int> big((size_t)n_frames + 1, 0);
-  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel(n_frames, offsets, cones, poses, out, big.data(), &g_prm); });
+  // the host library's choice (fsdp_lib.hip launch_sort): the 128-cone state when no frame of the batch holds more
+  int max_cones = 0;
+  for (int f = 0; f < n_frames; f++) max_cones = std::max(max_cones, (int)(offsets[f + 1] - offsets[f]));
+  if (max_cones <= fsdp::SortShared128::MAX_N && !getenv("FSDP_NO_SORT128"))
+    emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel_128(n_frames, offsets, cones, poses, out, big.data(), &g_prm); });
+  else
+    emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel(n_frames, offsets, cones, poses, out, big.data(), &g_prm); });
   g_last_big = big[0];
   if (big[0] > 0) {
     std::vector<fsdp::SortSharedBig> state(2);

@@ -322,6 +322,34 @@ def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, mode):
     assert ("path_prep_kernel<8>" in names) == mode.startswith("packed"), names
 
 
+def test_both_sorting_state_sizes_equal_oracle(pkg, monkeypatch):
+    """A batch whose frames hold at most 128 cones is sorted by sort_kernel_128 (half-size frame state, four wavefronts per
+    SIMD), any other batch by sort_kernel (255 cones): same results from both, equal to the oracle."""
+    off, cones, poses = pkg.synth.make_replay_batch(512, 64, 0.15, seed=31, color=True)
+    off2, cones2, poses2 = pkg.synth.make_replay_batch(256, 60, 0.0, seed=32, frame_noise=0.3, random_pose=True, color=False)
+    with oracle_lib.math_mode(1):
+        refs = [oracle_lib.plan_batch(o, c, p, n_threads=os.cpu_count() or 1) for o, c, p in ((off, cones, poses), (off2, cones2, poses2))]
+    ctx = pkg.Context(device=0)
+    small = [ctx.plan_batch(o, c, p) for o, c, p in ((off, cones, poses), (off2, cones2, poses2))]
+    assert "sort_kernel_128" in ctx.stage_names()
+    monkeypatch.setenv("FSDP_NO_SORT128", "1")
+    ctx2 = pkg.Context(device=0)
+    large = [ctx2.plan_batch(o, c, p) for o, c, p in ((off, cones, poses), (off2, cones2, poses2))]
+    assert "sort_kernel_128" not in ctx2.stage_names()
+    for a, b, ref in zip(small, large, refs):
+        _assert_equal_to_oracle(a, ref)
+        for f in a.dtype.names:
+            assert a[f].tobytes() == b[f].tobytes(), f
+    # 129 cones in one frame of the batch: the library takes the 255-cone kernel by itself
+    off3, cones3, poses3 = pkg.synth.make_replay_batch(8, 65, 0.15, seed=33, color=True)
+    monkeypatch.delenv("FSDP_NO_SORT128")
+    ctx3 = pkg.Context(device=0)
+    res3 = ctx3.plan_batch(off3, cones3, poses3)
+    assert "sort_kernel_128" not in ctx3.stage_names()
+    with oracle_lib.math_mode(1):
+        _assert_equal_to_oracle(res3, oracle_lib.plan_batch(off3, cones3, poses3))
+
+
 def test_rccl_single_rank_communicator(pkg, monkeypatch):
     """fsdp_comm_* (RCCL behind the C ABI, no PyTorch): a one-rank communicator on this GPU — unique id, ncclCommInitRank,
     ncclCommCount, broadcast of the skidpad track table, all-reduce, barrier.  N > 1 differs only in the rank count."""
