@@ -113,6 +113,7 @@ def load() -> ctypes.CDLL:
     lib.fsdp_stage_names.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
     lib.fsdp_time_runs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.fsdp_time_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.fsdp_time_detail.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.fsdp_time_results.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.fsdp_comm_unique_id.argtypes = [ctypes.c_void_p]
     lib.fsdp_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
@@ -128,7 +129,7 @@ def load() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_default_params", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
-    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_time_reserve", "fsdp_time_results", "fsdp_stage_names", "fsdp_resident_frames",
+    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_time_reserve", "fsdp_time_results", "fsdp_time_detail", "fsdp_stage_names", "fsdp_resident_frames",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
@@ -276,6 +277,11 @@ class Context:
     def time_reserve(self, iters: int):
         """Create the events of an `iters`-pass timed region ahead of time."""
         self._check(self._lib.fsdp_time_reserve(self._h, int(iters)), "fsdp_time_reserve")
+
+    def time_detail(self, every_kernel: bool):
+        """Events around every kernel launch of the next time_runs (True, the default) or only around the path stage's
+        main kernel of every pass (False: the other kernels' times come back as 0)."""
+        self._check(self._lib.fsdp_time_detail(self._h, 1 if every_kernel else 0), "fsdp_time_detail")
 
     def time_results(self):
         """(ms of the whole region, summed ms per kernel) of the most recent time_runs."""

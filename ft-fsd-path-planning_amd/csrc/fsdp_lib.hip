@@ -80,6 +80,8 @@ struct fsdp_ctx {
   bool no_sort128 = getenv("FSDP_NO_SORT128") != nullptr;  // experiments: always the 255-cone state
   std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
   int timed_iters = 0, timed_stages = 0;  // the most recent fsdp_time_runs (fsdp_time_results reads its events)
+  bool time_main_only = false;            // fsdp_time_detail: events only around the path stage's main kernel
+  std::vector<unsigned> tev_recorded;     // per pass of the most recent fsdp_time_runs: which of its events were recorded
   bool primed[FSDP_MAX_OVERLAP] = {};     // slot i has executed a pass of the current packing (its stream / hardware queue is set up)
   // skidpad mission
   double* d_table = nullptr;
@@ -277,9 +279,17 @@ constexpr int MAX_STAGES = FSDP_MAX_STAGES;
 struct StageEvents {  // optional timing: ev[k] is recorded before stage k, ev[n_stages] after the last
   hipEvent_t* ev = nullptr;
   int n = 0;
+  bool main_only = false;   // record only the events around the path stage's main kernel (and the last one of the pass)
+  unsigned recorded = 0;    // bit k: ev[k] was recorded
 };
-static void mark(const Slot& q, StageEvents* t) {
-  if (t && t->ev) (void)hipEventRecord(t->ev[t->n++], q.stream);
+enum MarkKind { MARK_PLAIN = 0, MARK_MAIN = 1, MARK_LAST = 2 };
+static void mark(const Slot& q, StageEvents* t, MarkKind kind = MARK_PLAIN) {
+  if (!t || !t->ev) return;
+  if (!t->main_only || kind != MARK_PLAIN) {
+    (void)hipEventRecord(t->ev[t->n], q.stream);
+    t->recorded |= 1u << t->n;
+  }
+  t->n++;
 }
 
 template <int GF>
@@ -312,27 +322,28 @@ static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
   const bool split = c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH;
   c->stage_names = std::string((c->max_cones <= SortShared128::MAX_N && !c->no_sort128) ? "sort_kernel_128" : "sort_kernel") + ",match_kernel<" +
                    std::to_string(MATCH_G) + ">,";
-  mark(q, t);
   (void)hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream);
   if (!split) {
+    mark(q, t, MARK_MAIN);
     hipLaunchKernelGGL(path_kernel<PATH_G_SMALL>, dim3(n), dim3(WAVE), 0, q.stream, n, c->d_poses, q.d_match, c->d_default_path, prev,
                        c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
     c->stage_names += "path_kernel<64>,";
   } else {
+    mark(q, t);
     const bool packed = c->force_pack ? c->force_pack == 2 : (long long)n * c->overlap >= PACK_FRAMES;
     const int gf = packed ? c->fit_g : 16;
     if (packed)
       launch_prep<8>(c, q, prev);
     else
       launch_prep<16>(c, q, prev);
-    mark(q, t);
+    mark(q, t, MARK_MAIN);
     if (gf == 4)
       launch_fit<4>(c, q);
     else if (gf == 8)
       launch_fit<8>(c, q);
     else
       launch_fit<16>(c, q);
-    mark(q, t);
+    mark(q, t, MARK_MAIN);
     if (packed)
       launch_finish<8>(c, q);
     else
@@ -340,12 +351,12 @@ static void launch_path(fsdp_ctx* c, const Slot& q, StageEvents* t = nullptr) {
     const std::string g = packed ? "8" : "16";
     c->stage_names += "path_prep_kernel<" + g + ">,fit_kernel<" + std::to_string(gf) + ">,path_finish_kernel<" + g + ">,";
   }
-  mark(q, t);
+  mark(q, t, split ? MARK_PLAIN : MARK_MAIN);
   const int rb = n < 1024 ? n : 1024;  // one wavefront per SIMD at most; blocks beyond the list's length return at once
   hipLaunchKernelGGL(path_retry_kernel, dim3(rb), dim3(WAVE), 0, q.stream, c->d_poses, q.d_match, c->d_default_path, prev, c->d_gpath,
                      c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
   c->stage_names += "path_retry_kernel";
-  mark(q, t);
+  mark(q, t, MARK_LAST);
 }
 
 // sorting -> matching -> path stage of the resident batch on slot q
@@ -765,6 +776,7 @@ int fsdp_time_results(fsdp_ctx* c, float* ms_total, float* ms_stage) {
     for (int it = 0; it < c->timed_iters; it++)
       for (int st = 0; st < c->timed_stages; st++) {
         float t;
+        if ((c->tev_recorded[it] >> st & 3u) != 3u) continue;  // a kernel the region did not bracket: its time stays 0
         HIP_TRY(c, hipEventElapsedTime(&t, c->tev[(size_t)TIMING_EPP * (size_t)it + st], c->tev[(size_t)TIMING_EPP * (size_t)it + st + 1]));
         ms_stage[st] += t;
       }
@@ -800,6 +812,7 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
     started[i] = false;
   }
   int n_stages = 0;
+  c->tev_recorded.assign((size_t)iters, 0u);
   for (int it = 0; it < iters; it++) {
     const int si = (c->overlap > 1) ? (int)(c->turn++ % (unsigned)c->overlap) : 0;
     const Slot q = slot_of(c, si);
@@ -808,8 +821,10 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
     started[si] = true;
     StageEvents t;
     t.ev = &c->tev[(size_t)EPP * (size_t)it];
+    t.main_only = c->time_main_only;
     launch_pass(c, q, &t);
     n_stages = t.n - 1;
+    c->tev_recorded[it] = t.recorded;
     last_of_slot[si] = it;
   }
   // the end event follows the last pass of every slot
@@ -823,6 +838,12 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
   c->timed_iters = iters;
   c->timed_stages = n_stages;
   if (ms_total || ms_stage) return fsdp_time_results(c, ms_total, ms_stage);
+  return 0;
+}
+
+int fsdp_time_detail(fsdp_ctx* c, int every_kernel) {
+  if (!c) return 1;
+  c->time_main_only = every_kernel == 0;
   return 0;
 }
 

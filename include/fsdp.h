@@ -183,6 +183,12 @@ int fsdp_time_runs(fsdp_ctx* ctx, int iters, float* ms_total, float* ms_stage);
  * enqueues the passes and returns
  * when the last one has finished (no event is read), fsdp_time_results reads the times of that most recent region. */
 int fsdp_time_reserve(fsdp_ctx* ctx, int iters);
+/* Which launches the next fsdp_time_runs brackets with events: every kernel (1, the default), or only the main kernel of
+ * the path stage — fit_kernel, or path_kernel<64> for small batches — of every pass (0): an event record is a packet in
+ * the stream's queue, and seven of them per pass cost about 3 % of the throughput of overlapped passes.  ms_stage entries
+ * of kernels that were not bracketed are 0.  (Reference: the Timer context managers of full_pipeline.py:113-176 time the
+ * stages on the host; they are switched off in the reference's own benchmark runs.) */
+int fsdp_time_detail(fsdp_ctx* ctx, int every_kernel);
 int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
 /* comma-separated kernel names behind ms_stage of the most recent pass, e.g.
  * "sort_kernel,match_kernel,path_prep_kernel<8>,fit_kernel<8>,path_finish_kernel<8>,path_retry_kernel" */

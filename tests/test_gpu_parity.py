@@ -287,6 +287,15 @@ def test_overlapped_passes_equal_serial_passes(pkg):
     assert ctx.time_results() == (tot3, st3)  # reading twice is harmless
     got = ctx.download()
     assert got["path"].tobytes() == ref["path"].tobytes()
+    # events only around the path stage's main kernel (what bench.py's timed region records): the other kernels read 0
+    ctx.time_detail(False)
+    assert ctx.time_runs(7, collect=False) is None
+    tot4, st4 = ctx.time_results()
+    main = [n.startswith(("fit_kernel", "path_kernel<64>")) for n in ctx.stage_names()]
+    assert tot4 > 0 and sum(main) == 1 and st4[main.index(True)] > 0 and st4[0] == 0 and st4[1] == 0, (ctx.stage_names(), st4)
+    assert ctx.download()["path"].tobytes() == ref["path"].tobytes()
+    ctx.time_detail(True)
+    assert all(x > 0 for x in ctx.time_runs(3)[1])
     ctx.set_overlap(2)
     # a different batch through the same overlapped context
     off2, cones2, poses2 = pkg.synth.make_replay_batch(700, 64, 0.15, seed=12, color=False)

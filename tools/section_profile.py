@@ -17,7 +17,7 @@ so.parent.mkdir(exist_ok=True)
 KERNELS = {"fit": 1, "prep": 2, "finish": 3}
 which = next((a[len("--kernel="):] for a in sys.argv[1:] if a.startswith("--kernel=")), "fit")
 sys.argv = [a for a in sys.argv if not a.startswith("--kernel=")]
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-sink-insts-to-avoid-spills=1", "-fPIC", "-shared",
                 "-DFSDP_PROFILE", f"-DFSDP_PROFILE_KERNEL={KERNELS[which]}", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so), "-ldl"], check=True, capture_output=True)
 import os
 

@@ -14,7 +14,7 @@ sys.path.insert(0, str(ROOT))
 PKG = ROOT / "ft-fsd-path-planning_amd"
 so = ROOT / "gpurun_out" / "libfsdp_prof.so"
 so.parent.mkdir(exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-sink-insts-to-avoid-spills=1", "-fPIC", "-shared",
                 "-DFSDP_PROFILE", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so), "-ldl"], check=True, capture_output=True)
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 pkg._capi.LIB_PATH = so
