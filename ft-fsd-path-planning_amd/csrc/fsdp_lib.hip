@@ -1134,7 +1134,7 @@ extern "C" int fsdp_debug_refit(fsdp_ctx* c, int32_t* n_knots, double* knots34, 
   const int n = c->n_frames;
   std::vector<FitRec> recs((size_t)n);
   std::vector<PathMid> mids((size_t)n);
-  const size_t fit_off = (size_t)(11 * PATH_CAP + ARENA_B + DENSE_CAP) * sizeof(double);  // frame_arena(): A.fit
+  const size_t fit_off = (size_t)ARENA_FIT * sizeof(double);  // frame_arena(): A.fit
   HIP_TRY(c, hipMemcpy2DAsync(recs.data(), sizeof(FitRec), (const char*)q.d_arena + fit_off, sizeof(double) * ARENA_DOUBLES,
                               sizeof(FitRec), (size_t)n, hipMemcpyDeviceToHost, q.stream));
   HIP_TRY(c, hipMemcpyAsync(mids.data(), q.d_mid, sizeof(PathMid) * (size_t)n, hipMemcpyDeviceToHost, q.stream));

@@ -35,7 +35,10 @@ constexpr int FIT_KNOTS = 16;  // knots the kernels of the three-kernel path sta
 constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
 constexpr int FITREC_DOUBLES = 112;  // >= sizeof(FitRec) / 8
 constexpr int BAND_DOUBLES = 112;    // >= 6 * (FIT_KNOTS + 2): band triangle + right-hand sides of fit_kernel's fit
-constexpr int ARENA_DOUBLES = 3 * PATH_CAP + 8 * PATH_CAP + ARENA_B + DENSE_CAP + FITREC_DOUBLES + BAND_DOUBLES;  // x | y | u | records | ...
+constexpr int ARENA_REC = 3 * PATH_CAP;                  // basis records (32 bytes per point), then one interval byte per point
+constexpr int ARENA_BMAT = ARENA_REC + 4 * PATH_CAP + PATH_CAP / 8;  // rows of the smoothness matrix
+constexpr int ARENA_FIT = ARENA_BMAT + ARENA_B + DENSE_CAP;          // FitRec
+constexpr int ARENA_DOUBLES = ARENA_FIT + FITREC_DOUBLES + BAND_DOUBLES;  // x | y | u | records | intervals | b | filtered curvature | FitRec | band
 // knots / coefficients of the refit (fit #2) on their way from fit_kernel to path_finish_kernel
 struct FitRec {
   int32_t n, ier, status, pad;
@@ -50,7 +53,7 @@ struct PathMid {
   int32_t status, fallback, off, n;
 };
 static_assert(ARENA_B >= DENSE_CAP, "raw curvature of a LEAN workspace lives in the smoothness-matrix rows");
-static_assert(ARENA_DOUBLES % 8 == 0 && (3 * PATH_CAP) % 8 == 0, "basis records must stay 64-byte aligned");
+static_assert(ARENA_DOUBLES % 8 == 0 && ARENA_REC % 8 == 0 && PATH_CAP % 64 == 0 && ARENA_BMAT % 8 == 0, "basis records must stay 64-byte aligned");
 struct Arena {
   double* x;
   double* y;
@@ -773,8 +776,9 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame, const Par
   A.x = b;
   A.y = b + PATH_CAP;
   A.u = b + 2 * PATH_CAP;
-  A.bc.rec = (BRec*)(b + 3 * PATH_CAP);  // 64-byte aligned: ARENA_DOUBLES and 3 * PATH_CAP are multiples of 8
-  A.bc.b = b + 11 * PATH_CAP;
+  A.bc.rec = (BRec*)(b + ARENA_REC);  // 64-byte aligned: ARENA_DOUBLES and ARENA_REC are multiples of 8
+  A.bc.l = (uint8_t*)(b + ARENA_REC + 4 * PATH_CAP);
+  A.bc.b = b + ARENA_BMAT;
   A.filt = A.bc.b + ARENA_B;
   A.curv = A.bc.b;
   A.fit = (FitRec*)(A.filt + DENSE_CAP);
@@ -1064,10 +1068,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
   PROF_FLUSH_K(2);
 }
 
+#ifndef FSDP_FIT_WAVES
+#define FSDP_FIT_WAVES 3
+#endif
 // the refit: utils/spline_fit.py:95-128 (splprep, k = 3, s = 0.2) of the arena polyline [off, off + n), G lanes per frame
 template <int G, int NKC>
 // (three wavefronts per SIMD: 168 registers, measured +2 % frames/s over two)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FSDP_FIT_WAVES))) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                  int* __restrict__ retry, const Params* __restrict__ prm) {
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;

@@ -80,11 +80,14 @@ struct SplineWS {
 // wavefronts fit a SIMD's share of the LDS.  The band triangle and its right-hand sides are not here: during an
 // observation pass they live in the registers of the Givens quad, between passes in the frame's scratch (`band`:
 // (NK + 2) x 4 rows, then 2 (NK + 2) right-hand sides), where back-substitution and the smoothing iteration fetch them.
+#ifndef FSDP_FIT_CH8
+#define FSDP_FIT_CH8 16
+#endif
 template <int G, int NKC>
 struct FitWS {
   static constexpr int GRP = G;
   static constexpr int NK = NKC;
-  static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : (G >= 8 ? 16 : 8));
+  static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : (G >= 8 ? FSDP_FIT_CH8 : 8));
   static constexpr bool BAND_GLOBAL = true;
   double t[NK + 2];
   double c[2 * (NK + 2)];
@@ -104,24 +107,25 @@ struct FitWS {
   __device__ __forceinline__ double& Gm(int i, int j) { return g_[i][j - 1]; }
 };
 
-// Per-point basis cache in the frame's HBM/L2 scratch: one 64-byte record per data point — the K+1 non-zero B-spline
-// values, the point itself and its knot interval — written by the observation pass of the current knot set and re-read
-// by the residual pass and by every f(p) evaluation of the smoothing iteration (same knots => same values; saves the
-// interval search and the de Boor recursion with its six divisions per point and pass).  A record is a cache line half:
-// a lane moves it with four 16-byte accesses, the lanes of a group touch consecutive records.
+// Per-point basis cache in the frame's HBM/L2 scratch: one 32-byte record per data point — the K+1 non-zero B-spline
+// values — and one byte per point for its knot interval, written by the observation pass of the current knot set and
+// re-read by the residual pass and by every f(p) evaluation of the smoothing iteration (same knots => same values; saves
+// the interval search and the de Boor recursion with its six divisions per point and pass).  A lane moves a record with
+// two 16-byte accesses, the lanes of a group touch consecutive records; the data point itself is read from the polyline
+// arrays (8 bytes per lane and coordinate, consecutive lanes on consecutive doubles).  49 bytes per point and pass
+// instead of the 64-byte records {h, x, y, interval} of the earlier layout: the refit streams ~10 such passes over 480
+// points per frame, and with the chip full of fit wavefronts that stream is a few TB/s.
 struct alignas(16) D2 {
   double a, b;
 };
-struct alignas(64) BRec {
+struct alignas(32) BRec {
   D2 h01, h23;  // basis values h[0..3] (unused entries of lower degrees are 0)
-  D2 xy;        // the data point
-  int32_t l;    // knot interval
-  int32_t pad[3];
 };
-static_assert(sizeof(BRec) == 64, "basis record is one 64-byte line");
+static_assert(sizeof(BRec) == 32, "basis record");
 struct BasisCache {
   BRec* rec;
-  double* b;  // (NK + 2) x 5 rows of the smoothness matrix (fpdisc) of the running fit, row-major, element (i, j) at 5 i + j - 1
+  uint8_t* l;  // knot interval per data point (<= NK_MAX)
+  double* b;   // (NK + 2) x 5 rows of the smoothness matrix (fpdisc) of the running fit, row-major, element (i, j) at 5 i + j - 1
 };
 
 struct SplineFit {
@@ -610,7 +614,7 @@ struct ResidualBatch {
 
   // Loads are unconditional (rows past the end re-read the last record, index clamped) so that all of a super-chunk's
   // loads sit in one basic block and fly together; only the stores of compute() are predicated.
-  __device__ __forceinline__ void load(const BasisCache& bc, int base, int cnt, int m) {
+  __device__ __forceinline__ void load(const BasisCache& bc, const double* X, const double* Y, int base, int cnt, int m) {
     (void)cnt;
     const int lane = Grp<G>::lane();
 #pragma unroll
@@ -618,19 +622,19 @@ struct ResidualBatch {
       int it = base + q * G + lane;
       it = it < m ? it : m - 1;
       const BRec* p = &bc.rec[it];
-      const D2 a = p->h01, b = p->h23, c = p->xy;
+      const D2 a = p->h01, b = p->h23;
       const double hh[4] = {a.a, a.b, b.a, b.b};
 #pragma unroll
       for (int j = 0; j < k1; j++) hv[q][j] = hh[j];
       // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
       // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point
-      lv[q] = p->l + 1;
+      lv[q] = (int)bc.l[it] + 1;
       if constexpr (FLAGS) {
-        const int lp = bc.rec[it > 0 ? it - 1 : 0].l + 1;
+        const int lp = (int)bc.l[it > 0 ? it - 1 : 0] + 1;
         lpv[q] = it > 0 ? lp : k2;
       }
-      xv[q] = c.a;
-      yv[q] = c.b;
+      xv[q] = X[it];
+      yv[q] = Y[it];
     }
   }
 
@@ -793,8 +797,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
               BRec* p = &bc.rec[it];
               p->h01 = D2{hf[0], hf[1]};
               p->h23 = D2{hf[2], hf[3]};
-              p->xy = D2{pxv[q], pyv[q]};
-              p->l = l;
+              bc.l[it] = (uint8_t)l;
             }
           }
           GR::sync();
@@ -953,14 +956,14 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         int32_t* const fbuf = (int32_t*)ws.xq;  // xq | yq: 4 * CH flags
         ResidualBatch<K, G, true, CH> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
         auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
-        ra.load(bc, 0, clampc(m), m);
+        ra.load(bc, X, Y, 0, clampc(m), m);
         for (int base = 0; base < m; base += HALVES * SC) {
           const int cnt_a = clampc(m - base);
           const int cnt_b = (HALVES == 2) ? clampc(m - base - SC) : 0;
           const int cnt = cnt_a + cnt_b;
-          if constexpr (HALVES == 2) rb.load(bc, base + SC, cnt_b, m);
+          if constexpr (HALVES == 2) rb.load(bc, X, Y, base + SC, cnt_b, m);
           ra.compute(ws, cnt_a, n, tbuf, fbuf);
-          ra.load(bc, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
+          ra.load(bc, X, Y, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
           if constexpr (HALVES == 2) rb.compute(ws, cnt_b, n, tbuf + SC, fbuf + SC);
           GR::sync();
           for (int r0 = 0; r0 < cnt; r0 += 8) {  // operands eight at a time (one LDS round trip), order kept
@@ -1210,15 +1213,15 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         double* const tbuf = &ws.hq[0][0];  // 4 * CH terms
         ResidualBatch<K, G, false, CH> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
         auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
-        ra.load(bc, 0, clampc(m), m);
+        ra.load(bc, X, Y, 0, clampc(m), m);
         for (int base = 0; base < m; base += HALVES * SC) {
           const int cnt_a = clampc(m - base);
           const int cnt_b = (HALVES == 2) ? clampc(m - base - SC) : 0;
           {
             PROF(28);
-            if constexpr (HALVES == 2) rb.load(bc, base + SC, cnt_b, m);
+            if constexpr (HALVES == 2) rb.load(bc, X, Y, base + SC, cnt_b, m);
             ra.compute(ws, cnt_a, n, tbuf, nullptr);
-            ra.load(bc, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
+            ra.load(bc, X, Y, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
             if constexpr (HALVES == 2) rb.compute(ws, cnt_b, n, tbuf + SC, nullptr);
             GR::sync();
           }
