@@ -59,7 +59,9 @@ struct fsdp_ctx {
   // further sets of intermediates + streams (fsdp_set_overlap): consecutive fsdp_run passes rotate through the sets, so
   // the next passes start while the slowest wavefronts of the previous ones are still finishing
   int force_path_mode = 0;    // 0 = by batch size; 1 = one kernel (64 lanes per frame); 2 = three kernels (FSDP_PATH_MODE=mono|split)
-  int fit_g = 8;              // lanes per frame of fit_kernel when frames are packed (FSDP_FIT_G=4|8; measured: tools/ab_variants.py)
+  int fit_g = 4;              // lanes per frame of fit_kernel when frames are packed: 4 = exactly the Givens quad, sixteen frames
+                              // per wavefront (FSDP_FIT_G=4|8; +1.6 % frames/s over 8 since the basis records are 32 bytes:
+                              // tools/ab_variants.py)
   int force_pack = 0;         // 0 = by frames in flight; 1 = 4 frames per wavefront; 2 = packed (FSDP_PACK=0|1)
   std::string stage_names;    // kernels of the most recent pass, comma-separated
   bool profile_sort = false;  // profiling build: which kernel fsdp_profile_path runs
@@ -485,7 +487,7 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   c->device = device;
   c->mission = mission;
   if (const char* e = getenv("FSDP_PATH_MODE")) c->force_path_mode = !strcmp(e, "mono") ? 1 : (!strcmp(e, "split") ? 2 : 0);
-  if (const char* e = getenv("FSDP_FIT_G")) c->fit_g = atoi(e) == 4 ? 4 : 8;
+  if (const char* e = getenv("FSDP_FIT_G")) c->fit_g = atoi(e) == 8 ? 8 : 4;
   if (const char* e = getenv("FSDP_PACK")) c->force_pack = atoi(e) ? 2 : 1;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -313,7 +313,7 @@ def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, mode):
     frame; the fit kernel optionally 4) that bench.py's overlapped passes run.  The environment pins the choice; every
     instantiation must reproduce the oracle bit for bit."""
     env = {"mono64": {"FSDP_PATH_MODE": "mono"}, "split16": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "0"},
-           "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1"},
+           "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "8"},
            "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4"}}[mode]
     for k, v in env.items():
         monkeypatch.setenv(k, v)

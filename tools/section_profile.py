@@ -39,7 +39,7 @@ assert rc == 0
 import os
 # large batches run the three-kernel path stage: the profile below is the selected kernel's (--kernel=fit|prep|finish;
 # fit_kernel: FSDP_FIT_G lanes per frame, prep / finish: 8)
-G = (int(os.environ.get("FSDP_FIT_G", "8")) if which == "fit" else 8) if N > 1024 else 64
+G = (int(os.environ.get("FSDP_FIT_G", "4")) if which == "fit" else 8) if N > 1024 else 64
 print(f"== {which} kernel ==")
 FPW = 64 // G
 out = out[: (N + FPW - 1) // FPW]
