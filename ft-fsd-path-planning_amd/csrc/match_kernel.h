@@ -14,6 +14,9 @@
 #pragma once
 #include "fsdp_device.h"
 
+#ifndef FSDP_MATCH_WAVES
+#define FSDP_MATCH_WAVES 4
+#endif
 namespace fsdp {
 
 struct MatchShared {
@@ -295,7 +298,7 @@ constexpr int MATCH_G = 32;  // lanes per frame (>= MAX_MATCH + 1: the insertion
 static_assert(MATCH_G > MAX_MATCH, "matching walks its lists one cone per lane");
 // (four wavefronts per SIMD, 126 registers: measured +2 % frames/s over the two the allocator takes unasked)
 template <int G>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) match_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FSDP_MATCH_WAVES))) match_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,
                                                    const double* __restrict__ cones_xyt, const double* __restrict__ poses,
                                                    const SortOut* __restrict__ sorted, MatchOut* __restrict__ out,
                                                    const Params* __restrict__ prm) {

@@ -18,7 +18,8 @@ import oracle_lib  # noqa: E402
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 MODES = {"mono64": {"FSDP_PATH_MODE": "mono"}, "split16": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "0"},
-         "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1"}}
+         "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "8"},
+         "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4"}}
 ctxs = {}
 for name, env in MODES.items():
     for k in ("FSDP_PATH_MODE", "FSDP_PACK", "FSDP_FIT_G"):

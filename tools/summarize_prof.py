@@ -74,7 +74,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     print(f"== rocprofv3 --pmc pass: {sub} (per-dispatch averages of the 4096-frame launches) ==")
     # (dispatches of other sizes — the default-path kernel, flip-count frames — are excluded by their grid size)
     q = ("select c.kernel_name, c.counter_name, avg(c.value), count(*) from counters_collection c "
-         "where c.grid_size >= 4096 * 8 group by c.kernel_name, c.counter_name")
+         "where c.grid_size >= 4096 * 4 group by c.kernel_name, c.counter_name")
     try:
         rows = list(con.execute(q))
     except sqlite3.OperationalError:
