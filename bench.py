@@ -294,6 +294,12 @@ def main():
                 "valu_insts_per_frame_all_kernels": _all_kernel_insts(pmc, names),
                 "valu_issue_util": (_all_kernel_insts(pmc, names) * n_local * 4 / (elapsed / args.steps * 2.4e9 * 1024)
                                     if _all_kernel_insts(pmc, names) else None),
+                # the same with the issue cost measured on this chip when every SIMD holds four wavefronts of independent
+                # FP64 chains (tools/ubench/fp64_rate.hip, profiles/r02_fp64_issue_rate.txt: v_fma_f64 4.6, v_mul / v_add_f64
+                # 5.0 cycles per wave-instruction at the reported 2.4 GHz, i.e. 68 TFLOP/s FMA): an upper estimate — the 32-bit
+                # part of the mix (selects, DPP moves, integer work) issues faster
+                "valu_issue_util_at_measured_fp64_cost": (_all_kernel_insts(pmc, names) * n_local * 4.8 / (elapsed / args.steps * 2.4e9 * 1024)
+                                                          if _all_kernel_insts(pmc, names) else None),
                 "note": f"algorithmic bytes/frame = {algo_bytes} (SURVEY 8d) x {n_local} frames / average duration of the dominant "
                         "kernel's launches in the timed region (kernel_ms_timed_region: HIP events on the streams the kernel "
                         "runs on; passes overlap, so a launch shares the chip with the other streams' kernels — kernel_ms = "
