@@ -257,40 +257,9 @@ __device__ __forceinline__ void fpback(EL el, const double* z, int n, int k, dou
 // with one correction (v_div_fmas) and v_div_fixup.  The scaling and the fix-up only act when an exponent sits near the
 // limits of the format; for operands in a safe band the sequence below is the same arithmetic on the same operands and
 // returns the same (correctly rounded) bits with 8 instead of 11 instructions — and two quotients over one denominator
-// share the refined reciprocal (11 instead of 22).  div_safe() is the guard: callers count operands outside
-// [2^-256, 2^256] and such a frame is re-planned with plain divisions (ST_RETRY, path_kernel.h).
-__device__ __forceinline__ unsigned hi_word(double v) {
-#ifdef FSDP_EMU
-  uint64_t u;
-  memcpy(&u, &v, sizeof(u));
-  return (unsigned)(u >> 32);
-#else
-  return (unsigned)__double2hiint(v);
-#endif
-}
-__device__ __forceinline__ bool div_safe(double v) {  // finite, non-zero, exponent in [-256, 256]
-  return (((hi_word(v) >> 20) & 0x7ffu) - 0x2ffu) <= 0x200u;
-}
-// max(|a|, b) / min(|a|, b) of numbers that are never NaN: one v_max_f64 / v_min_f64 each (the absolute value is a source
-// modifier; fmax() would first quiet both operands)
-__device__ __forceinline__ double max_abs_nn(double a, double b) {
-#ifdef FSDP_EMU
-  return fabs(a) >= b ? fabs(a) : b;
-#else
-  double r;
-  asm("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-#endif
-}
-__device__ __forceinline__ double min_abs_nn(double a, double b) {
-#ifdef FSDP_EMU
-  return fabs(a) >= b ? b : fabs(a);
-#else
-  double r;
-  asm("v_min_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-#endif
-}
+// share the refined reciprocal (11 instead of 22).  The guard: callers flag operands outside [2^-255, 2^255]
+// (float compares on the operands; the knot differences once per knot set) and such a frame is re-planned with plain
+// divisions (ST_RETRY, path_kernel.h).
 __device__ __forceinline__ double rcp_refined(double d) {
 #ifdef FSDP_EMU
   return d;  // (the emulator divides directly, see div_rcp)
@@ -343,9 +312,12 @@ __device__ __forceinline__ double sqrt_1_2(double x) {
 template <bool FAST>
 __device__ __forceinline__ void fpbspl3(const double* t, double x, int l, double* h /*[0..3]*/, int& bad) {
   const double tm2 = t[l - 2], tm1 = t[l - 1], t0 = t[l], tp1 = t[l + 1], tp2 = t[l + 2], tp3 = t[l + 3];
+  // FAST: the denominators are differences of knots — their exponent band is checked once per knot set by the caller
+  // (knot_differences_safe) — so only the numerators (partial basis values: 0 or in [2^-255, 2^255]) are checked per point
+  bool ok = true;
   auto quot = [&](double num, double den) {
     if constexpr (FAST) {
-      bad |= (int)((den != 0.0) & !(div_safe(den) & ((num == 0.0) | div_safe(num))));
+      ok = ok & ((num == 0.0) | ((num >= 0x1p-255) & (num <= 0x1p255)));
       return div_rcp(num, den, rcp_refined(den));
     } else {
       return num / den;
@@ -409,6 +381,23 @@ __device__ __forceinline__ void fpbspl3(const double* t, double x, int l, double
   h[1] = h2;
   h[2] = h3;
   h[3] = h4;
+  if constexpr (FAST) bad |= (int)!ok;
+}
+
+// The denominators of fpbspl3 are t(a + j) - t(a), j = 1..3: every one of the current knot vector t(1..n) must be 0
+// (coincident knots: that term is skipped) or inside the exponent band of the scaling-free division.  One lane per knot.
+template <int G>
+__device__ __forceinline__ bool knot_differences_safe(const double* t, int n) {
+  bool badk = false;
+  for (int a = 1 + Grp<G>::lane(); a <= n; a += G) {
+#pragma unroll
+    for (int j = 1; j <= 3; j++) {
+      const int b = a + j <= n ? a + j : n;
+      const double d = t[b] - t[a];
+      badk |= !((d == 0.0) | ((d >= 0x1p-255) & (d <= 0x1p255)));
+    }
+  }
+  return Grp<G>::ballot(badk) == 0ull;
 }
 
 // ---- 4-stage systolic Givens pipeline (degree 3) ------------------------------------------------------
@@ -749,6 +738,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       fp = 0.0;
       GivLane gst;
       giv_init(gst);
+      if constexpr (FAST && K == 3) {
+        if (!knot_differences_safe<G>(ws.t, n)) gst.bad = 1;
+      }
       int lvq[CH / G] = {};  // knot intervals of this lane's rows of the current chunk
       int lres = k1;  // this lane's previous knot interval (data are increasing: the search resumes there)
       // ---- observation rows: basis values per lane, Givens rotations group-uniform in data order ----
