@@ -260,6 +260,26 @@ __device__ __forceinline__ void fpback(EL el, const double* z, int n, int k, dou
 // share the refined reciprocal (11 instead of 22).  The guard: callers flag operands outside [2^-255, 2^255]
 // (float compares on the operands; the knot differences once per knot set) and such a frame is re-planned with plain
 // divisions (ST_RETRY, path_kernel.h).
+// max(|a|, b) / min(|a|, b) of numbers that are never NaN: one v_max_f64 / v_min_f64 each (the absolute value is a source
+// modifier; fmax() would first quiet both operands)
+__device__ __forceinline__ double max_abs_nn(double a, double b) {
+#ifdef FSDP_EMU
+  return fabs(a) >= b ? fabs(a) : b;
+#else
+  double r;
+  asm("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
+}
+__device__ __forceinline__ double min_abs_nn(double a, double b) {
+#ifdef FSDP_EMU
+  return fabs(a) >= b ? b : fabs(a);
+#else
+  double r;
+  asm("v_min_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
+}
 __device__ __forceinline__ double rcp_refined(double d) {
 #ifdef FSDP_EMU
   return d;  // (the emulator divides directly, see div_rcp)
