@@ -1154,7 +1154,7 @@ extern "C" int fsdp_debug_refit(fsdp_ctx* c, int32_t* n_knots, double* knots34, 
 // ---- device arithmetic self-test ------------------------------------------------------------------------------------------
 // The hand-rolled sequences of spline_device.h against the compiler's IEEE operations, element-wise on the device:
 // out[0][i] = sqrt_1_2(x[i]), out[1][i] = sqrt(x[i]) (x in [1, 2]); out[2][i] = div_rcp(a[i], b[i], rcp_refined(b[i])),
-// out[3][i] = a[i] / b[i]; out[4][i] = div_safe(a[i]) && div_safe(b[i]).
+// out[3][i] = a[i] / b[i]; out[4][i] = in_div_band(a[i]) && in_div_band(b[i]).
 __global__ void math_selftest_kernel(int n, const double* __restrict__ x, const double* __restrict__ a, const double* __restrict__ b,
                                      double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1163,7 +1163,7 @@ __global__ void math_selftest_kernel(int n, const double* __restrict__ x, const 
   out[(size_t)n + i] = sqrt(x[i]);
   out[2 * (size_t)n + i] = div_rcp(a[i], b[i], rcp_refined(b[i]));
   out[3 * (size_t)n + i] = a[i] / b[i];
-  out[4 * (size_t)n + i] = (div_safe(a[i]) && div_safe(b[i])) ? 1.0 : 0.0;
+  out[4 * (size_t)n + i] = (in_div_band(a[i]) && in_div_band(b[i])) ? 1.0 : 0.0;
 }
 
 extern "C" int fsdp_selftest_math(fsdp_ctx* c, int n, const double* x, const double* a, const double* b, double* out5n) {

@@ -260,6 +260,8 @@ __device__ __forceinline__ void fpback(EL el, const double* z, int n, int k, dou
 // share the refined reciprocal (11 instead of 22).  The guard: callers flag operands outside [2^-255, 2^255]
 // (float compares on the operands; the knot differences once per knot set) and such a frame is re-planned with plain
 // divisions (ST_RETRY, path_kernel.h).
+// the exponent band the guards of the scaling-free division accept (what fsdp_selftest_math checks the sequence on)
+__device__ __forceinline__ bool in_div_band(double v) { return fabs(v) >= 0x1p-255 && fabs(v) <= 0x1p255; }
 // max(|a|, b) / min(|a|, b) of numbers that are never NaN: one v_max_f64 / v_min_f64 each (the absolute value is a source
 // modifier; fmax() would first quiet both operands)
 __device__ __forceinline__ double max_abs_nn(double a, double b) {
