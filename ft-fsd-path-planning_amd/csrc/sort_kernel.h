@@ -153,6 +153,32 @@ __device__ inline bool inside_ellipse_at(double px, double py, double cx, double
   return crit < 1;
 }
 
+// The same test for the search (end_configurations.py:282-300), where the direction is an edge of the attempt: (ex, ey) =
+// last cone - cone before it, ang = atan2(ey, ex) as stored when the last cone was a candidate.  cos / sin of that angle
+// are ex / |e| and ey / |e| up to a few ulp, and the criterion is compared with 1: it is formed from the normalised edge
+// (reciprocal square root with one Newton step, no libm call), which decides unless it lies within 1e-6 of the boundary —
+// ten orders of magnitude above the difference between the two formulations; only then the reference's own arithmetic
+// (cos / sin of the stored angle) is evaluated.  FSDP_EXACT_ELLIPSE: always the latter (A/B builds).
+__device__ inline bool inside_ellipse_of_edge(double px, double py, double cx, double cy, double ex, double ey, double ang, double major,
+                                              double minor) {
+#ifndef FSDP_EXACT_ELLIPSE
+  const double n2 = ex * ex + ey * ey;
+#ifdef FSDP_EMU
+  const double rn = 1.0 / sqrt(n2);
+#else
+  double rn = __builtin_amdgcn_rsq(n2);  // (n2 = 0: inf / NaN below -> the exact path)
+  rn = rn * (1.5 - 0.5 * n2 * rn * rn);
+#endif
+  const double c = ex * rn, s = ey * rn;
+  const double x = px - cx, y = py - cy;
+  const double qx = x * c + y * s, qy = y * c - x * s;
+  const double crit = (qx * qx) / (major * major) + (qy * qy) / (minor * minor);
+  if (crit < 1.0 - 1e-6) return true;
+  if (crit > 1.0 + 1e-6) return false;
+#endif
+  return inside_ellipse_at(px, py, cx, cy, ang, major, minor);
+}
+
 // end_configurations.py:108-223 for ONE candidate neighbour `cand` of the popped node.
 // check_if_neighbor_lies_between_last_in_attempt_and_candidate (:226-257) for one (candidate, neighbour) pair
 template <class SH>
@@ -185,7 +211,7 @@ __device__ inline bool candidate_can_be_added(const SH& S, const Params& P, int 
   int sl = (pos >= 1) ? S.attempt[side][pos - 1] : 0;
   if (pos >= 1) {
     // direction of the ellipse = the edge attempt[pos-1] -> node, whose atan2 is ang_sl (same operands)
-    if (!inside_ellipse_at(cx, cy, lx, ly, ang_sl, 6, 3)) return false;
+    if (!inside_ellipse_of_edge(cx, cy, lx, ly, lx - S.x[sl], ly - S.y[sl], ang_sl, 6, 3)) return false;
   }
   if (pos == 0) {
     double a_n = atan2(cy - py, cx - px);
