@@ -249,8 +249,10 @@ def main():
     if rank == 0:
         value = frames_global * args.steps / elapsed
         dom = int(np.argmax(stage_ms))
-        assert main_ms[dom] > 0, (names, main_ms, stage_ms)  # the kernel bracketed in the timed region IS the dominant one
-        achieved = algo_bytes * n_local / (main_ms[dom] * 1e-3) / 1e9
+        # the kernel bracketed in the timed region (fit_kernel) is the dominant one on the bench workload; where another
+        # kernel takes longer per launch (config 4: the sorting kernel over 200 cones), its duration comes from the repeat
+        dom_ms = main_ms[dom] if main_ms[dom] > 0 else stage_ms[dom]
+        achieved = algo_bytes * n_local / (dom_ms * 1e-3) / 1e9
         pmc = _pmc(pkg)
         pk = (pmc or {}).get(names[dom], {})
         out = {
@@ -283,7 +285,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pk.get("hbm_bytes_per_launch", 0) / 1e9 if pk.get("hbm_bytes_per_launch") else None,
-                "kernel_ms_timed_region": main_ms[dom],
+                "kernel_ms_timed_region": main_ms[dom] if main_ms[dom] > 0 else None,
+                "kernel_bracketed_in_timed_region": names[int(np.argmax(main_ms))],
                 "kernel_ms": {n: m for n, m in zip(names, stage_ms)},
                 "kernel_ms_serial": {n: m for n, m in zip(names_serial, serial_ms)},
                 "ms_per_step_serial": ser_total_ms / n_ser,
