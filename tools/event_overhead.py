@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the per-kernel HIP events of the timed region cost: 20 passes through fsdp_time_runs (events around every launch)
-against 20 plain fsdp_run calls, same box, alternating.  python tools/chunk_probe.py"""
+against 20 plain fsdp_run calls, same box, alternating.  python tools/event_overhead.py"""
 import importlib, sys, time, os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
