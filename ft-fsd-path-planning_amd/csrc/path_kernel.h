@@ -53,7 +53,7 @@ struct PathMid {
   int32_t status, fallback, off, n;
 };
 static_assert(ARENA_B >= DENSE_CAP, "raw curvature of a LEAN workspace lives in the smoothness-matrix rows");
-static_assert(ARENA_DOUBLES % 8 == 0 && ARENA_REC % 8 == 0 && PATH_CAP % 64 == 0 && ARENA_BMAT % 8 == 0, "basis records must stay 64-byte aligned");
+static_assert(ARENA_DOUBLES % 8 == 0 && ARENA_REC % 8 == 0 && PATH_CAP % 64 == 0 && ARENA_BMAT % 8 == 0, "basis records must stay 32-byte aligned (the arena itself is 64-byte aligned)");
 struct Arena {
   double* x;
   double* y;
@@ -776,7 +776,7 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame, const Par
   A.x = b;
   A.y = b + PATH_CAP;
   A.u = b + 2 * PATH_CAP;
-  A.bc.rec = (BRec*)(b + ARENA_REC);  // 64-byte aligned: ARENA_DOUBLES and ARENA_REC are multiples of 8
+  A.bc.rec = (BRec*)(b + ARENA_REC);  // 32-byte records on a 64-byte boundary: ARENA_DOUBLES and ARENA_REC are multiples of 8
   A.bc.l = (uint8_t*)(b + ARENA_REC + 4 * PATH_CAP);
   A.bc.b = b + ARENA_BMAT;
   A.filt = A.bc.b + ARENA_B;

@@ -191,7 +191,7 @@ int fsdp_time_reserve(fsdp_ctx* ctx, int iters);
 int fsdp_time_detail(fsdp_ctx* ctx, int every_kernel);
 int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
 /* comma-separated kernel names behind ms_stage of the most recent pass, e.g.
- * "sort_kernel,match_kernel,path_prep_kernel<8>,fit_kernel<8>,path_finish_kernel<8>,path_retry_kernel" */
+ * "sort_kernel_128,match_kernel<32>,path_prep_kernel<8>,fit_kernel<4>,path_finish_kernel<8>,path_retry_kernel" */
 int fsdp_stage_names(fsdp_ctx* ctx, char* out, int cap);
 
 /* Stage-level entry points (README "parts of the pipeline are also available as individual classes"). */
