@@ -618,7 +618,9 @@ __device__ __forceinline__ void giv_feed(WS& ws, GivLane& st, int r0, int r1) {
 #endif
 template <int K, int G, bool FLAGS, int CHV>
 struct ResidualBatch {
-  static constexpr int ROUNDS = (4 * CHV / G > RB_MAX_ROUNDS) ? RB_MAX_ROUNDS : 4 * CHV / G;
+  // (4 lanes per frame: fit_kernel<4> runs at two wavefronts per SIMD and has the registers for four rounds in flight)
+  static constexpr int RB_CAP = (G == 4) ? 2 * RB_MAX_ROUNDS : RB_MAX_ROUNDS;
+  static constexpr int ROUNDS = (4 * CHV / G > RB_CAP) ? RB_CAP : 4 * CHV / G;
   static constexpr int k1 = K + 1, k2 = K + 2;
   double hv[ROUNDS][K + 1], xv[ROUNDS], yv[ROUNDS];
   int lv[ROUNDS], lpv[ROUNDS];
