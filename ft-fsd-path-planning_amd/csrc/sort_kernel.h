@@ -1203,19 +1203,24 @@ __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32
   bool coloured = false;
   for (int i = lane; i < n; i += WAVE) coloured = coloured || S.type[i] == T_LEFT || S.type[i] == T_RIGHT;
   const bool colourless = __ballot(coloured) == 0ull;
-  if (status == ST_OK) {
+#ifndef FSDP_SORT_STOP
+#define FSDP_SORT_STOP 9  // (instruction accounting builds stop the stage after phase 1..4: tools/sort_phase_insts.sh)
+#endif
+  if (status == ST_OK && FSDP_SORT_STOP > 1) {
     sort_side_prepare(S, P, n, T_LEFT, 0, px, py, dx, dy, false);
     // (the left call returns before building the adjacency when it finds no start cone or n < 3)
     const bool left_built = S.adj_built != 0;
     sort_side_prepare(S, P, n, T_RIGHT, 1, px, py, dx, dy, colourless && left_built);
-    sort_dfs_both(S, P, px, py, dx, dy);
-    status = sort_side_finish(S, n, T_LEFT, 0, px, py, dx, dy);
-    __syncthreads();
-    if (status == ST_OK) status = sort_side_finish(S, n, T_RIGHT, 1, px, py, dx, dy);
+    if (FSDP_SORT_STOP > 2) sort_dfs_both(S, P, px, py, dx, dy);
+    if (FSDP_SORT_STOP > 3) {
+      status = sort_side_finish(S, n, T_LEFT, 0, px, py, dx, dy);
+      __syncthreads();
+      if (status == ST_OK) status = sort_side_finish(S, n, T_RIGHT, 1, px, py, dx, dy);
+    }
   }
   __syncthreads();
   int nl = 0, nr = 0;
-  if (status == ST_OK) combine_sides(S, nl, nr);
+  if (status == ST_OK && FSDP_SORT_STOP > 4) combine_sides(S, nl, nr);
   if (lane == 0) {
     o->status = status;
     o->n_left = nl;
