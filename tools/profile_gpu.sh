@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cd /tmp
 # the profiled command = the bench's timed region (passes overlapped) followed by its serial reference leg; the single-frame
 # latency loop and the CPU baseline are switched off so that per-dispatch averages are those of the 4096-frame launches
-BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-latency"
+BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 rocprofv3 --kernel-trace --stats -d $OUT/trace_serial -o trace -- $BENCH --no-overlap > $OUT/trace_serial.log 2>&1
