@@ -9,4 +9,4 @@ from .planner import (CapacityError, ConeTypes, MissionTypes, PathPlanner, Refer
 from . import dist, replay, skidpad, stages, synth  # noqa: F401
 from .stages import CalculatePath, ConeMatching, ConeSorting, ConeMatchingInput, ConeSortingInput, PathCalculationInput  # noqa: F401
 from .skidpad import SkidpadBatch  # noqa: F401
-from ._capi import Context, FsdpError, RESULT_DTYPE  # noqa: F401
+from ._capi import Context, FsdpError, RESULT_DTYPE, pinned_copy, pinned_empty  # noqa: F401

@@ -121,6 +121,18 @@ def load() -> ctypes.CDLL:
     lib.fsdp_comm_allreduce.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int]
     for name in ("fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_barrier", "fsdp_comm_destroy"):
         getattr(lib, name).argtypes = [ctypes.c_void_p]
+    lib.fsdp_host_alloc.restype = ctypes.c_void_p
+    lib.fsdp_host_alloc.argtypes = [ctypes.c_size_t]
+    lib.fsdp_host_free.argtypes = [ctypes.c_void_p]
+    lib.fsdp_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.fsdp_host_unregister.argtypes = [ctypes.c_void_p]
+    lib.fsdp_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
+    lib.fsdp_collect.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+    lib.fsdp_ticket_done.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+    lib.fsdp_skidpad_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
+    lib.fsdp_route_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong)]
     if lib.fsdp_result_size() != RESULT_DTYPE.itemsize:
         raise FsdpError(f"fsdp_frame_result layout mismatch: {lib.fsdp_result_size()} != {RESULT_DTYPE.itemsize}")
     _lib = lib
@@ -135,7 +147,43 @@ EXPORTED_SYMBOLS = [
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
+    "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
+    "fsdp_skidpad_submit", "fsdp_route_stats",
 ]
+
+
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """A NumPy array in page-locked host memory (fsdp_host_alloc): what Context.submit can copy to / from asynchronously.
+    Freed when the array (and every view of it) is gone."""
+    import weakref
+
+    lib = load()
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    nbytes = max(1, n * dtype.itemsize)
+    ptr = lib.fsdp_host_alloc(nbytes)
+    if not ptr:
+        raise FsdpError(f"fsdp_host_alloc({nbytes}) failed")
+    buf = (ctypes.c_byte * nbytes).from_address(ptr)
+    weakref.finalize(buf, lib.fsdp_host_free, ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def pinned_copy(a, dtype=None) -> np.ndarray:
+    a = np.asarray(a, dtype=dtype)
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
+class Ticket:
+    """One batch in flight (Context.submit): keeps the buffers alive until it is collected."""
+
+    __slots__ = ("id", "out", "info", "_keep")
+
+    def __init__(self, id_, out, info, keep):
+        self.id, self.out, self.info, self._keep = id_, out, info, keep
+
 
 
 def _dp(a):
@@ -229,6 +277,36 @@ class Context:
         prev = None if prev_paths is None else _dp(np.ascontiguousarray(prev_paths, np.float64).reshape(len(poses), PATH_POINTS, 4))
         self._check(self._lib.fsdp_path_batch(self._h, len(poses), _dp(poses), prev, ctypes.c_void_p(results.ctypes.data)), "fsdp_path_batch")
         return results
+
+    # streams of batches: several different batches in flight (fsdp_submit / fsdp_collect)
+    def submit(self, offsets, cones, poses, prev_paths=None, out=None) -> Ticket:
+        """Enqueue one batch (H2D, the kernels of a pass, D2H) on the next pass slot and return at once.  Arrays made by
+        ``pinned_empty`` / ``pinned_copy`` are transferred asynchronously; others are accepted but staged.  ``out``: the
+        RESULT_DTYPE array the results go to (default: a new pinned array).  Raises when every slot holds a ticket."""
+        offsets, cones, poses, n = self._prep(offsets, cones, poses)
+        prev = None if prev_paths is None else np.ascontiguousarray(prev_paths, dtype=np.float64).reshape(n, PATH_POINTS, 4)
+        if out is None:
+            out = pinned_empty(n, RESULT_DTYPE)
+        assert out.dtype == RESULT_DTYPE and len(out) == n and out.flags.c_contiguous
+        t = ctypes.c_longlong(-1)
+        self._check(self._lib.fsdp_submit(self._h, n, offsets.ctypes.data, cones.ctypes.data if len(cones) else None, poses.ctypes.data,
+                                          None if prev is None else prev.ctypes.data, out.ctypes.data, ctypes.byref(t)), "fsdp_submit")
+        return Ticket(int(t.value), out, None, (offsets, cones, poses, prev))
+
+    def collect(self, ticket: Ticket) -> np.ndarray:
+        """Wait for this ticket only; returns its result array."""
+        self._check(self._lib.fsdp_collect(self._h, ctypes.c_longlong(ticket.id)), "fsdp_collect")
+        ticket._keep = None
+        return ticket.out
+
+    def ticket_done(self, ticket: Ticket) -> bool:
+        return int(self._lib.fsdp_ticket_done(self._h, ctypes.c_longlong(ticket.id))) == 1
+
+    def route_stats(self):
+        """(sort_big_kernel expected, path_retry_kernel expected, passes re-run because a route kernel was missing)."""
+        a, b, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        self._check(self._lib.fsdp_route_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(r)), "fsdp_route_stats")
+        return bool(a.value), bool(b.value), int(r.value)
 
     # resident API
     def upload(self, offsets, cones, poses):

@@ -1,0 +1,116 @@
+// Last kernel of a pass: the three stage records of every frame -> one fsdp_frame_result (include/fsdp.h) in HBM, laid out
+// exactly as the C ABI hands it to the caller, so the result leaves the GPU with ONE device-to-host copy straight into the
+// caller's (pinned) buffer and the host never touches a frame (it used to rebuild 2.4 KB per frame from three copies: at
+// 5 M frames/s that is 12 GB/s of host memcpy on one thread).  Pure data movement: one lane per 4-byte word, consecutive
+// lanes on consecutive words of the destination, every source run contiguous (the records are written once by the stage
+// kernels and read once here: 2.4 KB in, 2.4 KB out per frame, ~20 MB per 4096-frame pass).
+//
+// It also closes the pass's bookkeeping on the device: the lengths of the two hand-off lists (frames beyond the sorting
+// kernel's LDS capacities; frames for the exact path kernel) go to the slot's host-visible trailer and the counters are
+// reset for the slot's next pass — the host learns from the trailer whether the route kernels it did (not) launch were
+// needed (fsdp_lib.hip verify_pass), and no hipMemsetAsync sits between the kernels of a pass any more.
+#pragma once
+
+#include <stddef.h>
+
+#include "../../include/fsdp.h"
+#include "fsdp_device.h"
+
+namespace fsdp {
+
+struct PassTrailer {
+  int32_t n_big;    // frames sort_kernel appended to the big list in this pass
+  int32_t n_retry;  // frames the path stage's fast kernels appended to the retry list
+  int32_t seq;      // pass counter of the slot (written last)
+  int32_t pad;
+};
+
+constexpr int RESULT_WORDS = (int)(sizeof(fsdp_frame_result) / 4);
+static_assert(sizeof(fsdp_frame_result) % 4 == 0, "result words");
+
+// word w of a frame's result <- which record, which word (all fields are 4- or 8-byte scalars at 4-byte granularity)
+#define FSDP_RW(field) ((int)(offsetof(fsdp_frame_result, field) / 4))
+#define FSDP_SW(field) ((int)(offsetof(SortOut, field) / 4))
+#define FSDP_MW(field) ((int)(offsetof(MatchOut, field) / 4))
+#define FSDP_PW(field) ((int)(offsetof(PathOut, field) / 4))
+
+// skid != 0: a skidpad step — no sorting / matching records: those fields read as the reference's empty intermediates
+// (counts 0, indices -1), status and path come from the path record.
+__global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortOut* __restrict__ sorted, const MatchOut* __restrict__ matched,
+                                                        const PathOut* __restrict__ paths, fsdp_frame_result* __restrict__ results,
+                                                        int* __restrict__ big, int* __restrict__ retry, PassTrailer* __restrict__ trailer,
+                                                        int seq) {
+  const long long total = (long long)n_frames * RESULT_WORDS;
+  const int32_t* s32 = (const int32_t*)sorted;
+  const int32_t* m32 = (const int32_t*)matched;
+  const int32_t* p32 = (const int32_t*)paths;
+  int32_t* r32 = (int32_t*)results;
+  constexpr int SW = (int)(sizeof(SortOut) / 4), MW = (int)(sizeof(MatchOut) / 4), PW = (int)(sizeof(PathOut) / 4);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)(idx / RESULT_WORDS);
+    const int w = (int)(idx - (long long)f * RESULT_WORDS);
+    const int32_t* s = s32 ? s32 + (size_t)f * SW : nullptr;
+    const int32_t* m = m32 ? m32 + (size_t)f * MW : nullptr;
+    const int32_t* p = p32 + (size_t)f * PW;
+    int32_t v;
+    if (w >= FSDP_RW(path) && w < FSDP_RW(n_configs_left)) {
+      v = p[FSDP_PW(path) + (w - FSDP_RW(path))];
+    } else if (w >= FSDP_RW(left_v) && w < FSDP_RW(path)) {  // left_v | right_v | l2r | r2l: contiguous in both structs
+      if (m)
+        v = m[FSDP_MW(left_v) + (w - FSDP_RW(left_v))];
+      else
+        v = (w >= FSDP_RW(l2r)) ? -1 : 0;
+    } else if (w == FSDP_RW(status)) {
+      // fsdp_lib.hip assemble(): the latest stage that reported something decides
+      int st = s ? s[FSDP_SW(status)] : 0;
+      if (m && m[FSDP_MW(status)] != 0) st = m[FSDP_MW(status)];
+      if (p[FSDP_PW(status)] != 0) st = p[FSDP_PW(status)];
+      v = st;
+    } else if (w < FSDP_RW(n_left_v)) {  // n_left, n_right, left_idx, right_idx: contiguous in both structs
+      if (s)
+        v = s[FSDP_SW(n_left) + (w - FSDP_RW(n_left))];
+      else
+        v = (w >= FSDP_RW(left_idx)) ? -1 : 0;
+    } else if (w == FSDP_RW(n_left_v)) {
+      v = m ? m[FSDP_MW(n_left_v)] : 0;
+    } else if (w == FSDP_RW(n_right_v)) {
+      v = m ? m[FSDP_MW(n_right_v)] : 0;
+    } else if (w < FSDP_RW(left_v)) {
+      v = 0;  // alignment padding
+    } else if (w < FSDP_RW(best_cost_left)) {  // n_configs_left/right, first_k_left/right: contiguous in both structs
+      v = s ? s[FSDP_SW(n_configs_left) + (w - FSDP_RW(n_configs_left))] : 0;
+    } else if (w < FSDP_RW(path_fallback)) {
+      v = s ? s[FSDP_SW(best_cost_left) + (w - FSDP_RW(best_cost_left))] : 0;
+    } else if (w == FSDP_RW(path_fallback)) {
+      v = p[FSDP_PW(fallback)];
+    } else {
+      v = p[FSDP_PW(n_dense)];
+    }
+    r32[idx] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && trailer != nullptr) {
+    // (the stage kernels finished before this kernel started: same stream)
+    const int nb = big ? big[0] : 0, nr = retry ? retry[0] : 0;
+    if (big) big[0] = 0;
+    if (retry) retry[0] = 0;
+    __hip_atomic_store(&trailer->n_big, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&trailer->n_retry, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&trailer->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// layout facts the word map above relies on
+static_assert(offsetof(fsdp_frame_result, right_idx) - offsetof(fsdp_frame_result, n_left) == offsetof(SortOut, right_idx) - offsetof(SortOut, n_left), "sort run");
+static_assert(offsetof(fsdp_frame_result, n_left_v) == offsetof(fsdp_frame_result, right_idx) + sizeof(int32_t) * MAX_LEN, "sort run end");
+static_assert(offsetof(fsdp_frame_result, r2l) - offsetof(fsdp_frame_result, left_v) == offsetof(MatchOut, r2l) - offsetof(MatchOut, left_v), "match run");
+static_assert(offsetof(fsdp_frame_result, path) == offsetof(fsdp_frame_result, r2l) + sizeof(int32_t) * MAX_MATCH, "match run end");
+static_assert(offsetof(fsdp_frame_result, n_configs_left) == offsetof(fsdp_frame_result, path) + sizeof(double) * 4 * PATH_POINTS, "path run end");
+static_assert(offsetof(fsdp_frame_result, first_k_right) - offsetof(fsdp_frame_result, n_configs_left) ==
+                  offsetof(SortOut, first_k_right) - offsetof(SortOut, n_configs_left), "diagnostics run");
+static_assert(offsetof(fsdp_frame_result, best_cost_left) == offsetof(fsdp_frame_result, first_k_right) + 8, "diagnostics run end");
+static_assert(offsetof(fsdp_frame_result, best_cost_right) - offsetof(fsdp_frame_result, best_cost_left) ==
+                  offsetof(SortOut, best_cost_right) - offsetof(SortOut, best_cost_left), "cost run");
+static_assert(offsetof(fsdp_frame_result, path_fallback) == offsetof(fsdp_frame_result, best_cost_right) + 8, "cost run end");
+static_assert(offsetof(fsdp_frame_result, n_dense) == offsetof(fsdp_frame_result, path_fallback) + 4 && sizeof(fsdp_frame_result) == offsetof(fsdp_frame_result, n_dense) + 4, "tail");
+
+}  // namespace fsdp

@@ -667,6 +667,7 @@ __device__ __forceinline__ int mpc_finish(PS& S, const Arena& A, bool fitted, co
     if (fitted) {
       PROF(5);
       n4 = arange_len(A.prm->mpc_path_length * 1.5, A.prm->predict_every);
+      if (n4 > PATH_CAP) return ST_OVERFLOW_PATH;  // (fsdp_create refuses such parameters; never write past the polyline)
       eval_spline<CUBIC>(S.ws, f, A.prm->predict_every, n4, A.x, A.y, nullptr);
     }
     int nseg = n4 - 1;

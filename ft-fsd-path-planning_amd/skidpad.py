@@ -76,6 +76,30 @@ class SkidpadBatch:
             "fsdp_skidpad_step")
         return res, info
 
+    def submit(self, cone_offsets, cones_xyt, poses, out=None, info=None) -> "_capi.Ticket":
+        """One step as a ticket (fsdp_skidpad_submit): the steps' kernels run in submit order, their transfers overlap the
+        neighbouring steps' kernels.  Up to the context's overlap depth tickets may be outstanding (``set_overlap``)."""
+        off, cones, poses, n = self._ctx._prep(cone_offsets, cones_xyt, poses)
+        assert n == self.n
+        if out is None:
+            out = _capi.pinned_empty(n, _capi.RESULT_DTYPE)
+        if info is None:
+            info = np.zeros(n, dtype=INFO_DTYPE)
+        t = ctypes.c_longlong(-1)
+        self._ctx._check(
+            self._ctx._lib.fsdp_skidpad_submit(self._ctx._h, ctypes.c_int(n), off.ctypes.data, cones.ctypes.data if len(cones) else None,
+                                               poses.ctypes.data, out.ctypes.data, info.ctypes.data, ctypes.byref(t)),
+            "fsdp_skidpad_submit")
+        return _capi.Ticket(int(t.value), out, info, (off, cones, poses))
+
+    def collect(self, ticket):
+        self._ctx._check(self._ctx._lib.fsdp_collect(self._ctx._h, ctypes.c_longlong(ticket.id)), "fsdp_collect")
+        ticket._keep = None
+        return ticket.out, ticket.info
+
+    def set_overlap(self, depth: int):
+        self._ctx.set_overlap(depth)
+
     def time_path(self, iters: int) -> float:
         t = ctypes.c_float()
         self._ctx._check(self._ctx._lib.fsdp_skidpad_time_path(self._ctx._h, ctypes.c_int(iters), ctypes.byref(t)), "fsdp_skidpad_time_path")

@@ -132,7 +132,7 @@ const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creat
 /* calculate_path_in_global_frame for a batch of independent frames (fresh-planner semantics).
  * cone_offsets: (n_frames+1) CSR offsets; cones_xyt: (total,3) rows [x,y,ConeTypes] — the reference's own
  * flattened layout (core_trace_sorter.py:37-54); poses: (n_frames,4) rows [px,py,dir_x,dir_y].
- * Host buffers; does H2D, the three kernels and D2H on the context's stream, then synchronises. */
+ * Host buffers; does H2D, the kernels of a pass and D2H on the context's stream, then synchronises. */
 int fsdp_plan_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
                     const double* poses, fsdp_frame_result* results);
 
@@ -151,24 +151,57 @@ int fsdp_set_previous_paths(fsdp_ctx* ctx, const double* prev_paths);
  * planner) is host code, the device gets the transformed pose, empty cone lists and the relocalizer's known path. */
 int fsdp_set_global_path(fsdp_ctx* ctx, const double* xy, int n);
 
-/* The same in three steps so a caller (bench, pipelined replay) can keep inputs resident in HBM. */
+/* ---- streams of batches: several DIFFERENT batches in flight -------------------------------------------------------------
+ * The reference's only harness feeds the planner a stream of frames, one call after the other (demo/json_demo.py:103-131);
+ * the batched form of that stream is a sequence of batches.  A context keeps up to `depth` of them in flight
+ * (fsdp_set_overlap): every pass slot owns a HIP stream, device copies of its batch's inputs, the intermediates of a pass
+ * and a result block (assembled on the device in the layout of the fsdp_frame_result struct), so
+ *   fsdp_submit  = host -> device of the batch, the kernels of its pass, device -> host of its results, all enqueued on
+ *                  the slot's stream; returns at once with a ticket;
+ *   fsdp_collect = waits for that ticket only; afterwards `results` (the pointer given to fsdp_submit) holds the batch's
+ *                  results, exactly what fsdp_plan_batch[_sequential] returns for the same inputs.
+ * Tickets count up from 0; ticket t occupies slot t % depth, so at most `depth` tickets are outstanding (fsdp_submit
+ * returns 4 when the slot it needs still holds an uncollected ticket) and they may be collected in any order.  The
+ * caller's buffers must stay valid and untouched from submit to collect.  For the transfers to be asynchronous they must
+ * be page-locked: allocate them with fsdp_host_alloc or pin existing memory with fsdp_host_register; pageable buffers
+ * are accepted (inputs are then copied before fsdp_submit returns, results pass through a pinned block of the slot and a
+ * memcpy in fsdp_collect).  prev_paths: (n_frames,40,4) as for fsdp_plan_batch_sequential, or NULL.
+ * While tickets are outstanding the blocking / resident entry points of the context return an error. */
+void* fsdp_host_alloc(size_t bytes);            /* page-locked host memory (hipHostMalloc), NULL on failure */
+void fsdp_host_free(void* p);
+int fsdp_host_register(void* p, size_t bytes);  /* pin memory the caller owns (hipHostRegister) */
+int fsdp_host_unregister(void* p);
+int fsdp_submit(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses,
+                const double* prev_paths, fsdp_frame_result* results, long long* ticket);
+int fsdp_collect(fsdp_ctx* ctx, long long ticket);
+int fsdp_ticket_done(fsdp_ctx* ctx, long long ticket); /* 1: fsdp_collect will not block; 0: still running; -1: unknown ticket */
+
+/* The resident form: one batch stays in HBM and is planned again and again (the benchmark's step; a caller that plans the
+ * same frames under several global paths / previous paths). */
 int fsdp_upload(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses);
-int fsdp_run(fsdp_ctx* ctx);      /* enqueue sorting, matching, path kernels on the context stream (async) */
-int fsdp_sync(fsdp_ctx* ctx);     /* wait for the stream */
-int fsdp_resident_frames(const fsdp_ctx* ctx); /* frames of the batch the context currently holds (what fsdp_download writes) */
+int fsdp_run(fsdp_ctx* ctx);      /* enqueue one pass over the resident batch on the next slot's stream (async) */
+int fsdp_sync(fsdp_ctx* ctx);     /* wait for all passes in flight */
+int fsdp_resident_frames(const fsdp_ctx* ctx); /* frames of the most recent pass (what fsdp_download writes) */
 int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
 
-/* Pass overlap for streams of batches (a replay feeds one batch after the other): depth d (<= FSDP_MAX_OVERLAP) gives
- * the context d HIP streams and d sets of intermediate buffers; consecutive fsdp_run passes rotate through them, so the
- * next passes fill the compute units that the slowest frames of the previous ones no longer occupy.  fsdp_sync waits for
- * all passes in flight, fsdp_download returns the most recent one.  depth 1 (default) = strictly one pass after the
- * other.  Every stream takes one of the HIP runtime's hardware queues (environment variable GPU_MAX_HW_QUEUES, default 4):
- * with more streams than queues two passes share a queue and serialize — raise GPU_MAX_HW_QUEUES above the depth
- * (bench.py sets 16 for its depth of 10).  Every extra depth costs one more set of intermediate buffers (~0.13 MB per
- * frame).  Measured at 4096 frames x 128 cones: the steady rate saturates at depth 8; a run of 20 passes is fastest with
- * 10 in flight (two full rounds instead of 8 + 8 + 4). */
+/* Pass overlap: depth d (<= FSDP_MAX_OVERLAP) gives the context d pass slots (HIP stream + buffers each); fsdp_submit
+ * tickets and consecutive fsdp_run passes rotate through them, so the next passes fill the compute units that the slowest
+ * frames of the previous ones no longer occupy, and one batch's transfers run under the other batches' kernels.
+ * fsdp_sync waits for all passes in flight, fsdp_download returns the most recent one.  depth 1 (default) = strictly one
+ * pass after the other.  Every stream takes one of the HIP runtime's hardware queues (environment variable
+ * GPU_MAX_HW_QUEUES, default 4): with more streams than queues two passes share a queue and serialize — raise
+ * GPU_MAX_HW_QUEUES above the depth (bench.py sets 16 for its depth of 10).  Every extra depth costs one more set of
+ * buffers (~0.1 MB per frame).  Measured at 4096 frames x 128 cones: the steady rate saturates at depth 8; a run of 20
+ * passes is fastest with 10 in flight (two full rounds instead of 8 + 8 + 4). */
 #define FSDP_MAX_OVERLAP 16
 int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
+
+/* The kernels that only serve frames the fast kernels hand on (sort_big_kernel: frames beyond the sorting kernel's LDS
+ * capacities; path_retry_kernel: the exact one-frame-per-wavefront path stage) are launched with a pass only when the
+ * context expects them to be needed; the last kernel of every pass reports the hand-off lists' lengths, and a pass that
+ * needed a kernel it was not given is run again with it before its results are handed out (then the kernel stays part of
+ * every pass until 64 passes in a row did not need it).  Results never depend on this.  Diagnostics: */
+int fsdp_route_stats(fsdp_ctx* ctx, int* expect_big, int* expect_retry, long long* reruns);
 
 /* Enqueue `iters` back-to-back passes over the resident batch (rotating through the slots when passes overlap; no host
  * synchronisation in between) and time them with HIP events recorded on the streams the kernels run on.
@@ -191,7 +224,7 @@ int fsdp_time_reserve(fsdp_ctx* ctx, int iters);
 int fsdp_time_detail(fsdp_ctx* ctx, int every_kernel);
 int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
 /* comma-separated kernel names behind ms_stage of the most recent pass, e.g.
- * "sort_kernel_128,match_kernel<32>,path_prep_kernel<8>,fit_kernel<4>,path_finish_kernel<8>,path_retry_kernel" */
+ * "sort_kernel_128,match_kernel<32>,path_prep_kernel<8>,fit_kernel<4>,path_finish_kernel<8>,assemble_kernel" */
 int fsdp_stage_names(fsdp_ctx* ctx, char* out, int cap);
 
 /* Stage-level entry points (README "parts of the pipeline are also available as individual classes"). */
@@ -233,6 +266,12 @@ int fsdp_skidpad_reset(fsdp_ctx* ctx, int n_instances);
 /* one frame for every instance; results[i].path is in the caller's (original) frame like the reference's return value */
 int fsdp_skidpad_step(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offsets, const double* cones_xyt,
                       const double* poses, fsdp_frame_result* results, fsdp_skidpad_info* info);
+/* The same as a ticket (fsdp_collect / fsdp_ticket_done as above): the steps' kernels run in submit order on the context's
+ * main stream (the planner states chain step to step), step k + 1's inputs go up and step k - 1's results come down on the
+ * slots' own streams meanwhile.  A replay knows the frames of the next steps ahead of the planner, which is what makes
+ * submitting ahead meaningful; fsdp_skidpad_step = submit + collect. */
+int fsdp_skidpad_submit(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offsets, const double* cones_xyt,
+                        const double* poses, fsdp_frame_result* results, fsdp_skidpad_info* info, long long* ticket);
 /* time `iters` repetitions of the path kernel of the last step with HIP events (state is restored afterwards) */
 int fsdp_skidpad_time_path(fsdp_ctx* ctx, int iters, float* ms_total);
 

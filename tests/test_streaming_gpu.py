@@ -1,0 +1,122 @@
+"""Streams of batches through the asynchronous pair of the C ABI (fsdp_submit / fsdp_collect, include/fsdp.h): K different
+batches through depth D must return, byte for byte, what K serial fsdp_plan_batch calls return — whatever slot a batch ran
+in, whether its buffers were page-locked or not, and whether the route kernels (sort_big_kernel, path_retry_kernel) had
+been predicted for its pass or the pass had to be repeated with them.  The counterpart in the reference is its one harness,
+the frame-after-frame loop of demo/json_demo.py:103-131."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("ft-fsd-path-planning_amd")
+
+
+def _batches(pkg, golden_dir):
+    """Thirteen different batches: sizes 1 .. 1500 frames, coloured / colourless, 24-100 cones per side, two golden sets
+    whose frames leave the fast kernels (300 / 600-cone frames and 190-end-configuration lattices -> sort_big_kernel;
+    the noisy colourless set -> path_retry_kernel), and an empty batch."""
+    out = []
+    for i, (n, per_side, noise, color) in enumerate([(1500, 64, 0.15, True), (1, 64, 0.15, True), (700, 64, 0.15, False), (1300, 100, 0.1, True),
+                                                     (64, 24, 0.3, False), (1100, 64, 0.2, True)]):
+        out.append(pkg.synth.make_replay_batch(n, per_side, noise, seed=100 + i, color=color))
+    for name in ("big_frames", "cfg4_noisy_nocolor", "lattice", "fuzz"):
+        g = np.load(golden_dir / f"{name}.npz")
+        out.append((g["offsets"], g["cones"], g["poses"]))
+    # 1300 noisy colourless frames: above the one-kernel batch size, ~4 % of them leave the packed path kernels (retry list)
+    out.append(pkg.synth.make_replay_batch(1300, 100, 0.0, seed=103, color=False, frame_noise=0.3, random_pose=True))
+    out.insert(3, (np.zeros(1, np.int32), np.zeros((0, 3)), np.zeros((0, 4))))
+    out.append(pkg.synth.make_replay_batch(1200, 64, 0.15, seed=7, color=True))
+    return out
+
+
+def _same(a, b):
+    return a.dtype == b.dtype and len(a) == len(b) and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("depth,pinned", [(1, True), (4, True), (4, False), (10, True)])
+def test_different_batches_in_flight_equal_serial_calls(pkg, golden_dir, depth, pinned):
+    batches = _batches(pkg, golden_dir)
+    serial = pkg.Context(device=0)
+    ref = [serial.plan_batch(*b) for b in batches]
+    serial.close()
+    ctx = pkg.Context(device=0)
+    ctx.set_overlap(depth)
+    if pinned:
+        batches = [(pkg.pinned_copy(o, np.int32), pkg.pinned_copy(c, np.float64), pkg.pinned_copy(p, np.float64)) for o, c, p in batches]
+    got = [None] * len(batches)
+    inflight = []
+    for k, b in enumerate(batches):
+        if len(inflight) == depth:
+            j, t = inflight.pop(0)
+            got[j] = ctx.collect(t)
+        out = None if pinned else np.zeros(len(b[0]) - 1, pkg.RESULT_DTYPE)
+        inflight.append((k, ctx.submit(*b, out=out)))
+    # the rest in reverse order: tickets may be collected in any order
+    for j, t in reversed(inflight):
+        got[j] = ctx.collect(t)
+    for k in range(len(batches)):
+        assert _same(got[k], ref[k]), (k, depth, pinned)
+    big, retry, reruns = ctx.route_stats()
+    # big_frames / lattice need sort_big_kernel, the noisy set path_retry_kernel: the first such pass had not been given
+    # the kernel and was repeated with it
+    assert reruns >= 1 and big and retry
+    ctx.close()
+
+
+def test_route_prediction_never_changes_results(pkg, golden_dir, monkeypatch):
+    """The same stream with both route kernels forced into every pass (FSDP_ALWAYS_ROUTE): no pass is repeated, same bytes."""
+    batches = _batches(pkg, golden_dir)
+    a = pkg.Context(device=0)
+    a.set_overlap(3)
+    monkeypatch.setenv("FSDP_ALWAYS_ROUTE", "1")
+    b = pkg.Context(device=0)
+    b.set_overlap(3)
+    for batch in batches:
+        ra = a.collect(a.submit(*batch))
+        rb = b.collect(b.submit(*batch))
+        assert _same(ra, rb)
+    assert b.route_stats()[2] == 0 and a.route_stats()[2] >= 1
+
+
+def test_submit_with_previous_paths_and_slot_accounting(pkg):
+    off, cones, poses = pkg.synth.make_replay_batch(300, 64, 0.15, seed=5, color=True)
+    # frames without cones fall back to the previous path: the per-frame previous paths must reach the kernels
+    off2 = np.zeros(301, np.int32)
+    rng = np.random.default_rng(0)
+    ctx = pkg.Context(device=0)
+    first = ctx.plan_batch(off, cones, poses)
+    prev = first["path"] + rng.normal(0, 1e-3, first["path"].shape) * (np.arange(4) > 0)
+    ref = ctx.plan_batch_sequential(off2, np.zeros((0, 3)), poses, prev)
+    ctx.set_overlap(2)
+    t0 = ctx.submit(off2, np.zeros((0, 3)), poses, prev_paths=prev)
+    t1 = ctx.submit(off, cones, poses)
+    with pytest.raises(pkg.FsdpError, match="collect ticket 0 first"):
+        ctx.submit(off, cones, poses)  # both slots hold a ticket
+    with pytest.raises(pkg.FsdpError, match="not collected"):
+        ctx.plan_batch(off, cones, poses)  # blocking calls wait for nobody's tickets
+    assert _same(ctx.collect(t1), first)
+    assert _same(ctx.collect(t0), ref)
+    with pytest.raises(pkg.FsdpError, match="unknown ticket"):
+        ctx.collect(t0)
+    # the resident form still works afterwards, on the same slots
+    ctx.upload(off, cones, poses)
+    for _ in range(3):
+        ctx.run()
+    assert _same(ctx.download(), first)
+    ctx.close()
+
+
+def test_large_mpc_path_length_is_refused_or_flagged(pkg):
+    """ceil(1.5 * mpc_path_length / predict_every) beyond the working polyline must never write past it."""
+    with pytest.raises(pkg.FsdpError, match="working polyline"):
+        pkg.Context(device=0, params=dict(mpc_path_length=100.0))
+    ctx = pkg.Context(device=0, params=dict(mpc_path_length=90.0))  # 1350 points + slack: still inside
+    off, cones, poses = pkg.synth.make_replay_batch(64, 64, 0.15, seed=5, color=True)
+    res = ctx.plan_batch(off, cones, poses)
+    assert (res["status"] == 0).all() and np.isfinite(res["path"]).all()
+    ctx.close()
