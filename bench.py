@@ -103,6 +103,52 @@ def cpu_baseline(off, cones, poses, budget_s: float = 12.0):
     }
 
 
+def streaming_leg(pkg, ctx, per_gpu: int, depth: int, n_batches: int, seed0: int):
+    """Host -> host: `n_batches` DIFFERENT batches (a different synthetic track each) through `depth` pass slots with
+    fsdp_submit / fsdp_collect — every batch is copied to the GPU, planned and its results copied back inside the
+    timed region, all buffers page-locked (fsdp_host_alloc).  This is the rate a caller of the public API gets for a
+    stream of batches (the reference's harness feeds frames one after the other, demo/json_demo.py:103-131)."""
+    batches = []
+    for k in range(n_batches):
+        off, cones, poses = pkg.synth.make_replay_batch(per_gpu, CONES_PER_SIDE, 0.15, seed=seed0 + 1000 + k, color=True)
+        batches.append((pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64)))
+    outs = [pkg.pinned_empty(per_gpu, pkg.RESULT_DTYPE) for _ in range(n_batches)]
+    ctx.set_overlap(depth)
+    for k in range(min(depth, n_batches)):  # warm-up: every slot's stream, buffers and staging exist
+        ctx.collect(ctx.submit(*batches[k], out=outs[k]))
+    reruns0 = ctx.route_stats()[2]
+    inflight = []
+    t0 = time.perf_counter()
+    for k in range(n_batches):
+        if len(inflight) == depth:
+            ctx.collect(inflight.pop(0))
+        inflight.append(ctx.submit(*batches[k], out=outs[k]))
+    for t in inflight:
+        ctx.collect(t)
+    el = time.perf_counter() - t0
+    # one pass at a time through the same entry points, for comparison (what plan_batch-style calls deliver)
+    n_ser = min(8, n_batches)
+    t1 = time.perf_counter()
+    for k in range(n_ser):
+        ctx.collect(ctx.submit(*batches[k], out=outs[k]))
+    el_ser = time.perf_counter() - t1
+    # the streamed results are the serial results
+    chk = ctx.plan_batch(*batches[n_batches - 1])
+    same = chk.tobytes() == outs[n_batches - 1].tobytes()
+    bad = int(sum(int((o["status"] != 0).sum()) for o in outs))
+    h2d = sum(a.nbytes for a in batches[0])
+    d2h = outs[0].nbytes
+    return {
+        "value": per_gpu * n_batches / el, "unit": "frames/s", "batches": n_batches, "frames_per_batch": per_gpu, "depth": depth,
+        "seconds": el, "one_batch_at_a_time_frames_per_s": per_gpu * n_ser / el_ser,
+        "pcie_bytes_per_batch": {"h2d": int(h2d), "d2h": int(d2h)},
+        "pcie_GBps": {"h2d": h2d * n_batches / el / 1e9, "d2h": d2h * n_batches / el / 1e9},
+        "last_batch_equals_serial_plan_batch": bool(same), "frames_with_nonzero_status": bad,
+        "passes_rerun_for_routes": ctx.route_stats()[2] - reruns0,
+        "what": "different batches host -> host (page-locked buffers), H2D + kernels + D2H of every batch inside the timed region",
+    }
+
+
 def _lib_hash(pkg) -> str:
     import hashlib
 
@@ -169,17 +215,27 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency loop and the golden flip count (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
     ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..16)")
+    ap.add_argument("--stream-batches", type=int, default=40, help="different batches of the host -> host streaming leg (0: skip)")
     args = ap.parse_args()
 
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    n_dev = pkg._capi.load().fsdp_device_count()
+    share = os.environ.get("FSDP_SHARE_GPU") == "1"  # testing only: several ranks on one GPU (RCCL refuses that -> tcp-fallback)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: be the launcher — one rank per GPU with the launch contract's environment
+        if n_dev < args.gpus and not share:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible")
+        sys.exit(pkg.dist.spawn_ranks([str(Path(__file__).resolve()), *sys.argv[1:]], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    ctx = pkg.Context(device=local_rank, mission=int(pkg.MissionTypes.trackdrive))
-    d = pkg.dist.Dist(ctx)  # WORLD_SIZE > 1: ncclCommInitRank on this rank's GPU (RCCL over xGMI), id exchange over TCP
+    ctx = pkg.Context(device=local_rank % max(n_dev, 1) if share else local_rank, mission=int(pkg.MissionTypes.trackdrive))
+    # WORLD_SIZE > 1: ncclCommInitRank on this rank's GPU (RCCL over xGMI; its id travels over the TCP star of dist.py, which
+    # also carries the collectives if RCCL fails on any rank)
+    d = pkg.dist.Dist(ctx)
     world = d.world
     assert "torch" not in sys.modules, "the product path must not pull in PyTorch"
     if args.gpus != world and rank == 0:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: reporting n_gpus = {world}", file=sys.stderr)
 
     # the only collectives on this path: rank 0 broadcasts the constant previous-path table (RCCL over xGMI), every
     # rank checks it against the table its own GPU computed at context creation; then barriers / one max-reduction
@@ -207,8 +263,8 @@ def main():
     # a replay is a stream of batches: consecutive passes rotate through `overlap` HIP streams / buffer sets so that the
     # next passes fill the compute units the slowest frames of the previous ones no longer occupy (fsdp_set_overlap)
     overlap = 1 if args.no_overlap else args.overlap
-    if n_local * overlap > 131072:  # every pass in flight keeps its own intermediates (~0.13 MB per frame): bound them to ~17 GB
-        overlap = max(2, 131072 // n_local)
+    if n_local * overlap > 131072:  # every pass in flight keeps its own intermediates (~0.1 MB per frame): bound them to ~13 GB
+        overlap = max(1, 131072 // n_local)
     ctx.set_overlap(overlap)
     ctx.upload(off, cones, poses)
 
@@ -274,7 +330,8 @@ def main():
                 "frames_global": frames_global,
                 "cones_per_frame": cones_per_frame,
                 "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; communicator: "
-                               + (f"RCCL, {d.comm_size} rank(s) (ncclCommCount)" if d._active else "none (single process)"),
+                               + d.describe(),
+                "communicator": d.transport,
                 "pass_overlap": overlap,
             },
             "roofline": {
@@ -313,6 +370,8 @@ def main():
             "arc_extension_frames": arc_frames,
             "lib_sha256_16": _lib_hash(pkg),
         }
+        if args.config == 2 and args.stream_batches > 0:
+            out["streaming"] = streaming_leg(pkg, ctx, n_local, overlap, args.stream_batches, d.shard_seed(1))
         if world == 1 and not args.no_latency:
             # sample-count flips against the reference, measured on the committed golden fuzz set
             out["flip_count"] = golden_flip_count(pkg, ctx)

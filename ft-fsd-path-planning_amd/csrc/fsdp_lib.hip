@@ -351,8 +351,8 @@ static void launch_finish(fsdp_ctx* c, Work& q, int n) {
 // each: exactly the Givens quad) and the kernels around it 8; below that, 4 frames per wavefront everywhere.
 constexpr int PACK_FRAMES = 12288;
 
-// the path stage's fast kernels (no route, no assembly)
-static void launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, std::string& names) {
+// the path stage's fast kernels (no route, no assembly); returns whether it was the three-kernel form
+static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, std::string& names) {
   const double* prev = in.use_prev ? in.d_prev : nullptr;
   const int n = in.n_frames;
   const bool split = c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH;
@@ -384,6 +384,7 @@ static void launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
     const std::string g = packed ? "8" : "16";
     names += "path_prep_kernel<" + g + ">,fit_kernel<" + std::to_string(gf) + ">,path_finish_kernel<" + g + ">,";
   }
+  return split;
 }
 static void launch_path_retry(fsdp_ctx* c, Work& q, const Inputs& in) {
   const double* prev = in.use_prev ? in.d_prev : nullptr;
@@ -418,13 +419,15 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t = 
   mark(q, t);
   launch_match(c, q, in);
   names += "match_kernel<" + std::to_string(MATCH_G) + ">,";
-  launch_path(c, q, in, t, names);
+  const bool split = launch_path(c, q, in, t, names);
+  MarkKind after_path = split ? MARK_PLAIN : MARK_MAIN;  // (the one-kernel path stage is the main kernel: close its bracket)
   if (with_retry) {
-    mark(q, t);
+    mark(q, t, after_path);
+    after_path = MARK_PLAIN;
     launch_path_retry(c, q, in);
     names += "path_retry_kernel,";
   }
-  mark(q, t);
+  mark(q, t, after_path);
   launch_assemble(c, q, in.n_frames, false);
   names += "assemble_kernel";
   mark(q, t, MARK_LAST);

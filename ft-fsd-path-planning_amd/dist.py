@@ -1,15 +1,31 @@
 """Multi-GPU plumbing: one process per GPU, RCCL over xGMI through the C ABI (include/fsdp.h fsdp_comm_*).  No PyTorch.
 
 Frames are independent, so there is NO data-path collective: each rank plans its own contiguous shard.
-RCCL carries only the start-up broadcast of constant tables (skidpad track table, consistency check of the constant
-previous path) and the benchmark's barrier / max-reduction.
+The communicator carries only the start-up broadcast of constant tables (skidpad track table, consistency check of the
+constant previous path) and the benchmark's barrier / max-reduction.
 
-Launch contract: the launcher (``python -m torch.distributed.run``, or anything else) sets RANK / LOCAL_RANK / WORLD_SIZE /
-MASTER_ADDR / MASTER_PORT; this module only reads the environment.  The one thing RCCL needs out of band is its 128-byte
-unique id: rank 0 creates it (``fsdp_comm_unique_id``) and serves it to the other ranks over one TCP connection each
-(stdlib sockets).  MASTER_PORT itself belongs to the launcher's store, so the exchange uses the first free port of
-``[MASTER_PORT + 1, MASTER_PORT + PORT_SPAN]``; clients find it by a handshake that carries a launch key (the launcher's pid,
-which all ranks of one launch share, plus WORLD_SIZE), so a port held by a stranger is skipped.
+Launch contract: the launcher (``python -m torch.distributed.run``, ``bench.py --gpus N`` itself, or anything else) sets
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; this module only reads the environment.
+
+Two transports, one interface (``Dist.broadcast_array / broadcast_check_table / max_over_ranks / sum_over_ranks /
+barrier``):
+
+* **rccl** — ``ncclBroadcast`` / ``ncclAllReduce`` on the context's stream (csrc/fsdp_comm.h).  The one thing RCCL needs
+  out of band, its 128-byte unique id, travels over the TCP star below.
+* **tcp-fallback** — a star of stdlib sockets around rank 0 (every other rank holds one connection to it): the three
+  collectives this path needs move a few hundred bytes at start-up and 8 bytes per reduction, so a socket round trip
+  costs nothing that matters.  It is always set up when WORLD_SIZE > 1, because it is also how the ranks *agree* on the
+  transport: each rank tries ``ncclCommInitRank`` and one test all-reduce in a helper thread with a deadline
+  (``FSDP_RCCL_INIT_TIMEOUT``, default 180 s) and the ranks take the minimum of their verdicts over TCP — if RCCL fails or
+  hangs on any rank, ALL ranks use the star, and the run loses the collective's transport, not its result.
+  ``FSDP_COMM=tcp`` skips RCCL altogether; ``FSDP_COMM=rccl`` makes an RCCL failure fatal.
+
+Rendezvous: MASTER_PORT itself belongs to the launcher's store, so rank 0 listens on the first free port of
+``[MASTER_PORT + 1, MASTER_PORT + PORT_SPAN]``; clients find it by a handshake that carries a launch key derived from
+values every rank of a launch shares (``FSDP_LAUNCH_KEY`` if set, else TORCHELASTIC_RUN_ID, MASTER_ADDR, MASTER_PORT,
+WORLD_SIZE), so a port held by a stranger — or by another launch's rank 0 — is skipped.  The exchange is NOT
+authenticated: the key only tells launches apart; anyone who can reach the port and knows these values can read the
+RCCL id.  Run it on a trusted network (single node: 127.0.0.1).
 """
 from __future__ import annotations
 
@@ -18,101 +34,173 @@ import hashlib
 import os
 import socket
 import struct
+import threading
 import time
 
 import numpy as np
 
 ID_BYTES = 128
 PORT_SPAN = 32
-_MAGIC = b"FSDPID1\0"
+_MAGIC = b"FSDPID2\0"
+_OPS = {0: np.add.reduce, 1: np.maximum.reduce, 2: np.minimum.reduce}
 
 
 def _launch_key(world: int) -> bytes:
-    """16 bytes every rank of one launch computes alike: run id / launcher pid / world size."""
-    run = os.environ.get("FSDP_LAUNCH_KEY") or f"{os.environ.get('TORCHELASTIC_RUN_ID', '')}:{os.getppid()}"
-    return hashlib.sha256(f"{run}:{world}:{os.environ.get('MASTER_PORT', '')}".encode()).digest()[:16]
+    """16 bytes every rank of one launch computes alike, from launcher-provided shared values only."""
+    run = os.environ.get("FSDP_LAUNCH_KEY")
+    if not run:
+        run = ":".join(os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
+    return hashlib.sha256(f"{run}:{world}".encode()).digest()[:16]
 
 
 def _recv_exact(sock: socket.socket, n: int) -> bytes:
-    buf = b""
+    buf = bytearray()
     while len(buf) < n:
-        chunk = sock.recv(n - len(buf))
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
         if not chunk:
-            raise ConnectionError("peer closed during the unique-id exchange")
+            raise ConnectionError("peer closed the connection")
         buf += chunk
-    return buf
+    return bytes(buf)
 
 
-def serve_unique_id(uid: bytes, world: int, addr: str, base_port: int, timeout: float = 300.0) -> None:
-    """Rank 0: hand `uid` to the world - 1 other ranks (each connects once, proves the launch key, names its rank)."""
-    assert len(uid) == ID_BYTES
-    key = _launch_key(world)
-    srv = None
-    for port in range(base_port + 1, base_port + 1 + PORT_SPAN):
-        s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        try:
-            s.bind((addr, port))
-            s.listen(world)
-            srv = s
-            break
-        except OSError:
-            s.close()
-    if srv is None:
-        raise RuntimeError(f"no free port in [{base_port + 1}, {base_port + PORT_SPAN}] for the RCCL unique-id exchange")
-    deadline = time.monotonic() + timeout
-    served = set()
-    try:
-        while len(served) < world - 1:
-            srv.settimeout(max(0.1, deadline - time.monotonic()))
-            try:
-                conn, _ = srv.accept()
-            except socket.timeout:
-                raise TimeoutError(f"unique-id exchange: only ranks {sorted(served)} of {world - 1} connected") from None
-            with conn:
-                conn.settimeout(10.0)
+def _send_msg(sock: socket.socket, payload: bytes) -> None:
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_msg(sock: socket.socket) -> bytes:
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class Star:
+    """The TCP star around rank 0: persistent connections, length-prefixed messages, deterministic reductions (rank
+    order).  Collective calls must be made by every rank in the same order."""
+
+    def __init__(self, rank: int, world: int, addr: str, base_port: int, connect_timeout: float = 120.0, io_timeout: float = 900.0):
+        self.rank, self.world = rank, world
+        self.peers = {}   # rank 0: {rank: socket}
+        self.sock = None  # ranks > 0: the connection to rank 0
+        key = _launch_key(world)
+        if rank == 0:
+            srv = None
+            for port in range(base_port + 1, base_port + 1 + PORT_SPAN):
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
                 try:
-                    hello = _recv_exact(conn, len(_MAGIC) + 16 + 4)
-                except (ConnectionError, socket.timeout):
-                    continue
-                rank = struct.unpack("<i", hello[-4:])[0]
-                if hello[: len(_MAGIC)] != _MAGIC or hello[len(_MAGIC) : len(_MAGIC) + 16] != key or not (0 < rank < world):
-                    conn.sendall(b"NO")  # a stranger, or a rank of another launch
-                    continue
-                conn.sendall(b"OK" + uid)
-                served.add(rank)
-    finally:
-        srv.close()
-
-
-def fetch_unique_id(rank: int, world: int, addr: str, base_port: int, timeout: float = 300.0) -> bytes:
-    """Ranks > 0: find rank 0's port in the span and fetch the id."""
-    hello = _MAGIC + _launch_key(world) + struct.pack("<i", rank)
-    deadline = time.monotonic() + timeout
-    while time.monotonic() < deadline:
-        for port in range(base_port + 1, base_port + 1 + PORT_SPAN):
+                    s.bind((addr, port))
+                    s.listen(world + 8)
+                    srv = s
+                    break
+                except OSError:
+                    s.close()
+            if srv is None:
+                raise RuntimeError(f"no free port in [{base_port + 1}, {base_port + PORT_SPAN}] for the rank rendezvous")
+            deadline = time.monotonic() + connect_timeout
             try:
-                with socket.create_connection((addr, port), timeout=2.0) as s:
-                    s.settimeout(10.0)
-                    s.sendall(hello)
-                    if _recv_exact(s, 2) == b"OK":
-                        return _recv_exact(s, ID_BYTES)
-            except (OSError, ConnectionError):
-                continue
-        time.sleep(0.05)
-    raise TimeoutError("unique-id exchange: rank 0 not found")
+                while len(self.peers) < world - 1:
+                    srv.settimeout(max(0.1, deadline - time.monotonic()))
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        raise TimeoutError(f"rank rendezvous: only ranks {sorted(self.peers)} of {world - 1} connected within {connect_timeout:.0f} s") from None
+                    conn.settimeout(10.0)
+                    try:
+                        hello = _recv_exact(conn, len(_MAGIC) + 16 + 4)
+                    except (ConnectionError, socket.timeout, OSError):
+                        conn.close()
+                        continue
+                    r = struct.unpack("<i", hello[-4:])[0]
+                    if hello[: len(_MAGIC)] != _MAGIC or hello[len(_MAGIC): len(_MAGIC) + 16] != key or not (0 < r < world) or r in self.peers:
+                        try:
+                            conn.sendall(b"NO")  # a stranger, or a rank of another launch
+                        finally:
+                            conn.close()
+                        continue
+                    conn.sendall(b"OK")
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.settimeout(io_timeout)
+                    self.peers[r] = conn
+            finally:
+                srv.close()
+        else:
+            hello = _MAGIC + key + struct.pack("<i", rank)
+            deadline = time.monotonic() + connect_timeout
+            refused = 0
+            while self.sock is None and time.monotonic() < deadline:
+                for port in range(base_port + 1, base_port + 1 + PORT_SPAN):
+                    try:
+                        s = socket.create_connection((addr, port), timeout=2.0)
+                    except OSError:
+                        continue
+                    try:
+                        s.settimeout(10.0)
+                        s.sendall(hello)
+                        ans = _recv_exact(s, 2)
+                    except (OSError, ConnectionError):
+                        s.close()
+                        continue
+                    if ans == b"OK":
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        s.settimeout(io_timeout)
+                        self.sock = s
+                        break
+                    refused += ans == b"NO"
+                    s.close()
+                if self.sock is None:
+                    time.sleep(0.05)
+            if self.sock is None:
+                raise TimeoutError(
+                    f"rank rendezvous: rank 0 not found on {addr}:[{base_port + 1}, {base_port + PORT_SPAN}] within {connect_timeout:.0f} s"
+                    + (f" ({refused} answers from servers of another launch: the ranks do not share a launch key — set FSDP_LAUNCH_KEY "
+                       "to the same value on every rank, or give all ranks the same TORCHELASTIC_RUN_ID / MASTER_ADDR / MASTER_PORT / WORLD_SIZE)" if refused else ""))
 
+    # -- primitives --------------------------------------------------------------------------------------------------------
+    def _root_collect(self, mine: bytes):
+        """rank 0: payloads of all ranks in rank order."""
+        out = [mine]
+        for r in range(1, self.world):
+            out.append(_recv_msg(self.peers[r]))
+        return out
 
-def exchange_unique_id(rank: int, world: int, make_id, addr: str | None = None, base_port: int | None = None) -> bytes:
-    """All ranks call this; returns the same 128 bytes everywhere.  make_id() runs on rank 0 only."""
-    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-    base_port = int(os.environ.get("MASTER_PORT", "29531")) if base_port is None else base_port
-    if rank == 0:
-        uid = bytes(make_id())
-        if world > 1:
-            serve_unique_id(uid, world, addr, base_port)
-        return uid
-    return fetch_unique_id(rank, world, addr, base_port)
+    def _root_send_all(self, payload: bytes) -> None:
+        for r in range(1, self.world):
+            _send_msg(self.peers[r], payload)
+
+    def broadcast(self, payload, src: int = 0) -> bytes:
+        if self.world == 1:
+            return bytes(payload)
+        if self.rank == 0:
+            data = bytes(payload) if src == 0 else _recv_msg(self.peers[src])
+            self._root_send_all(data)
+            return data
+        if self.rank == src:
+            _send_msg(self.sock, bytes(payload))
+        return _recv_msg(self.sock)
+
+    def allreduce(self, values: np.ndarray, op: int) -> np.ndarray:
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if self.world == 1:
+            return v.copy()
+        if self.rank == 0:
+            parts = [np.frombuffer(b, dtype=np.float64) for b in self._root_collect(v.tobytes())]
+            res = _OPS[op](np.stack(parts), axis=0)
+            self._root_send_all(res.tobytes())
+            return res.reshape(v.shape)
+        _send_msg(self.sock, v.tobytes())
+        return np.frombuffer(_recv_msg(self.sock), dtype=np.float64).reshape(v.shape).copy()
+
+    def barrier(self) -> None:
+        n = self.allreduce(np.array([1.0]), 0)
+        if int(n[0]) != self.world:
+            raise RuntimeError("barrier: rank count mismatch")
+
+    def close(self) -> None:
+        for s in list(self.peers.values()) + ([self.sock] if self.sock else []):
+            try:
+                s.close()
+            except OSError:
+                pass
+        self.peers, self.sock = {}, None
 
 
 def frame_range(rank: int, world: int, n_total: int):
@@ -122,41 +210,128 @@ def frame_range(rank: int, world: int, n_total: int):
     return lo, min(lo + per, n_total)
 
 
+def _call_with_deadline(fn, seconds: float):
+    """Run fn() in a daemon thread; (True, result) or (False, exception | 'timeout').  A call that never returns (a hung
+    RCCL bootstrap) leaves its thread behind — the process goes on over TCP."""
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except BaseException as e:  # noqa: BLE001 — reported to the caller
+            box["e"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return False, "timeout"
+    if "e" in box:
+        return False, box["e"]
+    return True, box.get("r")
+
+
 class Dist:
-    """Rank bookkeeping + the RCCL communicator of one context.  ``Dist(ctx)`` with WORLD_SIZE == 1 does nothing
-    unless FSDP_FORCE_DIST=1 (a one-rank communicator, to exercise the RCCL plumbing on a single GPU)."""
+    """Rank bookkeeping + the communicator of one context.  ``Dist(ctx)`` with WORLD_SIZE == 1 does nothing unless
+    FSDP_FORCE_DIST=1 (a one-rank RCCL communicator, to exercise the RCCL plumbing on a single GPU).  ``Dist()`` without a
+    context gives the TCP transport alone (CPU tests, host-only tools)."""
 
     def __init__(self, ctx=None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self._ctx = None
-        self._active = False
+        self._active = False       # an RCCL communicator carries the collectives
+        self.transport = "none"    # "none" (single process) | "rccl" | "tcp-fallback"
+        self.fallback_reason = None
+        self._star = None
+        if self.world > 1:
+            addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+            base_port = int(os.environ.get("MASTER_PORT", "29531"))
+            self._star = Star(self.rank, self.world, addr, base_port,
+                              connect_timeout=float(os.environ.get("FSDP_RENDEZVOUS_TIMEOUT", "120")),
+                              io_timeout=float(os.environ.get("FSDP_COMM_TIMEOUT", "900")))
+            self.transport = "tcp-fallback"
+            self.fallback_reason = "no context attached"
         if ctx is not None:
             self.attach(ctx)
+
+    # -- RCCL ---------------------------------------------------------------------------------------------------------------
+    def _try_rccl(self, ctx):
+        lib = ctx._lib
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
+        uid = None
+        err = None
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(ID_BYTES)
+            if lib.fsdp_comm_unique_id(buf) != 0:
+                err = "fsdp_comm_unique_id: " + lib.fsdp_last_error(None).decode()  # (creation-time errors live outside any context)
+                uid = bytes(ID_BYTES)
+            else:
+                uid = buf.raw
+        if self._star is not None:
+            uid = self._star.broadcast(uid if self.rank == 0 else b"", 0)
+            ok_id = float(self._star.allreduce(np.array([0.0 if err else 1.0]), 2)[0])
+            if ok_id != 1.0:
+                return err or "rank 0 could not create the RCCL unique id"
+        elif err:
+            return err
+
+        def init_and_test():
+            ctx._check(lib.fsdp_comm_init(ctx._h, self.rank, self.world, uid), "fsdp_comm_init")
+            v = np.array([1.0])
+            ctx._check(lib.fsdp_comm_allreduce(ctx._h, v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1, 0), "fsdp_comm_allreduce")
+            if int(v[0]) != self.world:
+                raise RuntimeError(f"test all-reduce returned {v[0]} for {self.world} ranks")
+            return True
+
+        ok, what = _call_with_deadline(init_and_test, float(os.environ.get("FSDP_RCCL_INIT_TIMEOUT", "180")))
+        return None if ok else f"{what}"
 
     def attach(self, ctx) -> None:
         """Create this rank's communicator on ctx's GPU (collective: every rank must call)."""
         self._ctx = ctx
+        want = os.environ.get("FSDP_COMM", "").lower()
         if not (self.world > 1 or os.environ.get("FSDP_FORCE_DIST") == "1"):
             return
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
-        lib = ctx._lib
+        if want == "tcp":
+            self.fallback_reason = "FSDP_COMM=tcp"
+            return
+        why = self._try_rccl(ctx)
+        # every rank must come to the same conclusion: the minimum of the verdicts, over the transport that always works
+        all_ok = why is None
+        if self._star is not None:
+            all_ok = float(self._star.allreduce(np.array([1.0 if why is None else 0.0]), 2)[0]) == 1.0
+        if all_ok:
+            self._active = True
+            self.transport = "rccl"
+            self.fallback_reason = None
+            assert self.comm_size == self.world and int(ctx._lib.fsdp_comm_rank(ctx._h)) == self.rank
+            return
+        if why is None:
+            ctx._lib.fsdp_comm_destroy(ctx._h)  # mine works, another rank's does not
+            why = "RCCL failed on another rank"
+        if want == "rccl" or self._star is None:
+            raise RuntimeError(f"RCCL communicator unavailable: {why}")
+        self.fallback_reason = why
+        if self.rank == 0:
+            import sys
 
-        def make_id():
-            buf = ctypes.create_string_buffer(ID_BYTES)
-            ctx._check(lib.fsdp_comm_unique_id(buf), "fsdp_comm_unique_id")
-            return buf.raw
-
-        uid = exchange_unique_id(self.rank, self.world, make_id)
-        ctx._check(lib.fsdp_comm_init(ctx._h, self.rank, self.world, uid), "fsdp_comm_init")
-        self._active = True
-        assert self.comm_size == self.world and int(lib.fsdp_comm_rank(ctx._h)) == self.rank
+            print(f"fsdp dist: RCCL unavailable ({why}); collectives over the TCP star", file=sys.stderr)
 
     @property
     def comm_size(self) -> int:
-        """Rank count RCCL reports (ncclCommCount); 1 without a communicator."""
-        return int(self._ctx._lib.fsdp_comm_size(self._ctx._h)) if self._active else 1
+        """Rank count of the communicator in use (ncclCommCount for RCCL)."""
+        if self._active:
+            return int(self._ctx._lib.fsdp_comm_size(self._ctx._h))
+        return self.world if self._star is not None else 1
+
+    def describe(self) -> str:
+        if self.transport == "rccl":
+            return f"rccl, {self.comm_size} rank(s) (ncclCommCount)"
+        if self.transport == "tcp-fallback":
+            return f"tcp-fallback, {self.world} rank(s) ({self.fallback_reason})"
+        return "none (single process)"
 
     def shard_seed(self, base_seed: int) -> int:
         """Weak scaling: each rank replays its own synthetic track (fixed frames per GPU)."""
@@ -165,6 +340,7 @@ class Dist:
     def frame_range(self, n_total: int):
         return frame_range(self.rank, self.world, n_total)
 
+    # -- collectives ----------------------------------------------------------------------------------------------------------
     def broadcast_array(self, arr, shape, dtype=np.float64, src: int = 0) -> np.ndarray:
         """Track-map broadcast: rank `src` owns a constant table (skidpad known path 5786 x 2 f64 =
         92 576 B, noise table) and broadcasts it once at start-up; the other ranks pass arr=None."""
@@ -175,6 +351,9 @@ class Dist:
         if self._active:
             self._ctx._check(self._ctx._lib.fsdp_comm_broadcast(self._ctx._h, ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf.nbytes), src),
                              "fsdp_comm_broadcast")
+        elif self._star is not None:
+            data = self._star.broadcast(buf.tobytes() if self.rank == src else b"", src)
+            buf = np.frombuffer(data, dtype=dtype).reshape(shape).copy()
         return buf
 
     def broadcast_check_table(self, table: np.ndarray) -> bool:
@@ -185,18 +364,23 @@ class Dist:
         return self._reduce(same, 2) == 1.0
 
     def _reduce(self, value: float, op: int) -> float:
-        if not self._active:
-            return float(value)
-        v = np.array([value], dtype=np.float64)
-        self._ctx._check(self._ctx._lib.fsdp_comm_allreduce(self._ctx._h, v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1, op), "fsdp_comm_allreduce")
-        return float(v[0])
+        if self._active:
+            v = np.array([value], dtype=np.float64)
+            self._ctx._check(self._ctx._lib.fsdp_comm_allreduce(self._ctx._h, v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1, op), "fsdp_comm_allreduce")
+            return float(v[0])
+        if self._star is not None:
+            return float(self._star.allreduce(np.array([value], dtype=np.float64), op)[0])
+        return float(value)
 
     def barrier(self):
-        """Waits for this rank's passes in flight, then for every rank (all-reduce rendezvous)."""
+        """Waits for this rank's passes in flight, then for every rank."""
         if self._active:
             self._ctx._check(self._ctx._lib.fsdp_comm_barrier(self._ctx._h), "fsdp_comm_barrier")
-        elif self._ctx is not None:
+            return
+        if self._ctx is not None:
             self._ctx.sync()
+        if self._star is not None:
+            self._star.barrier()
 
     def max_over_ranks(self, value: float) -> float:
         return self._reduce(value, 1)
@@ -208,3 +392,42 @@ class Dist:
         if self._active:
             self._ctx._lib.fsdp_comm_destroy(self._ctx._h)
             self._active = False
+        if self._star is not None:
+            self._star.close()
+            self._star = None
+
+
+def spawn_ranks(argv, n: int, env_extra=None, timeout: float | None = None) -> int:
+    """Launcher-less multi-GPU start: run ``python argv...`` as n ranks of one node (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / a free MASTER_PORT / a fresh FSDP_LAUNCH_KEY), rank 0's stdout passed through.  Returns the
+    worst exit code.  What ``python -m torch.distributed.run --nproc-per-node n`` does for this package, without torch."""
+    import secrets
+    import subprocess
+    import sys
+
+    with socket.socket() as s:  # a free port; the rendezvous uses the span above it
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    if port > 65000:
+        port = 29531
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "FSDP_LAUNCH_KEY": env.get("FSDP_LAUNCH_KEY") or secrets.token_hex(8), "FSDP_SPAWNED": "1"})
+        if r == 0:
+            key = env["FSDP_LAUNCH_KEY"]
+        env["FSDP_LAUNCH_KEY"] = key
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = None if timeout is None else time.monotonic() + timeout
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(None if deadline is None else max(1.0, deadline - time.monotonic()))))
+        except subprocess.TimeoutExpired:
+            rc = max(rc, 124)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+    return rc

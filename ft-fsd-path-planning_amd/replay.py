@@ -7,8 +7,8 @@ loop :103-131).  Same file schema: a list of {"car_position":[x,y], "car_directi
 Two replay modes:
   per-frame : one PathPlanner, one calculate_path_in_global_frame call per frame, wall-clock per call (what the
               reference's demo measures; for the skidpad mission this is the stateful sequence);
-  --batched : all frames of the recording as ONE batch of independent frames through plan_batch (fresh-planner
-              semantics per frame; trackdrive/autocross recordings only).
+  --batched : the frames of the recording as a stream of batches of independent frames (fresh-planner semantics per
+              frame; trackdrive/autocross recordings only), several batches in flight (fsdp_submit / fsdp_collect).
 """
 from __future__ import annotations
 
@@ -61,14 +61,40 @@ def replay_per_frame(mission, positions, directions, observations, device=None):
     return np.array(paths), np.array(times), reloc_frame, planner.relocalization_info
 
 
-def replay_batched(mission, positions, directions, observations, device=None, repeats: int = 5):
+def replay_batched(mission, positions, directions, observations, device=None, repeats: int = 5, batch_frames: int = 4096, depth: int = 4):
+    """The recording as a stream of batches of `batch_frames` frames, `depth` of them in flight (fsdp_submit /
+    fsdp_collect: a batch's transfers run under the other batches' kernels; page-locked buffers).  Returns the results of
+    all frames in recording order and the seconds one replay of the whole recording took (host buffers to host buffers)."""
+    from . import _capi
+
     planner = PathPlanner(mission, device=device)
-    off, cones, poses = pack_frames(list(zip(observations, positions, directions)))
-    planner.plan_batch(off, cones, poses)  # warm-up
+    ctx = planner._ctx
+    frames = list(zip(observations, positions, directions))
+    chunks = []
+    for lo in range(0, len(frames), batch_frames):
+        off, cones, poses = pack_frames(frames[lo:lo + batch_frames])
+        chunks.append((_capi.pinned_copy(off, np.int32), _capi.pinned_copy(cones, np.float64), _capi.pinned_copy(poses, np.float64),
+                       _capi.pinned_empty(len(poses), _capi.RESULT_DTYPE)))
+    depth = max(1, min(depth, len(chunks)))
+    ctx.set_overlap(depth)
+
+    def one_replay():
+        inflight = []
+        for off, cones, poses, out in chunks:
+            if len(inflight) == depth:
+                ctx.collect(inflight.pop(0))
+            inflight.append(ctx.submit(off, cones, poses, out=out))
+        for t in inflight:
+            ctx.collect(t)
+
+    one_replay()  # warm-up
     t0 = time.perf_counter()
     for _ in range(repeats):
-        res = planner.plan_batch(off, cones, poses)
-    return res, (time.perf_counter() - t0) / repeats
+        one_replay()
+    sec = (time.perf_counter() - t0) / repeats
+    res = np.concatenate([np.array(c[3]) for c in chunks]) if chunks else np.zeros(0, _capi.RESULT_DTYPE)
+    ctx.set_overlap(1)
+    return res, sec
 
 
 def main(argv=None):
@@ -78,12 +104,14 @@ def main(argv=None):
     ap.add_argument("--batched", action="store_true")
     ap.add_argument("--output-path", "-o", type=Path, default=None)
     ap.add_argument("--device", type=int, default=None)
+    ap.add_argument("--batch-frames", type=int, default=4096, help="--batched: frames per batch of the stream")
+    ap.add_argument("--depth", type=int, default=4, help="--batched: batches in flight")
     a = ap.parse_args(argv)
     mission = select_mission_by_filename(a.data_path.name)
     positions, directions, observations = load_data_json(a.data_path, a.remove_color_info)
     out = {"file": str(a.data_path), "mission": mission.name, "frames": len(positions)}
     if a.batched:
-        res, sec = replay_batched(mission, positions, directions, observations, a.device)
+        res, sec = replay_batched(mission, positions, directions, observations, a.device, batch_frames=a.batch_frames, depth=a.depth)
         out.update(mode="batched", seconds_per_batch=sec, frames_per_s=len(res) / sec,
                    status_histogram={int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))})
         paths = res["path"]

@@ -1,15 +1,25 @@
-"""The N > 1 plumbing (ft-fsd-path-planning_amd/dist.py, used by bench.py) on CPU with two real processes:
-the RCCL unique-id exchange over TCP (what fsdp_comm_init needs out of band), the launch-key handshake, contiguous
-frame-range sharding of a global batch (BASELINE config 4) and weak-scaling seeds.  The RCCL calls themselves need GPUs:
-tests/test_gpu_parity.py::test_rccl_single_rank_communicator runs them with a one-rank communicator."""
+"""The N > 1 plumbing (ft-fsd-path-planning_amd/dist.py, used by bench.py) on CPU with 2 and 3 real processes: the rank
+rendezvous with its launch-key handshake, the three collectives the bench needs — broadcast of a constant table
+(``broadcast_check_table``), a scalar all-reduce (``max_over_ranks`` / ``sum_over_ranks``) and the barrier — over the
+transport that needs no GPU (the TCP star, which is also what every run falls back to when RCCL fails on any rank),
+contiguous frame-range sharding of a global batch (BASELINE config 4), weak-scaling seeds, and the launcher-less start
+(``dist.spawn_ranks``, what ``python bench.py --gpus N`` uses when no launcher set WORLD_SIZE).  The RCCL calls themselves
+need GPUs: tests/test_gpu_parity.py::test_rccl_single_rank_communicator runs them with a one-rank communicator."""
 import importlib
+import json
 import multiprocessing as mp
 import os
 import socket
+import subprocess
 import sys
+import textwrap
+import time
+from pathlib import Path
 
 import numpy as np
 import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def _free_port():
@@ -17,25 +27,44 @@ def _free_port():
     s.bind(("127.0.0.1", 0))
     p = s.getsockname()[1]
     s.close()
-    return p
+    return p if p < 65000 else 29531
 
 
 def _worker(rank, world, port, key, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       FSDP_LAUNCH_KEY=key)
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
-    d = pkg.dist.Dist()  # no context: rank bookkeeping only (no GPU here)
-    assert (d.rank, d.world) == (rank, world)
-    # rank 0 makes the 128 "unique id" bytes (on a GPU box: fsdp_comm_unique_id), the others fetch them
-    uid = pkg.dist.exchange_unique_id(rank, world, lambda: bytes((7 * i + 3) % 256 for i in range(128)))
+    d = pkg.dist.Dist()  # no context (no GPU here): the TCP star carries the collectives
+    assert (d.rank, d.world, d.transport, d.comm_size) == (rank, world, "tcp-fallback", world)
+    # broadcast of a constant table from rank 0 (on a GPU box: the skidpad track table / the previous-path table)
+    table = np.arange(5786 * 2, dtype=np.float64).reshape(5786, 2) * 0.25
+    got = d.broadcast_array(table if rank == 0 else None, (5786, 2))
+    same = d.broadcast_check_table(table)
+    # a rank whose own copy differs by one bit makes the check fail on EVERY rank
+    mine = table.copy()
+    if rank == world - 1:
+        mine.view(np.uint64)[17, 1] ^= 1
+    differs = d.broadcast_check_table(mine)
+    # broadcast from a non-zero source goes through rank 0
+    from_last = d.broadcast_array(np.full(3, 7.5) if rank == world - 1 else None, (3,), src=world - 1)
+    d.barrier()
+    mx = d.max_over_ranks(10.0 + rank)
+    sm = d.sum_over_ranks(float(rank + 1))
+    t0 = time.perf_counter()
+    for _ in range(200):
+        d.max_over_ranks(1.0)
+    rtt = (time.perf_counter() - t0) / 200
+    d.barrier()
     lo, hi = d.frame_range(65536)
     off, cones, poses = pkg.synth.make_config4_shard(lo, lo + 4, 100, 0.1, seed=7)  # the first 4 frames of this rank's shard
     off2, cones2, _ = pkg.synth.make_replay_batch(8, 16, 0.1, seed=d.shard_seed(5))
-    q.put((rank, uid, (lo, hi), float(cones[:, :2].sum()), cones.shape, float(cones2[:, :2].sum()), "torch" in sys.modules))
+    q.put((rank, bool(np.array_equal(got, table)), same, differs, from_last.tolist(), mx, sm, (lo, hi), float(cones[:, :2].sum()), cones.shape,
+           float(cones2[:, :2].sum()), "torch" in sys.modules, rtt))
+    d.close()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_unique_id_exchange_and_sharding(world):
+def test_collectives_and_sharding_with_real_processes(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -46,30 +75,33 @@ def test_unique_id_exchange_and_sharding(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = bytes((7 * i + 3) % 256 for i in range(128))
-    assert all(r[1] == want for r in res)
+    assert all(r[1] and r[2] for r in res), "table broadcast / check"
+    assert not any(r[3] for r in res), "a one-bit difference on one rank must fail the check everywhere"
+    assert all(r[4] == [7.5, 7.5, 7.5] for r in res)
+    assert all(r[5] == 10.0 + world - 1 for r in res) and all(r[6] == world * (world + 1) / 2 for r in res)
     per = -(-65536 // world)
-    assert [r[2] for r in res] == [(min(k * per, 65536), min((k + 1) * per, 65536)) for k in range(world)]
-    assert res[-1][2][1] == 65536 and sum(hi - lo for _, _, (lo, hi), *_ in res) == 65536
-    assert len({r[3] for r in res}) == world and len({r[5] for r in res}) == world  # different shards / tracks
-    assert all(r[4] == (800, 3) for r in res)
-    assert not any(r[6] for r in res), "dist.py must not import torch"
+    assert [r[7] for r in res] == [(min(k * per, 65536), min((k + 1) * per, 65536)) for k in range(world)]
+    assert res[-1][7][1] == 65536 and sum(r[7][1] - r[7][0] for r in res) == 65536
+    assert len({r[8] for r in res}) == world and len({r[10] for r in res}) == world  # different shards / tracks
+    assert all(r[9] == (800, 3) for r in res)
+    assert not any(r[11] for r in res), "dist.py must not import torch"
+    assert all(r[12] < 0.05 for r in res), "a scalar all-reduce over the star takes well under 50 ms"
 
 
-def test_stranger_on_the_port_is_skipped():
-    """A listener that is not rank 0 of this launch (wrong key) must not be mistaken for it."""
+def test_stranger_and_other_launch_on_the_port_span_are_skipped():
+    """A listener that is not rank 0 of this launch (garbage answers), and a rank 0 of ANOTHER launch (answers NO), sit on
+    the first ports of the span: the client must find its own rank 0 behind them."""
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    import threading
+
     port = _free_port()
-    os.environ["FSDP_LAUNCH_KEY"] = "launch-A"
-    # a stranger holds base_port + 1 and answers garbage
     stranger = socket.socket()
     stranger.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     stranger.bind(("127.0.0.1", port + 1))
     stranger.listen(4)
-    import threading
 
     def babble():
-        for _ in range(2):
+        while True:
             try:
                 c, _ = stranger.accept()
                 c.recv(64)
@@ -79,14 +111,69 @@ def test_stranger_on_the_port_is_skipped():
                 return
 
     threading.Thread(target=babble, daemon=True).start()
-    uid = bytes(range(128))
-    t = threading.Thread(target=pkg.dist.serve_unique_id, args=(uid, 2, "127.0.0.1", port), daemon=True)
-    t.start()
-    got = pkg.dist.fetch_unique_id(1, 2, "127.0.0.1", port, timeout=30)
-    t.join(timeout=30)
+    stars = {}
+
+    def rank0(key, name):
+        os.environ["FSDP_LAUNCH_KEY"] = key  # (read at construction)
+        stars[name] = pkg.dist.Star(0, 2, "127.0.0.1", port, connect_timeout=30)
+
+    os.environ["FSDP_LAUNCH_KEY"] = "launch-B"
+    tb = threading.Thread(target=rank0, args=("launch-B", "B"), daemon=True)
+    tb.start()
+    time.sleep(0.5)  # B's rank 0 holds port + 2
+    ta = threading.Thread(target=rank0, args=("launch-A", "A"), daemon=True)
+    ta.start()
+    time.sleep(0.5)  # A's rank 0 holds port + 3
+    os.environ["FSDP_LAUNCH_KEY"] = "launch-A"
+    client = pkg.dist.Star(1, 2, "127.0.0.1", port, connect_timeout=30)
+    ta.join(timeout=30)
+    assert "A" in stars and not ta.is_alive()
+    got = []
+    th = threading.Thread(target=lambda: got.append(stars["A"].allreduce(np.array([1.0, 5.0]), 1)), daemon=True)
+    th.start()
+    mine = client.allreduce(np.array([3.0, 2.0]), 1)
+    th.join(timeout=10)
+    assert mine.tolist() == [3.0, 5.0] and got[0].tolist() == [3.0, 5.0]
+    # launch B never gets its rank 1: a clear timeout, not a hang
+    client.close()
+    stars["A"].close()
     stranger.close()
     del os.environ["FSDP_LAUNCH_KEY"]
-    assert got == uid
+
+
+def test_missing_rank_times_out_with_a_clear_message():
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    port = _free_port()
+    with pytest.raises(TimeoutError, match="rank 0 not found"):
+        pkg.dist.Star(1, 2, "127.0.0.1", port, connect_timeout=1.0)
+    with pytest.raises(TimeoutError, match="only ranks"):
+        pkg.dist.Star(0, 2, "127.0.0.1", port, connect_timeout=1.0)
+
+
+def test_launcherless_start_spawns_the_ranks(tmp_path):
+    """dist.spawn_ranks (bench.py --gpus N without a launcher): N processes with the launch contract's environment that
+    find each other and run the collectives; rank 0's stdout passes through."""
+    script = tmp_path / "ranks.py"
+    script.write_text(textwrap.dedent(f"""
+        import importlib, json, os, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        pkg = importlib.import_module("ft-fsd-path-planning_amd")
+        d = pkg.dist.Dist()
+        tot = d.sum_over_ranks(float(d.rank + 1))
+        d.barrier()
+        if d.rank == 0:
+            print(json.dumps({{"world": d.world, "sum": tot, "transport": d.transport, "spawned": os.environ.get("FSDP_SPAWNED")}}))
+        d.close()
+    """))
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(f"""
+        import importlib, sys
+        sys.path.insert(0, {str(ROOT)!r})
+        pkg = importlib.import_module("ft-fsd-path-planning_amd")
+        sys.exit(pkg.dist.spawn_ranks([{str(script)!r}], 3, timeout=120))
+    """)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"world": 3, "sum": 6.0, "transport": "tcp-fallback", "spawned": "1"}
 
 
 def test_config4_union_does_not_depend_on_rank_count():

@@ -254,7 +254,7 @@ def test_replay_cli_roundtrip(pkg, golden_dir, tmp_path):
     f.write_text(json.dumps(frames))
     pos, dirs, obs = pkg.replay.load_data_json(f)
     paths, times, reloc, info = pkg.replay.replay_per_frame(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0)
-    res, sec = pkg.replay.replay_batched(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0, repeats=1)
+    res, sec = pkg.replay.replay_batched(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0, repeats=1, batch_frames=5, depth=3)
     assert np.array_equal(paths, res["path"]) and reloc is None and info is None
     assert np.abs(paths - g["path"][:16]).max() < 1e-5
 
@@ -369,7 +369,7 @@ def test_rccl_single_rank_communicator(pkg, monkeypatch):
     monkeypatch.setenv("RANK", "0")
     c = pkg.Context(device=0, mission=int(pkg.MissionTypes.trackdrive))
     d = pkg.dist.Dist(c)
-    assert d._active and d.comm_size == 1
+    assert d._active and d.comm_size == 1 and d.transport == "rccl"
     table = pkg.skidpad.load_tables()[0]
     got = d.broadcast_array(table, table.shape)
     assert np.array_equal(got, table)

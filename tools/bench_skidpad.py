@@ -36,8 +36,15 @@ T = len(g["poses"])
 batches = [sk.batch_for_step(g, t, tf) for t in range(T)]
 batch = pkg.SkidpadBatch(n, device=local_rank, table=table)
 assert np.array_equal(batch.tables[1], noise)
+DEPTH = int(os.environ.get("FSDP_SKID_DEPTH", "4"))
+batches = [tuple(pkg.pinned_copy(a, dt) for a, dt in zip(b, (np.int32, np.float64, np.float64))) for b in batches]
+outs = [pkg.pinned_empty(n, pkg.RESULT_DTYPE) for _ in range(DEPTH + 1)]
+batch.set_overlap(DEPTH)
 for t in range(3):  # warm-up on a throw-away state (reference demo does the same, json_demo.py:89-94)
     batch.step(*batches[t])
+for t in range(DEPTH):
+    batch.collect(batch.submit(*batches[t], out=outs[t]))
+# (a) one step at a time: submit + collect (what a live car does)
 batch.reset()
 d.barrier()
 t0 = time.perf_counter()
@@ -46,14 +53,34 @@ for t in range(T):
     res, info = batch.step(*batches[t])
     status += res["status"] != 0
 d.barrier()
+el_step = d.max_over_ranks(time.perf_counter() - t0)
+ref_last = res["path"].copy()
+# (b) the replay as a stream: up to DEPTH steps submitted ahead (fsdp_skidpad_submit): step k + 1's inputs go up and
+# step k - 1's results come down while step k's kernels run; the planner states chain on the device
+batch.reset()
+d.barrier()
+t0 = time.perf_counter()
+status = np.zeros(n, np.int64)
+inflight = []
+for t in range(T):
+    if len(inflight) == DEPTH:
+        res, info = batch.collect(inflight.pop(0))
+        status += res["status"] != 0
+    inflight.append(batch.submit(*batches[t], out=outs[t % (DEPTH + 1)]))
+for tk in inflight:
+    res, info = batch.collect(tk)
+    status += res["status"] != 0
+d.barrier()
 el = d.max_over_ranks(time.perf_counter() - t0)
+assert np.array_equal(res["path"], ref_last, equal_nan=True), "pipelined steps differ from one-at-a-time steps"
 kms = batch.time_path(10) / 10
 reloc = d.sum_over_ranks(float(info["relocalized"].sum()))
 bad = d.sum_over_ranks(float(status.sum()))
 if rank == 0:
     print(json.dumps({"config": "BASELINE configs[4]: skidpad, batch=%d perturbed starts x %d frames on %d GPU(s)" % (n_total, T, d.world),
-                      "frames_per_s_incl_pcie": n_total * T / el, "seconds": el, "relocalized": int(reloc),
+                      "frames_per_s_incl_pcie": n_total * T / el, "seconds": el, "steps_in_flight": DEPTH,
+                      "frames_per_s_incl_pcie_one_step_at_a_time": n_total * T / el_step, "relocalized": int(reloc),
                       "frames_with_nonzero_status": int(bad), "skid_path_kernel_ms_per_step": kms,
                       "frames_per_s_kernel_only_per_gpu": n / (kms * 1e-3),
-                      "tables": "rank 0 loads them, RCCL broadcast to the others" if d._active else "single process"}))
+                      "tables": ("rank 0 loads them, broadcast to the others; communicator " + d.describe()) if d.world > 1 or d._active else "single process"}))
 d.close()
