@@ -120,7 +120,7 @@ def streaming_leg(pkg, ctx, per_gpu: int, depth: int, n_batches: int, seed0: int
     inflight = []
     t0 = time.perf_counter()
     for k in range(n_batches):
-        if len(inflight) == depth:
+        if len(inflight) == ctx.ticket_capacity:
             ctx.collect(inflight.pop(0))
         inflight.append(ctx.submit(*batches[k], out=outs[k]))
     for t in inflight:
@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency loop and the golden flip count (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
     ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..16)")
+    ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic track (config 2; rank r replays seed + r)")
     ap.add_argument("--stream-batches", type=int, default=40, help="different batches of the host -> host streaming leg (0: skip)")
     args = ap.parse_args()
 
@@ -245,7 +246,7 @@ def main():
         # weak scaling: this rank's own 4096-frame replay (a different track per rank)
         per_gpu = args.frames or FRAMES_PER_GPU
         cones_per_frame = 2 * CONES_PER_SIDE
-        off, cones, poses = pkg.synth.make_replay_batch(per_gpu, CONES_PER_SIDE, 0.15, seed=d.shard_seed(1), color=True)
+        off, cones, poses = pkg.synth.make_replay_batch(per_gpu, CONES_PER_SIDE, 0.15, seed=d.shard_seed(args.seed), color=True)
         frames_global = per_gpu * world
         workload = f"BASELINE configs[1]: batch={per_gpu} synthetic autocross replay frames per GPU, 64 L + 64 R coloured cones"
         scaling = "weak"
@@ -371,7 +372,7 @@ def main():
             "lib_sha256_16": _lib_hash(pkg),
         }
         if args.config == 2 and args.stream_batches > 0:
-            out["streaming"] = streaming_leg(pkg, ctx, n_local, overlap, args.stream_batches, d.shard_seed(1))
+            out["streaming"] = streaming_leg(pkg, ctx, n_local, overlap, args.stream_batches, d.shard_seed(args.seed))
         if world == 1 and not args.no_latency:
             # sample-count flips against the reference, measured on the committed golden fuzz set
             out["flip_count"] = golden_flip_count(pkg, ctx)

@@ -130,6 +130,7 @@ def load() -> ctypes.CDLL:
                                 ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     lib.fsdp_collect.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
     lib.fsdp_ticket_done.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+    lib.fsdp_ticket_capacity.argtypes = [ctypes.c_void_p]
     lib.fsdp_skidpad_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     lib.fsdp_route_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong)]
@@ -148,7 +149,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
     "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
-    "fsdp_skidpad_submit", "fsdp_route_stats",
+    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity",
 ]
 
 
@@ -298,6 +299,11 @@ class Context:
         self._check(self._lib.fsdp_collect(self._h, ctypes.c_longlong(ticket.id)), "fsdp_collect")
         ticket._keep = None
         return ticket.out
+
+    @property
+    def ticket_capacity(self) -> int:
+        """Tickets that may be outstanding at the current overlap depth (two per pass slot)."""
+        return int(self._lib.fsdp_ticket_capacity(self._h))
 
     def ticket_done(self, ticket: Ticket) -> bool:
         return int(self._lib.fsdp_ticket_done(self._h, ctypes.c_longlong(ticket.id))) == 1

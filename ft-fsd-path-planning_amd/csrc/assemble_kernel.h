@@ -39,7 +39,8 @@ static_assert(sizeof(fsdp_frame_result) % 4 == 0, "result words");
 __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortOut* __restrict__ sorted, const MatchOut* __restrict__ matched,
                                                         const PathOut* __restrict__ paths, fsdp_frame_result* __restrict__ results,
                                                         int* __restrict__ big, int* __restrict__ retry, PassTrailer* __restrict__ trailer,
-                                                        int seq) {
+                                                        int seq, const int32_t* __restrict__ extra_src = nullptr, int32_t* __restrict__ extra_dst = nullptr,
+                                                        int extra_words = 0) {
   const long long total = (long long)n_frames * RESULT_WORDS;
   const int32_t* s32 = (const int32_t*)sorted;
   const int32_t* m32 = (const int32_t*)matched;
@@ -88,6 +89,9 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
     }
     r32[idx] = v;
   }
+  // a second, plain block of words on the same trip (skidpad steps: the planners' SkidInfo records to the caller's side)
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < extra_words; idx += (long long)gridDim.x * blockDim.x)
+    extra_dst[idx] = extra_src[idx];
   if (blockIdx.x == 0 && threadIdx.x == 0 && trailer != nullptr) {
     // (the stage kernels finished before this kernel started: same stream)
     const int nb = big ? big[0] : 0, nr = retry ? retry[0] : 0;
@@ -96,6 +100,51 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
     __hip_atomic_store(&trailer->n_big, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&trailer->n_retry, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&trailer->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// First kernel of a ticket's pass when the caller's input buffers are page-locked: the batch comes over PCIe by plain
+// loads from host memory (the GPU maps page-locked host memory into its address space) into the slot's device buffers —
+// up to four segments (offsets, cones, poses, previous paths) in one launch.  Why a kernel and not hipMemcpyAsync: the
+// copies of the SDMA engines are ordered against the kernels of a stream through cross-engine signals, and with ten
+// streams each alternating copy / kernels / copy the runtime's submission stalled for milliseconds at a time (measured:
+// profiles/r03_streaming.txt); as kernels, a batch's transfers are ordinary packets of its own stream.  16 bytes per lane
+// and load, four loads in flight per lane: 256 workgroups keep ~1 MB on the wire, enough for the link's latency x bandwidth.
+struct CopySeg {
+  const void* src;
+  void* dst;
+  unsigned long long bytes;  // multiple of 4
+};
+struct CopySegs {
+  CopySeg seg[4];
+  int n;
+};
+__global__ void __launch_bounds__(256) stage_in_kernel(CopySegs S) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long nth = (unsigned long long)gridDim.x * blockDim.x;
+  for (int k = 0; k < S.n; k++) {
+    const char* src = (const char*)S.seg[k].src;
+    char* dst = (char*)S.seg[k].dst;
+    const unsigned long long bytes = S.seg[k].bytes;
+    if ((((unsigned long long)src | (unsigned long long)dst) & 15ull) == 0) {
+      const unsigned long long n16 = bytes / 16;
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const u4* s4 = (const u4*)src;
+      u4* d4 = (u4*)dst;
+      unsigned long long i = tid;
+      for (; i + 3 * nth < n16; i += 4 * nth) {
+        const u4 a = __builtin_nontemporal_load(s4 + i), b = __builtin_nontemporal_load(s4 + i + nth),
+                    c = __builtin_nontemporal_load(s4 + i + 2 * nth), d = __builtin_nontemporal_load(s4 + i + 3 * nth);
+        d4[i] = a;
+        d4[i + nth] = b;
+        d4[i + 2 * nth] = c;
+        d4[i + 3 * nth] = d;
+      }
+      for (; i < n16; i += nth) d4[i] = __builtin_nontemporal_load(s4 + i);
+      for (unsigned long long w = n16 * 4 + tid; w < bytes / 4; w += nth) ((uint32_t*)dst)[w] = ((const uint32_t*)src)[w];
+    } else {
+      for (unsigned long long w = tid; w < bytes / 4; w += nth) ((uint32_t*)dst)[w] = ((const uint32_t*)src)[w];
+    }
   }
 }
 

@@ -33,6 +33,20 @@ static_assert(FSDP_MAX_LEN == MAX_LEN && FSDP_MAX_MATCH == MAX_MATCH && FSDP_PAT
 
 static thread_local std::string g_create_error;
 
+// FSDP_TRACE=1: host-side duration of the steps of fsdp_submit that take longer than 0.5 ms, to stderr (diagnostics)
+#include <chrono>
+static const bool g_trace = getenv("FSDP_TRACE") != nullptr;
+struct TraceStep {
+  const char* what;
+  std::chrono::steady_clock::time_point t0;
+  explicit TraceStep(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
+  ~TraceStep() {
+    if (!g_trace) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > 0.5) fprintf(stderr, "[fsdp trace] %s: %.3f ms\n", what, ms);
+  }
+};
+
 constexpr int SORT_BIG_BLOCKS = 32;
 
 // one batch of frames on the device (CSR offsets, flattened cones, poses, optional previous paths)
@@ -48,6 +62,11 @@ struct Inputs {
   int max_cones = 0;      // most cones in a frame (picks the sorting kernel's state size)
   bool use_prev = false;  // d_prev holds this batch's previous paths
 };
+
+// Tickets queue up behind each other on a slot's stream (stream order protects the slot's buffers), so a slot always has
+// its next batch waiting when the current one ends — the host's collect / submit round trip is off the GPU's critical path.
+constexpr int SLOT_QUEUE = 2;   // tickets per slot
+constexpr int N_TRAILERS = 4;   // pass trailers per slot: two queued tickets + one repeated pass are distinguishable
 
 // one pass slot: a stream, the inputs of the batch submitted to it, the intermediates of a pass and its results
 struct Work {
@@ -65,21 +84,36 @@ struct Work {
   SkidInfo* d_skid_info = nullptr;        // skidpad contexts
   SortSharedBig* d_sort_big = nullptr;    // frame states of sort_big_kernel, allocated when the route is first needed
   int cap_frames = 0;
-  PassTrailer* h_trailer = nullptr;  // pinned, host-coherent, written by assemble_kernel
-  PassTrailer* d_trailer = nullptr;  // its device address
+  PassTrailer* h_trailer = nullptr;  // N_TRAILERS of them: pinned, host-coherent, written by assemble_kernel (pass seq -> seq % N_TRAILERS)
+  PassTrailer* d_trailer = nullptr;  // their device address
   int seq = 0;                       // passes launched on this slot
   // the most recent pass launched on the slot (verify_pass re-runs it with the route kernels when they were needed)
   const Inputs* pass_in = nullptr;
   bool ran_big = false, ran_retry = false, unverified = false, pass_skid = false;
-  // ticket of fsdp_submit / fsdp_skidpad_submit that occupies the slot (-1: free)
-  long long ticket = -1;
-  fsdp_frame_result* user_results = nullptr;
-  fsdp_skidpad_info* user_info = nullptr;
-  bool via_stage = false;                // results go through h_stage (the caller's buffer is pageable)
-  fsdp_frame_result* h_stage = nullptr;  // pinned
-  SkidInfo* h_info = nullptr;            // pinned
-  int cap_stage = 0, cap_info = 0;
-  hipEvent_t ev_in = nullptr, ev_done = nullptr;  // skidpad: inputs uploaded / kernels done
+  fsdp_frame_result* result_dst = nullptr;  // where assemble_kernel writes the next pass's results: NULL = d_result; a ticket with a
+                                            // page-locked result buffer: that buffer, straight over PCIe (no copy command at all)
+  // tickets of fsdp_submit / fsdp_skidpad_submit queued on this slot's stream (id -1: free entry)
+  struct Ticket {
+    long long id = -1;
+    int n = 0;
+    bool skid = false;
+    int seq = 0;                       // the slot's pass counter of this ticket's pass (its trailer: seq % N_TRAILERS)
+    bool ran_big = false, ran_retry = false;
+    // the caller's buffers: valid and untouched until fsdp_collect (a pass that has to be repeated reads them again)
+    const int32_t* off = nullptr;
+    const double* cones = nullptr;
+    const double* poses = nullptr;
+    const double* prev = nullptr;
+    size_t total = 0;
+    int max_cones = 0;
+    fsdp_frame_result* user_results = nullptr;
+    fsdp_skidpad_info* user_info = nullptr;
+    bool via_stage = false;                // results go through h_stage (the caller's buffer is pageable)
+    fsdp_frame_result* h_stage = nullptr;  // pinned
+    SkidInfo* h_info = nullptr;            // pinned
+    int cap_stage = 0, cap_info = 0;
+    hipEvent_t done = nullptr;             // recorded behind the ticket's last command
+  } tk[SLOT_QUEUE];
 };
 
 struct fsdp_ctx {
@@ -175,8 +209,10 @@ static int ensure_inputs(fsdp_ctx* c, Inputs& in, int n_frames, size_t n_cones, 
     in.cap_frames = n_frames;
   }
   if (n_cones > in.cap_cones || !in.d_cones) {
-    HIP_TRY(c, regrow(in.d_cones, 3 * n_cones));
-    in.cap_cones = n_cones;
+    // (with headroom: a replay's cone count creeps up from step to step, and hipFree synchronises the whole device)
+    const size_t want = n_cones + n_cones / 2 + 64;
+    HIP_TRY(c, regrow(in.d_cones, 3 * want));
+    in.cap_cones = want;
   }
   if (with_prev && n_frames > in.cap_prev) {
     HIP_TRY(c, regrow(in.d_prev, (size_t)PATH_POINTS * 4 * (size_t)n_frames));
@@ -196,8 +232,8 @@ static void free_inputs(Inputs& in) {
 static int ensure_work(fsdp_ctx* c, Work& w, int n) {
   if (!w.stream) HIP_TRY(c, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
   if (!w.h_trailer) {
-    HIP_TRY(c, hipHostMalloc((void**)&w.h_trailer, sizeof(PassTrailer), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(w.h_trailer, 0, sizeof(PassTrailer));
+    HIP_TRY(c, hipHostMalloc((void**)&w.h_trailer, sizeof(PassTrailer) * N_TRAILERS, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(w.h_trailer, 0, sizeof(PassTrailer) * N_TRAILERS);
     HIP_TRY(c, hipHostGetDevicePointer((void**)&w.d_trailer, w.h_trailer, 0));
   }
   if (n <= w.cap_frames) return 0;
@@ -232,10 +268,11 @@ static void free_work(Work& w) {
   (void)hipFree(w.d_skid_info);
   (void)hipFree(w.d_sort_big);
   if (w.h_trailer) (void)hipHostFree(w.h_trailer);
-  if (w.h_stage) (void)hipHostFree(w.h_stage);
-  if (w.h_info) (void)hipHostFree(w.h_info);
-  if (w.ev_in) (void)hipEventDestroy(w.ev_in);
-  if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+  for (Work::Ticket& t : w.tk) {
+    if (t.h_stage) (void)hipHostFree(t.h_stage);
+    if (t.h_info) (void)hipHostFree(t.h_info);
+    if (t.done) (void)hipEventDestroy(t.done);
+  }
 }
 
 // pinned result staging of the stage-level entry points, n frames
@@ -256,17 +293,19 @@ static int ensure_staging(fsdp_ctx* c, int n) {
   return 0;
 }
 
-// is p page-locked host memory the GPU can DMA to / from asynchronously (fsdp_host_alloc, hipHostRegister)?
-static bool is_pinned(const void* p) {
-  if (!p) return false;
+// p as the GPU addresses it if p is page-locked host memory (fsdp_host_alloc, fsdp_host_register: mapped into the device's
+// address space, reachable by kernels and by asynchronous copies), else NULL
+static void* device_view(const void* p) {
+  if (!p) return nullptr;
   hipPointerAttribute_t a;
   memset(&a, 0, sizeof(a));
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();  // (an unregistered pointer is an error in older runtimes: not ours to keep)
-    return false;
+    return nullptr;
   }
-  return a.type == hipMemoryTypeHost;
+  return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
 }
+static bool is_pinned(const void* p) { return device_view(p) != nullptr; }
 
 #ifdef FSDP_LDS_KNOBS
 // experiment builds only: extra dynamic LDS per workgroup (bytes) from the environment, to probe occupancy sensitivity
@@ -392,15 +431,21 @@ static void launch_path_retry(fsdp_ctx* c, Work& q, const Inputs& in) {
   hipLaunchKernelGGL(path_retry_kernel, dim3(rb), dim3(WAVE), 0, q.stream, in.d_poses, q.d_match, c->d_default_path, prev, c->d_gpath,
                      c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
 }
-static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid) {
+static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid, fsdp_frame_result* dst = nullptr, hipStream_t stream = nullptr,
+                            const SkidInfo* info_src = nullptr, SkidInfo* info_dst = nullptr) {
   (void)c;
   const long long words = (long long)n * RESULT_WORDS;
   long long blocks = (words + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
+  // results that go straight to host memory leave at the link's pace: a few hundred wavefronts keep it busy, more would
+  // only sit on the SIMDs' wavefront slots with their stores pending while the other slots' kernels wait for a place
+  static const int host_blocks = getenv("FSDP_ASM_BLOCKS") ? atoi(getenv("FSDP_ASM_BLOCKS")) : 128;
+  const long long cap = dst ? host_blocks : 16384;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   q.seq++;
-  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, q.stream, n, skid ? (const SortOut*)nullptr : q.d_sort,
-                     skid ? (const MatchOut*)nullptr : q.d_match, q.d_path, q.d_result, q.d_big, q.d_retry, q.d_trailer, q.seq);
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, stream ? stream : q.stream, n, skid ? (const SortOut*)nullptr : q.d_sort,
+                     skid ? (const MatchOut*)nullptr : q.d_match, q.d_path, dst ? dst : q.d_result, q.d_big, q.d_retry, q.d_trailer + (q.seq % N_TRAILERS), q.seq,
+                     (const int32_t*)info_src, (int32_t*)info_dst, info_dst ? (int)(sizeof(SkidInfo) / 4) * n : 0);
 }
 
 // sorting -> matching -> path stage -> result assembly of batch `in` on slot q
@@ -428,7 +473,7 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t = 
     names += "path_retry_kernel,";
   }
   mark(q, t, after_path);
-  launch_assemble(c, q, in.n_frames, false);
+  launch_assemble(c, q, in.n_frames, false, q.result_dst);
   names += "assemble_kernel";
   mark(q, t, MARK_LAST);
   c->stage_names = names;
@@ -441,11 +486,12 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t = 
   return 0;
 }
 
-static PassTrailer read_trailer(const Work& q) {
+static PassTrailer read_trailer(const Work& q, int seq) {
+  const PassTrailer* h = q.h_trailer + (seq % N_TRAILERS);
   PassTrailer tr;
-  tr.seq = __atomic_load_n(&q.h_trailer->seq, __ATOMIC_ACQUIRE);
-  tr.n_big = __atomic_load_n(&q.h_trailer->n_big, __ATOMIC_RELAXED);
-  tr.n_retry = __atomic_load_n(&q.h_trailer->n_retry, __ATOMIC_RELAXED);
+  tr.seq = __atomic_load_n(&h->seq, __ATOMIC_ACQUIRE);
+  tr.n_big = __atomic_load_n(&h->n_big, __ATOMIC_RELAXED);
+  tr.n_retry = __atomic_load_n(&h->n_retry, __ATOMIC_RELAXED);
   tr.pad = 0;
   return tr;
 }
@@ -460,7 +506,7 @@ static int verify_pass(fsdp_ctx* c, Work& q, bool* rerun = nullptr) {
     return 0;
   }
   q.unverified = false;
-  const PassTrailer tr = read_trailer(q);
+  const PassTrailer tr = read_trailer(q, q.seq);
   if (tr.seq != q.seq) {
     c->err = "internal: pass trailer out of date (slot " + std::to_string(q.index) + ")";
     return 2;
@@ -500,8 +546,7 @@ static int sync_all(fsdp_ctx* c) {
     Work& w = c->slot[i];
     if (!w.stream) continue;
     HIP_TRY(c, hipStreamSynchronize(w.stream));
-    if (w.ticket < 0)
-      if (int rc = verify_pass(c, w)) return rc;  // (a ticket's pass is settled by its fsdp_collect)
+    if (int rc = verify_pass(c, w)) return rc;  // (a ticket's pass is settled by its fsdp_collect: it never sets `unverified`)
   }
   return 0;
 }
@@ -588,6 +633,25 @@ static int upload_inputs(fsdp_ctx* c, Inputs& in, hipStream_t stream, int n_fram
   if (total) HIP_TRY(c, hipMemcpyAsync(in.d_cones, cones, sizeof(double) * 3 * total, hipMemcpyHostToDevice, stream));
   HIP_TRY(c, hipMemcpyAsync(in.d_poses, poses, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, stream));
   if (prev) HIP_TRY(c, hipMemcpyAsync(in.d_prev, prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n_frames, hipMemcpyHostToDevice, stream));
+  return 0;
+}
+
+// the same through stage_in_kernel: every source is page-locked host memory
+static int stage_inputs(fsdp_ctx* c, Inputs& in, hipStream_t stream, int n_frames, const int32_t* off, const double* cones, const double* poses,
+                        const double* prev, size_t total, int max_cones) {
+  if (int rc = ensure_inputs(c, in, n_frames > 0 ? n_frames : 1, total, prev != nullptr)) return rc;
+  in.n_frames = n_frames;
+  in.max_cones = max_cones;
+  in.use_prev = prev != nullptr;
+  if (n_frames == 0) return 0;
+  CopySegs S;
+  S.n = 0;
+  S.seg[S.n++] = CopySeg{device_view(off), in.d_off, sizeof(int32_t) * ((unsigned long long)n_frames + 1)};
+  if (total) S.seg[S.n++] = CopySeg{device_view(cones), in.d_cones, sizeof(double) * 3ull * total};
+  S.seg[S.n++] = CopySeg{device_view(poses), in.d_poses, sizeof(double) * 4ull * (unsigned long long)n_frames};
+  if (prev) S.seg[S.n++] = CopySeg{device_view(prev), in.d_prev, sizeof(double) * PATH_POINTS * 4ull * (unsigned long long)n_frames};
+  static const int stage_blocks = getenv("FSDP_STAGE_BLOCKS") ? atoi(getenv("FSDP_STAGE_BLOCKS")) : 256;
+  hipLaunchKernelGGL(stage_in_kernel, dim3(stage_blocks), dim3(256), 0, stream, S);
   return 0;
 }
 
@@ -897,10 +961,78 @@ int fsdp_set_global_path(fsdp_ctx* c, const double* xy, int n) {
 }
 
 // ---- streams of batches: submit / collect ------------------------------------------------------------------------------
-// One batch per ticket; up to `overlap depth` tickets in flight, each on its own slot: host -> device of the batch, the
-// kernels of its pass and device -> host of its results are enqueued on the slot's stream by fsdp_submit, which returns at
-// once (for page-locked buffers: fsdp_host_alloc / fsdp_host_register; pageable buffers work, but their copies are staged
-// and block the caller).
+// One batch per ticket.  Ticket t goes to slot t % depth and is queued on that slot's stream behind the slot's previous
+// ticket (up to SLOT_QUEUE per slot): host -> device of the batch, the kernels of its pass and device -> host of its results
+// are enqueued by fsdp_submit, which returns at once.  Page-locked buffers (fsdp_host_alloc / fsdp_host_register) are read
+// and written by kernels of the stream itself (stage_in_kernel, assemble_kernel); pageable ones work, but their copies are
+// staged by the runtime and block the caller.
+static Work::Ticket* find_ticket(fsdp_ctx* c, long long ticket, Work** slot) {
+  if (ticket < 0) return nullptr;
+  for (int i = 0; i < FSDP_MAX_OVERLAP; i++)
+    for (Work::Ticket& t : c->slot[i].tk)
+      if (t.id == ticket) {
+        if (slot) *slot = &c->slot[i];
+        return &t;
+      }
+  return nullptr;
+}
+
+// enqueue ticket t's batch on slot q: inputs, the pass, the results' way back, the ticket's event
+static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_routes) {
+  static const bool force_sdma = getenv("FSDP_STREAM_SDMA") != nullptr;  // experiments: copy engines also for page-locked buffers
+  const int n = t.n;
+  // a bigger batch than the slot has seen: its buffers are replaced — not under the feet of the passes queued on the stream
+  if (n > q.cap_frames || n > q.in.cap_frames || t.total > q.in.cap_cones || (t.prev && n > q.in.cap_prev)) HIP_TRY(c, hipStreamSynchronize(q.stream));
+  if (int rc = ensure_work(c, q, n > 0 ? n : 1)) return rc;
+  const bool in_pinned = !force_sdma && n > 0 && is_pinned(t.off) && is_pinned(t.poses) && (t.total == 0 || is_pinned(t.cones)) &&
+                         (!t.prev || is_pinned(t.prev));
+  const bool out_pinned = n > 0 && is_pinned(t.user_results);
+  {
+    TraceStep ts("submit: host -> device");
+    if (in_pinned) {
+      if (int rc = stage_inputs(c, q.in, q.stream, n, t.off, t.cones, t.poses, t.prev, t.total, t.max_cones)) return rc;
+    } else if (int rc = upload_inputs(c, q.in, q.stream, n, t.off, t.cones, t.poses, t.prev, t.total, t.max_cones)) {
+      return rc;
+    }
+  }
+  t.via_stage = false;
+  if (n > 0) {
+    q.result_dst = (out_pinned && !force_sdma) ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
+    int rc;
+    {
+      TraceStep ts("submit: kernel launches");
+      rc = launch_pass(c, q, q.in, nullptr, force_routes);
+    }
+    const bool direct = q.result_dst != nullptr;
+    q.result_dst = nullptr;
+    q.unverified = false;  // settled by fsdp_collect through the ticket
+    if (rc) return rc;
+    t.seq = q.seq;
+    t.ran_big = q.ran_big;
+    t.ran_retry = q.ran_retry;
+    if (!direct) {
+      TraceStep ts("submit: device -> host copy");
+      fsdp_frame_result* dst = t.user_results;
+      if (!out_pinned) {
+        if (n > t.cap_stage) {
+          if (t.h_stage) (void)hipHostFree(t.h_stage);
+          t.h_stage = nullptr;
+          t.cap_stage = 0;
+          HIP_TRY(c, hipHostMalloc((void**)&t.h_stage, sizeof(fsdp_frame_result) * (size_t)n, hipHostMallocDefault));
+          t.cap_stage = n;
+        }
+        dst = t.h_stage;
+        t.via_stage = true;
+      }
+      HIP_TRY(c, hipMemcpyAsync(dst, q.d_result, sizeof(fsdp_frame_result) * (size_t)n, hipMemcpyDeviceToHost, q.stream));
+    }
+    HIP_TRY(c, hipGetLastError());
+  }
+  if (!t.done) HIP_TRY(c, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(t.done, q.stream));
+  return 0;
+}
+
 int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses, const double* prev_paths,
                 fsdp_frame_result* results, long long* ticket) {
   if (!c || !ticket) return 1;
@@ -919,57 +1051,49 @@ int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
   if (int rc = check_batch(c, n_frames, off, cones, poses, &total, &max_cones)) return rc;
   const int si = (int)(c->next_ticket % c->overlap);
   Work& q = c->slot[si];
-  if (q.ticket >= 0) {
-    c->err = "fsdp_submit: all " + std::to_string(c->overlap) + " slots hold a ticket; collect ticket " + std::to_string(q.ticket) + " first";
+  Work::Ticket* t = nullptr;
+  long long oldest = -1;
+  for (Work::Ticket& e : q.tk) {
+    if (e.id < 0 && !t) t = &e;
+    if (e.id >= 0 && (oldest < 0 || e.id < oldest)) oldest = e.id;
+  }
+  if (!t) {
+    c->err = "fsdp_submit: " + std::to_string(c->outstanding) + " tickets outstanding (at most " + std::to_string(SLOT_QUEUE) + " per slot, " +
+             std::to_string(c->overlap) + " slots); collect ticket " + std::to_string(oldest) + " first";
     return 4;
   }
-  if (int rc = ensure_work(c, q, n_frames > 0 ? n_frames : 1)) return rc;
+  if (!q.stream) {
+    if (int rc = ensure_work(c, q, n_frames > 0 ? n_frames : 1)) return rc;
+  }
   if (q.unverified) {  // an fsdp_run pass nobody waited for
     HIP_TRY(c, hipStreamSynchronize(q.stream));
     if (int rc = verify_pass(c, q)) return rc;
   }
-  if (int rc = upload_inputs(c, q.in, q.stream, n_frames, off, cones, poses, prev_paths, total, max_cones)) return rc;
-  q.user_results = results;
-  q.user_info = nullptr;
-  q.via_stage = false;
-  if (n_frames > 0) {
-    if (int rc = launch_pass(c, q, q.in)) return rc;
-    fsdp_frame_result* dst = results;
-    if (!is_pinned(results)) {
-      if (n_frames > q.cap_stage) {
-        if (q.h_stage) (void)hipHostFree(q.h_stage);
-        q.h_stage = nullptr;
-        q.cap_stage = 0;
-        HIP_TRY(c, hipHostMalloc((void**)&q.h_stage, sizeof(fsdp_frame_result) * (size_t)n_frames, hipHostMallocDefault));
-        q.cap_stage = n_frames;
-      }
-      dst = q.h_stage;
-      q.via_stage = true;
-    }
-    HIP_TRY(c, hipMemcpyAsync(dst, q.d_result, sizeof(fsdp_frame_result) * (size_t)n_frames, hipMemcpyDeviceToHost, q.stream));
-    HIP_TRY(c, hipGetLastError());
-  }
-  q.ticket = c->next_ticket++;
+  t->n = n_frames;
+  t->skid = false;
+  t->off = off;
+  t->cones = cones;
+  t->poses = poses;
+  t->prev = prev_paths;
+  t->total = total;
+  t->max_cones = max_cones;
+  t->user_results = results;
+  t->user_info = nullptr;
+  if (int rc = enqueue_ticket(c, q, *t, false)) return rc;
+  t->id = c->next_ticket++;
   c->outstanding++;
   c->last_slot = si;
-  *ticket = q.ticket;
+  *ticket = t->id;
   return 0;
 }
 
-static Work* find_ticket(fsdp_ctx* c, long long ticket) {
-  if (ticket < 0) return nullptr;
-  for (int i = 0; i < FSDP_MAX_OVERLAP; i++)
-    if (c->slot[i].ticket == ticket) return &c->slot[i];
-  return nullptr;
-}
-
-// 1: the ticket's results are in the caller's buffer once fsdp_collect is called (it will not block); 0: still running; < 0: unknown ticket
+// 1: fsdp_collect will not block (unless the pass has to be repeated with a route kernel); 0: still running; < 0: unknown ticket
 int fsdp_ticket_done(fsdp_ctx* c, long long ticket) {
   if (!c) return -1;
-  Work* q = find_ticket(c, ticket);
-  if (!q) return -1;
+  Work::Ticket* t = find_ticket(c, ticket, nullptr);
+  if (!t) return -1;
   (void)hipSetDevice(c->device);
-  hipError_t e = hipStreamQuery(q->stream);
+  hipError_t e = hipEventQuery(t->done);
   if (e == hipSuccess) return 1;
   (void)hipGetLastError();
   return 0;
@@ -977,46 +1101,71 @@ int fsdp_ticket_done(fsdp_ctx* c, long long ticket) {
 
 int fsdp_collect(fsdp_ctx* c, long long ticket) {
   if (!c) return 1;
-  Work* qp = find_ticket(c, ticket);
-  if (!qp) {
+  Work* qp = nullptr;
+  Work::Ticket* tp = find_ticket(c, ticket, &qp);
+  if (!tp) {
     c->err = "fsdp_collect: unknown ticket " + std::to_string(ticket);
     return 1;
   }
   Work& q = *qp;
-  HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(q.stream));
-  const int n = q.pass_skid ? c->n_instances : q.in.n_frames;
+  Work::Ticket& t = *tp;
   int rc = 0;
-  if (n > 0 && !q.pass_skid) {
-    bool rerun = false;
-    rc = verify_pass(c, q, &rerun);
-    if (rc == 0 && rerun) {  // the pass needed a route kernel it had not been given: its results are final only now
-      hipError_t e = hipMemcpyAsync(q.via_stage ? q.h_stage : q.user_results, q.d_result, sizeof(fsdp_frame_result) * (size_t)n,
-                                    hipMemcpyDeviceToHost, q.stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(q.stream);
-      if (e != hipSuccess) {
-        c->err = std::string("fsdp_collect: ") + hipGetErrorString(e);
-        rc = 2;
+  hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = hipEventSynchronize(t.done);
+  if (e != hipSuccess) {
+    c->err = std::string("fsdp_collect: ") + hipGetErrorString(e);
+    rc = 2;
+  }
+  const int n = t.n;
+  if (rc == 0 && n > 0 && !t.skid) {
+    // did the pass get the route kernels it needed?  (its own trailer: later passes of the slot write other ones)
+    const PassTrailer tr = read_trailer(q, t.seq);
+    if (tr.seq != t.seq) {
+      c->err = "internal: trailer of ticket " + std::to_string(ticket) + " overwritten";
+      rc = 2;
+    } else {
+      auto track = [](bool needed, bool& expect, int& clean) {
+        if (needed) {
+          expect = true;
+          clean = 0;
+        } else if (expect && ++clean >= ROUTE_DECAY) {
+          expect = false;
+          clean = 0;
+        }
+      };
+      track(tr.n_big > 0, c->expect_big, c->clean_big);
+      track(tr.n_retry > 0, c->expect_retry, c->clean_retry);
+      if ((tr.n_big > 0 && !t.ran_big) || (tr.n_retry > 0 && !t.ran_retry)) {
+        // the whole ticket once more, with both route kernels, behind whatever the slot's stream holds by now (the
+        // caller's buffers are still his to leave alone: the batch is read again from them)
+        c->reruns++;
+        rc = enqueue_ticket(c, q, t, true);
+        if (rc == 0 && (e = hipEventSynchronize(t.done)) != hipSuccess) {
+          c->err = std::string("fsdp_collect: ") + hipGetErrorString(e);
+          rc = 2;
+        }
       }
     }
   }
   if (rc == 0 && n > 0) {
-    if (q.via_stage) memcpy(q.user_results, q.h_stage, sizeof(fsdp_frame_result) * (size_t)n);
-    if (q.user_info && q.h_info)
+    if (t.via_stage) memcpy(t.user_results, t.h_stage, sizeof(fsdp_frame_result) * (size_t)n);
+    if (t.user_info && t.h_info)
       for (int i = 0; i < n; i++) {
-        q.user_info[i].relocalized = q.h_info[i].relocalized;
-        q.user_info[i].index_along_path = q.h_info[i].index_along_path;
-        q.user_info[i].translation[0] = q.h_info[i].translation[0];
-        q.user_info[i].translation[1] = q.h_info[i].translation[1];
-        q.user_info[i].rotation = q.h_info[i].rotation;
+        t.user_info[i].relocalized = t.h_info[i].relocalized;
+        t.user_info[i].index_along_path = t.h_info[i].index_along_path;
+        t.user_info[i].translation[0] = t.h_info[i].translation[0];
+        t.user_info[i].translation[1] = t.h_info[i].translation[1];
+        t.user_info[i].rotation = t.h_info[i].rotation;
       }
   }
-  q.ticket = -1;
-  q.user_results = nullptr;
-  q.user_info = nullptr;
+  t.id = -1;
+  t.user_results = nullptr;
+  t.user_info = nullptr;
   c->outstanding--;
   return rc;
 }
+
+int fsdp_ticket_capacity(const fsdp_ctx* c) { return c ? c->overlap * (c->mission == 2 ? 1 : SLOT_QUEUE) : 0; }
 
 int fsdp_route_stats(fsdp_ctx* c, int* expect_big, int* expect_retry, long long* reruns) {
   if (!c) return 1;
@@ -1448,10 +1597,12 @@ static void launch_skid(fsdp_ctx* c, Work& q, const Inputs& in, bool reloc) {
                      c->d_skid_status, q.d_path, q.d_skid_info);
 }
 
-// One frame for every planner instance, asynchronously: the step's inputs go up on the slot's own stream while the
-// previous step's kernels run on the main stream, its kernels follow in step order on the main stream, and its results
-// come down on the slot's stream while the next step's kernels run.  (A replay knows its frames ahead of the planner; a
-// live car submits and collects one step at a time, which is what fsdp_skidpad_step does.)
+// One frame for every planner instance, asynchronously.  The planner states chain step to step, so all steps run on the
+// context's main stream in submit order; a step's transfers are kernels of that same stream when the caller's buffers are
+// page-locked (stage_in_kernel reads the inputs from host memory, assemble_kernel writes results and planner information
+// into it), so nothing ever waits for the host: a replay that knows its frames ahead submits ahead (up to `depth` steps,
+// each with its own input buffers on the device) and collects behind.  (A live car submits and collects one step at a
+// time, which is what fsdp_skidpad_step does.)
 int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const double* cones, const double* poses,
                         fsdp_frame_result* results, fsdp_skidpad_info* info, long long* ticket) {
   if (!c || !ticket) return 1;
@@ -1466,66 +1617,64 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
   if (int rc = check_batch(c, n_instances, off, cones, poses, &total, &max_cones)) return rc;
   const int si = (int)(c->next_ticket % c->overlap);
   Work& q = c->slot[si];
-  if (q.ticket >= 0) {
-    c->err = "fsdp_skidpad_submit: all " + std::to_string(c->overlap) + " slots hold a ticket; collect ticket " + std::to_string(q.ticket) + " first";
+  Work::Ticket& t = q.tk[0];  // one step per slot: the slots only hold the steps' buffers, every command goes to the main stream
+  if (t.id >= 0) {
+    c->err = "fsdp_skidpad_submit: all " + std::to_string(c->overlap) + " slots hold a ticket; collect ticket " + std::to_string(t.id) + " first";
     return 4;
   }
+  // (buffers that must grow are replaced: not under the feet of the steps queued on the main stream)
+  if (n_instances > q.cap_frames || n_instances > c->slot[0].cap_frames || n_instances > q.in.cap_frames || total > q.in.cap_cones)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (int rc = ensure_work(c, q, n_instances)) return rc;
   if (int rc = ensure_work(c, c->slot[0], n_instances)) return rc;  // the arena of the kernels
-  if (!q.ev_in) {
-    HIP_TRY(c, hipEventCreateWithFlags(&q.ev_in, hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
-  }
-  // (the slot's stream: its previous step's result copy is done — the ticket was collected)
-  hipStream_t xs = si == 0 ? c->stream : q.stream;
-  if (int rc = upload_inputs(c, q.in, xs, n_instances, off, cones, poses, nullptr, total, max_cones)) return rc;
-  if (si != 0) {
-    HIP_TRY(c, hipEventRecord(q.ev_in, xs));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, q.ev_in, 0));
+  hipStream_t xs = c->stream;
+  const bool in_pinned = is_pinned(off) && is_pinned(poses) && (total == 0 || is_pinned(cones));
+  if (in_pinned) {
+    if (int rc = stage_inputs(c, q.in, xs, n_instances, off, cones, poses, nullptr, total, max_cones)) return rc;
+  } else if (int rc = upload_inputs(c, q.in, xs, n_instances, off, cones, poses, nullptr, total, max_cones)) {
+    return rc;
   }
   launch_skid(c, q, q.in, true);
-  launch_assemble(c, q, n_instances, true);
-  HIP_TRY(c, hipGetLastError());
-  if (si != 0) {
-    HIP_TRY(c, hipEventRecord(q.ev_done, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(xs, q.ev_done, 0));
-  }
   q.pass_in = &q.in;
   q.pass_skid = true;
   q.unverified = false;
-  q.user_results = results;
-  q.user_info = info;
-  q.via_stage = false;
-  if (results) {
-    fsdp_frame_result* dst = results;
-    if (!is_pinned(results)) {
-      if (n_instances > q.cap_stage) {
-        if (q.h_stage) (void)hipHostFree(q.h_stage);
-        q.h_stage = nullptr;
-        q.cap_stage = 0;
-        HIP_TRY(c, hipHostMalloc((void**)&q.h_stage, sizeof(fsdp_frame_result) * (size_t)n_instances, hipHostMallocDefault));
-        q.cap_stage = n_instances;
-      }
-      dst = q.h_stage;
-      q.via_stage = true;
-    }
-    HIP_TRY(c, hipMemcpyAsync(dst, q.d_result, sizeof(fsdp_frame_result) * (size_t)n_instances, hipMemcpyDeviceToHost, xs));
+  t.n = n_instances;
+  t.skid = true;
+  t.user_results = results;
+  t.user_info = info;
+  t.via_stage = false;
+  if (info && n_instances > t.cap_info) {
+    if (t.h_info) (void)hipHostFree(t.h_info);
+    t.h_info = nullptr;
+    t.cap_info = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&t.h_info, sizeof(SkidInfo) * (size_t)n_instances, hipHostMallocDefault));
+    t.cap_info = n_instances;
   }
-  if (info) {
-    if (n_instances > q.cap_info) {
-      if (q.h_info) (void)hipHostFree(q.h_info);
-      q.h_info = nullptr;
-      q.cap_info = 0;
-      HIP_TRY(c, hipHostMalloc((void**)&q.h_info, sizeof(SkidInfo) * (size_t)n_instances, hipHostMallocDefault));
-      q.cap_info = n_instances;
+  // page-locked results: assemble_kernel writes them into the caller's buffer (over PCIe); the planners' information
+  // records ride along into the ticket's pinned block
+  fsdp_frame_result* direct = results ? (fsdp_frame_result*)device_view(results) : nullptr;
+  if (results || info)
+    launch_assemble(c, q, results ? n_instances : 0, true, direct, xs, info ? q.d_skid_info : nullptr,
+                    info ? (SkidInfo*)device_view(t.h_info) : nullptr);
+  HIP_TRY(c, hipGetLastError());
+  if (results && !direct) {
+    if (n_instances > t.cap_stage) {
+      if (t.h_stage) (void)hipHostFree(t.h_stage);
+      t.h_stage = nullptr;
+      t.cap_stage = 0;
+      HIP_TRY(c, hipHostMalloc((void**)&t.h_stage, sizeof(fsdp_frame_result) * (size_t)n_instances, hipHostMallocDefault));
+      t.cap_stage = n_instances;
     }
-    HIP_TRY(c, hipMemcpyAsync(q.h_info, q.d_skid_info, sizeof(SkidInfo) * (size_t)n_instances, hipMemcpyDeviceToHost, xs));
+    t.via_stage = true;
+    HIP_TRY(c, hipMemcpyAsync(t.h_stage, q.d_result, sizeof(fsdp_frame_result) * (size_t)n_instances, hipMemcpyDeviceToHost, xs));
   }
+  if (!t.done) HIP_TRY(c, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(t.done, xs));
   c->last_slot = si;
   c->last_n = n_instances;
-  q.ticket = c->next_ticket++;
+  t.id = c->next_ticket++;
   c->outstanding++;
-  *ticket = q.ticket;
+  *ticket = t.id;
   return 0;
 }
 

@@ -81,7 +81,7 @@ def replay_batched(mission, positions, directions, observations, device=None, re
     def one_replay():
         inflight = []
         for off, cones, poses, out in chunks:
-            if len(inflight) == depth:
+            if len(inflight) == ctx.ticket_capacity:
                 ctx.collect(inflight.pop(0))
             inflight.append(ctx.submit(off, cones, poses, out=out))
         for t in inflight:

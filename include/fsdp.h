@@ -160,12 +160,15 @@ int fsdp_set_global_path(fsdp_ctx* ctx, const double* xy, int n);
  *                  the slot's stream; returns at once with a ticket;
  *   fsdp_collect = waits for that ticket only; afterwards `results` (the pointer given to fsdp_submit) holds the batch's
  *                  results, exactly what fsdp_plan_batch[_sequential] returns for the same inputs.
- * Tickets count up from 0; ticket t occupies slot t % depth, so at most `depth` tickets are outstanding (fsdp_submit
- * returns 4 when the slot it needs still holds an uncollected ticket) and they may be collected in any order.  The
+ * Tickets count up from 0; ticket t is queued on slot t % depth behind that slot's previous ticket, two tickets per slot
+ * (so a slot's next batch is already waiting on its stream when the current one ends, and the caller's collect / submit
+ * round trip costs the GPU nothing): at most fsdp_ticket_capacity = 2 x depth tickets are outstanding (fsdp_submit returns
+ * 4 when the slot it needs is full: collect ticket t - 2 x depth first); they may be collected in any order.  The
  * caller's buffers must stay valid and untouched from submit to collect.  For the transfers to be asynchronous they must
- * be page-locked: allocate them with fsdp_host_alloc or pin existing memory with fsdp_host_register; pageable buffers
- * are accepted (inputs are then copied before fsdp_submit returns, results pass through a pinned block of the slot and a
- * memcpy in fsdp_collect).  prev_paths: (n_frames,40,4) as for fsdp_plan_batch_sequential, or NULL.
+ * be page-locked: allocate them with fsdp_host_alloc or pin existing memory with fsdp_host_register — the batch then
+ * crosses PCIe inside kernels of the slot's own stream (one reads the inputs from host memory, the last one of the pass
+ * writes the results into it; no copy-engine command at all); pageable buffers are accepted (inputs are then copied
+ * before fsdp_submit returns, results pass through a pinned block and a memcpy in fsdp_collect).  prev_paths: (n_frames,40,4) as for fsdp_plan_batch_sequential, or NULL.
  * While tickets are outstanding the blocking / resident entry points of the context return an error. */
 void* fsdp_host_alloc(size_t bytes);            /* page-locked host memory (hipHostMalloc), NULL on failure */
 void fsdp_host_free(void* p);
@@ -175,6 +178,7 @@ int fsdp_submit(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const 
                 const double* prev_paths, fsdp_frame_result* results, long long* ticket);
 int fsdp_collect(fsdp_ctx* ctx, long long ticket);
 int fsdp_ticket_done(fsdp_ctx* ctx, long long ticket); /* 1: fsdp_collect will not block; 0: still running; -1: unknown ticket */
+int fsdp_ticket_capacity(const fsdp_ctx* ctx);         /* tickets that may be outstanding at the current depth */
 
 /* The resident form: one batch stays in HBM and is planned again and again (the benchmark's step; a caller that plans the
  * same frames under several global paths / previous paths). */

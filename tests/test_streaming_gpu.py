@@ -50,8 +50,9 @@ def test_different_batches_in_flight_equal_serial_calls(pkg, golden_dir, depth, 
         batches = [(pkg.pinned_copy(o, np.int32), pkg.pinned_copy(c, np.float64), pkg.pinned_copy(p, np.float64)) for o, c, p in batches]
     got = [None] * len(batches)
     inflight = []
+    assert ctx.ticket_capacity == 2 * depth  # two tickets queue on every slot's stream
     for k, b in enumerate(batches):
-        if len(inflight) == depth:
+        if len(inflight) == ctx.ticket_capacity:
             j, t = inflight.pop(0)
             got[j] = ctx.collect(t)
         out = None if pinned else np.zeros(len(b[0]) - 1, pkg.RESULT_DTYPE)
@@ -92,11 +93,11 @@ def test_submit_with_previous_paths_and_slot_accounting(pkg):
     first = ctx.plan_batch(off, cones, poses)
     prev = first["path"] + rng.normal(0, 1e-3, first["path"].shape) * (np.arange(4) > 0)
     ref = ctx.plan_batch_sequential(off2, np.zeros((0, 3)), poses, prev)
-    ctx.set_overlap(2)
+    ctx.set_overlap(1)
     t0 = ctx.submit(off2, np.zeros((0, 3)), poses, prev_paths=prev)
     t1 = ctx.submit(off, cones, poses)
     with pytest.raises(pkg.FsdpError, match="collect ticket 0 first"):
-        ctx.submit(off, cones, poses)  # both slots hold a ticket
+        ctx.submit(off, cones, poses)  # the slot's queue holds two tickets
     with pytest.raises(pkg.FsdpError, match="not collected"):
         ctx.plan_batch(off, cones, poses)  # blocking calls wait for nobody's tickets
     assert _same(ctx.collect(t1), first)
