@@ -218,6 +218,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic track (config 2; rank r replays seed + r)")
     ap.add_argument("--stream-batches", type=int, default=40, help="different batches of the host -> host streaming leg (0: skip)")
     args = ap.parse_args()
+    if os.environ.get("FSDP_HANG_DUMP"):  # diagnostics: Python stacks of all threads after N seconds, then exit
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["FSDP_HANG_DUMP"]), exit=True)
 
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
     n_dev = pkg._capi.load().fsdp_device_count()
@@ -387,9 +391,24 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(off, cones, poses)
                 out["p50_single_frame_vs_cpu_1thread"] = out["p50_single_frame_us"] / out["cpu_baseline"]["single_thread_us_per_frame"]
-        print(json.dumps(out))
-    d.barrier()
-    d.close()
+        print(json.dumps(out), flush=True)
+    # The line is out.  Tear-down (last barrier, ncclCommDestroy, hipHostFree of ~1 GB of page-locked buffers, the HIP
+    # runtime's own exit handlers) has nothing left to report, and a benchmark process that hangs on its way out after a
+    # successful run would cost the caller its whole time limit (seen once on the GPU box, not reproducible): give it 30 s,
+    # then leave without it.
+    import threading
+
+    sys.stdout.flush()
+    sys.stderr.flush()
+    killer = threading.Timer(30.0, lambda: os._exit(0))
+    killer.daemon = True
+    killer.start()
+    try:
+        d.barrier()
+        d.close()
+    finally:
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
