@@ -76,6 +76,27 @@ static void fill_match(const Pts& lv, const Pts& rv, const std::vector<int>& l2r
 
 extern "C" {
 
+// decision margins of the sorting stage (oracle_internal.h MarginRec): enable / reset, read (9 classes x 6 values:
+// min non-zero margin, decisions, below 1e-6, below 1e-9, below 1e-12, exactly zero)
+void fsdo_margins_enable(int on) {
+  g_margins = MarginRec();
+  g_margins.on = on != 0;
+  for (int i = 0; i < MG_CLASSES; i++) {
+    g_margins.min_margin[i] = 1e300;
+    g_margins.n[i] = g_margins.below_1e6[i] = g_margins.below_1e9[i] = g_margins.below_1e12[i] = g_margins.zero[i] = 0;
+  }
+}
+void fsdo_margins_get(double* out54) {
+  for (int i = 0; i < MG_CLASSES; i++) {
+    out54[6 * i + 0] = g_margins.min_margin[i];
+    out54[6 * i + 1] = (double)g_margins.n[i];
+    out54[6 * i + 2] = (double)g_margins.below_1e6[i];
+    out54[6 * i + 3] = (double)g_margins.below_1e9[i];
+    out54[6 * i + 4] = (double)g_margins.below_1e12[i];
+    out54[6 * i + 5] = (double)g_margins.zero[i];
+  }
+}
+
 void fsdo_sort_frame(const double* xyt, int n, const double* pose, fsdo_frame_result* o) {
   clear_result(o);
   try {

@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE (oracle) — internal declarations shared by the oracle's translation units.
 #pragma once
+#include <cmath>
 #include <vector>
 
 #include "fsd_oracle.h"
@@ -42,6 +43,43 @@ struct SideResult {
 };
 
 typedef std::vector<Vec2> Pts;
+
+// Decision margins of the sorting stage (diagnostics, tools/sort_margins.py): every discrete decision that hangs on a libm
+// value — atan2 / acos compared with a threshold, or the arg-min over configuration costs that hold such values — records
+// how far the value was from the threshold / the runner-up.  Off unless fsdo_margins_enable(1); single-threaded use.
+enum MarginClass {
+  MG_START_BEARING = 0,   // core_trace_sorter.py:379-407: bearing sign, pi/10, pi - pi/5
+  MG_SECOND_SIDE = 1,     // end_configurations.py:260-278: sign of the bearing difference, 5 deg
+  MG_ABS_ANGLE = 2,       // :172-205 |difference| vs threshold_absolute_angle
+  MG_DIR_ANGLE = 3,       // :172-205 difference vs +-threshold_directional_angle
+  MG_SIGN_FLIP = 4,       // :196-205 sign(difference) vs sign(difference_2), |difference - difference_2| vs 1.3
+  MG_ACOS_THRESHOLDS = 5, // vec_angle_between vs 150 deg / 90 deg / search_angle / 2 / 40 deg (in the cosine: |cos - cos thr|)
+  MG_WRONG_DIRECTION = 6, // cost_function.py:149-188 sign and 40 deg of the turn angles
+  MG_COST_ARGMIN = 7,     // relative gap between the best and the second-best configuration cost
+  MG_COMBINE = 8,         // combine_traces.py:150-257 angle signs / 5 deg
+  MG_CLASSES = 9
+};
+struct MarginRec {
+  bool on = false;
+  double min_margin[MG_CLASSES];
+  long long n[MG_CLASSES], below_1e6[MG_CLASSES], below_1e9[MG_CLASSES], below_1e12[MG_CLASSES], zero[MG_CLASSES];
+};
+extern MarginRec g_margins;
+static inline void margin(int cls, double value, double thr) {
+  if (!g_margins.on) return;
+  const double m = std::fabs(value - thr);
+  if (!(m == m)) return;
+  MarginRec& r = g_margins;
+  r.n[cls]++;
+  if (m == 0.0) {  // value == threshold exactly: equal operands (straight / lattice tracks), the same bits under any libm
+    r.zero[cls]++;
+    return;
+  }
+  if (m < r.min_margin[cls]) r.min_margin[cls] = m;
+  if (m < 1e-6) r.below_1e6[cls]++;
+  if (m < 1e-9) r.below_1e9[cls]++;
+  if (m < 1e-12) r.below_1e12[cls]++;
+}
 
 // sorting.cpp
 SideResult configs_for_one_side(const Frame& f, int cone_type);

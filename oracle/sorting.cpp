@@ -11,6 +11,9 @@
 
 namespace fsdo {
 
+MarginRec g_margins;
+
+
 static const int T_UNKNOWN = 0, T_RIGHT = 1, T_LEFT = 2;
 
 static inline int invert_cone_type(int t) {  // utils/cone_types.py:22-34
@@ -49,6 +52,11 @@ static void mask_first(const Frame& f, int cone_type, std::vector<double>& dist,
     bool side = (sgn == want);
     bool a_max = std::fabs(ang) < PI - PI / 5;
     bool a_min = std::fabs(ang) > PI / 10;
+    if (in_ell && f.type[i] == T_UNKNOWN) {  // (only there does the bearing decide anything)
+      margin(MG_START_BEARING, ang, 0.0);
+      margin(MG_START_BEARING, std::fabs(ang), PI - PI / 5);
+      margin(MG_START_BEARING, std::fabs(ang), PI / 10);
+    }
     bool right_color = (f.type[i] == cone_type);
     bool mask_side = (side && a_max && a_min) || right_color;
     bool not_opp = (f.type[i] != invert_cone_type(cone_type));
@@ -236,6 +244,10 @@ static void neighbor_mask(const Frame& f, int cone_type, const std::vector<int>&
       double diff = angle_difference(a_n, a_car);
       double want = (cone_type == T_LEFT) ? 1.0 : -1.0;
       bool ok = (np_sign(diff) == want) || (std::fabs(diff) < deg2rad(5));
+      if (can[i]) {
+        margin(MG_SECOND_SIDE, diff, 0.0);
+        margin(MG_SECOND_SIDE, std::fabs(diff), deg2rad(5));
+      }
       can[i] = can[i] && ok;
     }
   }
@@ -249,6 +261,7 @@ static void neighbor_mask(const Frame& f, int cone_type, const std::vector<int>&
       double lx = f.x[last] - f.x[nb], ly = f.y[last] - f.y[nb];
       double cx = f.x[cand] - f.x[nb], cy = f.y[cand] - f.y[nb];
       double dc = norm2(cx, cy), dl = norm2(lx, ly);
+      if (dc < 6.0 && dl < 6.0) margin(MG_ACOS_THRESHOLDS, std::cos(vec_angle_between(lx, ly, cx, cy)), std::cos(deg2rad(150)));
       if (dc < 6.0 && dl < 6.0 && vec_angle_between(lx, ly, cx, cy) > deg2rad(150)) {
         can[i] = 0;
         break;
@@ -263,6 +276,8 @@ static void neighbor_mask(const Frame& f, int cone_type, const std::vector<int>&
       double angle_2 = std::atan2(l2cy, l2cx);
       double difference = angle_difference(angle_2, angle_1);
       double len = norm2(l2cx, l2cy);
+      margin(MG_ABS_ANGLE, std::fabs(difference), thr_abs);
+      if (!(std::fabs(difference) > thr_abs) && !(len < 4.0)) margin(MG_DIR_ANGLE, difference, cone_type == T_LEFT ? thr_dir : -thr_dir);
       if (std::fabs(difference) > thr_abs)
         can[i] = 0;
       else if (cone_type == T_LEFT)
@@ -274,12 +289,18 @@ static void neighbor_mask(const Frame& f, int cone_type, const std::vector<int>&
         double t2sx = f.x[sl] - f.x[tl], t2sy = f.y[sl] - f.y[tl];
         double angle_3 = std::atan2(t2sy, t2sx);
         double difference_2 = angle_difference(angle_1, angle_3);
+        if (can[i]) {
+          margin(MG_SIGN_FLIP, difference, 0.0);
+          margin(MG_SIGN_FLIP, difference_2, 0.0);
+          if (np_sign(difference) != np_sign(difference_2)) margin(MG_SIGN_FLIP, std::fabs(difference - difference_2), 1.3);
+        }
         if (np_sign(difference) != np_sign(difference_2) && std::fabs(difference - difference_2) > 1.3) can[i] = 0;
       }
     }
     if (can[i] && pos == 1) {
       int st = attempt[0];
       double off = vec_angle_between(f.dx, f.dy, cpx - f.x[st], cpy - f.y[st]);
+      margin(MG_ACOS_THRESHOLDS, std::cos(off), 0.0);
       can[i] = can[i] && (off < PI / 2);
     }
     if (can[i] && pos >= 0) {
@@ -483,6 +504,8 @@ static void cones_on_each_side(const Frame& f, const std::vector<Config>& config
         double vx = f.x[idx] - f.x[cj], vy = f.y[idx] - f.y[cj];
         bool g = vec_angle_between(vx, vy, dir.x, dir.y) < search_angle / 2;
         bool bd = vec_angle_between(vx, vy, -dir.x, -dir.y) < search_angle / 2;
+        margin(MG_ACOS_THRESHOLDS, std::cos(vec_angle_between(vx, vy, dir.x, dir.y)), std::cos(search_angle / 2));
+        margin(MG_ACOS_THRESHOLDS, std::cos(vec_angle_between(vx, vy, -dir.x, -dir.y)), std::cos(search_angle / 2));
         good[ci] += g;
         bad[ci] += bd;
       }
@@ -583,6 +606,8 @@ static std::vector<double> cost_configurations(const Frame& f, const std::vector
       std::vector<double> sel;
       for (int l = 0; l + 1 < len - 1; l++) {
         double diff = angle_difference(ang[l], ang[l + 1]);
+        margin(MG_WRONG_DIRECTION, diff, 0.0);
+        if (np_sign(diff) == unwanted) margin(MG_WRONG_DIRECTION, std::fabs(diff), deg2rad(40));
         if (np_sign(diff) == unwanted && std::fabs(diff) > deg2rad(40)) sel.push_back(diff);
       }
       wrong_cost = std::fabs(np_sum(sel));
@@ -614,6 +639,10 @@ SideResult configs_for_one_side(const Frame& f, int cone_type) {
   if (configs.empty()) return res;  // NoPathError
   std::vector<double> costs = cost_configurations(f, configs, cone_type);
   std::vector<int> order = argsort(costs);
+  if (order.size() > 1) {
+    const double c0 = costs[order[0]], c1 = costs[order[1]];
+    margin(MG_COST_ARGMIN, (c1 - c0) / std::fmax(std::fabs(c0), 1e-300), 0.0);  // relative gap to the runner-up
+  }
   for (int i : order) {
     res.configs.push_back(configs[i]);
     res.costs.push_back(costs[i]);
@@ -627,6 +656,7 @@ static double angle_change_at(const Frame& f, const std::vector<int>& cfg, int p
   int p = cfg[pos - 1], c = cfg[pos], nx = cfg[pos + 1];
   double a_next = std::atan2(f.y[nx] - f.y[c], f.x[nx] - f.x[c]);
   double a_prev = std::atan2(f.y[p] - f.y[c], f.x[p] - f.x[c]);
+  margin(MG_COMBINE, angle_difference(a_next, a_prev), 0.0);
   return angle_difference(a_next, a_prev);
 }
 
