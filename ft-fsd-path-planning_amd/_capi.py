@@ -210,6 +210,21 @@ class Context:
             raise FsdpError(f"fsdp_create failed ({rc}): {lib.fsdp_last_error(None).decode()}")
         self._lib, self._h, self.device, self.n_frames = lib, h, device, 0
 
+    @property
+    def horizon(self) -> int:
+        """mpc_prediction_horizon of this context: rows of a path (the result struct holds 40, the rest NaN)."""
+        return int(self.params.mpc_prediction_horizon)
+
+    def pad_paths(self, paths) -> np.ndarray:
+        """(n, horizon, 4) previous paths as the reference keeps them -> the (n, 40, 4) block the C ABI reads."""
+        p = np.asarray(paths, dtype=np.float64)
+        p = p.reshape(-1, p.shape[-2], 4)
+        if p.shape[1] == PATH_POINTS:
+            return np.ascontiguousarray(p)
+        out = np.full((len(p), PATH_POINTS, 4), np.nan)
+        out[:, : p.shape[1]] = p
+        return out
+
     def _check(self, rc, what):
         if rc != 0:
             raise FsdpError(f"{what} failed ({rc}): {self._lib.fsdp_last_error(self._h).decode()}")
@@ -247,7 +262,8 @@ class Context:
     def plan_batch_sequential(self, offsets, cones, poses, prev_paths) -> np.ndarray:
         """plan_batch with a per-frame previous path (n_frames,40,4): the stateful fallbacks of the reference."""
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
-        prev = np.ascontiguousarray(prev_paths, dtype=np.float64).reshape(n, PATH_POINTS, 4)
+        prev = self.pad_paths(prev_paths)
+        assert len(prev) == n
         out = np.zeros(n, dtype=RESULT_DTYPE)
         self._check(self._lib.fsdp_plan_batch_sequential(self._h, n, _ip(offsets), _dp(cones), _dp(poses), _dp(prev), ctypes.c_void_p(out.ctypes.data)), "fsdp_plan_batch_sequential")
         self.n_frames = n
@@ -275,7 +291,7 @@ class Context:
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 4)
         results = np.ascontiguousarray(results)
         assert results.dtype == RESULT_DTYPE and len(results) == len(poses)
-        prev = None if prev_paths is None else _dp(np.ascontiguousarray(prev_paths, np.float64).reshape(len(poses), PATH_POINTS, 4))
+        prev = None if prev_paths is None else _dp(self.pad_paths(prev_paths))
         self._check(self._lib.fsdp_path_batch(self._h, len(poses), _dp(poses), prev, ctypes.c_void_p(results.ctypes.data)), "fsdp_path_batch")
         return results
 
@@ -285,7 +301,7 @@ class Context:
         ``pinned_empty`` / ``pinned_copy`` are transferred asynchronously; others are accepted but staged.  ``out``: the
         RESULT_DTYPE array the results go to (default: a new pinned array).  Raises when every slot holds a ticket."""
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
-        prev = None if prev_paths is None else np.ascontiguousarray(prev_paths, dtype=np.float64).reshape(n, PATH_POINTS, 4)
+        prev = None if prev_paths is None else self.pad_paths(prev_paths)
         if out is None:
             out = pinned_empty(n, RESULT_DTYPE)
         assert out.dtype == RESULT_DTYPE and len(out) == n and out.flags.c_contiguous

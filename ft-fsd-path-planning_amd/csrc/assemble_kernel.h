@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
                                                         const PathOut* __restrict__ paths, fsdp_frame_result* __restrict__ results,
                                                         int* __restrict__ big, int* __restrict__ retry, PassTrailer* __restrict__ trailer,
                                                         int seq, const int32_t* __restrict__ extra_src = nullptr, int32_t* __restrict__ extra_dst = nullptr,
-                                                        int extra_words = 0) {
+                                                        int extra_words = 0, const int32_t* __restrict__ remap = nullptr,
+                                                        const int32_t* __restrict__ remap_off = nullptr) {
   const long long total = (long long)n_frames * RESULT_WORDS;
   const int32_t* s32 = (const int32_t*)sorted;
   const int32_t* m32 = (const int32_t*)matched;
@@ -72,6 +73,8 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
         v = s[FSDP_SW(n_left) + (w - FSDP_RW(n_left))];
       else
         v = (w >= FSDP_RW(left_idx)) ? -1 : 0;
+      // (use_unknown_cones = False, filter_kernel.h: the sorter saw a compacted frame; indices go out in the caller's index space)
+      if (remap && w >= FSDP_RW(left_idx) && v >= 0) v = remap[remap_off[f] + v];
     } else if (w == FSDP_RW(n_left_v)) {
       v = m ? m[FSDP_MW(n_left_v)] : 0;
     } else if (w == FSDP_RW(n_right_v)) {
@@ -80,6 +83,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
       v = 0;  // alignment padding
     } else if (w < FSDP_RW(best_cost_left)) {  // n_configs_left/right, first_k_left/right: contiguous in both structs
       v = s ? s[FSDP_SW(n_configs_left) + (w - FSDP_RW(n_configs_left))] : 0;
+      if (remap && w >= FSDP_RW(first_k_left) && v >= 0) v = remap[remap_off[f] + v];
     } else if (w < FSDP_RW(path_fallback)) {
       v = s ? s[FSDP_SW(best_cost_left) + (w - FSDP_RW(best_cost_left))] : 0;
     } else if (w == FSDP_RW(path_fallback)) {

@@ -45,8 +45,7 @@ constexpr int ST_RETRY = 299;  // internal: the fast kernels hand the frame to t
 
 // The reference's configuration constants (fsd_path_planning/config.py:33-41,48,55-59,124-129), one device copy per
 // context (fsdp_create): the kernels read them with scalar loads.  Structural ones are bounded by the compiled capacities
-// (max_n_neighbors <= KNN, max_length <= MAX_LEN); mpc_prediction_horizon = 40, max_deg = 3, use_unknown_cones = True and
-// matches_should_be_monotonic = False (the pipeline's choice, full_pipeline.py:65) are fixed.
+// (max_n_neighbors <= KNN, max_length <= MAX_LEN, mpc_prediction_horizon <= PATH_POINTS).
 struct Params {
   // sorting_cones (config.py:33-41)
   int32_t max_n_neighbors, max_length;
@@ -55,6 +54,11 @@ struct Params {
   double min_track_width, max_search_range, max_search_angle;
   // calculate_path (config.py:48,55-59)
   double smoothing, predict_every, maximal_distance_for_valid_path, mpc_path_length;
+  // the ones that select a branch rather than a threshold
+  int32_t max_deg;                      // config.py:48: degree of fits #1 / #2 is clip(points - 1, 1, max_deg) (utils/spline_fit.py:113)
+  int32_t horizon;                      // config.py:58 mpc_prediction_horizon: rows of a path (<= PATH_POINTS, the stride of every path array)
+  int32_t matches_should_be_monotonic;  // config.py:124-146, functional_cone_matching.py:164-171
+  int32_t use_unknown_cones;            // config.py:40, core_cone_sorting.py:114 (0: cones of type UNKNOWN are dropped before sorting)
 };
 
 #define FSDP_PI 3.14159265358979323846

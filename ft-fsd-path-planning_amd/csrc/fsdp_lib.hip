@@ -23,6 +23,7 @@
 #include "path_kernel.h"
 #include "skidpad_kernel.h"
 #include "assemble_kernel.h"
+#include "filter_kernel.h"
 #include "fsdp_comm.h"
 
 using namespace fsdp;
@@ -84,6 +85,13 @@ struct Work {
   SkidInfo* d_skid_info = nullptr;        // skidpad contexts
   SortSharedBig* d_sort_big = nullptr;    // frame states of sort_big_kernel, allocated when the route is first needed
   int cap_frames = 0;
+  // use_unknown_cones = False (filter_kernel.h): the batch without its UNKNOWN cones, and the way back for the indices
+  int32_t* f_cnt = nullptr;
+  int32_t* f_off = nullptr;
+  double* f_cones = nullptr;
+  int32_t* f_map = nullptr;
+  int f_cap_frames = 0;
+  size_t f_cap_cones = 0;
   PassTrailer* h_trailer = nullptr;  // N_TRAILERS of them: pinned, host-coherent, written by assemble_kernel (pass seq -> seq % N_TRAILERS)
   PassTrailer* d_trailer = nullptr;  // their device address
   int seq = 0;                       // passes launched on this slot
@@ -267,6 +275,10 @@ static void free_work(Work& w) {
   (void)hipFree(w.d_result);
   (void)hipFree(w.d_skid_info);
   (void)hipFree(w.d_sort_big);
+  (void)hipFree(w.f_cnt);
+  (void)hipFree(w.f_off);
+  (void)hipFree(w.f_cones);
+  (void)hipFree(w.f_map);
   if (w.h_trailer) (void)hipHostFree(w.h_trailer);
   for (Work::Ticket& t : w.tk) {
     if (t.h_stage) (void)hipHostFree(t.h_stage);
@@ -394,7 +406,8 @@ constexpr int PACK_FRAMES = 12288;
 static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, std::string& names) {
   const double* prev = in.use_prev ? in.d_prev : nullptr;
   const int n = in.n_frames;
-  const bool split = c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH;
+  // (the packed kernels hold degree-3 fits only: a context with max_deg < 3 plans every batch with the one-kernel stage)
+  const bool split = c->params.max_deg != 3 ? false : (c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH);
   if (!split) {
     mark(q, t, MARK_MAIN);
     hipLaunchKernelGGL(path_kernel<PATH_G_SMALL>, dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
@@ -432,7 +445,8 @@ static void launch_path_retry(fsdp_ctx* c, Work& q, const Inputs& in) {
                      c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
 }
 static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid, fsdp_frame_result* dst = nullptr, hipStream_t stream = nullptr,
-                            const SkidInfo* info_src = nullptr, SkidInfo* info_dst = nullptr) {
+                            const SkidInfo* info_src = nullptr, SkidInfo* info_dst = nullptr, const int32_t* remap = nullptr,
+                            const int32_t* remap_off = nullptr) {
   (void)c;
   const long long words = (long long)n * RESULT_WORDS;
   long long blocks = (words + 255) / 256;
@@ -445,14 +459,44 @@ static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid, fsdp_frame_r
   q.seq++;
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, stream ? stream : q.stream, n, skid ? (const SortOut*)nullptr : q.d_sort,
                      skid ? (const MatchOut*)nullptr : q.d_match, q.d_path, dst ? dst : q.d_result, q.d_big, q.d_retry, q.d_trailer + (q.seq % N_TRAILERS), q.seq,
-                     (const int32_t*)info_src, (int32_t*)info_dst, info_dst ? (int)(sizeof(SkidInfo) / 4) * n : 0);
+                     (const int32_t*)info_src, (int32_t*)info_dst, info_dst ? (int)(sizeof(SkidInfo) / 4) * n : 0, remap, remap_off);
+}
+
+// use_unknown_cones = False: the batch without its UNKNOWN cones into the slot's filter buffers; returns the view the
+// stage kernels plan (same poses / previous paths)
+static int launch_filter(fsdp_ctx* c, Work& q, const Inputs& in, Inputs* view) {
+  if (in.cap_frames > q.f_cap_frames || !q.f_off) {
+    HIP_TRY(c, hipStreamSynchronize(q.stream));
+    HIP_TRY(c, regrow(q.f_cnt, (size_t)in.cap_frames));
+    HIP_TRY(c, regrow(q.f_off, (size_t)in.cap_frames + 1));
+    q.f_cap_frames = in.cap_frames;
+  }
+  if (in.cap_cones > q.f_cap_cones || !q.f_cones) {
+    HIP_TRY(c, hipStreamSynchronize(q.stream));
+    HIP_TRY(c, regrow(q.f_cones, 3 * in.cap_cones));
+    HIP_TRY(c, regrow(q.f_map, in.cap_cones));
+    q.f_cap_cones = in.cap_cones;
+  }
+  const int n = in.n_frames;
+  hipLaunchKernelGGL(filter_count_kernel, dim3(n), dim3(WAVE), 0, q.stream, n, in.d_off, in.d_cones, q.f_cnt);
+  hipLaunchKernelGGL(filter_scan_kernel, dim3(1), dim3(1024), 0, q.stream, n, q.f_cnt, q.f_off);
+  hipLaunchKernelGGL(filter_scatter_kernel, dim3(n), dim3(WAVE), 0, q.stream, n, in.d_off, in.d_cones, q.f_off, q.f_cones, q.f_map);
+  *view = in;
+  view->d_off = q.f_off;
+  view->d_cones = q.f_cones;
+  return 0;
 }
 
 // sorting -> matching -> path stage -> result assembly of batch `in` on slot q
-static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t = nullptr, bool force_routes = false) {
+static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t = nullptr, bool force_routes = false) {
   c->primed[q.index] = true;
   const bool with_big = force_routes || c->always_route || c->expect_big;
   const bool with_retry = force_routes || c->always_route || c->expect_retry;
+  Inputs fin;
+  const bool filtered = !c->params.use_unknown_cones;
+  if (filtered)
+    if (int rc = launch_filter(c, q, in_, &fin)) return rc;
+  const Inputs& in = filtered ? fin : in_;
   std::string names = std::string(sort128(c, in) ? "sort_kernel_128" : "sort_kernel") + ",";
   mark(q, t);
   launch_sort(c, q, in);
@@ -473,11 +517,11 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t = 
     names += "path_retry_kernel,";
   }
   mark(q, t, after_path);
-  launch_assemble(c, q, in.n_frames, false, q.result_dst);
+  launch_assemble(c, q, in.n_frames, false, q.result_dst, nullptr, nullptr, nullptr, filtered ? q.f_map : nullptr, filtered ? q.f_off : nullptr);
   names += "assemble_kernel";
   mark(q, t, MARK_LAST);
   c->stage_names = names;
-  q.pass_in = &in;
+  q.pass_in = &in_;
   q.ran_big = with_big;
   q.ran_retry = with_retry;
   q.unverified = true;
@@ -698,10 +742,9 @@ static const char* check_params(const fsdp_params& p) {
   if (!(p.smoothing > 0) || !(p.predict_every > 0)) return "smoothing / predict_every must be positive";
   if (!(p.mpc_path_length > 0) || !(p.maximal_distance_for_valid_path >= 0)) return "mpc_path_length must be positive";
   if (!(p.min_track_width > 0) || !(p.max_search_range > 0)) return "min_track_width / max_search_range must be positive";
-  if (p.max_deg != 3) return "max_deg is fixed at 3";
-  if (p.mpc_prediction_horizon != FSDP_PATH_POINTS) return "mpc_prediction_horizon is fixed at 40 (the shape of the result)";
-  if (!p.use_unknown_cones) return "use_unknown_cones = False is not supported";
-  if (p.matches_should_be_monotonic) return "matches_should_be_monotonic = True is not supported (the pipeline uses False, full_pipeline.py:65)";
+  if (p.max_deg < 1 || p.max_deg > 3) return "max_deg must be in 1..3";
+  if (p.mpc_prediction_horizon < 1 || p.mpc_prediction_horizon > FSDP_PATH_POINTS)
+    return "mpc_prediction_horizon must be in 1..40 (a path of the result holds 40 rows)";
   // the dense path update (fit #1 evaluated every predict_every over <= ~80 m) must fit the working polyline
   if (p.predict_every < 0.05) return "predict_every below 0.05 exceeds the working polyline capacity";
   // the refit is evaluated every predict_every up to 1.5 * mpc_path_length (core_calculate_path.py:248-251) into the same
@@ -757,6 +800,10 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   c->params.predict_every = pp.predict_every;
   c->params.maximal_distance_for_valid_path = pp.maximal_distance_for_valid_path;
   c->params.mpc_path_length = pp.mpc_path_length;
+  c->params.max_deg = pp.max_deg;
+  c->params.horizon = pp.mpc_prediction_horizon;
+  c->params.matches_should_be_monotonic = pp.matches_should_be_monotonic ? 1 : 0;
+  c->params.use_unknown_cones = pp.use_unknown_cones ? 1 : 0;
   if (e == hipSuccess) e = hipMalloc(&c->d_params, sizeof(Params));
   if (e == hipSuccess) e = hipMemcpyAsync(c->d_params, &c->params, sizeof(Params), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMalloc(&c->d_default_path, sizeof(double) * PATH_POINTS * 4);
@@ -1369,15 +1416,40 @@ int fsdp_sort_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double*
   Work& q = c->slot[0];
   if (int rc = ensure_work(c, q, n_frames)) return rc;
   if (int rc = upload_inputs(c, q.in, q.stream, n_frames, off, cones, poses, nullptr, total, max_cones)) return rc;
-  launch_sort(c, q, q.in);
-  if (int rc = launch_sort_big(c, q, q.in)) return rc;
+  Inputs fin;
+  const bool filtered = !c->params.use_unknown_cones;
+  if (filtered)
+    if (int rc = launch_filter(c, q, q.in, &fin)) return rc;
+  const Inputs& in = filtered ? fin : q.in;
+  launch_sort(c, q, in);
+  if (int rc = launch_sort_big(c, q, in)) return rc;
   HIP_TRY(c, hipMemsetAsync(q.d_big, 0, sizeof(int), q.stream));  // (no assemble_kernel follows to reset the list)
   if (int rcs = ensure_staging(c, n_frames)) return rcs;
   HIP_TRY(c, hipMemcpyAsync(c->h_sort, q.d_sort, sizeof(SortOut) * n_frames, hipMemcpyDeviceToHost, q.stream));
+  std::vector<int32_t> map, moff;
+  if (filtered) {  // indices back into the caller's index space (what assemble_kernel does for a full pass)
+    map.resize(total ? total : 1);
+    moff.resize((size_t)n_frames + 1);
+    HIP_TRY(c, hipMemcpyAsync(map.data(), q.f_map, sizeof(int32_t) * total, hipMemcpyDeviceToHost, q.stream));
+    HIP_TRY(c, hipMemcpyAsync(moff.data(), q.f_off, sizeof(int32_t) * ((size_t)n_frames + 1), hipMemcpyDeviceToHost, q.stream));
+  }
   HIP_TRY(c, hipStreamSynchronize(q.stream));
   for (int i = 0; i < n_frames; i++) {
     memset(&results[i], 0, sizeof(fsdp_frame_result));
     assemble(&c->h_sort[i], nullptr, nullptr, &results[i]);
+    if (filtered) {
+      auto back = [&](int32_t& v) {
+        if (v >= 0) v = map[(size_t)moff[i] + v];
+      };
+      for (int k = 0; k < MAX_LEN; k++) {
+        back(results[i].left_idx[k]);
+        back(results[i].right_idx[k]);
+      }
+      for (int k = 0; k < 2; k++) {
+        back(results[i].first_k_left[k]);
+        back(results[i].first_k_right[k]);
+      }
+    }
   }
   return 0;
 }

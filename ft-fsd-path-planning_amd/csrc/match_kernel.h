@@ -110,8 +110,24 @@ __device__ inline void matches_for_side(MatchShared& S, const Params& P, const d
         best = j;
       }
     }
-    S.match[lane] = S.anyok[lane] ? best : -1;
+    S.match[lane] = best;
   }
+  Grp<G>::sync();
+  // matches_should_be_monotonic (functional_cone_matching.py:164-171): entry i survives iff its (raw) match index equals the
+  // running maximum of the raw indices up to i; then entries without any potential match go (:174)
+  int raw = -1;
+  bool keep = false;
+  if (lane < n) {
+    raw = S.match[lane];
+    keep = S.anyok[lane] != 0;
+    if (P.matches_should_be_monotonic) {
+      int mx = S.match[0];
+      for (int j = 1; j <= lane; j++) mx = S.match[j] > mx ? S.match[j] : mx;
+      keep = keep && raw == mx;
+    }
+  }
+  Grp<G>::sync();
+  if (lane < n) S.match[lane] = keep ? raw : -1;
   Grp<G>::sync();
 }
 

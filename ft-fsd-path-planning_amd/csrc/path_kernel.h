@@ -218,35 +218,39 @@ __device__ inline void circle_fit(const double* px, const double* py, int idx0, 
   orad = sqrt(fabs(Xc * Xc + Yc * Yc + Mz));
 }
 
-// det([[1,x0,y0],[1,x1,y1],[1,x2,y2]]) via LU with partial pivoting (what numpy.linalg.det does)
+// sign-exact det([[1,x0,y0],[1,x1,y1],[1,x2,y2]]) as numpy.linalg.det computes it (LAPACK dgetrf of OpenBLAS)
 __device__ inline double det3_lu(double x0, double y0, double x1, double y1, double x2, double y2) {
-  double a[3][3] = {{1.0, x0, y0}, {1.0, x1, y1}, {1.0, x2, y2}};
+#define FABS fabs
+#define FMA fma
+  // OpenBLAS' unblocked LU (lapack/getf2/getf2.c: what dgetrf runs for n <= DTB_ENTRIES / 2), left-looking, on the
+  // column-major copy NumPy hands to LAPACK; only the SIGN of the determinant is used by the callers.
+  //   column 0 = (1,1,1): pivot row 0, multipliers 1 * (1 / 1) = 1.
+  //   column 1: b_i = x_i - 1 * x_0 (gemv, alpha = -1); pivot = first largest |b_i|; rows swapped in columns 0..1;
+  //             multiplier l21 = b_2 * (1 / b_1)  — scaled by the RECIPROCAL of the pivot (dscal), two roundings.
+  //   column 2: pivots applied; u12 = y_1 - 1 * y_0 (forward substitution, ddot of one element);
+  //             u22 = y_2 - t with t = fma(l21, u12, fma(l20, y_0, 0)) — dgemv_n's scalar tail for one row accumulates
+  //             temp += a * x (contracted to an fma by the compiler the library is built with), then y += alpha * temp.
+  // Checked against numpy.linalg.det on 64 000 exactly / nearly collinear and general triples: same sign on all of them
+  // (tests/test_oracle_numpy_semantics.py); the textbook right-looking order agrees on 98 % only.
+  double b1 = x1 - x0, b2 = x2 - x0;  // (l10 = l20 = 1)
+  double ya = y1, yb = y2;
   int sign = 1;
-  for (int k = 0; k < 3; k++) {
-    int p = k;
-    double best = fabs(a[k][k]);
-    for (int i = k + 1; i < 3; i++)
-      if (fabs(a[i][k]) > best) {
-        best = fabs(a[i][k]);
-        p = i;
-      }
-    if (a[p][k] == 0.0) return 0.0;
-    if (p != k) {
-      for (int j = 0; j < 3; j++) {
-        double t = a[p][j];
-        a[p][j] = a[k][j];
-        a[k][j] = t;
-      }
-      sign = -sign;
-    }
-    double inv = 1.0 / a[k][k];
-    for (int i = k + 1; i < 3; i++) a[i][k] *= inv;
-    for (int j = k + 1; j < 3; j++)
-      for (int i = k + 1; i < 3; i++) a[i][j] -= a[i][k] * a[k][j];
+  if (!(FABS(b1) >= FABS(b2))) {  // idamax: first of the largest
+    double t = b1;
+    b1 = b2;
+    b2 = t;
+    ya = y2;
+    yb = y1;
+    sign = -1;
   }
-  double det = 1.0;
-  for (int k = 0; k < 3; k++) det *= a[k][k];
-  return sign * det;
+  if (b1 == 0.0) return 0.0;  // singular (info > 0): numpy returns 0
+  const double l21 = b2 * (1.0 / b1);
+  const double u12 = ya - y0;
+  const double t = FMA(l21, u12, y0);  // fma(l20 = 1, y0, 0) = y0 exactly
+  const double u22 = yb - t;
+  return (double)sign * b1 * u22;
+#undef FABS
+#undef FMA
 }
 
 __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
@@ -301,9 +305,9 @@ __device__ __forceinline__ double build_parameter(PS& S, const Arena& A, int off
 // four points sends the frame to the exact kernel (ST_RETRY).
 template <int G, bool FAST, bool CUBIC = false, class PS>
 __device__ __forceinline__ int fit_polyline(PS& S, const Arena& A, int off, int m, double smoothing, SplineFit& f,
-                                   double& max_u) {
+                                   double& max_u, int max_deg = 3) {
   int k = m - 1;
-  k = k < 1 ? 1 : (k > 3 ? 3 : k);
+  k = k < 1 ? 1 : (k > max_deg ? max_deg : k);  // np.clip(len(trace) - 1, 1, max_deg), utils/spline_fit.py:113
   if constexpr (CUBIC) {
     if (k < 3) return ST_RETRY;
     max_u = build_parameter<G>(S, A, off, m);
@@ -345,7 +349,8 @@ __device__ __forceinline__ int parameterize_path(PS& S, const Arena& A, int off,
   double path_length = np_sum_run(seg, n - 1);
   int n10 = (n - 1) < 10 ? (n - 1) : 10;
   double mean_pd = np_sum_small(seg, n10) / (double)n10;
-  double predict_every = path_length / PATH_POINTS / 3;
+  const int H = A.prm->horizon;  // mpc_prediction_horizon: rows of the result (stride PATH_POINTS)
+  double predict_every = path_length / H / 3;
   int skip;
   {
     double q = predict_every / mean_pd;
@@ -462,22 +467,27 @@ __device__ __forceinline__ int parameterize_path(PS& S, const Arena& A, int off,
   GR::sync();
   // _sample_path_parameters_for_prediction_horizon :252-295: np.linspace(0, L-1, 40, dtype=int)
   {
-    const double step = ((double)(L - 1) - 0.0) / (double)(PATH_POINTS - 1);
+    const double step = ((double)(L - 1) - 0.0) / (double)(H - 1);
     auto sample_index = [&](int i) {
+      if (H == 1) return 0;  // np.linspace(0, L - 1, 1) = [0.]
       double v = (double)i * step + 0.0;
-      if (i == PATH_POINTS - 1) v = (double)(L - 1);
+      if (i == H - 1) v = (double)(L - 1);
       return (int)floor(v);
     };
     bool dup = false;
-    for (int i = lane; i < PATH_POINTS; i += G)
+    for (int i = lane; i < H; i += G)
       if (i > 0 && sample_index(i - 1) == sample_index(i)) dup = true;
     if (GR::ballot(dup) != 0ull) return 1;  // "Indices of resampled path appear twice" (ValueError)
     for (int i = lane; i < PATH_POINTS; i += G) {
-      int idx = sample_index(i);
-      out[i][0] = (double)idx * predict_every;  // np.arange(0, max_u, step)[idx]
-      out[i][1] = DX[idx];
-      out[i][2] = DY[idx];
-      out[i][3] = filt[idx];
+      if (i < H) {
+        int idx = sample_index(i);
+        out[i][0] = (double)idx * predict_every;  // np.arange(0, max_u, step)[idx]
+        out[i][1] = DX[idx];
+        out[i][2] = DY[idx];
+        out[i][3] = filt[idx];
+      } else {
+        out[i][0] = out[i][1] = out[i][2] = out[i][3] = NAN;  // rows beyond the horizon do not exist in the reference
+      }
     }
   }
   *n_dense = L;
@@ -692,7 +702,7 @@ __device__ __forceinline__ int do_all_mpc(PS& S, const Arena& A, int n, double p
   if (fitted) {
     double max_u;
     PROF(4);
-    rc = fit_polyline<G, FAST>(S, A, off, n, A.prm->smoothing, f, max_u);
+    rc = fit_polyline<G, FAST>(S, A, off, n, A.prm->smoothing, f, max_u, A.prm->max_deg);
     if (rc) return rc;
   }
   return mpc_finish<G, FAST>(S, A, fitted, f, out, n_dense);
@@ -716,11 +726,11 @@ __device__ __forceinline__ int overwrite_if_too_far(const Arena& A, int n1, doub
   if (bv > A.prm->maximal_distance_for_valid_path) {
     *fallback |= 4;
     GR::sync();
-    for (int i = lane; i < PATH_POINTS; i += G) {
+    for (int i = lane; i < A.prm->horizon; i += G) {
       A.x[1 + i] = prev[4 * i + 1];
       A.y[1 + i] = prev[4 * i + 2];
     }
-    n1 = PATH_POINTS;
+    n1 = A.prm->horizon;
     GR::sync();
   }
   return n1;
@@ -742,11 +752,11 @@ __device__ __forceinline__ int finish_path(PS& S, const Arena& A, int n1, double
     if (attempt == 1) {
       *fallback |= 8;
       GR::sync();
-      for (int i = lane; i < PATH_POINTS; i += G) {
+      for (int i = lane; i < A.prm->horizon; i += G) {
         A.x[1 + i] = prev[4 * i + 1];
         A.y[1 + i] = prev[4 * i + 2];
       }
-      n1 = PATH_POINTS;
+      n1 = A.prm->horizon;
       GR::sync();
     }
     rc = do_all_mpc<G, FAST>(S, A, n1, px, py, dx, dy, out, fallback, n_dense);
@@ -803,7 +813,7 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
   SplineFit f;
   double max_u;
   constexpr bool FAST = false;  // one-off per context: plain divisions
-  int rc = fit_polyline<G, FAST>(S, A, 0, PATH_POINTS, A.prm->smoothing, f, max_u);
+  int rc = fit_polyline<G, FAST>(S, A, 0, PATH_POINTS, A.prm->smoothing, f, max_u, A.prm->max_deg);
   int n1 = arange_len(max_u, A.prm->predict_every);
   if (rc == 0 && n1 <= PATH_CAP) {
     spline_eval(S.ws, f, A.prm->predict_every, n1, A.x, A.y, nullptr);
@@ -936,11 +946,11 @@ __device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut*
     GR::sync();
     if (use_prev) {
       fallback |= 1;
-      for (int i = lane; i < PATH_POINTS; i += G) {
+      for (int i = lane; i < A.prm->horizon; i += G) {
         A.x[i] = prev[4 * i + 1];
         A.y[i] = prev[4 * i + 2];
       }
-      nc = PATH_POINTS;
+      nc = A.prm->horizon;
     }
     GR::sync();
   }
@@ -951,7 +961,7 @@ __device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut*
       SplineFit f;
       double max_u;
       PROF(1);
-      int rc = fit_polyline<G, FAST, CUBIC>(S, A, 0, nc, A.prm->smoothing, f, max_u);
+      int rc = fit_polyline<G, FAST, CUBIC>(S, A, 0, nc, A.prm->smoothing, f, max_u, A.prm->max_deg);
       if (rc == 0) {
         n1 = arange_len(max_u, A.prm->predict_every);
         if (n1 + 1 + 50 > PATH_CAP) {
@@ -970,11 +980,11 @@ __device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut*
         break;
       }
       fallback |= 2;
-      for (int i = lane; i < PATH_POINTS; i += G) {
+      for (int i = lane; i < A.prm->horizon; i += G) {
         A.x[i] = prev[4 * i + 1];
         A.y[i] = prev[4 * i + 2];
       }
-      nc = PATH_POINTS;
+      nc = A.prm->horizon;
       GR::sync();
     }
   }

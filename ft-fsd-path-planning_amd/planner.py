@@ -197,7 +197,7 @@ class PathPlanner:
         else:
             r = self._ctx.plan_batch(off0, none, pose_k)[0]
         raise_for_status(r["status"])
-        path = np.array(r["path"])
+        path = np.array(r["path"][: self._ctx.horizon])
         self._prev = path.copy()  # the path stage keeps its history in the frame it computed in
         if acc.is_relocalized:
             path[:, 1:3], _ = acc.to_original_frame(path[:, 1:3], np.zeros(len(path)))
@@ -229,7 +229,7 @@ class PathPlanner:
             res, info = self._skid.step(np.array([0, len(xyt)], np.int32), xyt, pose[None])
             self._skid_info = info[0]
             raise_for_status(res[0]["status"])
-            path = np.array(res[0]["path"])
+            path = np.array(res[0]["path"][: self._ctx.horizon])
             if not return_intermediate_results:
                 return path
             e2, ei = np.zeros((0, 2)), np.zeros(0, dtype=int)
@@ -242,7 +242,7 @@ class PathPlanner:
         else:
             r = self._ctx.plan_batch(off1, xyt, pose[None])[0]
         raise_for_status(r["status"])
-        path = np.array(r["path"])
+        path = np.array(r["path"][: self._ctx.horizon])  # (mpc_prediction_horizon, 4) like the reference's return value
         if self.stateful:
             self._prev = path.copy()
         if not return_intermediate_results:

@@ -25,11 +25,16 @@ _shared_ctx = {}
 
 
 def _ctx(device=None, params=None):
-    """One context per (device, parameter set)."""
+    """One context per (device, parameter set); the eight most recently used are kept (a parameter sweep through the stage
+    classes would otherwise pile up contexts, each with its device buffers)."""
     key = (device, tuple(sorted((params or {}).items())))
-    if key not in _shared_ctx:
-        _shared_ctx[key] = _capi.Context(device=device, mission=4, params=params)
-    return _shared_ctx[key]
+    ctx = _shared_ctx.pop(key, None)
+    if ctx is None:
+        ctx = _capi.Context(device=device, mission=4, params=params)
+    _shared_ctx[key] = ctx  # (most recent last)
+    while len(_shared_ctx) > 8:
+        _shared_ctx.pop(next(iter(_shared_ctx))).close()
+    return ctx
 
 
 def _overrides(defaults, kwargs):
@@ -164,7 +169,7 @@ class CalculatePath:
                 ctx.set_global_path(None)
         _check(out["status"])
         self.last_result = out
-        path = np.array(out["path"])
+        path = np.array(out["path"][: ctx.horizon])
         if self.stateful:
             self._prev = path.copy()
         return path, None

@@ -88,10 +88,13 @@ typedef struct fsdp_ctx fsdp_ctx;
 /* The reference's configuration constants — the kwargs of ConeSorting (sorting_cones/core_cone_sorting.py:49-100), ConeMatching
  * (cone_matching/core_cone_matching.py:50-71) and CalculatePath (calculate_path/core_calculate_path.py:69-110), whose defaults
  * are the factories of fsd_path_planning/config.py:28-163.  fsdp_default_params fills those defaults.  A context keeps its own
- * copy on the device.  Structural parameters are bounded by the compiled capacities (max_n_neighbors <= 5, max_length <= 12);
- * max_deg (3), mpc_prediction_horizon (40: the shape of the result), use_unknown_cones (True) and
- * matches_should_be_monotonic (False, the pipeline's choice: full_pipeline.py:65) are accepted only at these values
- * (fsdp_create fails otherwise: no silent substitution). */
+ * copy on the device.  Every value the reference accepts is accepted, within the compiled capacities of the structural
+ * ones: max_n_neighbors <= 5, max_length <= 12, mpc_prediction_horizon <= 40 (a path of the result holds 40 rows: with a
+ * horizon h < 40 rows [h, 40) are NaN, and previous paths handed in are read up to row h), max_deg in 1..3 (fits of degree
+ * < 3 take the one-frame-per-wavefront path kernel).  use_unknown_cones = 0 drops the cones of type UNKNOWN before sorting
+ * (core_cone_sorting.py:113-115); the sorted indices still refer to the caller's array.  matches_should_be_monotonic is the
+ * branch of functional_cone_matching.py:164-171 (the pipeline passes False, full_pipeline.py:65; ConeMatching's own default
+ * factory passes True, config.py:131-146).  fsdp_create fails on anything outside (no silent substitution). */
 typedef struct {
   /* config.py:33-41 get_cone_sorting_config */
   int32_t max_n_neighbors;

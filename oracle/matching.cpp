@@ -74,8 +74,17 @@ static void matches_for_side(const Pts& cones, int cone_type, const Pts& other, 
           best = j;
         }
       }
-      matches[i] = any[i] ? best : -1;
+      matches[i] = best;
     }
+    if (g_prm.matches_should_be_monotonic) {  // functional_cone_matching.py:164-171
+      int current_max = matches[0];
+      for (int i = 1; i < M; i++) {
+        current_max = std::max(current_max, matches[i]);
+        matches[i] = (matches[i] != current_max) ? -1 : current_max;
+      }
+    }
+    for (int i = 0; i < M; i++)
+      if (!any[i]) matches[i] = -1;  // :174
   }
 }
 

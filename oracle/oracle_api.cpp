@@ -17,13 +17,20 @@ static Frame make_frame(const double* xyt, int n, const double* pose) {
   Frame f;
   f.n = n;
   f.x.resize(n);
-  f.y.resize(n);
-  f.type.resize(n);
+  f.x.clear();
+  f.y.clear();
+  f.type.clear();
+  f.orig.clear();
   for (int i = 0; i < n; i++) {
-    f.x[i] = xyt[3 * i];
-    f.y[i] = xyt[3 * i + 1];
-    f.type[i] = (int)xyt[3 * i + 2];
+    const int t = (int)xyt[3 * i + 2];
+    // core_cone_sorting.py:113-115: use_unknown_cones = False empties the UNKNOWN list before the cones are flattened
+    if (!g_prm.use_unknown_cones && t == 0) continue;
+    f.x.push_back(xyt[3 * i]);
+    f.y.push_back(xyt[3 * i + 1]);
+    f.type.push_back(t);
+    f.orig.push_back(i);
   }
+  f.n = (int)f.x.size();
   f.px = pose[0];
   f.py = pose[1];
   f.dx = pose[2];
@@ -41,17 +48,18 @@ static void clear_result(fsdo_frame_result* o) {
     for (int j = 0; j < 4; j++) o->path[i][j] = NAN;
 }
 
-static void fill_sort(const std::vector<int>& l, const std::vector<int>& r, const SideResult& L, const SideResult& R,
+static void fill_sort(const Frame& f, const std::vector<int>& l, const std::vector<int>& r, const SideResult& L, const SideResult& R,
                       fsdo_frame_result* o) {
   o->n_left = (int)l.size();
   o->n_right = (int)r.size();
-  for (size_t i = 0; i < l.size(); i++) o->left_idx[i] = l[i];
-  for (size_t i = 0; i < r.size(); i++) o->right_idx[i] = r[i];
+  // indices are reported in the caller's array (f.orig is the identity unless UNKNOWN cones were dropped)
+  for (size_t i = 0; i < l.size(); i++) o->left_idx[i] = f.orig[l[i]];
+  for (size_t i = 0; i < r.size(); i++) o->right_idx[i] = f.orig[r[i]];
   o->n_configs_left = L.has ? (int)L.configs.size() : 0;
   o->n_configs_right = R.has ? (int)R.configs.size() : 0;
   for (int i = 0; i < 2; i++) {
-    o->first_k_left[i] = L.first_k[i];
-    o->first_k_right[i] = R.first_k[i];
+    o->first_k_left[i] = L.first_k[i] >= 0 ? f.orig[L.first_k[i]] : -1;
+    o->first_k_right[i] = R.first_k[i] >= 0 ? f.orig[R.first_k[i]] : -1;
   }
   if (L.has) o->best_cost_left = L.costs[0];
   if (R.has) o->best_cost_right = R.costs[0];
@@ -75,6 +83,12 @@ static void fill_match(const Pts& lv, const Pts& rv, const std::vector<int>& l2r
 }
 
 extern "C" {
+
+// np_compat.h det3_lu for the tests: xy6 = x0,y0,x1,y1,x2,y2 -> determinant of [[1,x0,y0],[1,x1,y1],[1,x2,y2]] (sign-exact)
+double fsdo_det3(const double* xy6) {
+  const double h[3][3] = {{1.0, xy6[0], xy6[1]}, {1.0, xy6[2], xy6[3]}, {1.0, xy6[4], xy6[5]}};
+  return det3_lu(h);
+}
 
 // decision margins of the sorting stage (oracle_internal.h MarginRec): enable / reset, read (9 classes x 6 values:
 // min non-zero margin, decisions, below 1e-6, below 1e-9, below 1e-12, exactly zero)
@@ -104,7 +118,7 @@ void fsdo_sort_frame(const double* xyt, int n, const double* pose, fsdo_frame_re
     std::vector<int> l, r;
     SideResult L, R;
     sort_frame(f, l, r, &L, &R);
-    fill_sort(l, r, L, R, o);
+    fill_sort(f, l, r, L, R, o);
   } catch (RefUndefined& e) {
     o->status = e.code;
   }
@@ -167,7 +181,7 @@ void fsdo_plan_frame_global(const double* xyt, int n, const double* pose, const 
     std::vector<int> l, r;
     SideResult L, R;
     sort_frame(f, l, r, &L, &R);
-    fill_sort(l, r, L, R, o);
+    fill_sort(f, l, r, L, R, o);
     Pts sl(l.size()), sr(r.size()), lv, rv;
     for (size_t i = 0; i < l.size(); i++) sl[i] = Vec2{f.x[l[i]], f.y[l[i]]};
     for (size_t i = 0; i < r.size(); i++) sr[i] = Vec2{f.x[r[i]], f.y[r[i]]};
@@ -257,7 +271,7 @@ int fsdo_plan_frame_capture(const double* cones_xyt, int n, const double* pose, 
   return (int)cap.size();
 }
 void fsdo_set_math_mode(int mode) { fsdo::g_math_mode = mode; }
-// 13 values in the order of OParams (ints as doubles); NULL restores the reference's defaults.  Not thread-safe: call
+// 17 values in the order of OParams (ints as doubles); NULL restores the reference's defaults.  Not thread-safe: call
 // between batches.
 void fsdo_set_params(const double* v) {
   fsdo::OParams p;
@@ -275,6 +289,10 @@ void fsdo_set_params(const double* v) {
     p.predict_every = v[10];
     p.maximal_distance_for_valid_path = v[11];
     p.mpc_path_length = v[12];
+    p.max_deg = (int)v[13];
+    p.horizon = (int)v[14];
+    p.matches_should_be_monotonic = (int)v[15];
+    p.use_unknown_cones = (int)v[16];
   }
   fsdo::g_prm = p;
   fsdo::rebuild_default_previous_path();

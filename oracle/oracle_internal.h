@@ -17,6 +17,9 @@ struct OParams {
          threshold_absolute_angle = 65 * (PI / 180.0);
   double min_track_width = 3.0, max_search_range = 5.0, max_search_angle = 50 * (PI / 180.0);
   double smoothing = 0.2, predict_every = 0.1, maximal_distance_for_valid_path = 5.0, mpc_path_length = 20.0;
+  // config.py:48 max_deg, :58 mpc_prediction_horizon, :124-146 matches_should_be_monotonic (the pipeline's choice: False,
+  // full_pipeline.py:65), :40 use_unknown_cones
+  int max_deg = 3, horizon = 40, matches_should_be_monotonic = 0, use_unknown_cones = 1;
 };
 extern OParams g_prm;
 struct Spline;
@@ -24,6 +27,7 @@ extern thread_local std::vector<Spline>* g_fit_capture;
 void rebuild_default_previous_path();
 
 struct Frame {
+  std::vector<int> orig;  // index of every cone in the caller's array (cones of type UNKNOWN are dropped when use_unknown_cones is off)
   int n = 0;
   std::vector<double> x, y;
   std::vector<int> type;

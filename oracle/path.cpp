@@ -28,8 +28,7 @@ double m_sin(double a) { return g_math_mode ? detm::det_sin(a) : std::sin(a); }
 #define MAX_DIST_VALID_PATH (g_prm.maximal_distance_for_valid_path)
 #define MPC_PATH_LENGTH (g_prm.mpc_path_length)
 OParams g_prm;
-static const int MAX_DEG = 3;
-static const int HORIZON = FSDO_PATH_POINTS;
+#define HORIZON (g_prm.horizon)  // mpc_prediction_horizon (<= FSDO_PATH_POINTS, the stride of the path arrays)
 
 // utils/math_utils.py:579-646 circle_fit (hyper fit); returns (cx, cy, r)
 void circle_fit(const Pts& p, double& ocx, double& ocy, double& orad) {
@@ -89,7 +88,7 @@ struct Fitted {
 // optional capture of every fit of a frame, in call order (fsdo_plan_frame_capture: per-stage intermediates for the tests)
 thread_local std::vector<Spline>* g_fit_capture = nullptr;
 
-static Fitted spline_fit(const Pts& trace, double smoothing, double predict_every) {
+static Fitted spline_fit(const Pts& trace, double smoothing, double predict_every, int max_deg) {
   Fitted f;
   f.predict_every = predict_every;
   const int m = (int)trace.size();
@@ -97,7 +96,7 @@ static Fitted spline_fit(const Pts& trace, double smoothing, double predict_ever
     f.null = true;
     return f;
   }
-  int k = std::min(std::max(m - 1, 1), MAX_DEG);
+  int k = std::min(std::max(m - 1, 1), max_deg);  // np.clip(len(trace) - 1, 1, max_deg)
   std::vector<double> u(m), x(m), y(m);
   double acc = 0.0;  // np.cumsum: sequential
   u[0] = 0.0;
@@ -207,7 +206,7 @@ static void parameterize_path(const Pts& path, double out[][4]) {
   }
   Pts skipped;
   for (int i = 0; i < n; i += skip) skipped.push_back(path[i]);
-  Fitted fit = spline_fit(skipped, 0.01, predict_every);
+  Fitted fit = spline_fit(skipped, 0.01, predict_every, 3);  // path_parameterization.py:155-157: max_deg = 3 here, whatever the configuration
   // _calculate_path_curvature :163-193
   std::vector<double> ue;
   Pts pts = spline_predict(fit, fit.max_u, &ue);
@@ -224,7 +223,7 @@ static void parameterize_path(const Pts& path, double out[][4]) {
   for (int i = 0; i < HORIZON; i++) {
     double v = (double)i * step + 0.0;
     if (i == HORIZON - 1) v = (double)(L - 1);
-    idx[i] = (long)std::floor(v);
+    idx[i] = HORIZON == 1 ? 0 : (long)std::floor(v);  // np.linspace(0, L - 1, 1) = [0.]
   }
   for (int i = 1; i < HORIZON; i++)
     if (idx[i] == idx[i - 1]) throw PyValueError{2};  // "Indices of resampled path appear twice"
@@ -234,6 +233,7 @@ static void parameterize_path(const Pts& path, double out[][4]) {
     out[i][2] = pts[idx[i]].y;
     out[i][3] = filt[idx[i]];
   }
+  for (int i = HORIZON; i < FSDO_PATH_POINTS; i++) out[i][0] = out[i][1] = out[i][2] = out[i][3] = NAN;  // rows the reference's path does not have
 }
 
 // core_calculate_path.py:430-457 connect_path_to_car
@@ -332,7 +332,7 @@ void do_all_mpc(const Pts& path_update, Vec2 pos, Vec2 dir, double out[][4], int
   Pts p2 = extend_path(p1, pos, dir, flags);
   Pts p3 = remove_path_behind_car(p2, pos);
   // refit_path_for_mpc_with_safety_factor :239-259
-  Fitted fit = spline_fit(p3, SMOOTHING, PREDICT_EVERY);
+  Fitted fit = spline_fit(p3, SMOOTHING, PREDICT_EVERY, g_prm.max_deg);
   Pts p4 = spline_predict(fit, MPC_PATH_LENGTH * 1.5);
   // remove_path_not_in_prediction_horizon :467-499
   int nseg = (int)p4.size() - 1;
@@ -379,7 +379,7 @@ static void build_default() {
     q.y *= np_sign(max_angle);
     chord[i] = q;
   }
-  Fitted fit = spline_fit(chord, SMOOTHING, PREDICT_EVERY);
+  Fitted fit = spline_fit(chord, SMOOTHING, PREDICT_EVERY, g_prm.max_deg);
   Pts initial = spline_predict(fit, fit.max_u);
   parameterize_path(initial, g_default);
 }
@@ -457,11 +457,11 @@ void calculate_path(const Pts& left_v, const Pts& right_v, const std::vector<int
   // fit_matches_as_spline :207-223
   Pts path_update;
   try {
-    Fitted f = spline_fit(center, SMOOTHING, PREDICT_EVERY);
+    Fitted f = spline_fit(center, SMOOTHING, PREDICT_EVERY, g_prm.max_deg);
     path_update = spline_predict(f, f.max_u);
   } catch (PyValueError&) {
     out.fallback |= 2;
-    Fitted f = spline_fit(prev_xy, SMOOTHING, PREDICT_EVERY);
+    Fitted f = spline_fit(prev_xy, SMOOTHING, PREDICT_EVERY, g_prm.max_deg);
     path_update = spline_predict(f, f.max_u);
   }
   finish_path(path_update, prev_xy, pos, dir, out);

@@ -215,8 +215,8 @@ static void skidpad_step(SkidpadPlanner& P, const double* xyt, int n, const doub
       path_update.push_back(Vec2{r.x + pos.x, r.y + pos.y});
     }
   }
-  Pts prev_xy(FSDO_PATH_POINTS);
-  for (int i = 0; i < FSDO_PATH_POINTS; i++) prev_xy[i] = Vec2{P.prev[i][1], P.prev[i][2]};
+  Pts prev_xy(g_prm.horizon);
+  for (int i = 0; i < g_prm.horizon; i++) prev_xy[i] = Vec2{P.prev[i][1], P.prev[i][2]};
   PathOut po;
   po.fallback = 0;
   finish_path(path_update, prev_xy, pos, dir, po);

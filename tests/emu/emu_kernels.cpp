@@ -6,6 +6,7 @@
 #include "../../ft-fsd-path-planning_amd/csrc/match_kernel.h"
 #include "../../ft-fsd-path-planning_amd/csrc/path_kernel.h"
 #include "../../ft-fsd-path-planning_amd/csrc/skidpad_kernel.h"
+#include "../../ft-fsd-path-planning_amd/csrc/filter_kernel.h"
 
 #include <mutex>
 #include <vector>
@@ -19,7 +20,7 @@ struct AlignedArena {
 };
 
 // configuration constants handed to the kernels (emu_set_params; defaults = fsd_path_planning/config.py)
-static fsdp::Params g_prm = {5, 12, 6.5, 6.0, 40 * FSDP_DEG, 65 * FSDP_DEG, 3.0, 5.0, 50 * FSDP_DEG, 0.2, 0.1, 5.0, 20.0};
+static fsdp::Params g_prm = {5, 12, 6.5, 6.0, 40 * FSDP_DEG, 65 * FSDP_DEG, 3.0, 5.0, 50 * FSDP_DEG, 0.2, 0.1, 5.0, 20.0, 3, 40, 0, 1};
 static double g_default_path[fsdp::PATH_POINTS * 4];
 static const double* g_prev_paths = nullptr;
 static const double* g_gpath = nullptr;
@@ -125,7 +126,7 @@ int emu_sizeof_sort_out() { return (int)sizeof(fsdp::SortOut); }
 int emu_sizeof_match_out() { return (int)sizeof(fsdp::MatchOut); }
 int emu_sizeof_path_out() { return (int)sizeof(fsdp::PathOut); }
 
-void emu_sort(int n_frames, const int32_t* offsets, const double* cones, const double* poses, fsdp::SortOut* out) {
+static void emu_sort_plain(int n_frames, const int32_t* offsets, const double* cones, const double* poses, fsdp::SortOut* out) {
   std::vector<int> big((size_t)n_frames + 1, 0);
   // the host library's choice (fsdp_lib.hip launch_sort): the 128-cone state when no frame of the batch holds more
   int max_cones = 0;
@@ -140,9 +141,52 @@ void emu_sort(int n_frames, const int32_t* offsets, const double* cones, const d
     emu::launch(2, 64, [&]() { fsdp::sort_big_kernel(offsets, cones, poses, out, big.data(), state.data(), &g_prm); });
   }
 }
+// use_unknown_cones = False: the filter kernels in front (fsdp_lib.hip launch_filter); f_off / f_cones describe the batch
+// the other kernels plan, f_map the way back for indices
+static std::vector<int32_t> g_f_off, g_f_map;
+static std::vector<double> g_f_cones;
+static void emu_filter(int n_frames, const int32_t* offsets, const double* cones) {
+  std::vector<int32_t> cnt((size_t)n_frames + 1, 0);
+  g_f_off.assign((size_t)n_frames + 1, 0);
+  const size_t total = (size_t)offsets[n_frames];
+  g_f_cones.assign(3 * total + 3, 0.0);
+  g_f_map.assign(total + 1, 0);
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::filter_count_kernel(n_frames, offsets, cones, cnt.data()); });
+  emu::launch(1, 64, [&]() { fsdp::filter_scan_kernel(n_frames, cnt.data(), g_f_off.data()); });
+  emu::launch((unsigned)n_frames, 64, [&]() { fsdp::filter_scatter_kernel(n_frames, offsets, cones, g_f_off.data(), g_f_cones.data(), g_f_map.data()); });
+}
+void emu_sort(int n_frames, const int32_t* offsets, const double* cones, const double* poses, fsdp::SortOut* out) {
+  if (g_prm.use_unknown_cones) {
+    emu_sort_plain(n_frames, offsets, cones, poses, out);
+    return;
+  }
+  emu_filter(n_frames, offsets, cones);
+  emu_sort_plain(n_frames, g_f_off.data(), g_f_cones.data(), poses, out);
+}
+// indices of a filtered sort back into the caller's array (assemble_kernel's remap); no-op with use_unknown_cones on
+void emu_sort_remap(int n_frames, fsdp::SortOut* out) {
+  if (g_prm.use_unknown_cones) return;
+  for (int f = 0; f < n_frames; f++) {
+    auto back = [&](int32_t& v) {
+      if (v >= 0) v = g_f_map[(size_t)g_f_off[f] + v];
+    };
+    for (int k = 0; k < fsdp::MAX_LEN; k++) {
+      back(out[f].left_idx[k]);
+      back(out[f].right_idx[k]);
+    }
+    for (int k = 0; k < 2; k++) {
+      back(out[f].first_k_left[k]);
+      back(out[f].first_k_right[k]);
+    }
+  }
+}
 void emu_match(int n_frames, const int32_t* offsets, const double* cones, const double* poses, const fsdp::SortOut* sorted,
                fsdp::MatchOut* out) {
   constexpr unsigned per = 64 / fsdp::MATCH_G;
+  if (!g_prm.use_unknown_cones) {  // (call after emu_sort of the same batch, before emu_sort_remap)
+    offsets = g_f_off.data();
+    cones = g_f_cones.data();
+  }
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::match_kernel<fsdp::MATCH_G>(n_frames, offsets, cones, poses, sorted, out, &g_prm); });
 }
 int emu_sizeof_skid_state() { return (int)sizeof(fsdp::SkidState); }
@@ -180,9 +224,10 @@ void emu_skidpad_constants(const double* table_xy, int n_table, double* out5) {
   emu::launch(1, 64, [&]() { fsdp::skid_centers_kernel(table_xy, n_table, scratch.data(), out5); });
 }
 
-// 13 values in the order of fsdp::Params (ints as doubles); resets the cached default path
+// 17 values in the order of fsdp::Params (ints as doubles); resets the cached default path
 void emu_set_params(const double* v) {
-  g_prm = fsdp::Params{(int32_t)v[0], (int32_t)v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]};
+  g_prm = fsdp::Params{(int32_t)v[0], (int32_t)v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12],
+                       (int32_t)v[13], (int32_t)v[14], (int32_t)v[15], (int32_t)v[16]};
   build_default();
 }
 void emu_set_prev_paths(const double* p) { g_prev_paths = p; }

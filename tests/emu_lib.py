@@ -110,6 +110,7 @@ def plan(offsets, cones, poses, group=8):
 
     s = sort(offsets, cones, poses)
     m = match(offsets, cones, poses, s)
+    lib().emu_sort_remap(ctypes.c_int(len(s)), ctypes.c_void_p(s.ctypes.data))  # (use_unknown_cones = False: indices back to the caller's array)
     p = path(poses, m, group)
     res = np.zeros(len(s), oracle_lib.RESULT_DTYPE)
     for k in ("n_left", "n_right", "left_idx", "right_idx", "n_configs_left", "n_configs_right", "first_k_left",

@@ -33,7 +33,10 @@ synth = importlib.import_module("ft-fsd-path-planning_amd.synth")
 MAX_LEN, MAX_MATCH = 12, 24
 
 
-def capture(offsets, cones, poses, frames=None, params=None):
+def capture(offsets, cones, poses, frames=None, params=None, flattened=True):
+    """flattened=False: the frame goes to the reference as the five per-type lists (its cones must be stored in type order, so
+    that the reference's flattened index space is the stored one); with use_unknown_cones=False the reference's indices then
+    count from the first known cone and are shifted by the frame's number of UNKNOWN cones into the stored index space."""
     if frames is None:
         frames = range(len(offsets) - 1)
     frames = list(frames)
@@ -76,12 +79,15 @@ def capture(offsets, cones, poses, frames=None, params=None):
         xyt = cones[offsets[f] : offsets[f + 1]]
         sub_cones.append(xyt)
         sub_off.append(sub_off[-1] + len(xyt))
-        r = refharness.run_frame(xyt, poses[f], params=params)
+        r = refharness.run_frame(xyt, poses[f], params=params, flattened=flattened)
+        shift = int((xyt[:, 2] == 0).sum()) if (not flattened and params and params.get("use_unknown_cones") is False) else 0
+        if not flattened:
+            assert np.all(np.diff(xyt[:, 2]) >= 0), "cones must be stored in type order"
         for side, t in (("left", 2), ("right", 1)):
             out["first_k_tie"][k, 0 if side == "left" else 1] = bool((r.get("first_k_tie") or {}).get(t, False))
             fk = (r.get("first_k") or {}).get(t)
             if fk is not None:
-                out[f"first_k_{side}"][k, : len(fk)] = fk
+                out[f"first_k_{side}"][k, : len(fk)] = np.asarray(fk) + shift
             costs = r.get(f"{side}_costs")
             if costs is not None and len(costs):
                 out[f"n_configs_{side}"][k] = len(costs)
@@ -101,8 +107,8 @@ def capture(offsets, cones, poses, frames=None, params=None):
         out["ok"][k] = True
         lc, rc = r["left_config"], r["right_config"]
         out["n_left"][k], out["n_right"][k] = len(lc), len(rc)
-        out["left_idx"][k, : len(lc)] = lc
-        out["right_idx"][k, : len(rc)] = rc
+        out["left_idx"][k, : len(lc)] = lc + shift
+        out["right_idx"][k, : len(rc)] = rc + shift
         lv, rv = r["left_v"], r["right_v"]
         assert len(lv) <= MAX_MATCH and len(rv) <= MAX_MATCH
         out["n_left_v"][k], out["n_right_v"][k] = len(lv), len(rv)
@@ -110,7 +116,7 @@ def capture(offsets, cones, poses, frames=None, params=None):
         out["right_v"][k, : len(rv)] = rv
         out["l2r"][k, : len(lv)] = r["l2r"]
         out["r2l"][k, : len(rv)] = r["r2l"]
-        out["path"][k] = r["path"]
+        out["path"][k, : len(r["path"])] = r["path"]  # (mpc_prediction_horizon rows; the rest stays NaN)
     out["offsets"] = np.array(sub_off, np.int32)
     out["cones"] = np.concatenate(sub_cones).reshape(-1, 3) if sub_cones else np.zeros((0, 3))
     out["poses"] = np.ascontiguousarray(poses[frames])
@@ -311,6 +317,62 @@ def params_golden():
         d["param_values"] = np.array([float(v) for v in prm.values()])
         np.savez_compressed(HERE / f"{name}.npz", **d)
         print(name, "frames", len(d["ok"]), "ok", int(d["ok"].sum()), "exc", sorted(set(d["exc"].tolist()) - {""}))
+
+
+PARAM_SETS_R3 = {
+    # round 3: the values the library used to refuse
+    "params_monotonic": dict(matches_should_be_monotonic=True),
+    "params_deg2": dict(max_deg=2),
+    "params_deg1": dict(max_deg=1),
+    "params_horizon": dict(mpc_prediction_horizon=25),
+    "params_no_unknown": dict(use_unknown_cones=False),
+}
+
+
+def with_unknown_cones(off, cones, frac, seed):
+    """A copy of the batch in which a random `frac` of every frame's cones is of type UNKNOWN, rows of a frame in type
+    order (the order the reference flattens per-type lists in)."""
+    rng = np.random.default_rng(seed)
+    out = cones.copy()
+    for f in range(len(off) - 1):
+        a, b = off[f], off[f + 1]
+        blk = out[a:b]
+        blk[rng.random(b - a) < frac, 2] = 0.0
+        out[a:b] = blk[np.argsort(blk[:, 2], kind="stable")]
+    return out
+
+
+def params_golden_r3():
+    refharness.load()
+    o2, c2, p2 = synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
+    o3, c3, p3 = synth.make_replay_batch(4096, 64, 0.15, seed=1, color=False)
+    of, cf, pf = fuzz_frames(13, 100)
+    for name, prm in PARAM_SETS_R3.items():
+        if name == "params_no_unknown":
+            cu2, cuf = with_unknown_cones(o2, c2, 0.3, 5), with_unknown_cones(of, cf, 0.3, 6)
+            parts = [capture(o2, cu2, p2, range(0, 4096, 128), params=prm, flattened=False), capture(of, cuf, pf, params=prm, flattened=False)]
+        else:
+            parts = [capture(o2, c2, p2, range(0, 4096, 128), params=prm), capture(o3, c3, p3, range(64, 4096, 256), params=prm),
+                     capture(of, cf, pf, params=prm)]
+        d = {}
+        for k in parts[0]:
+            if k == "offsets":
+                offs, base = [np.zeros(1, np.int32)], 0
+                for q in parts:
+                    offs.append(q["offsets"][1:] + base)
+                    base += int(q["offsets"][-1])
+                d[k] = np.concatenate(offs).astype(np.int32)
+            else:
+                d[k] = np.concatenate([q[k] for q in parts])
+        d["param_names"] = np.array(list(prm.keys()))
+        d["param_values"] = np.array([float(v) for v in prm.values()])
+        np.savez_compressed(HERE / f"{name}.npz", **d)
+        print(name, "frames", len(d["ok"]), "ok", int(d["ok"].sum()), "exc", sorted(set(d["exc"].tolist()) - {""}))
+
+
+if __name__ == "__main__" and "--params-r3" in sys.argv:
+    params_golden_r3()
+    sys.exit(0)
 
 
 def add_intermediates():

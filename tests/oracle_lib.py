@@ -233,8 +233,10 @@ class SkidpadPlanner:
 
 PARAM_ORDER = ["max_n_neighbors", "max_length", "max_dist", "max_dist_to_first", "threshold_directional_angle",
                "threshold_absolute_angle", "min_track_width", "max_search_range", "max_search_angle", "smoothing", "predict_every",
-               "maximal_distance_for_valid_path", "mpc_path_length"]
-PARAM_DEFAULTS = [5, 12, 6.5, 6.0, float(np.deg2rad(40)), float(np.deg2rad(65)), 3.0, 5.0, float(np.deg2rad(50)), 0.2, 0.1, 5.0, 20.0]
+               "maximal_distance_for_valid_path", "mpc_path_length", "max_deg", "mpc_prediction_horizon", "matches_should_be_monotonic",
+               "use_unknown_cones"]
+PARAM_DEFAULTS = [5, 12, 6.5, 6.0, float(np.deg2rad(40)), float(np.deg2rad(65)), 3.0, 5.0, float(np.deg2rad(50)), 0.2, 0.1, 5.0, 20.0,
+                  3, 40, 0, 1]
 
 
 def param_vector(overrides=None):

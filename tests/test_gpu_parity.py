@@ -80,7 +80,8 @@ def _assert_equal_to_oracle(res, ref):
     assert np.array_equal(res["left_v"][ok], ref["left_v"][ok])
     assert np.array_equal(res["right_v"][ok], ref["right_v"][ok])
     assert np.array_equal(res["path_fallback"][ok], ref["path_fallback"][ok])
-    err = np.abs(res["path"][ok] - ref["path"][ok]).reshape(ok.sum(), -1).max(axis=1) if ok.any() else np.zeros(0)
+    assert np.array_equal(np.isnan(res["path"][ok]), np.isnan(ref["path"][ok]))  # (rows beyond a shorter horizon: NaN on both sides)
+    err = np.nan_to_num(np.abs(res["path"][ok] - ref["path"][ok]), nan=0.0).reshape(ok.sum(), -1).max(axis=1) if ok.any() else np.zeros(0)
     assert (err <= 1e-9).all(), (float(err.max()), int((err > 1e-9).sum()))
 
 
@@ -408,7 +409,7 @@ def test_two_contexts_interleaved_from_one_thread(pkg):
     b.close()
 
 
-@pytest.mark.parametrize("name", ["params_sort", "params_path"])
+@pytest.mark.parametrize("name", ["params_sort", "params_path", "params_monotonic", "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"])
 def test_non_default_parameters(pkg, golden_dir, name):
     """fsdp_create with a parameter block: the reference's stage classes constructed with non-default kwargs (goldens:
     make_golden.py params_golden) — indices bit-equal, paths within 1e-5 of the reference, bit-equal to the oracle."""
@@ -436,8 +437,8 @@ def test_non_default_parameters(pkg, golden_dir, name):
 
 
 def test_parameters_outside_the_kernels_capacities_are_refused(pkg):
-    for bad in (dict(max_n_neighbors=6), dict(max_length=13), dict(max_deg=2), dict(mpc_prediction_horizon=50),
-                dict(use_unknown_cones=False), dict(matches_should_be_monotonic=True)):
+    for bad in (dict(max_n_neighbors=6), dict(max_length=13), dict(max_deg=4), dict(max_deg=0), dict(mpc_prediction_horizon=50),
+                dict(mpc_prediction_horizon=0), dict(mpc_path_length=100.0)):
         with pytest.raises(pkg.FsdpError):
             pkg.Context(device=0, mission=4, params=bad)
     with pytest.raises(TypeError):

@@ -51,7 +51,7 @@ def test_empty_and_tiny_frames():
         assert np.isfinite(r["path"]).all()
 
 
-@pytest.mark.parametrize("name", ["params_sort", "params_path"])
+@pytest.mark.parametrize("name", ["params_sort", "params_path", "params_monotonic", "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"])
 def test_oracle_with_non_default_parameters(golden_dir, name):
     """The reference's stage classes constructed with non-default kwargs (fixtures: make_golden.py params_golden): the
     oracle with the same constants (fsdo_set_params) reproduces indices, matches and paths."""
@@ -74,7 +74,7 @@ def test_oracle_with_non_default_parameters(golden_dir, name):
     assert np.array_equal(r["left_idx"], d["left_idx"][:2])
 
 
-@pytest.mark.parametrize("name", SETS + ["params_sort", "params_path"])
+@pytest.mark.parametrize("name", SETS + ["params_sort", "params_path", "params_monotonic", "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"])
 def test_oracle_splines_match_reference_per_frame(golden_dir, name):
     """Per-stage intermediates of the path stage: every smoothing spline a frame fits — fit #1 of the centre
     points, the refit, the parameterization fit, plus the fallback fits where they happen — captured from the reference's

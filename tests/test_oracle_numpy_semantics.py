@@ -60,3 +60,36 @@ def test_pairwise_sum(golden_dir):
 
     for k in range(1, 400):
         assert z["sums"][k - 1] == pw(v[:k])
+
+
+def test_det3_sign_is_numpy_linalg_det_sign():
+    """path_parameterization.py:86-92 takes the sign of the curvature from np.linalg.det of three homogeneous points; on an
+    exactly straight stretch the determinant is zero up to rounding and its sign is the rounding of OpenBLAS' LU.  The
+    restatement (np_compat.h det3_lu: left-looking getf2, reciprocal scaling, fused one-row gemv) gives NumPy's sign on
+    collinear, nearly collinear, permuted and general triples at scales 1e-2 .. 1e4 m."""
+    import ctypes
+
+    import oracle_lib
+
+    L = oracle_lib.lib()
+    L.fsdo_det3.restype = ctypes.c_double
+    rng = np.random.default_rng(3)
+    bad = zeros = 0
+    n = 20000
+    for k in range(n):
+        sc = 10.0 ** rng.uniform(-2, 4)
+        p0, d = rng.normal(0, sc, 2), rng.normal(0, 1, 2)
+        t1, t2 = rng.uniform(0.01, 5, 2)
+        p = np.array([p0, p0 + t1 * d, p0 + (t1 + t2) * d])
+        if k % 4 == 1:
+            p += rng.normal(0, 1e-13 * sc, p.shape)
+        elif k % 4 == 2:
+            p = p[rng.permutation(3)]
+        elif k % 4 == 3:
+            p = rng.normal(0, sc, (3, 2))
+        ref = np.sign(np.linalg.det(np.column_stack((np.ones(3), p))))
+        mine = np.sign(L.fsdo_det3(p.ravel().ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        bad += ref != mine
+        zeros += ref == 0
+    assert bad == 0, (bad, n)
+    assert zeros > n // 10  # exact zeros are part of the contract (the reference then returns curvature 0)
