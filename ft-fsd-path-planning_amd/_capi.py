@@ -149,7 +149,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
     "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
-    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity",
+    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3",
 ]
 
 
@@ -410,6 +410,13 @@ class Context:
         x, a, b = (np.ascontiguousarray(v, np.float64) for v in (x, a, b))
         out = np.zeros((5, len(x)))
         self._check(self._lib.fsdp_selftest_math(self._h, len(x), _dp(x), _dp(a), _dp(b), _dp(out)), "fsdp_selftest_math")
+        return out
+
+    def selftest_det3(self, xy6) -> np.ndarray:
+        """det3_lu of (n,6) rows x0,y0,x1,y1,x2,y2 on the device."""
+        xy6 = np.ascontiguousarray(xy6, np.float64).reshape(-1, 6)
+        out = np.zeros(len(xy6))
+        self._check(self._lib.fsdp_selftest_det3(self._h, len(xy6), _dp(xy6), _dp(out)), "fsdp_selftest_det3")
         return out
 
     def default_path(self) -> np.ndarray:

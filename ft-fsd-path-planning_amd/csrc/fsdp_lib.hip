@@ -410,8 +410,19 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
   const bool split = c->params.max_deg != 3 ? false : (c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH);
   if (!split) {
     mark(q, t, MARK_MAIN);
-    hipLaunchKernelGGL(path_kernel<PATH_G_SMALL>, dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
-                       c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
+    // Plain IEEE divisions / square roots throughout for contexts with max_deg < 3 (and FSDP_EXACT_PATH, experiments): the
+    // shortened sequences of spline_device.h are validated bit for bit on cubic fits (goldens, 786 k fuzz frames); with
+    // max_deg = 1 the path is a polyline, whole curvature windows are exactly collinear, and the sign of a determinant that
+    // is zero up to rounding showed a last-bit difference of unsampled dense points between the two variants on the GPU
+    // (65 of 148 frames of tests/golden/params_deg1.npz; the exact variant equals the oracle on all of them).
+    static const bool exact_env = getenv("FSDP_EXACT_PATH") != nullptr;
+    const bool exact = exact_env || c->params.max_deg != 3;
+    if (exact)
+      hipLaunchKernelGGL((path_kernel<PATH_G_SMALL, false>), dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
+                         c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
+    else
+      hipLaunchKernelGGL(path_kernel<PATH_G_SMALL>, dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
+                         c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
     names += "path_kernel<64>,";
   } else {
     mark(q, t);
@@ -1843,6 +1854,31 @@ extern "C" int fsdp_selftest_math(fsdp_ctx* c, int n, const double* x, const dou
   (void)hipFree(dx);
   (void)hipFree(da);
   (void)hipFree(db);
+  (void)hipFree(dout);
+  HIP_TRY(c, e);
+  return 0;
+}
+
+// det3_lu (path_kernel.h: the sign of numpy.linalg.det of three homogeneous points) element-wise on the device
+__global__ void det3_selftest_kernel(int n, const double* __restrict__ xy6, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* p = xy6 + 6 * (size_t)i;
+  out[i] = det3_lu(p[0], p[1], p[2], p[3], p[4], p[5]);
+}
+extern "C" int fsdp_selftest_det3(fsdp_ctx* c, int n, const double* xy6, double* out) {
+  if (!c || n <= 0 || !xy6 || !out) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *dx = nullptr, *dout = nullptr;
+  HIP_TRY(c, hipMalloc(&dx, sizeof(double) * 6 * (size_t)n));
+  HIP_TRY(c, hipMalloc(&dout, sizeof(double) * (size_t)n));
+  hipError_t e = hipMemcpyAsync(dx, xy6, sizeof(double) * 6 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(det3_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dx, dout);
+    e = hipMemcpyAsync(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dx);
   (void)hipFree(dout);
   HIP_TRY(c, e);
   return 0;

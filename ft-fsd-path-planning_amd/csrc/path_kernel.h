@@ -1169,7 +1169,7 @@ __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* _
 #ifndef FSDP_PATH_WAVES
 #define FSDP_PATH_WAVES 1
 #endif
-template <int G>
+template <int G, bool FAST = true>
 __global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames, const double* __restrict__ poses,
                                                      const MatchOut* __restrict__ matched,
                                                      const double* __restrict__ default_path,
@@ -1181,7 +1181,7 @@ __global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames,
   const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
   PROF_INIT();
   if (frame < n_frames) {
-    path_frame<G, true>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out, prm);
+    path_frame<G, FAST>(S_all[Grp<G>::index()], frame, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out, prm);
     if (retry != nullptr && Grp<G>::lane() == 0 && (out[frame].status == ST_OVERFLOW_KNOTS || out[frame].status == ST_RETRY))
       retry[1 + atomicAdd(&retry[0], 1)] = frame;
   }  // (retry list on the device: used by the emulator harness; the library collects the list on the host)

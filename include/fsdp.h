@@ -312,6 +312,10 @@ int fsdp_debug_refit(fsdp_ctx* ctx, int32_t* n_knots, double* knots34, double* c
  * kernels replace sqrt on [1, 2] and divisions of safe-band operands by shorter sequences that must return the same bits. */
 int fsdp_selftest_math(fsdp_ctx* ctx, int n, const double* x, const double* a, const double* b, double* out5n);
 
+/* The device's restatement of numpy.linalg.det for three homogeneous points (calculate_path/path_parameterization.py:86-92
+ * takes the curvature's sign from it): xy6 = (n,6) rows x0,y0,x1,y1,x2,y2 -> out (n) determinants whose SIGN is NumPy's. */
+int fsdp_selftest_det3(fsdp_ctx* ctx, int n, const double* xy6, double* out);
+
 /* The constant initial previous path (core_calculate_path.py:103-107), (40,4), as computed on the device. */
 int fsdp_default_path(fsdp_ctx* ctx, double* out40x4);
 

@@ -545,3 +545,33 @@ def test_refit_spline_equals_oracle(pkg, ctx):
             assert np.array_equal(c[k, : n - 4], cx[: n - 4]) and np.array_equal(c[k, n : 2 * n - 4], cy[: n - 4]), k
             checked += 1
     assert checked >= 40
+
+
+def test_device_det3_sign_is_numpys(pkg, ctx):
+    """calculate_path/path_parameterization.py:86-92: the sign of the curvature is the sign of np.linalg.det of three
+    homogeneous points — zero up to rounding on a straight stretch.  The device's restatement (path_kernel.h det3_lu,
+    OpenBLAS' getf2 operation order) equals the oracle's bit for bit and NumPy's sign on this machine's NumPy as well."""
+    import ctypes
+
+    rng = np.random.default_rng(3)
+    rows = []
+    for k in range(20000):
+        sc = 10.0 ** rng.uniform(-2, 4)
+        p0, d = rng.normal(0, sc, 2), rng.normal(0, 1, 2)
+        t1, t2 = rng.uniform(0.01, 5, 2)
+        p = np.array([p0, p0 + t1 * d, p0 + (t1 + t2) * d])
+        if k % 4 == 1:
+            p += rng.normal(0, 1e-13 * sc, p.shape)
+        elif k % 4 == 2:
+            p = p[rng.permutation(3)]
+        elif k % 4 == 3:
+            p = rng.normal(0, sc, (3, 2))
+        rows.append(p.ravel())
+    rows = np.array(rows)
+    dev = ctx.selftest_det3(rows)
+    L = oracle_lib.lib()
+    L.fsdo_det3.restype = ctypes.c_double
+    host = np.array([L.fsdo_det3(r.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) for r in rows])
+    assert np.array_equal(dev, host)
+    ref = np.array([np.linalg.det(np.column_stack((np.ones(3), r.reshape(3, 2)))) for r in rows])
+    assert np.array_equal(np.sign(dev), np.sign(ref))
