@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
     ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..16)")
     ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic track (config 2; rank r replays seed + r)")
-    ap.add_argument("--stream-batches", type=int, default=40, help="different batches of the host -> host streaming leg (0: skip)")
+    ap.add_argument("--stream-batches", type=int, default=100, help="different batches of the host -> host streaming leg (0: skip)")
     args = ap.parse_args()
     if os.environ.get("FSDP_HANG_DUMP"):  # diagnostics: Python stacks of all threads after N seconds, then exit
         import faulthandler

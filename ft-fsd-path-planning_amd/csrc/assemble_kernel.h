@@ -107,9 +107,11 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
   }
 }
 
-// First kernel of a ticket's pass when the caller's input buffers are page-locked: the batch comes over PCIe by plain
-// loads from host memory (the GPU maps page-locked host memory into its address space) into the slot's device buffers —
-// up to four segments (offsets, cones, poses, previous paths) in one launch.  Why a kernel and not hipMemcpyAsync: the
+// Host -> device of a batch whose buffers are page-locked, as a kernel: the batch comes over PCIe by plain loads from host
+// memory (the GPU maps page-locked host memory into its address space) into the slot's device buffers — up to four
+// segments (offsets, cones, poses, previous paths) in one launch.  Used by the skidpad steps and by contexts that filter
+// the cones first; an ordinary ticket's batch is read by its sorting kernel itself (sort_kernel.h StageIn: +6 % frames/s
+// over this kernel in front of the pass).  Why a kernel and not hipMemcpyAsync: the
 // copies of the SDMA engines are ordered against the kernels of a stream through cross-engine signals, and with ten
 // streams each alternating copy / kernels / copy the runtime's submission stalled for milliseconds at a time (measured:
 // profiles/r03_streaming.txt); as kernels, a batch's transfers are ordinary packets of its own stream.  16 bytes per lane

@@ -62,6 +62,12 @@ struct Inputs {
   int n_frames = 0;
   int max_cones = 0;      // most cones in a frame (picks the sorting kernel's state size)
   bool use_prev = false;  // d_prev holds this batch's previous paths
+  // the next pass's sorting kernel brings the batch onto the device itself (sort_kernel.h StageIn): device views of the
+  // caller's page-locked buffers, valid for that one launch
+  const int32_t* h_off = nullptr;
+  const double* h_cones = nullptr;
+  const double* h_poses = nullptr;
+  const double* h_prev = nullptr;
 };
 
 // Tickets queue up behind each other on a slot's stream (stream order protects the slot's buffers), so a slot always has
@@ -358,12 +364,24 @@ static void mark(const Work& q, StageEvents* t, MarkKind kind = MARK_PLAIN) {
 static bool sort128(const fsdp_ctx* c, const Inputs& in) { return in.max_cones <= SortShared128::MAX_N && !c->no_sort128; }
 
 static void launch_sort(fsdp_ctx* c, Work& q, const Inputs& in) {
+  StageIn st;
+  if (in.h_off) {
+    st.src_off = in.h_off;
+    st.src_cones = in.h_cones;
+    st.src_poses = in.h_poses;
+    st.src_prev = in.h_prev;
+    st.dst_off = in.d_off;
+    st.dst_cones = in.d_cones;
+    st.dst_poses = in.d_poses;
+    st.dst_prev = in.d_prev;
+    st.n_frames = in.n_frames;
+  }
   if (sort128(c, in))
     hipLaunchKernelGGL(sort_kernel_128, dim3(in.n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_SORT"), q.stream, in.n_frames, in.d_off, in.d_cones,
-                       in.d_poses, q.d_sort, q.d_big, c->d_params);
+                       in.d_poses, q.d_sort, q.d_big, c->d_params, st);
   else
     hipLaunchKernelGGL(sort_kernel, dim3(in.n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_SORT"), q.stream, in.n_frames, in.d_off, in.d_cones, in.d_poses,
-                       q.d_sort, q.d_big, c->d_params);
+                       q.d_sort, q.d_big, c->d_params, st);
 }
 static int launch_sort_big(fsdp_ctx* c, Work& q, const Inputs& in) {
   if (!q.d_sort_big) HIP_TRY(c, hipMalloc(&q.d_sort_big, sizeof(SortSharedBig) * SORT_BIG_BLOCKS));
@@ -464,7 +482,8 @@ static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid, fsdp_frame_r
   // results that go straight to host memory leave at the link's pace: a few hundred wavefronts keep it busy, more would
   // only sit on the SIMDs' wavefront slots with their stores pending while the other slots' kernels wait for a place
   static const int host_blocks = getenv("FSDP_ASM_BLOCKS") ? atoi(getenv("FSDP_ASM_BLOCKS")) : 128;
-  const long long cap = dst ? host_blocks : 16384;
+  static const int dev_blocks = getenv("FSDP_ASM_DEV_BLOCKS") ? atoi(getenv("FSDP_ASM_DEV_BLOCKS")) : 16384;
+  const long long cap = dst ? host_blocks : dev_blocks;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   q.seq++;
@@ -1045,9 +1064,21 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
   const bool in_pinned = !force_sdma && n > 0 && is_pinned(t.off) && is_pinned(t.poses) && (t.total == 0 || is_pinned(t.cones)) &&
                          (!t.prev || is_pinned(t.prev));
   const bool out_pinned = n > 0 && is_pinned(t.user_results);
+  static const bool no_fuse = getenv("FSDP_STAGE_KERNEL") != nullptr;  // experiments: a separate stage_in_kernel in front of the pass
+  q.in.h_off = nullptr;
   {
     TraceStep ts("submit: host -> device");
-    if (in_pinned) {
+    if (in_pinned && !no_fuse && c->params.use_unknown_cones) {
+      // the pass's sorting kernel reads the batch from the caller's buffers and leaves the device copies (StageIn)
+      if (int rc = ensure_inputs(c, q.in, n, t.total, t.prev != nullptr)) return rc;
+      q.in.n_frames = n;
+      q.in.max_cones = t.max_cones;
+      q.in.use_prev = t.prev != nullptr;
+      q.in.h_off = (const int32_t*)device_view(t.off);
+      q.in.h_cones = t.total ? (const double*)device_view(t.cones) : (const double*)device_view(t.poses);  // (never read when total = 0)
+      q.in.h_poses = (const double*)device_view(t.poses);
+      q.in.h_prev = t.prev ? (const double*)device_view(t.prev) : nullptr;
+    } else if (in_pinned) {
       if (int rc = stage_inputs(c, q.in, q.stream, n, t.off, t.cones, t.poses, t.prev, t.total, t.max_cones)) return rc;
     } else if (int rc = upload_inputs(c, q.in, q.stream, n, t.off, t.cones, t.poses, t.prev, t.total, t.max_cones)) {
       return rc;
@@ -1063,6 +1094,7 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
     }
     const bool direct = q.result_dst != nullptr;
     q.result_dst = nullptr;
+    q.in.h_off = nullptr;  // (the views served that one sorting launch)
     q.unverified = false;  // settled by fsdp_collect through the ticket
     if (rc) return rc;
     t.seq = q.seq;

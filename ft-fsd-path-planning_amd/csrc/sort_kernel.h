@@ -1147,14 +1147,48 @@ __device__ inline void combine_sides(SH& S, int& nl, int& nr) {
   nr = rs;
 }
 
+// A ticket whose input buffers are page-locked host memory (fsdp_submit): the sorting kernel is the batch's way onto the
+// device.  Every frame's wavefront reads its offsets, pose and cone block straight from the caller's buffers over PCIe —
+// the cone block is read exactly once anyway, on its way into LDS — and leaves the copies in the slot's device buffers that
+// the kernels behind it (matching, path stage, the route kernels) read.  No separate copy command or copy kernel in front
+// of a pass: its ~0.25 ms of link time hides under the kernel's own work.  src_off == NULL: the inputs are on the device.
+struct StageIn {
+  const int32_t* src_off = nullptr;   // host views (the device's address of the page-locked buffers)
+  const double* src_cones = nullptr;
+  const double* src_poses = nullptr;
+  const double* src_prev = nullptr;   // optional previous paths (n_frames,40,4)
+  int32_t* dst_off = nullptr;         // = the kernel's cone_offsets / cones_xyt / poses arguments, writable
+  double* dst_cones = nullptr;
+  double* dst_poses = nullptr;
+  double* dst_prev = nullptr;
+  int n_frames = 0;
+};
+
 // The sorting stage of one frame on one wavefront; S = the frame state (LDS or global memory).
 template <class SH>
 __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
-                                  const double* __restrict__ poses, SortOut* __restrict__ out) {
+                                  const double* __restrict__ poses, SortOut* __restrict__ out, const StageIn& stage = StageIn()) {
   const int lane = lane_id();
-  const int off = cone_offsets[frame];
-  int n = cone_offsets[frame + 1] - off;
-  const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
+  const bool staging = stage.src_off != nullptr;
+  const int32_t* offs = staging ? stage.src_off : cone_offsets;
+  const double* pose_src = staging ? stage.src_poses : poses;
+  const int off = offs[frame];
+  int n = offs[frame + 1] - off;
+  const int n_all = n;
+  const double px = pose_src[4 * frame + 0], py = pose_src[4 * frame + 1], dx = pose_src[4 * frame + 2], dy = pose_src[4 * frame + 3];
+  if (staging) {
+    if (lane == 0) {
+      stage.dst_off[frame] = off;
+      if (frame == stage.n_frames - 1) stage.dst_off[frame + 1] = off + n;
+      stage.dst_poses[4 * frame + 0] = px;
+      stage.dst_poses[4 * frame + 1] = py;
+      stage.dst_poses[4 * frame + 2] = dx;
+      stage.dst_poses[4 * frame + 3] = dy;
+    }
+    if (stage.src_prev != nullptr)
+      for (int e = lane; e < PATH_POINTS * 4; e += WAVE)
+        stage.dst_prev[(size_t)frame * (PATH_POINTS * 4) + e] = stage.src_prev[(size_t)frame * (PATH_POINTS * 4) + e];
+  }
   SortOut* o = &out[frame];
   int status = ST_OK;
   if (n > SH::MAX_N) {
@@ -1163,9 +1197,11 @@ __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32
   }
   // stage the frame's cones: coalesced loads of the (n,3) row-major block (lane = consecutive doubles)
   {
-    const double* src = cones_xyt + 3 * (size_t)off;
+    const double* src = (staging ? stage.src_cones : cones_xyt) + 3 * (size_t)off;
+    double* copy = staging ? stage.dst_cones + 3 * (size_t)off : nullptr;
     for (int e = lane; e < 3 * n; e += WAVE) {
       double v = src[e];
+      if (staging) copy[e] = v;
       int i = e / 3, c = e - 3 * i;
       if (c == 0)
         S.x[i] = v;
@@ -1174,6 +1210,9 @@ __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32
       else
         S.type[i] = (uint8_t)(int)v;
     }
+    // (a frame beyond this state's capacity is planned by sort_big_kernel from the device copy: it needs all of its cones there)
+    if (staging && n != n_all)
+      for (int e = lane; e < 3 * n_all; e += WAVE) copy[e] = src[e];
   }
   __syncthreads();
   // per-cone scalars of mask_cone_can_be_first_in_config (core_trace_sorter.py:379-407)
@@ -1247,11 +1286,12 @@ __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32
 template <class SH>
 __device__ __forceinline__ void sort_kernel_body(SH& S, int n_frames, const int32_t* __restrict__ cone_offsets,
                                                  const double* __restrict__ cones_xyt, const double* __restrict__ poses,
-                                                 SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
+                                                 SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm,
+                                                 const StageIn& stage) {
   const int frame = blockIdx.x;
   if (frame >= n_frames) return;
   PROF_INIT();
-  sort_frame(S, *prm, frame, cone_offsets, cones_xyt, poses, out);
+  sort_frame(S, *prm, frame, cone_offsets, cones_xyt, poses, out, stage);
   if (big != nullptr && lane_id() == 0 && (out[frame].status == ST_OVERFLOW_CONES || out[frame].status == ST_OVERFLOW_ENDS))
     big[1 + atomicAdd(&big[0], 1)] = frame;
   PROF_FLUSH();
@@ -1261,9 +1301,10 @@ __device__ __forceinline__ void sort_kernel_body(SH& S, int n_frames, const int3
 // two; 40 bytes of spill).
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
 sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
-            const double* __restrict__ poses, SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
+            const double* __restrict__ poses, SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm,
+            StageIn stage = StageIn()) {
   __shared__ SortShared S;
-  sort_kernel_body(S, n_frames, cone_offsets, cones_xyt, poses, out, big, prm);
+  sort_kernel_body(S, n_frames, cone_offsets, cones_xyt, poses, out, big, prm, stage);
 }
 // The same code over a state for up to 128 cones (the host launches it when no frame of the batch holds more): the cone
 // arrays, neighbour lists and bit masks are half as long, which makes a frame SORT128_LDS and lets a SIMD hold
@@ -1273,9 +1314,10 @@ sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets, const double
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SORT128_WAVES)))
 sort_kernel_128(int n_frames, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,
-                const double* __restrict__ poses, SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm) {
+                const double* __restrict__ poses, SortOut* __restrict__ out, int* __restrict__ big, const Params* __restrict__ prm,
+                StageIn stage = StageIn()) {
   __shared__ SortShared128 S;
-  sort_kernel_body(S, n_frames, cone_offsets, cones_xyt, poses, out, big, prm);
+  sort_kernel_body(S, n_frames, cone_offsets, cones_xyt, poses, out, big, prm, stage);
 }
 
 // The frames sort_kernel could not hold in LDS, with the frame state in global memory (one SortSharedBig per block).
