@@ -22,7 +22,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "lib" / "libfsdp_hip.so"
 
-MAX_LEN, MAX_MATCH, PATH_POINTS, MAX_CONES = 12, 24, 40, 1024
+MAX_LEN, MAX_MATCH, PATH_POINTS, MAX_CONES = 12, 24, 40, 8192
 MAX_STAGES = 8  # FSDP_MAX_STAGES
 
 # numpy mirror of fsdp_frame_result (include/fsdp.h)

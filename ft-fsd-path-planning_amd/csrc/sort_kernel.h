@@ -36,7 +36,7 @@ namespace fsdp {
 
 // The frame state of the sorting stage.  Two instantiations: the product kernel keeps it in LDS (up to 255 cones with
 // one-byte indices, 64 raw end configurations per side); frames beyond either capacity are planned again by
-// sort_big_kernel with the same code over a state in global memory (1024 cones, 4096 raw end configurations) — the
+// sort_big_kernel with the same code over a state in global memory (8192 cones, 4096 raw end configurations) — the
 // reference's own buffers grow without bound (adjacency_matrix.py:21-31, end_configurations.py:74-105,346-348).
 template <int CAP_, class IDX_, int ENDS_>
 struct SortSharedT {
@@ -97,7 +97,7 @@ struct SortSharedT {
 };
 using SortShared = SortSharedT<MAX_CONES, uint8_t, MAX_ENDS>;          // LDS, product kernel
 using SortShared128 = SortSharedT<128, uint8_t, MAX_ENDS>;             // LDS, batches whose frames hold <= 128 cones
-constexpr int BIG_CONES = 1024, BIG_ENDS = 4096;
+constexpr int BIG_CONES = 8192, BIG_ENDS = 4096;  // (indices are int16: up to 32 766 would fit; a state is ~0.7 MB of HBM)
 using SortSharedBig = SortSharedT<BIG_CONES, int16_t, BIG_ENDS>;        // global memory, sort_big_kernel
 
 // ---- trace_sorter/line_segment_intersection.py:136-200 (epsilon 1e-6) ----

@@ -32,7 +32,7 @@ extern "C" {
 #define FSDP_MAX_LEN 12      /* config.py:36 max_length                         */
 #define FSDP_MAX_MATCH 24    /* cones incl. virtual per side after matching     */
 #define FSDP_PATH_POINTS 40  /* config.py:58 mpc_prediction_horizon             */
-#define FSDP_MAX_CONES 1024  /* cones per frame (frames beyond 255 are sorted with their state in global memory) */
+#define FSDP_MAX_CONES 8192  /* cones per frame (frames beyond 255 are sorted with their state in global memory) */
 
 /* ConeTypes — utils/cone_types.py:10-19 (values are part of the input format) */
 enum { FSDP_CONE_UNKNOWN = 0, FSDP_CONE_RIGHT = 1, FSDP_CONE_LEFT = 2, FSDP_CONE_ORANGE_SMALL = 3, FSDP_CONE_ORANGE_BIG = 4 };
@@ -46,7 +46,7 @@ enum {
   FSDP_REF_UNDEFINED_PATH = 103,      /* core_calculate_path.py:482-483 / second fallback    */
   FSDP_REF_UNDEFINED_MATCH_IDX = 104, /* core_calculate_path.py:544 index into empty array   */
   /* fixed device capacities exceeded (the reference's buffers grow without bound) */
-  FSDP_OVERFLOW_CONES = 201, /* more than 1024 cones in a frame */
+  FSDP_OVERFLOW_CONES = 201, /* more than 8192 cones in a frame */
   FSDP_OVERFLOW_ENDS = 202,  /* more than 4096 raw end configurations on one side */
   FSDP_OVERFLOW_PATH = 203,
   FSDP_OVERFLOW_KNOTS = 204, /* more than 64 knots (fits beyond the packed kernels' capacity are re-planned by the one-frame-per-wavefront kernel) */

@@ -169,22 +169,31 @@ def test_reference_shaped_single_frame_call(pkg, golden_dir):
 
 
 def test_edge_cases(pkg, ctx):
-    # empty batch, empty frames, < 3 cones, 300 random cones (beyond the LDS kernel: planned with the state in global
-    # memory), more cones than the library takes at all (status 201, no silent truncation)
+    # empty batch, empty frames, < 3 cones, 300 random cones, track frames of 1400 coloured / 3000 colourless cones (beyond
+    # the LDS kernel: planned with the state in global memory), more cones than the library takes at all (status 201, no
+    # silent truncation)
     assert len(ctx.plan_batch(np.zeros(1, np.int32), np.zeros((0, 3)), np.zeros((0, 4)))) == 0
-    off = np.array([0, 0, 1, 3, 3 + 300, 3 + 300 + 1100], np.int32)
     rng = np.random.default_rng(0)
-    cones = np.concatenate([np.array([[2.0, 1.5, 2]]), np.array([[2.0, 1.5, 2], [2.0, -1.5, 1]]),
-                            np.column_stack([rng.uniform(-30, 30, (300, 2)), np.zeros(300)]),
-                            np.column_stack([rng.uniform(-60, 60, (1100, 2)), np.zeros(1100)])])
-    poses = np.tile(np.array([0.0, 0, 1, 0]), (5, 1))
+    o1, c1, p1 = pkg.synth.make_replay_batch(1, 700, 0.1, seed=3, color=True)
+    o2, c2, p2 = pkg.synth.make_replay_batch(1, 1500, 0.1, seed=3, color=False)
+    blocks = [np.zeros((0, 3)), np.array([[2.0, 1.5, 2]]), np.array([[2.0, 1.5, 2], [2.0, -1.5, 1]]),
+              np.column_stack([rng.uniform(-30, 30, (300, 2)), np.zeros(300)]), c1, c2,
+              np.column_stack([rng.uniform(-150, 150, (8300, 2)), np.zeros(8300)])]
+    off = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.int32)
+    cones = np.concatenate(blocks)
+    poses = np.tile(np.array([0.0, 0, 1, 0]), (len(blocks), 1))
+    poses[4], poses[5] = p1[0], p2[0]
     r = ctx.plan_batch(off, cones, poses)
     with oracle_lib.math_mode(1):
-        ref = oracle_lib.plan_batch(off[:5], cones[: off[4]], poses[:4])
-    assert (r["status"][:3] == 0).all() and r["status"][4] == 201
-    assert r["status"][3] == ref["status"][3]
-    assert np.array_equal(r["left_idx"][3], ref["left_idx"][3]) and np.array_equal(r["right_idx"][3], ref["right_idx"][3])
-    assert np.nanmax(np.abs(r["path"][:4] - ref["path"])) < 1e-9 if np.isfinite(ref["path"]).any() else True
+        ref = oracle_lib.plan_batch(off[:7], cones[: off[6]], poses[:6])
+    assert (r["status"][:3] == 0).all() and r["status"][6] == 201
+    for k in (3, 4, 5):
+        assert r["status"][k] == ref["status"][k]
+        assert np.array_equal(r["left_idx"][k], ref["left_idx"][k]) and np.array_equal(r["right_idx"][k], ref["right_idx"][k]), k
+    assert r["n_left"][4] >= 10 and r["n_right"][4] >= 10 and r["n_left"][5] >= 8  # the big frames really are planned
+    ok = ref["status"] == 0
+    assert np.array_equal(np.isnan(r["path"][:6][ok]), np.isnan(ref["path"][ok]))
+    assert np.nanmax(np.abs(r["path"][:6][ok] - ref["path"][ok])) < 1e-9
     assert (r["n_left"][:3] == 0).all() and (r["path_fallback"][:3] & 1).all()
 
 
