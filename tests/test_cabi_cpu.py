@@ -22,7 +22,7 @@ def pkg():
 
 def test_library_exports_every_declared_symbol(pkg):
     header = (ROOT / "include" / "fsdp.h").read_text()
-    declared = set(re.findall(r"\b(fsdp_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(fsdp_[a-z0-9_]+)\s*\(", header))
     declared -= {"fsdp_ctx"}
     lib = ctypes.CDLL(str(pkg._capi.LIB_PATH))
     for sym in sorted(declared):
