@@ -73,14 +73,14 @@ for tk in inflight:
 d.barrier()
 el = d.max_over_ranks(time.perf_counter() - t0)
 assert np.array_equal(res["path"], ref_last, equal_nan=True), "pipelined steps differ from one-at-a-time steps"
-kms = batch.time_path(10) / 10
+kms = batch.time_path(10) / 10  # the path kernel repeated on the LAST frame of the replay (the car stands at the end of the track: the shortest path of the run)
 reloc = d.sum_over_ranks(float(info["relocalized"].sum()))
 bad = d.sum_over_ranks(float(status.sum()))
 if rank == 0:
     print(json.dumps({"config": "BASELINE configs[4]: skidpad, batch=%d perturbed starts x %d frames on %d GPU(s)" % (n_total, T, d.world),
                       "frames_per_s_incl_pcie": n_total * T / el, "seconds": el, "steps_in_flight": DEPTH,
                       "frames_per_s_incl_pcie_one_step_at_a_time": n_total * T / el_step, "relocalized": int(reloc),
-                      "frames_with_nonzero_status": int(bad), "skid_path_kernel_ms_per_step": kms,
-                      "frames_per_s_kernel_only_per_gpu": n / (kms * 1e-3),
+                      "frames_with_nonzero_status": int(bad), "ms_per_step": el / T * 1e3, "skid_path_kernel_ms_on_the_last_frame": kms,
+                      "note": "GPU-bound: one wavefront per planner instance, a step is the latency of one path stage (rocprofv3: the stream is busy 99 % of the run, profiles/r03_skidpad.txt); the transfers are kernels of the same stream",
                       "tables": ("rank 0 loads them, broadcast to the others; communicator " + d.describe()) if d.world > 1 or d._active else "single process"}))
 d.close()
