@@ -161,7 +161,7 @@ struct fsdp_ctx {
   int outstanding = 0;  // tickets submitted and not yet collected
   // The route kernels (sort_big_kernel, path_retry_kernel) are launched only when a pass is expected to need them: a pass
   // that turns out to need a kernel it did not get is re-run with it before anybody sees its results (verify_pass), and
-  // from then on the kernel is part of every pass until ROUTE_DECAY passes in a row came back with an empty list.
+  // from then on the kernel is part of every pass until ROUTE_DECAY (4096) passes in a row came back with an empty list.
   bool expect_big = false, expect_retry = false;
   int clean_big = 0, clean_retry = 0;
   bool always_route = getenv("FSDP_ALWAYS_ROUTE") != nullptr;  // experiments: launch both route kernels with every pass
@@ -189,7 +189,9 @@ struct fsdp_ctx {
   PathOut* h_path = nullptr;
   int cap_staging = 0;
 };
-constexpr int ROUTE_DECAY = 64;
+// (an empty route launch costs a stream ~1 % of a pass; a pass repeated because the kernel was missing costs a whole pass and
+// stalls the caller's collect: once needed, a route stays for a long time)
+constexpr int ROUTE_DECAY = 4096;
 
 #define HIP_TRY(ctx, call)                                                                       \
   do {                                                                                           \

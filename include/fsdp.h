@@ -207,7 +207,7 @@ int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
  * capacities; path_retry_kernel: the exact one-frame-per-wavefront path stage) are launched with a pass only when the
  * context expects them to be needed; the last kernel of every pass reports the hand-off lists' lengths, and a pass that
  * needed a kernel it was not given is run again with it before its results are handed out (then the kernel stays part of
- * every pass until 64 passes in a row did not need it).  Results never depend on this.  Diagnostics: */
+ * every pass until 4096 passes in a row did not need it).  Results never depend on this.  Diagnostics: */
 int fsdp_route_stats(fsdp_ctx* ctx, int* expect_big, int* expect_retry, long long* reruns);
 
 /* Enqueue `iters` back-to-back passes over the resident batch (rotating through the slots when passes overlap; no host

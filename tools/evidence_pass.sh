@@ -1,21 +1,23 @@
 #!/bin/bash
-# evidence pass: everything profiles/ holds for the round, with the library build of this snapshot
+# evidence pass of round 3: everything profiles/ holds for the round, taken with the library build of this snapshot.
+# Every command runs under `timeout` (a hung process would cost the box's whole limit).
 set -u
-R=gpurun_out/r02
+R=gpurun_out/r03
 mkdir -p $R
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $R/gpu_tests.txt
-python __graft_entry__.py smoke >> $R/gpu_tests.txt 2>&1
-bash tools/profile_gpu.sh r02 > $R/profile.log 2>&1
-cp gpurun_out/prof_r02/pmc_traffic.json profiles/pmc_traffic.json   # so that the bench lines below carry traffic / insts
-python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $R/bench_line.json
-python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_line_100steps.json
-python bench.py --config 4 --frames 8192 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_cfg4_shard.json
-FSDP_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_line_rccl_1rank.json
-python tools/bench_configs.py > $R/bench_configs.jsonl 2>&1
-python tools/batch_sweep.py > $R/batch_sweep.jsonl 2>&1
-python tools/overlap_depths.py default > $R/overlap_depths.txt 2>&1
-python tools/latency_breakdown.py > $R/latency_breakdown.txt 2>&1
-( echo "== fit_kernel<4> =="; python tools/section_profile.py; echo; echo "== path_prep_kernel<8> =="; python tools/section_profile.py --kernel=prep | tail -22; echo; echo "== path_finish_kernel<8> =="; python tools/section_profile.py --kernel=finish | tail -22; echo; echo "== sort_kernel, coloured =="; python tools/section_profile_sort.py ) > $R/kernel_sections.txt 2>&1
-( python tools/bench_skidpad.py; FSDP_FORCE_DIST=1 python tools/bench_skidpad.py ) > $R/skidpad.jsonl 2>&1
-
-cat $R/gpu_tests.txt; cut -c1-300 $R/bench_line.json
+T="timeout 600"
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $R/gpu_tests.txt
+$T python __graft_entry__.py smoke >> $R/gpu_tests.txt 2>&1
+timeout 2400 bash tools/profile_gpu.sh r03 > $R/profile.log 2>&1
+cp gpurun_out/prof_r03/pmc_traffic.json profiles/pmc_traffic.json   # so that the bench lines below carry traffic / insts
+$T python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $R/bench_line.json
+$T python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-latency 2>/dev/null | tail -1 > $R/bench_line_100steps.json
+$T python bench.py --config 4 --frames 8192 --no-cpu-baseline --no-latency 2>/dev/null | tail -1 > $R/bench_cfg4_shard.json
+FSDP_FORCE_DIST=1 $T python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-latency --stream-batches 0 2>/dev/null | grep '^{' | tail -1 > $R/bench_line_torchrun_rccl_1rank.json
+FSDP_SHARE_GPU=1 FSDP_RCCL_INIT_TIMEOUT=40 $T python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --no-latency --stream-batches 0 2>$R/bench_2ranks.err | grep '^{' | tail -1 > $R/bench_line_2ranks_one_gpu_tcp_fallback.json
+$T python tools/stream_probe.py > $R/streaming.jsonl 2>&1
+( $T python tools/bench_skidpad.py 1024; $T python tools/bench_skidpad.py 4096 ) > $R/skidpad.jsonl 2>&1
+$T python tools/bench_configs.py > $R/bench_configs.jsonl 2>&1
+$T python tools/latency_breakdown.py > $R/latency_breakdown.txt 2>&1
+$T python tools/overlap_depths.py default > $R/overlap_depths.txt 2>&1
+timeout 1500 python tests/fuzz_gpu_vs_oracle.py 2048 > $R/fuzz_gpu_vs_oracle.txt 2>&1
+cat $R/gpu_tests.txt; cut -c1-300 $R/bench_line.json; tail -3 $R/fuzz_gpu_vs_oracle.txt
