@@ -430,13 +430,8 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
   const bool split = c->params.max_deg != 3 ? false : (c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH);
   if (!split) {
     mark(q, t, MARK_MAIN);
-    // Plain IEEE divisions / square roots throughout for contexts with max_deg < 3 (and FSDP_EXACT_PATH, experiments): the
-    // shortened sequences of spline_device.h are validated bit for bit on cubic fits (goldens, 786 k fuzz frames); with
-    // max_deg = 1 the path is a polyline, whole curvature windows are exactly collinear, and the sign of a determinant that
-    // is zero up to rounding showed a last-bit difference of unsampled dense points between the two variants on the GPU
-    // (65 of 148 frames of tests/golden/params_deg1.npz; the exact variant equals the oracle on all of them).
-    static const bool exact_env = getenv("FSDP_EXACT_PATH") != nullptr;
-    const bool exact = exact_env || c->params.max_deg != 3;
+    // FSDP_EXACT_PATH (experiments / diagnostics): the instantiation with plain IEEE divisions and square roots throughout
+    static const bool exact = getenv("FSDP_EXACT_PATH") != nullptr;
     if (exact)
       hipLaunchKernelGGL((path_kernel<PATH_G_SMALL, false>), dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
                          c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
@@ -1850,6 +1845,16 @@ extern "C" int fsdp_debug_refit(fsdp_ctx* c, int32_t* n_knots, double* knots34, 
     memcpy(knots34 + (size_t)i * 34, recs[i].t, sizeof(double) * 34);
     memcpy(coeffs68 + (size_t)i * 68, recs[i].c, sizeof(double) * 68);
   }
+  return 0;
+}
+
+// raw doubles of a frame's scratch arena of the most recent pass (tests / debug builds)
+extern "C" int fsdp_debug_arena(fsdp_ctx* c, int frame, int offset, int count, double* out) {
+  if (!c || !out || frame < 0 || frame >= c->last_n || offset < 0 || count < 0 || offset + count > ARENA_DOUBLES) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = sync_all(c)) return rc;
+  Work& q = c->slot[c->last_slot];
+  HIP_TRY(c, copy_sync(c, out, q.d_arena + (size_t)frame * ARENA_DOUBLES + offset, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -492,6 +492,15 @@ __device__ __forceinline__ int parameterize_path(PS& S, const Arena& A, int off,
   }
   *n_dense = L;
   GR::sync();
+#ifdef FSDP_DEBUG_DENSE
+  // debug builds: the dense samples and the raw curvature where fsdp_debug_arena can read them (the polyline is dead here)
+  for (int i = lane; i < L; i += G) {
+    A.x[i] = DX[i];
+    A.y[i] = DY[i];
+    A.u[i] = curv[i];
+  }
+  GR::sync();
+#endif
   return 0;
 }
 

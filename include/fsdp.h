@@ -307,6 +307,9 @@ int fsdp_comm_destroy(fsdp_ctx* ctx);        /* also done by fsdp_destroy */
  * coefficients (n_frames,68) = x coefficients [0,n) then y coefficients [n,2n). */
 int fsdp_debug_refit(fsdp_ctx* ctx, int32_t* n_knots, double* knots34, double* coeffs68);
 
+/* Raw doubles [offset, offset + count) of frame `frame`'s scratch arena after the most recent pass (tests, debug builds). */
+int fsdp_debug_arena(fsdp_ctx* ctx, int frame, int offset, int count, double* out);
+
 /* Self-test of the device's hand-rolled FP64 sequences against the compiler's IEEE operations (n elements each; out5n =
  * [sqrt_1_2(x) | sqrt(x) | fast quotient a/b | IEEE a/b | operands inside the fast division's exponent band]): the spline
  * kernels replace sqrt on [1, 2] and divisions of safe-band operands by shorter sequences that must return the same bits. */
