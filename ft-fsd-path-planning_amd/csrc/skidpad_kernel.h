@@ -449,19 +449,23 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
   const double rcx = st->right_calc[0], rcy = st->right_calc[1];
   int n1 = 0;
   int new_index = st->index_along_path;
-  if (status == ST_OK) {
+  if (status == ST_OK && reloc) {
+    // full_pipeline.py:126-134: pose into the known map frame
+    double yaw = detm::det_atan2(dy, dx);
+    double sn, cs;
+    detm::det_sincos(rotation, sn, cs);
+    double qx = px + tx - T.ref_right[0], qy = py + ty - T.ref_right[1];
+    double rx = blas_dot2(qx, cs, qy, -sn), ry = blas_dot2(qx, sn, qy, cs);
+    px = rx + T.ref_right[0];
+    py = ry + T.ref_right[1];
+    yaw = yaw + rotation;
+    detm::det_sincos(yaw, dy, dx);
+  }
+  // the path update of this step into the arena polyline [1, 1 + n1): the window of the known path behind the closest
+  // point (SkidpadCalculatePath.fit_matches_as_spline, skidpad_calculate_path.py:49-71) or, before relocalization, the
+  // trivial path (calculate_trivial_path, core_calculate_path.py:127-134: chord[1:] rotated by the car yaw, + position)
+  auto fill_update = [&]() {
     if (reloc) {
-      // full_pipeline.py:126-134: pose into the known map frame
-      double yaw = detm::det_atan2(dy, dx);
-      double sn, cs;
-      detm::det_sincos(rotation, sn, cs);
-      double qx = px + tx - T.ref_right[0], qy = py + ty - T.ref_right[1];
-      double rx = blas_dot2(qx, cs, qy, -sn), ry = blas_dot2(qx, sn, qy, cs);
-      px = rx + T.ref_right[0];
-      py = ry + T.ref_right[1];
-      yaw = yaw + rotation;
-      detm::det_sincos(yaw, dy, dx);
-      // SkidpadCalculatePath.fit_matches_as_spline (skidpad_calculate_path.py:49-71)
       const int max_change = (int)(20 / T.mean_distance);
       int lo = st->index_along_path - max_change;
       lo = lo < 0 ? 0 : lo;
@@ -490,7 +494,6 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
         }
       }
     } else {
-      // calculate_trivial_path (core_calculate_path.py:127-134): chord[1:] rotated by the car yaw, + position
       double yaw = detm::det_atan2(dy, dx);
       double sn, cs;
       detm::det_sincos(yaw, sn, cs);
@@ -502,8 +505,21 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
       }
     }
     __syncthreads();
+  };
+  if (status == ST_OK) fill_update();
+  // The path stage with the shortened division / square-root sequences (spline_device.h: the same bits for operands inside
+  // their exponent band); a step that meets an operand outside the band (ST_RETRY) is planned again with the plain ones.
+  if (status == ST_OK) {
+    status = finish_path<WAVE, true>(S, A, n1, px, py, dx, dy, &st->prev[0][0], o->path, &fallback, &n_dense);
+    if (status == ST_RETRY || status == ST_OVERFLOW_KNOTS) {
+      __syncthreads();
+      status = ST_OK;
+      fallback = 0;
+      n_dense = 0;
+      fill_update();
+      if (status == ST_OK) status = finish_path<WAVE, false>(S, A, n1, px, py, dx, dy, &st->prev[0][0], o->path, &fallback, &n_dense);
+    }
   }
-  if (status == ST_OK) status = finish_path<WAVE, false>(S, A, n1, px, py, dx, dy, &st->prev[0][0], o->path, &fallback, &n_dense);
   __syncthreads();
   if (status == ST_OK) {
     // previous_paths[-1] <- this result (map frame); then path xy back to the original frame (full_pipeline.py:178-194)
