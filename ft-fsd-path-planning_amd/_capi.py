@@ -149,7 +149,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
     "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
-    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena",
+    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena", "fsdp_selftest_absminmax",
 ]
 
 
@@ -410,6 +410,13 @@ class Context:
         x, a, b = (np.ascontiguousarray(v, np.float64) for v in (x, a, b))
         out = np.zeros((5, len(x)))
         self._check(self._lib.fsdp_selftest_math(self._h, len(x), _dp(x), _dp(a), _dp(b), _dp(out)), "fsdp_selftest_math")
+        return out
+
+    def selftest_absminmax(self, a, b) -> np.ndarray:
+        """(2, n): max(|a|, b), min(|a|, b) as the device's Givens step computes them."""
+        a, b = (np.ascontiguousarray(v, np.float64) for v in (a, b))
+        out = np.zeros((2, len(a)))
+        self._check(self._lib.fsdp_selftest_absminmax(self._h, len(a), _dp(a), _dp(b), _dp(out)), "fsdp_selftest_absminmax")
         return out
 
     def selftest_det3(self, xy6) -> np.ndarray:

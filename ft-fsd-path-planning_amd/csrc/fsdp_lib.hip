@@ -1872,6 +1872,34 @@ __global__ void math_selftest_kernel(int n, const double* __restrict__ x, const 
   out[3 * (size_t)n + i] = a[i] / b[i];
   out[4 * (size_t)n + i] = (in_div_band(a[i]) && in_div_band(b[i])) ? 1.0 : 0.0;
 }
+// max_abs_nn / min_abs_nn (the one-instruction max(|a|, b) / min(|a|, b) of the Givens step) element-wise: out = [max | min]
+__global__ void absminmax_selftest_kernel(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = max_abs_nn(a[i], b[i]);
+  out[(size_t)n + i] = min_abs_nn(a[i], b[i]);
+}
+extern "C" int fsdp_selftest_absminmax(fsdp_ctx* c, int n, const double* a, const double* b, double* out2n) {
+  if (!c || n <= 0 || !a || !b || !out2n) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  HIP_TRY(c, hipMalloc(&da, bytes));
+  HIP_TRY(c, hipMalloc(&db, bytes));
+  HIP_TRY(c, hipMalloc(&dout, 2 * bytes));
+  hipError_t e = hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(absminmax_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, da, db, dout);
+    e = hipMemcpyAsync(out2n, dout, 2 * bytes, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  HIP_TRY(c, e);
+  return 0;
+}
 
 extern "C" int fsdp_selftest_math(fsdp_ctx* c, int n, const double* x, const double* a, const double* b, double* out5n) {
   if (!c || n <= 0 || !x || !a || !b || !out5n) return 1;

@@ -315,6 +315,10 @@ int fsdp_debug_arena(fsdp_ctx* ctx, int frame, int offset, int count, double* ou
  * kernels replace sqrt on [1, 2] and divisions of safe-band operands by shorter sequences that must return the same bits. */
 int fsdp_selftest_math(fsdp_ctx* ctx, int n, const double* x, const double* a, const double* b, double* out5n);
 
+/* max(|a|, b) and min(|a|, b) as the Givens step of the spline kernels takes them (one v_max_f64 / v_min_f64 with an
+ * absolute-value source modifier: spline_device.h max_abs_nn / min_abs_nn): out2n = [max (n) | min (n)]. */
+int fsdp_selftest_absminmax(fsdp_ctx* ctx, int n, const double* a, const double* b, double* out2n);
+
 /* The device's restatement of numpy.linalg.det for three homogeneous points (calculate_path/path_parameterization.py:86-92
  * takes the curvature's sign from it): xy6 = (n,6) rows x0,y0,x1,y1,x2,y2 -> out (n) determinants whose SIGN is NumPy's. */
 int fsdp_selftest_det3(fsdp_ctx* ctx, int n, const double* xy6, double* out);

@@ -496,6 +496,23 @@ def test_device_math_helpers(ctx):
     assert (o2[4] == 0.0).all()
 
 
+def test_device_abs_min_max_on_special_operands(ctx):
+    """max_abs_nn / min_abs_nn (inline v_max_f64 |a|, b / v_min_f64 |a|, b — the emulator replaces them by compares) on
+    everything a pivot / diagonal pair can be: ordinary values, +-0, denormals, equal magnitudes, infinities.  With a NaN
+    operand the instructions return the *other* operand (IEEE maxNum / minNum) where the compare form would hand NaN on; the
+    Givens step is only reached with finite rows (a NaN coordinate ends a frame in the stages before), so the contract is
+    'never NaN' and the test pins what the hardware does."""
+    rng = np.random.default_rng(1)
+    sp = np.array([0.0, -0.0, 5e-324, -5e-324, 2.2250738585072014e-308, -1e-310, 1.0, -1.0, 3.5, -3.5, 1e300, -1e300, np.inf, -np.inf])
+    a = np.concatenate([np.repeat(sp, len(sp)), rng.normal(0, 1, 1000) * 10.0 ** rng.uniform(-200, 200, 1000)])
+    b = np.abs(np.concatenate([np.tile(sp, len(sp)), rng.normal(0, 1, 1000) * 10.0 ** rng.uniform(-200, 200, 1000)]))  # ww >= 0
+    out = ctx.selftest_absminmax(a, b)
+    assert np.array_equal(out[0], np.maximum(np.abs(a), b)) and np.array_equal(out[1], np.minimum(np.abs(a), b))
+    assert not np.signbit(out[0][(a == 0) & (b == 0)]).any()  # |−0| = +0: no negative zero leaves the step
+    nan = ctx.selftest_absminmax(np.array([np.nan, 2.0]), np.array([3.0, np.nan]))
+    assert nan[0][0] == 3.0 and nan[1][0] == 3.0 and nan[0][1] == 2.0 and nan[1][1] == 2.0
+
+
 def test_large_sequential_batch_keeps_previous_paths_on_every_route(pkg, ctx, golden_dir):
     """A lock-step batch above the small-batch threshold (three-kernel path stage) with a caller-supplied previous path per
     frame: frames that fall back to their previous path (few cones), frames the fast kernels hand to the exact kernel
