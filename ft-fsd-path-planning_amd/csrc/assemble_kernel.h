@@ -1,9 +1,9 @@
 // Last kernel of a pass: the three stage records of every frame -> one fsdp_frame_result (include/fsdp.h) in HBM, laid out
 // exactly as the C ABI hands it to the caller, so the result leaves the GPU with ONE device-to-host copy straight into the
 // caller's (pinned) buffer and the host never touches a frame (it used to rebuild 2.4 KB per frame from three copies: at
-// 5 M frames/s that is 12 GB/s of host memcpy on one thread).  Pure data movement: one lane per 4-byte word, consecutive
-// lanes on consecutive words of the destination, every source run contiguous (the records are written once by the stage
-// kernels and read once here: 2.4 KB in, 2.4 KB out per frame, ~20 MB per 4096-frame pass).
+// 5 M frames/s that is 12 GB/s of host memcpy on one thread).  Pure data movement: consecutive lanes on consecutive 4-byte
+// words of the destination, every source run contiguous (the records are written once by the stage
+// kernels and read once here: 2.4 KB in, 2.4 KB out per frame, ~20 MB per 4096-frame pass).  One wavefront per frame.
 //
 // It also closes the pass's bookkeeping on the device: the lengths of the two hand-off lists (frames beyond the sorting
 // kernel's LDS capacities; frames for the exact path kernel) go to the slot's host-visible trailer and the counters are
@@ -42,56 +42,54 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
                                                         int seq, const int32_t* __restrict__ extra_src = nullptr, int32_t* __restrict__ extra_dst = nullptr,
                                                         int extra_words = 0, const int32_t* __restrict__ remap = nullptr,
                                                         const int32_t* __restrict__ remap_off = nullptr) {
-  const long long total = (long long)n_frames * RESULT_WORDS;
+  // One wavefront per frame and trip: the result is five contiguous runs of its stage records (the static_asserts below
+  // pin the layouts), each copied by consecutive lanes on consecutive 4-byte words — a handful of instructions per 64 words
+  // (a per-word lookup of "which record, which word" was 636 wave-instructions per frame, this is ~120).
   const int32_t* s32 = (const int32_t*)sorted;
   const int32_t* m32 = (const int32_t*)matched;
   const int32_t* p32 = (const int32_t*)paths;
   int32_t* r32 = (int32_t*)results;
   constexpr int SW = (int)(sizeof(SortOut) / 4), MW = (int)(sizeof(MatchOut) / 4), PW = (int)(sizeof(PathOut) / 4);
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int f = (int)(idx / RESULT_WORDS);
-    const int w = (int)(idx - (long long)f * RESULT_WORDS);
+  const int lane = (int)(threadIdx.x & 63);
+  const int waves_per_block = (int)(blockDim.x >> 6);
+  const long long wave0 = (long long)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+  const long long n_waves = (long long)gridDim.x * waves_per_block;
+  for (long long f = wave0; f < n_frames; f += n_waves) {
     const int32_t* s = s32 ? s32 + (size_t)f * SW : nullptr;
     const int32_t* m = m32 ? m32 + (size_t)f * MW : nullptr;
     const int32_t* p = p32 + (size_t)f * PW;
-    int32_t v;
-    if (w >= FSDP_RW(path) && w < FSDP_RW(n_configs_left)) {
-      v = p[FSDP_PW(path) + (w - FSDP_RW(path))];
-    } else if (w >= FSDP_RW(left_v) && w < FSDP_RW(path)) {  // left_v | right_v | l2r | r2l: contiguous in both structs
-      if (m)
-        v = m[FSDP_MW(left_v) + (w - FSDP_RW(left_v))];
-      else
-        v = (w >= FSDP_RW(l2r)) ? -1 : 0;
-    } else if (w == FSDP_RW(status)) {
-      // fsdp_lib.hip assemble(): the latest stage that reported something decides
+    int32_t* r = r32 + (size_t)f * RESULT_WORDS;
+    // status: the latest stage that reported something decides (fsdp_lib.hip assemble())
+    if (lane == 0) {
       int st = s ? s[FSDP_SW(status)] : 0;
       if (m && m[FSDP_MW(status)] != 0) st = m[FSDP_MW(status)];
       if (p[FSDP_PW(status)] != 0) st = p[FSDP_PW(status)];
-      v = st;
-    } else if (w < FSDP_RW(n_left_v)) {  // n_left, n_right, left_idx, right_idx: contiguous in both structs
-      if (s)
-        v = s[FSDP_SW(n_left) + (w - FSDP_RW(n_left))];
-      else
-        v = (w >= FSDP_RW(left_idx)) ? -1 : 0;
+      r[FSDP_RW(status)] = st;
+      r[FSDP_RW(n_left_v)] = m ? m[FSDP_MW(n_left_v)] : 0;
+      r[FSDP_RW(n_right_v)] = m ? m[FSDP_MW(n_right_v)] : 0;
+      for (int w = FSDP_RW(n_right_v) + 1; w < FSDP_RW(left_v); w++) r[w] = 0;  // alignment padding
+      r[FSDP_RW(path_fallback)] = p[FSDP_PW(fallback)];
+      r[FSDP_RW(n_dense)] = p[FSDP_PW(n_dense)];
+    }
+    // n_left, n_right, left_idx, right_idx
+    for (int w = FSDP_RW(n_left) + lane; w < FSDP_RW(n_left_v); w += 64) {
+      int32_t v = s ? s[FSDP_SW(n_left) + (w - FSDP_RW(n_left))] : ((w >= FSDP_RW(left_idx)) ? -1 : 0);
       // (use_unknown_cones = False, filter_kernel.h: the sorter saw a compacted frame; indices go out in the caller's index space)
       if (remap && w >= FSDP_RW(left_idx) && v >= 0) v = remap[remap_off[f] + v];
-    } else if (w == FSDP_RW(n_left_v)) {
-      v = m ? m[FSDP_MW(n_left_v)] : 0;
-    } else if (w == FSDP_RW(n_right_v)) {
-      v = m ? m[FSDP_MW(n_right_v)] : 0;
-    } else if (w < FSDP_RW(left_v)) {
-      v = 0;  // alignment padding
-    } else if (w < FSDP_RW(best_cost_left)) {  // n_configs_left/right, first_k_left/right: contiguous in both structs
-      v = s ? s[FSDP_SW(n_configs_left) + (w - FSDP_RW(n_configs_left))] : 0;
-      if (remap && w >= FSDP_RW(first_k_left) && v >= 0) v = remap[remap_off[f] + v];
-    } else if (w < FSDP_RW(path_fallback)) {
-      v = s ? s[FSDP_SW(best_cost_left) + (w - FSDP_RW(best_cost_left))] : 0;
-    } else if (w == FSDP_RW(path_fallback)) {
-      v = p[FSDP_PW(fallback)];
-    } else {
-      v = p[FSDP_PW(n_dense)];
+      r[w] = v;
     }
-    r32[idx] = v;
+    // left_v | right_v | l2r | r2l
+    for (int w = FSDP_RW(left_v) + lane; w < FSDP_RW(path); w += 64)
+      r[w] = m ? m[FSDP_MW(left_v) + (w - FSDP_RW(left_v))] : ((w >= FSDP_RW(l2r)) ? -1 : 0);
+    // path
+    for (int w = FSDP_RW(path) + lane; w < FSDP_RW(n_configs_left); w += 64) r[w] = p[FSDP_PW(path) + (w - FSDP_RW(path))];
+    // n_configs_left / right, first_k_left / right, best_cost_left / right
+    for (int w = FSDP_RW(n_configs_left) + lane; w < FSDP_RW(path_fallback); w += 64) {
+      int32_t v = 0;
+      if (s) v = (w < FSDP_RW(best_cost_left)) ? s[FSDP_SW(n_configs_left) + (w - FSDP_RW(n_configs_left))] : s[FSDP_SW(best_cost_left) + (w - FSDP_RW(best_cost_left))];
+      if (remap && w >= FSDP_RW(first_k_left) && w < FSDP_RW(best_cost_left) && v >= 0) v = remap[remap_off[f] + v];
+      r[w] = v;
+    }
   }
   // a second, plain block of words on the same trip (skidpad steps: the planners' SkidInfo records to the caller's side)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < extra_words; idx += (long long)gridDim.x * blockDim.x)

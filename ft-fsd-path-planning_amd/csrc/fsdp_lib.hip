@@ -474,8 +474,7 @@ static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid, fsdp_frame_r
                             const SkidInfo* info_src = nullptr, SkidInfo* info_dst = nullptr, const int32_t* remap = nullptr,
                             const int32_t* remap_off = nullptr) {
   (void)c;
-  const long long words = (long long)n * RESULT_WORDS;
-  long long blocks = (words + 255) / 256;
+  long long blocks = ((long long)n + 3) / 4;  // one wavefront per frame, four per workgroup (grid-stride beyond the cap)
   // results that go straight to host memory leave at the link's pace: a few hundred wavefronts keep it busy, more would
   // only sit on the SIMDs' wavefront slots with their stores pending while the other slots' kernels wait for a place
   static const int host_blocks = getenv("FSDP_ASM_BLOCKS") ? atoi(getenv("FSDP_ASM_BLOCKS")) : 128;
