@@ -73,7 +73,8 @@ struct Inputs {
 // Tickets queue up behind each other on a slot's stream (stream order protects the slot's buffers), so a slot always has
 // its next batch waiting when the current one ends — the host's collect / submit round trip is off the GPU's critical path.
 constexpr int SLOT_QUEUE = 2;   // tickets per slot
-constexpr int N_TRAILERS = 4;   // pass trailers per slot: two queued tickets + one repeated pass are distinguishable
+constexpr int N_TRAILERS = SLOT_QUEUE + 1;  // pass trailers per slot: one per ticket entry (a ticket may stay uncollected while the
+                                            // slot's other entry turns over many times) + one for resident / blocking passes
 
 // one pass slot: a stream, the inputs of the batch submitted to it, the intermediates of a pass and its results
 struct Work {
@@ -98,7 +99,8 @@ struct Work {
   int32_t* f_map = nullptr;
   int f_cap_frames = 0;
   size_t f_cap_cones = 0;
-  PassTrailer* h_trailer = nullptr;  // N_TRAILERS of them: pinned, host-coherent, written by assemble_kernel (pass seq -> seq % N_TRAILERS)
+  PassTrailer* h_trailer = nullptr;  // N_TRAILERS of them: pinned, host-coherent, written by assemble_kernel
+  int trailer_idx = SLOT_QUEUE;      // which one the next pass writes: a ticket's entry index, or SLOT_QUEUE (resident / blocking passes)
   PassTrailer* d_trailer = nullptr;  // their device address
   int seq = 0;                       // passes launched on this slot
   // the most recent pass launched on the slot (verify_pass re-runs it with the route kernels when they were needed)
@@ -111,7 +113,7 @@ struct Work {
     long long id = -1;
     int n = 0;
     bool skid = false;
-    int seq = 0;                       // the slot's pass counter of this ticket's pass (its trailer: seq % N_TRAILERS)
+    int seq = 0;                       // the slot's pass counter of this ticket's pass (checked against its trailer)
     bool ran_big = false, ran_retry = false;
     // the caller's buffers: valid and untouched until fsdp_collect (a pass that has to be repeated reads them again)
     const int32_t* off = nullptr;
@@ -158,6 +160,7 @@ struct fsdp_ctx {
   unsigned turn = 0;
   int last_slot = 0;
   long long next_ticket = 0;
+  int last_ticket_slot = -1;  // slot of the most recent ticket
   int outstanding = 0;  // tickets submitted and not yet collected
   // The route kernels (sort_big_kernel, path_retry_kernel) are launched only when a pass is expected to need them: a pass
   // that turns out to need a kernel it did not get is re-run with it before anybody sees its results (verify_pass), and
@@ -484,7 +487,7 @@ static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid, fsdp_frame_r
   if (blocks < 1) blocks = 1;
   q.seq++;
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, stream ? stream : q.stream, n, skid ? (const SortOut*)nullptr : q.d_sort,
-                     skid ? (const MatchOut*)nullptr : q.d_match, q.d_path, dst ? dst : q.d_result, q.d_big, q.d_retry, q.d_trailer + (q.seq % N_TRAILERS), q.seq,
+                     skid ? (const MatchOut*)nullptr : q.d_match, q.d_path, dst ? dst : q.d_result, q.d_big, q.d_retry, q.d_trailer + q.trailer_idx, q.seq,
                      (const int32_t*)info_src, (int32_t*)info_dst, info_dst ? (int)(sizeof(SkidInfo) / 4) * n : 0, remap, remap_off);
 }
 
@@ -556,8 +559,8 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
   return 0;
 }
 
-static PassTrailer read_trailer(const Work& q, int seq) {
-  const PassTrailer* h = q.h_trailer + (seq % N_TRAILERS);
+static PassTrailer read_trailer(const Work& q, int idx) {
+  const PassTrailer* h = q.h_trailer + idx;
   PassTrailer tr;
   tr.seq = __atomic_load_n(&h->seq, __ATOMIC_ACQUIRE);
   tr.n_big = __atomic_load_n(&h->n_big, __ATOMIC_RELAXED);
@@ -576,7 +579,7 @@ static int verify_pass(fsdp_ctx* c, Work& q, bool* rerun = nullptr) {
     return 0;
   }
   q.unverified = false;
-  const PassTrailer tr = read_trailer(q, q.seq);
+  const PassTrailer tr = read_trailer(q, SLOT_QUEUE);
   if (tr.seq != q.seq) {
     c->err = "internal: pass trailer out of date (slot " + std::to_string(q.index) + ")";
     return 2;
@@ -1083,6 +1086,7 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
   t.via_stage = false;
   if (n > 0) {
     q.result_dst = (out_pinned && !force_sdma) ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
+    q.trailer_idx = (int)(&t - q.tk);  // the ticket's own trailer
     int rc;
     {
       TraceStep ts("submit: kernel launches");
@@ -1090,6 +1094,7 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
     }
     const bool direct = q.result_dst != nullptr;
     q.result_dst = nullptr;
+    q.trailer_idx = SLOT_QUEUE;
     q.in.h_off = nullptr;  // (the views served that one sorting launch)
     q.unverified = false;  // settled by fsdp_collect through the ticket
     if (rc) return rc;
@@ -1135,19 +1140,32 @@ int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
   size_t total;
   int max_cones;
   if (int rc = check_batch(c, n_frames, off, cones, poses, &total, &max_cones)) return rc;
-  const int si = (int)(c->next_ticket % c->overlap);
-  Work& q = c->slot[si];
-  Work::Ticket* t = nullptr;
+  // the slot with the fewest tickets queued, starting from the one after the previous ticket's (in-order traffic: round robin)
+  int si = -1, best = SLOT_QUEUE;
   long long oldest = -1;
-  for (Work::Ticket& e : q.tk) {
-    if (e.id < 0 && !t) t = &e;
-    if (e.id >= 0 && (oldest < 0 || e.id < oldest)) oldest = e.id;
+  for (int k = 0; k < c->overlap; k++) {
+    const int i = (c->last_ticket_slot + 1 + k) % c->overlap;
+    int cnt = 0;
+    for (const Work::Ticket& e : c->slot[i].tk) {
+      if (e.id < 0) continue;
+      cnt++;
+      if (oldest < 0 || e.id < oldest) oldest = e.id;
+    }
+    if (cnt < best) {
+      best = cnt;
+      si = i;
+    }
   }
-  if (!t) {
-    c->err = "fsdp_submit: " + std::to_string(c->outstanding) + " tickets outstanding (at most " + std::to_string(SLOT_QUEUE) + " per slot, " +
-             std::to_string(c->overlap) + " slots); collect ticket " + std::to_string(oldest) + " first";
+  if (si < 0) {
+    c->err = "fsdp_submit: " + std::to_string(c->outstanding) + " tickets outstanding (" + std::to_string(SLOT_QUEUE) + " per slot, " +
+             std::to_string(c->overlap) + " slots): collect one first, e.g. ticket " + std::to_string(oldest);
     return 4;
   }
+  c->last_ticket_slot = si;
+  Work& q = c->slot[si];
+  Work::Ticket* t = nullptr;
+  for (Work::Ticket& e : q.tk)
+    if (e.id < 0 && !t) t = &e;
   if (!q.stream) {
     if (int rc = ensure_work(c, q, n_frames > 0 ? n_frames : 1)) return rc;
   }
@@ -1205,7 +1223,7 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
   const int n = t.n;
   if (rc == 0 && n > 0 && !t.skid) {
     // did the pass get the route kernels it needed?  (its own trailer: later passes of the slot write other ones)
-    const PassTrailer tr = read_trailer(q, t.seq);
+    const PassTrailer tr = read_trailer(q, (int)(&t - q.tk));
     if (tr.seq != t.seq) {
       c->err = "internal: trailer of ticket " + std::to_string(ticket) + " overwritten";
       rc = 2;

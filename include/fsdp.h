@@ -163,10 +163,11 @@ int fsdp_set_global_path(fsdp_ctx* ctx, const double* xy, int n);
  *                  the slot's stream; returns at once with a ticket;
  *   fsdp_collect = waits for that ticket only; afterwards `results` (the pointer given to fsdp_submit) holds the batch's
  *                  results, exactly what fsdp_plan_batch[_sequential] returns for the same inputs.
- * Tickets count up from 0; ticket t is queued on slot t % depth behind that slot's previous ticket, two tickets per slot
- * (so a slot's next batch is already waiting on its stream when the current one ends, and the caller's collect / submit
- * round trip costs the GPU nothing): at most fsdp_ticket_capacity = 2 x depth tickets are outstanding (fsdp_submit returns
- * 4 when the slot it needs is full: collect ticket t - 2 x depth first); they may be collected in any order.  The
+ * Tickets count up from 0; a ticket is queued on the slot that holds the fewest (round robin for in-order traffic), behind
+ * that slot's previous ticket, two tickets per slot (so a slot's next batch is already waiting on its stream when the
+ * current one ends, and the caller's collect / submit round trip costs the GPU nothing): at most fsdp_ticket_capacity =
+ * 2 x depth tickets are outstanding (fsdp_submit returns 4 beyond that: collect one first); they may be collected in any
+ * order.  The
  * caller's buffers must stay valid and untouched from submit to collect.  For the transfers to be asynchronous they must
  * be page-locked: allocate them with fsdp_host_alloc or pin existing memory with fsdp_host_register — the batch then
  * crosses PCIe inside kernels of the slot's own stream (one reads the inputs from host memory, the last one of the pass

@@ -96,7 +96,7 @@ def test_submit_with_previous_paths_and_slot_accounting(pkg):
     ctx.set_overlap(1)
     t0 = ctx.submit(off2, np.zeros((0, 3)), poses, prev_paths=prev)
     t1 = ctx.submit(off, cones, poses)
-    with pytest.raises(pkg.FsdpError, match="collect ticket 0 first"):
+    with pytest.raises(pkg.FsdpError, match="collect one first, e.g. ticket 0"):
         ctx.submit(off, cones, poses)  # the slot's queue holds two tickets
     with pytest.raises(pkg.FsdpError, match="not collected"):
         ctx.plan_batch(off, cones, poses)  # blocking calls wait for nobody's tickets
@@ -121,3 +121,54 @@ def test_large_mpc_path_length_is_refused_or_flagged(pkg):
     res = ctx.plan_batch(off, cones, poses)
     assert (res["status"] == 0).all() and np.isfinite(res["path"]).all()
     ctx.close()
+
+
+def test_random_ticket_traffic(pkg, golden_dir):
+    """Stress of the ticket machinery: 150 batches of random size (0 … 2600 frames: both path-stage forms, growing and
+    shrinking slot buffers), random kind (coloured / colourless / noisy / frames for the route kernels), page-locked or
+    pageable buffers at random, up to the context's ticket capacity in flight, collected in random order — every result
+    block must equal the serial call's, byte for byte."""
+    rng = np.random.default_rng(42)
+    big = np.load(golden_dir / "big_frames.npz")
+    pool = []
+    for k in range(24):
+        kind = k % 4
+        n = int(rng.choice([0, 1, 3, 17, 64, 300, 900, 1100, 1500, 2600]))
+        if kind == 0:
+            b = pkg.synth.make_replay_batch(max(n, 1), 64, 0.15, seed=300 + k, color=True)
+        elif kind == 1:
+            b = pkg.synth.make_replay_batch(max(n, 1), 32, 0.2, seed=300 + k, color=False)
+        elif kind == 2:
+            b = pkg.synth.make_replay_batch(max(n, 1), 100, 0.0, seed=300 + k, color=False, frame_noise=0.3, random_pose=True)
+        else:
+            b = (big["offsets"], big["cones"], big["poses"])
+        if n == 0:
+            b = (np.zeros(1, np.int32), np.zeros((0, 3)), np.zeros((0, 4)))
+        pool.append(b)
+    serial = pkg.Context(device=0)
+    ref = [serial.plan_batch(*b) for b in pool]
+    serial.close()
+    pinned_pool = [(pkg.pinned_copy(o, np.int32), pkg.pinned_copy(c, np.float64), pkg.pinned_copy(p, np.float64)) for o, c, p in pool]
+    for depth in (1, 3, 7):
+        ctx = pkg.Context(device=0)
+        ctx.set_overlap(depth)
+        inflight, done = [], 0
+        for it in range(150):
+            k = int(rng.integers(len(pool)))
+            while len(inflight) >= ctx.ticket_capacity or (inflight and rng.random() < 0.3):
+                j, t = inflight.pop(int(rng.integers(len(inflight))))
+                assert _same(ctx.collect(t), ref[j]), (depth, it, j)
+                done += 1
+                if len(inflight) < ctx.ticket_capacity and rng.random() < 0.5:
+                    break
+            pin = rng.random() < 0.6
+            b = pinned_pool[k] if pin else pool[k]
+            out = None if pin else np.zeros(len(pool[k][0]) - 1, pkg.RESULT_DTYPE)
+            inflight.append((k, ctx.submit(*b, out=out)))  # (never refused below the ticket capacity: any slot with room takes it)
+        for j, t in inflight:
+            assert _same(ctx.collect(t), ref[j])
+            done += 1
+        assert done == 150
+        # blocking calls work again once nothing is outstanding
+        assert _same(ctx.plan_batch(*pool[0]), ref[0])
+        ctx.close()
