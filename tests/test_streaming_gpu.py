@@ -104,6 +104,13 @@ def test_submit_with_previous_paths_and_slot_accounting(pkg):
     assert _same(ctx.collect(t0), ref)
     with pytest.raises(pkg.FsdpError, match="unknown ticket"):
         ctx.collect(t0)
+    # the same with page-locked buffers: the previous paths travel through the sorting kernel's own stage-in
+    pin = [pkg.pinned_copy(off2, np.int32), pkg.pinned_copy(np.zeros((0, 3))), pkg.pinned_copy(poses), pkg.pinned_copy(prev)]
+    assert _same(ctx.collect(ctx.submit(pin[0], pin[1], pin[2], prev_paths=pin[3])), ref)
+    # mixed frames (with cones) and previous paths, page-locked
+    ref2 = ctx.plan_batch_sequential(off, cones, poses, prev)
+    pin2 = [pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones), pkg.pinned_copy(poses), pkg.pinned_copy(prev)]
+    assert _same(ctx.collect(ctx.submit(pin2[0], pin2[1], pin2[2], prev_paths=pin2[3])), ref2)
     # the resident form still works afterwards, on the same slots
     ctx.upload(off, cones, poses)
     for _ in range(3):
