@@ -280,6 +280,20 @@ __device__ __forceinline__ T wave_bcast(T v, int src) {
   return __shfl(v, src, WAVE);
 }
 
+// a value every lane of the wavefront holds, moved to scalar registers (it stays out of the vector registers for as long as
+// it lives)
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double wave_uniform(double v) {
+  union {
+    double d;
+    int i[2];
+  } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+
 // argmin over (value, index) pairs with "first smallest" semantics (lowest index on ties);
 // lanes holding no candidate pass idx = -1.
 __device__ __forceinline__ void wave_argmin(double& v, int& idx) {

@@ -90,6 +90,7 @@ struct Work {
   PathMid* d_mid = nullptr;   // hand-over records of the three-kernel path stage
   fsdp_frame_result* d_result = nullptr;  // the pass's results in the ABI's layout (assemble_kernel)
   SkidInfo* d_skid_info = nullptr;        // skidpad contexts
+  int32_t* d_skid_status = nullptr;       // skid_reloc_kernel's status of the step this slot holds
   SortSharedBig* d_sort_big = nullptr;    // frame states of sort_big_kernel, allocated when the route is first needed
   int cap_frames = 0;
   // use_unknown_cones = False (filter_kernel.h): the batch without its UNKNOWN cones, and the way back for the indices
@@ -113,6 +114,7 @@ struct Work {
     long long id = -1;
     int n = 0;
     bool skid = false;
+    bool pending = false;  // skidpad step whose path kernel waits for the rest of its group (flush_skid)
     int seq = 0;                       // the slot's pass counter of this ticket's pass (checked against its trailer)
     bool ran_big = false, ran_retry = false;
     // the caller's buffers: valid and untouched until fsdp_collect (a pass that has to be repeated reads them again)
@@ -184,7 +186,12 @@ struct fsdp_ctx {
   bool have_tables = false;
   SkidState* d_skid = nullptr;
   SkidState* d_skid_backup = nullptr;
-  int32_t* d_skid_status = nullptr;
+  uint32_t* d_skid_sync = nullptr;   // [0] ticket counter of skid_path_kernel, [1 + i] steps instance i has published
+  uint32_t skid_ticket_base = 0;
+  int skid_step_no = 0;              // steps submitted since fsdp_skidpad_reset
+  int skid_group = 1;                // steps per skid_path_kernel launch when the caller submits ahead
+  int skid_pending[SKID_GROUP_MAX] = {};  // slots whose step waits for its group's launch, oldest first
+  int n_skid_pending = 0;
   int n_instances = 0;
   // pinned host staging of the stage-level entry points (hipHostMalloc; grown by ensure_staging)
   SortOut* h_sort = nullptr;
@@ -266,7 +273,10 @@ static int ensure_work(fsdp_ctx* c, Work& w, int n) {
   HIP_TRY(c, regrow(w.d_retry, m + 1));
   HIP_TRY(c, regrow(w.d_mid, m));
   HIP_TRY(c, regrow(w.d_result, m));
-  if (c->mission == 2) HIP_TRY(c, regrow(w.d_skid_info, m));
+  if (c->mission == 2) {
+    HIP_TRY(c, regrow(w.d_skid_info, m));
+    HIP_TRY(c, regrow(w.d_skid_status, m));
+  }
   // the list counters are zero between passes: assemble_kernel resets them at the end of every pass
   HIP_TRY(c, hipMemsetAsync(w.d_big, 0, sizeof(int), w.stream));
   HIP_TRY(c, hipMemsetAsync(w.d_retry, 0, sizeof(int), w.stream));
@@ -285,6 +295,7 @@ static void free_work(Work& w) {
   (void)hipFree(w.d_mid);
   (void)hipFree(w.d_result);
   (void)hipFree(w.d_skid_info);
+  (void)hipFree(w.d_skid_status);
   (void)hipFree(w.d_sort_big);
   (void)hipFree(w.f_cnt);
   (void)hipFree(w.f_off);
@@ -614,7 +625,9 @@ static int verify_pass(fsdp_ctx* c, Work& q, bool* rerun = nullptr) {
 }
 
 // wait for every pass in flight (all slots) and settle their routes
+static int flush_skid(fsdp_ctx* c);
 static int sync_all(fsdp_ctx* c) {
+  if (int rc = flush_skid(c)) return rc;
   for (int i = 0; i < FSDP_MAX_OVERLAP; i++) {
     Work& w = c->slot[i];
     if (!w.stream) continue;
@@ -879,7 +892,7 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_noise);
   (void)hipFree(c->d_skid);
   (void)hipFree(c->d_skid_backup);
-  (void)hipFree(c->d_skid_status);
+  (void)hipFree(c->d_skid_sync);
   (void)hipFree(c->d_default_path);
   (void)hipFree(c->d_params);
   if (c->h_sort) (void)hipHostFree(c->h_sort);
@@ -1197,6 +1210,7 @@ int fsdp_ticket_done(fsdp_ctx* c, long long ticket) {
   Work::Ticket* t = find_ticket(c, ticket, nullptr);
   if (!t) return -1;
   (void)hipSetDevice(c->device);
+  if (t->pending && flush_skid(c)) return -1;
   hipError_t e = hipEventQuery(t->done);
   if (e == hipSuccess) return 1;
   (void)hipGetLastError();
@@ -1215,6 +1229,8 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
   Work::Ticket& t = *tp;
   int rc = 0;
   hipError_t e = hipSetDevice(c->device);
+  if (t.pending)
+    if (int frc = flush_skid(c)) return frc;
   if (e == hipSuccess) e = hipEventSynchronize(t.done);
   if (e != hipSuccess) {
     c->err = std::string("fsdp_collect: ") + hipGetErrorString(e);
@@ -1699,7 +1715,7 @@ int fsdp_skidpad_reset(fsdp_ctx* c, int n_instances) {
   if (n_instances != c->n_instances) {
     HIP_TRY(c, regrow(c->d_skid, (size_t)n_instances));
     HIP_TRY(c, regrow(c->d_skid_backup, (size_t)n_instances));
-    HIP_TRY(c, regrow(c->d_skid_status, (size_t)n_instances));
+    HIP_TRY(c, regrow(c->d_skid_sync, (size_t)n_instances + 1));
     c->n_instances = n_instances;
   }
   // fresh planners: nothing latched, previous path = the constant initial path
@@ -1711,27 +1727,71 @@ int fsdp_skidpad_reset(fsdp_ctx* c, int n_instances) {
     memcpy(s.prev, def, sizeof(def));
   }
   HIP_TRY(c, copy_sync(c, c->d_skid, init.data(), sizeof(SkidState) * (size_t)n_instances, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemsetAsync(c->d_skid_sync, 0, sizeof(uint32_t) * ((size_t)n_instances + 1), c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->skid_ticket_base = 0;
+  c->skid_step_no = 0;
+  // steps per launch when the caller submits ahead: as many as put two wavefronts on every SIMD (256 CUs x 4 SIMDs; the
+  // kernel holds two per SIMD), FSDP_SKID_GROUP overrides
+  int group = 2048 / n_instances;
+  if (const char* e = getenv("FSDP_SKID_GROUP")) group = atoi(e);
+  c->skid_group = group < 1 ? 1 : group > SKID_GROUP_MAX ? SKID_GROUP_MAX : group;
   return 0;
 }
 
-// the kernels of one skidpad step on the context's main stream (the planner states chain step to step, so steps never
-// overlap each other — only their transfers do): inputs of slot `in`, outputs into slot q's records
-static void launch_skid(fsdp_ctx* c, Work& q, const Inputs& in, bool reloc) {
+// skid_path_kernel for the steps whose inputs, relocalization status and output records sit in slots[0 .. n_steps): one
+// wavefront per (instance, step), csrc/skidpad_kernel.h "Steps in flight"
+static void launch_skid_path(fsdp_ctx* c, const int* slots, int n_steps, int step0) {
   const int n = c->n_instances;
-  double* arena = c->slot[0].d_arena;
-  if (reloc)
-    hipLaunchKernelGGL(skid_reloc_kernel, dim3(n), dim3(WAVE), 0, c->stream, n, in.d_off, in.d_cones, in.d_poses, c->d_skid, c->tables, arena,
-                       c->d_skid_status);
-  hipLaunchKernelGGL(skid_path_kernel, dim3(n), dim3(WAVE), 0, c->stream, n, in.d_poses, c->d_skid, c->tables, c->d_chord, arena,
-                     c->d_skid_status, q.d_path, q.d_skid_info);
+  SkidGroup g;
+  memset(&g, 0, sizeof(g));
+  for (int k = 0; k < n_steps; k++) {
+    Work& q = c->slot[slots[k]];
+    g.step[k] = SkidStep{q.in.d_poses, q.d_skid_status, q.d_arena, q.d_path, q.d_skid_info};
+  }
+  g.n_steps = n_steps;
+  g.step0 = step0;
+  g.ticket_base = c->skid_ticket_base;
+  c->skid_ticket_base += (uint32_t)n * (uint32_t)n_steps;
+  hipLaunchKernelGGL(skid_path_kernel, dim3((unsigned)n * (unsigned)n_steps), dim3(WAVE), 0, c->stream, n, g, c->d_skid, c->tables, c->d_chord,
+                     c->d_skid_sync);
 }
 
-// One frame for every planner instance, asynchronously.  The planner states chain step to step, so all steps run on the
-// context's main stream in submit order; a step's transfers are kernels of that same stream when the caller's buffers are
-// page-locked (stage_in_kernel reads the inputs from host memory, assemble_kernel writes results and planner information
-// into it), so nothing ever waits for the host: a replay that knows its frames ahead submits ahead (up to `depth` steps,
-// each with its own input buffers on the device) and collects behind.  (A live car submits and collects one step at a
-// time, which is what fsdp_skidpad_step does.)
+// The path kernel, result assembly and completion event of the steps submitted so far whose launch was put off
+// (fsdp_skidpad_submit): one skid_path_kernel over all of them.
+static int flush_skid(fsdp_ctx* c) {
+  const int n_steps = c->n_skid_pending;
+  if (n_steps == 0) return 0;
+  c->n_skid_pending = 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int n = c->n_instances;
+  hipStream_t xs = c->stream;
+  launch_skid_path(c, c->skid_pending, n_steps, c->skid_step_no - n_steps);
+  for (int k = 0; k < n_steps; k++) {
+    Work& q = c->slot[c->skid_pending[k]];
+    Work::Ticket& t = q.tk[0];
+    t.pending = false;
+    // page-locked results: assemble_kernel writes them into the caller's buffer (over PCIe); the planners' information
+    // records ride along into the ticket's pinned block
+    fsdp_frame_result* direct = t.user_results ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
+    if (t.user_results || t.user_info)
+      launch_assemble(c, q, t.user_results ? n : 0, true, direct, xs, t.user_info ? q.d_skid_info : nullptr,
+                      t.user_info ? (SkidInfo*)device_view(t.h_info) : nullptr);
+    HIP_TRY(c, hipGetLastError());
+    if (t.via_stage) HIP_TRY(c, hipMemcpyAsync(t.h_stage, q.d_result, sizeof(fsdp_frame_result) * (size_t)n, hipMemcpyDeviceToHost, xs));
+    HIP_TRY(c, hipEventRecord(t.done, xs));
+  }
+  return 0;
+}
+
+// One frame for every planner instance, asynchronously.  Every command goes to the context's main stream in submit order;
+// a step's transfers are kernels of that same stream when the caller's buffers are page-locked (stage_in_kernel reads the
+// inputs from host memory, assemble_kernel writes results and planner information into it), so nothing ever waits for
+// the host: a replay that knows its frames ahead submits ahead (up to `depth` steps, each with its own buffers on the
+// device) and collects behind.  The inputs and the relocalization attempt of a step are enqueued at once; its path
+// kernel is put off until `skid_group` steps have been submitted — they share one launch, with one wavefront per
+// (instance, step) — or until somebody asks for the step (fsdp_collect, fsdp_ticket_done, any blocking call), so a live
+// car that submits and collects one step at a time (fsdp_skidpad_step) gets one launch per step.
 int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const double* cones, const double* poses,
                         fsdp_frame_result* results, fsdp_skidpad_info* info, long long* ticket) {
   if (!c || !ticket) return 1;
@@ -1752,10 +1812,11 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
     return 4;
   }
   // (buffers that must grow are replaced: not under the feet of the steps queued on the main stream)
-  if (n_instances > q.cap_frames || n_instances > c->slot[0].cap_frames || n_instances > q.in.cap_frames || total > q.in.cap_cones)
+  if (n_instances > q.cap_frames || n_instances > q.in.cap_frames || total > q.in.cap_cones) {
+    if (int rc = flush_skid(c)) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   if (int rc = ensure_work(c, q, n_instances)) return rc;
-  if (int rc = ensure_work(c, c->slot[0], n_instances)) return rc;  // the arena of the kernels
   hipStream_t xs = c->stream;
   const bool in_pinned = is_pinned(off) && is_pinned(poses) && (total == 0 || is_pinned(cones));
   if (in_pinned) {
@@ -1763,15 +1824,6 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
   } else if (int rc = upload_inputs(c, q.in, xs, n_instances, off, cones, poses, nullptr, total, max_cones)) {
     return rc;
   }
-  launch_skid(c, q, q.in, true);
-  q.pass_in = &q.in;
-  q.pass_skid = true;
-  q.unverified = false;
-  t.n = n_instances;
-  t.skid = true;
-  t.user_results = results;
-  t.user_info = info;
-  t.via_stage = false;
   if (info && n_instances > t.cap_info) {
     if (t.h_info) (void)hipHostFree(t.h_info);
     t.h_info = nullptr;
@@ -1779,31 +1831,36 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
     HIP_TRY(c, hipHostMalloc((void**)&t.h_info, sizeof(SkidInfo) * (size_t)n_instances, hipHostMallocDefault));
     t.cap_info = n_instances;
   }
-  // page-locked results: assemble_kernel writes them into the caller's buffer (over PCIe); the planners' information
-  // records ride along into the ticket's pinned block
-  fsdp_frame_result* direct = results ? (fsdp_frame_result*)device_view(results) : nullptr;
-  if (results || info)
-    launch_assemble(c, q, results ? n_instances : 0, true, direct, xs, info ? q.d_skid_info : nullptr,
-                    info ? (SkidInfo*)device_view(t.h_info) : nullptr);
-  HIP_TRY(c, hipGetLastError());
-  if (results && !direct) {
-    if (n_instances > t.cap_stage) {
-      if (t.h_stage) (void)hipHostFree(t.h_stage);
-      t.h_stage = nullptr;
-      t.cap_stage = 0;
-      HIP_TRY(c, hipHostMalloc((void**)&t.h_stage, sizeof(fsdp_frame_result) * (size_t)n_instances, hipHostMallocDefault));
-      t.cap_stage = n_instances;
-    }
-    t.via_stage = true;
-    HIP_TRY(c, hipMemcpyAsync(t.h_stage, q.d_result, sizeof(fsdp_frame_result) * (size_t)n_instances, hipMemcpyDeviceToHost, xs));
+  const bool direct = results && device_view(results);
+  if (results && !direct && n_instances > t.cap_stage) {
+    if (t.h_stage) (void)hipHostFree(t.h_stage);
+    t.h_stage = nullptr;
+    t.cap_stage = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&t.h_stage, sizeof(fsdp_frame_result) * (size_t)n_instances, hipHostMallocDefault));
+    t.cap_stage = n_instances;
   }
   if (!t.done) HIP_TRY(c, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
-  HIP_TRY(c, hipEventRecord(t.done, xs));
+  hipLaunchKernelGGL(skid_reloc_kernel, dim3((unsigned)n_instances), dim3(WAVE), 0, xs, n_instances, q.in.d_off, q.in.d_cones, q.in.d_poses,
+                     c->d_skid, c->tables, q.d_arena, q.d_skid_status, c->skid_step_no);
+  HIP_TRY(c, hipGetLastError());
+  c->skid_step_no++;
+  q.pass_in = &q.in;
+  q.pass_skid = true;
+  q.unverified = false;
+  t.n = n_instances;
+  t.skid = true;
+  t.pending = true;
+  t.user_results = results;
+  t.user_info = info;
+  t.via_stage = results && !direct;
+  c->skid_pending[c->n_skid_pending++] = si;
   c->last_slot = si;
   c->last_n = n_instances;
   t.id = c->next_ticket++;
   c->outstanding++;
   *ticket = t.id;
+  const int group = c->skid_group < c->overlap ? c->skid_group : c->overlap;
+  if (c->n_skid_pending >= group) return flush_skid(c);
   return 0;
 }
 
@@ -1829,7 +1886,7 @@ int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
   size_t bytes = sizeof(SkidState) * (size_t)c->n_instances;
   HIP_TRY(c, hipMemcpyAsync(c->d_skid_backup, c->d_skid, bytes, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
-  for (int i = 0; i < iters; i++) launch_skid(c, q, q.in, false);
+  for (int i = 0; i < iters; i++) launch_skid_path(c, &c->last_slot, 1, c->skid_step_no);  // (a step number of its own: nothing to wait for)
   HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
   HIP_TRY(c, hipEventSynchronize(c->ev[5]));
   float t = 0;

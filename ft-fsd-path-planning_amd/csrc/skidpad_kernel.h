@@ -22,9 +22,14 @@ namespace fsdp {
 constexpr int SKID_MAX_CLUSTERS = 64;
 constexpr int SKID_NEAR = 20;
 constexpr int ST_OVERFLOW_CLUSTERS = 205;
+constexpr int ST_SYNC_LOST = 206;  // internal: a step's wavefront never saw its predecessor's state published
+
+constexpr int SKID_HIST = 8;  // > SKID_GROUP_MAX
 
 struct SkidState {
-  int32_t has_original, relocalized, index_along_path, pad;
+  int32_t has_original, relocalized, index_along_path;
+  int32_t reloc_step;             // the step (since the reset) whose relocalization attempt latched the transform
+  int32_t index_hist[SKID_HIST];  // index_along_path after step g at [g % SKID_HIST]
   double orig[4];          // pose latched at the first relocalization attempt
   double translation[2];
   double right_calc[2];
@@ -162,7 +167,7 @@ __device__ inline void unrank3(int s, int m, int& a, int& b, int& c) {
 __global__ void __launch_bounds__(64) skid_reloc_kernel(int n_inst, const int32_t* __restrict__ cone_offsets,
                                                         const double* __restrict__ cones_xyt, const double* __restrict__ poses,
                                                         SkidState* __restrict__ states, SkidTables T, double* __restrict__ arena,
-                                                        int32_t* __restrict__ status_out) {
+                                                        int32_t* __restrict__ status_out, int step_no) {
   __shared__ SkidShared S;
   const int inst = blockIdx.x;
   if (inst >= n_inst) return;
@@ -426,64 +431,128 @@ __global__ void __launch_bounds__(64) skid_reloc_kernel(int n_inst, const int32_
     st->right_calc[0] = rcx;
     st->right_calc[1] = rcy;
     st->relocalized = 1;
+    st->reloc_step = step_no;
   }
 }
 
-__global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const double* __restrict__ poses,
-                                                          SkidState* __restrict__ states, SkidTables T,
-                                                          const double* __restrict__ chord, double* __restrict__ arena,
-                                                          const int32_t* __restrict__ status_in, PathOut* __restrict__ out,
-                                                          SkidInfo* __restrict__ info) {
+// Steps in flight.  A planner's steps chain through its state (window index, previous path), but almost all of a step —
+// the MPC refit of the window — depends on that state only through the window index, and the index a step leaves depends
+// on the poses alone (the reference moves it before the MPC step, skidpad_calculate_path.py:66-67: one 400-point arg-min
+// per step).  So one launch plans up to SKID_GROUP_MAX consecutive steps of every instance, one wavefront per (instance,
+// step): the wavefront of step g
+//   1. works out the index step g - 1 leaves from the index recorded before the launch (index_hist) and the poses of the
+//      launch's earlier steps,
+//   2. plans its step with it,
+//   3. waits until step g - 1 of its instance has published its state (sync[1 + inst] >= g), and
+//   4. keeps its result if the previous path was never read (fallback == 0: every read of it sets a bit) and the published
+//      index is the one it used — otherwise plans the step again from the published state, exactly as a launch of its
+//      own would;
+//   5. writes the state and publishes it (sync[1 + inst] = g + 1).
+// Results and states are therefore those of one launch per step, whatever the grouping.  Wavefronts take their
+// (step, instance) from a ticket counter in start order, step-major, so the wavefront a wait is for has always started:
+// no wait can be for work that is not resident or finished.  With 1024 instances two steps put two wavefronts on every
+// SIMD, where one issues an FP64 instruction every 8.7 cycles and two every 4.6.
+constexpr int SKID_GROUP_MAX = 4;
+
+struct SkidStep {
+  const double* poses;       // (n_inst, 4) of this step
+  const int32_t* status_in;  // skid_reloc_kernel's status of this step
+  double* arena;             // workspace of this step's wavefronts
+  PathOut* out;
+  SkidInfo* info;
+};
+
+struct SkidGroup {
+  SkidStep step[SKID_GROUP_MAX];
+  int32_t n_steps;
+  int32_t step0;          // number of the group's first step since fsdp_skidpad_reset
+  uint32_t ticket_base;   // value of the ticket counter before this launch
+};
+
+__global__ void __launch_bounds__(64, 2) skid_path_kernel(int n_inst, SkidGroup G, SkidState* states, SkidTables T,
+                                                          const double* __restrict__ chord, uint32_t* sync) {
   __shared__ PathShared<WAVE> S;
-  const int inst = blockIdx.x;
-  if (inst >= n_inst) return;
+  __shared__ uint32_t s_ticket;
+  __shared__ double s_prev[PATH_POINTS][4];
   const int lane = lane_id();
-  const Arena A = frame_arena(arena, inst, T.prm);
+  if (lane == 0) s_ticket = atomicAdd(&sync[0], 1u) - G.ticket_base;
+  __syncthreads();
+  const uint32_t ticket = s_ticket;
+  if (ticket >= (uint32_t)n_inst * (uint32_t)G.n_steps) return;
+  const int s = (int)(ticket / (uint32_t)n_inst), inst = (int)(ticket % (uint32_t)n_inst);
+  const int g = G.step0 + s;
+  const SkidStep& me = G.step[s];
+  const Arena A = frame_arena(me.arena, inst, T.prm);
   SkidState* st = &states[inst];
-  PathOut* o = &out[inst];
-  double px = poses[4 * inst + 0], py = poses[4 * inst + 1], dx = poses[4 * inst + 2], dy = poses[4 * inst + 3];
-  int status = status_in[inst];
-  int fallback = 0, n_dense = 0;
-  const bool reloc = st->relocalized != 0;
-  const double rotation = st->rotation, tx = st->translation[0], ty = st->translation[1];
-  const double rcx = st->right_calc[0], rcy = st->right_calc[1];
-  int n1 = 0;
-  int new_index = st->index_along_path;
-  if (status == ST_OK && reloc) {
-    // full_pipeline.py:126-134: pose into the known map frame
+  PathOut* o = &me.out[inst];
+  // written by skid_reloc_kernel only, i.e. before this launch
+  // (the transform is read where it is used rather than held in registers across the path stage)
+  const bool latched = wave_uniform(st->relocalized) != 0;
+  const int reloc_step = wave_uniform(st->reloc_step);
+  const int max_change = (int)(20 / T.mean_distance);
+
+  // full_pipeline.py:126-134: pose into the known map frame
+  auto map_pose = [&](const double* pose, double& px, double& py, double& dx, double& dy) {
+    px = pose[0], py = pose[1], dx = pose[2], dy = pose[3];
+    const double rotation = st->rotation;
     double yaw = detm::det_atan2(dy, dx);
     double sn, cs;
     detm::det_sincos(rotation, sn, cs);
-    double qx = px + tx - T.ref_right[0], qy = py + ty - T.ref_right[1];
+    double qx = px + st->translation[0] - T.ref_right[0], qy = py + st->translation[1] - T.ref_right[1];
     double rx = blas_dot2(qx, cs, qy, -sn), ry = blas_dot2(qx, sn, qy, cs);
     px = rx + T.ref_right[0];
     py = ry + T.ref_right[1];
     yaw = yaw + rotation;
     detm::det_sincos(yaw, dy, dx);
+    px = wave_uniform(px), py = wave_uniform(py), dx = wave_uniform(dx), dy = wave_uniform(dy);
+  };
+  // SkidpadCalculatePath.fit_matches_as_spline, skidpad_calculate_path.py:60-67: closest point of the known path within
+  // +-max_change of the index; -1: empty window
+  auto closest_in_window = [&](int index, double px, double py) {
+    int lo = index - max_change;
+    lo = lo < 0 ? 0 : lo;
+    int hi = index + max_change;
+    hi = hi > T.n_path ? T.n_path : hi;
+    if (hi <= lo) return -1;
+    double bv = 0.0;
+    int bi = -1;
+    for (int i = lo + lane; i < hi; i += WAVE) {
+      double d = norm_axis(px - T.path[2 * i], py - T.path[2 * i + 1]);
+      d = (d != d) ? -1.0 : d;  // np.argmin: the first NaN is the minimum (and every lane agrees on it); distances are >= 0
+      if (bi < 0 || d < bv) {
+        bv = d;
+        bi = i;
+      }
+    }
+    wave_argmin(bv, bi);
+    return wave_uniform(bi);
+  };
+
+  // 1. the index step g - 1 is expected to leave
+  int index_in = wave_uniform(st->index_hist[(G.step0 + SKID_HIST - 1) % SKID_HIST]);
+  for (int j = 0; j < s; j++) {
+    if (G.step[j].status_in[inst] != ST_OK || !(latched && reloc_step <= G.step0 + j)) continue;
+    double qx, qy, qdx, qdy;
+    map_pose(G.step[j].poses + 4 * inst, qx, qy, qdx, qdy);
+    const int bi = closest_in_window(index_in, qx, qy);
+    if (bi >= 0) index_in = bi;
   }
+
+  const bool reloc = latched && reloc_step <= g;
+  double px = wave_uniform(me.poses[4 * inst + 0]), py = wave_uniform(me.poses[4 * inst + 1]);
+  double dx = wave_uniform(me.poses[4 * inst + 2]), dy = wave_uniform(me.poses[4 * inst + 3]);
+  const int status_in = wave_uniform(me.status_in[inst]);
+  if (status_in == ST_OK && reloc) map_pose(me.poses + 4 * inst, px, py, dx, dy);
+  int status = ST_OK, fallback = 0, n_dense = 0, n1 = 0, new_index = index_in;
   // the path update of this step into the arena polyline [1, 1 + n1): the window of the known path behind the closest
-  // point (SkidpadCalculatePath.fit_matches_as_spline, skidpad_calculate_path.py:49-71) or, before relocalization, the
-  // trivial path (calculate_trivial_path, core_calculate_path.py:127-134: chord[1:] rotated by the car yaw, + position)
+  // point (skidpad_calculate_path.py:49-71) or, before relocalization, the trivial path (calculate_trivial_path,
+  // core_calculate_path.py:127-134: chord[1:] rotated by the car yaw, + position)
   auto fill_update = [&]() {
     if (reloc) {
-      const int max_change = (int)(20 / T.mean_distance);
-      int lo = st->index_along_path - max_change;
-      lo = lo < 0 ? 0 : lo;
-      int hi = st->index_along_path + max_change;
-      hi = hi > T.n_path ? T.n_path : hi;
-      if (hi <= lo) {
+      const int bi = closest_in_window(index_in, px, py);
+      if (bi < 0) {
         status = ST_REF_UNDEFINED_PATH;
       } else {
-        double bv = 0.0;
-        int bi = -1;
-        for (int i = lo + lane; i < hi; i += WAVE) {
-          double d = norm_axis(px - T.path[2 * i], py - T.path[2 * i + 1]);
-          if (bi < 0 || d < bv) {
-            bv = d;
-            bi = i;
-          }
-        }
-        wave_argmin(bv, bi);
         new_index = bi;
         int fin = bi + (int)(25 / T.mean_distance);
         fin = fin > T.n_path ? T.n_path : fin;
@@ -506,54 +575,109 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
     }
     __syncthreads();
   };
-  if (status == ST_OK) fill_update();
-  // The path stage with the shortened division / square-root sequences (spline_device.h: the same bits for operands inside
-  // their exponent band); a step that meets an operand outside the band (ST_RETRY) is planned again with the plain ones.
-  if (status == ST_OK) {
-    status = finish_path<WAVE, true>(S, A, n1, px, py, dx, dy, &st->prev[0][0], o->path, &fallback, &n_dense);
-    if (status == ST_RETRY || status == ST_OVERFLOW_KNOTS) {
-      __syncthreads();
-      status = ST_OK;
-      fallback = 0;
-      n_dense = 0;
-      fill_update();
-      if (status == ST_OK) status = finish_path<WAVE, false>(S, A, n1, px, py, dx, dy, &st->prev[0][0], o->path, &fallback, &n_dense);
+  bool sync_lost = false;
+  const double* prev = &st->prev[0][0];  // first round: whatever is there (a result that read it is not kept)
+#pragma unroll 1
+  for (int round = 0; round < 2; round++) {
+    // 2. (and 4.) the step from index_in
+    status = status_in;
+    fallback = n_dense = n1 = 0;
+    new_index = index_in;
+    if (status == ST_OK) fill_update();
+    // a car position that is not finite: the window index has moved (to the window's first point: np.argmin of NaNs), the
+    // MPC step raises whatever path it is given (the car position joins the path) — the reference's exception reaches
+    // the caller
+    if (status == ST_OK && !(fabs(px) < INFINITY && fabs(py) < INFINITY)) status = ST_REF_UNDEFINED_PATH;
+    // The path stage with the shortened division / square-root sequences (spline_device.h: the same bits for operands
+    // inside their exponent band); a step that meets an operand outside the band (ST_RETRY) is planned again with the
+    // plain ones.
+    if (status == ST_OK) {
+      status = finish_path<WAVE, true>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
+      if (status == ST_RETRY || status == ST_OVERFLOW_KNOTS) {
+        __syncthreads();
+        status = ST_OK;
+        fallback = 0;
+        n_dense = 0;
+        fill_update();
+        if (status == ST_OK) status = finish_path<WAVE, false>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
+      }
     }
+    __syncthreads();
+    if (round == 1) break;
+    // 3. step g - 1 of this instance has published its state
+    // (bounded, seconds: a wait that ends this way means a broken launch order — the step reports ST_SYNC_LOST instead of
+    // holding the GPU)
+    if (lane == 0) {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&sync[1 + inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)g && ++spins < (1u << 24))
+        __builtin_amdgcn_s_sleep(8);
+      s_ticket = spins;
+    }
+    __syncthreads();
+    if (s_ticket >= (1u << 24)) {
+      sync_lost = true;
+      break;
+    }
+    // the state behind the flag is read past the caches (agent-scope loads): no cache invalidation, the workspace of the
+    // path stage stays where it is
+    const int index_now = wave_uniform(__hip_atomic_load(&st->index_along_path, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (s == 0 || (index_now == index_in && fallback == 0)) break;  // (s == 0: the state was final before the launch)
+    index_in = index_now;
+    if (lane < PATH_POINTS)
+      for (int q = 0; q < 4; q++) s_prev[lane][q] = __hip_atomic_load(&st->prev[lane][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prev = &s_prev[0][0];
+    __syncthreads();
   }
-  __syncthreads();
+  __syncthreads();  // every lane has read the published index before lane 0 replaces it
+  if (sync_lost) {
+    if (lane < PATH_POINTS)
+      for (int q = 0; q < 4; q++) o->path[lane][q] = NAN;
+    if (lane == 0) {
+      o->status = ST_SYNC_LOST;
+      o->fallback = o->n_dense = o->pad = 0;
+      __hip_atomic_store(&sync[1 + inst], (uint32_t)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (later steps do not wait in turn)
+    }
+    return;
+  }
+  // 5. state and results
   if (status == ST_OK) {
     // previous_paths[-1] <- this result (map frame); then path xy back to the original frame (full_pipeline.py:178-194)
     if (lane < PATH_POINTS) {
       double u = o->path[lane][0], x = o->path[lane][1], y = o->path[lane][2], k = o->path[lane][3];
-      st->prev[lane][0] = u;
-      st->prev[lane][1] = x;
-      st->prev[lane][2] = y;
-      st->prev[lane][3] = k;
+      // (agent-scope stores: written through to where the next step's wavefront, on whatever XCD, reads them)
+      __hip_atomic_store(&st->prev[lane][0], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st->prev[lane][1], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st->prev[lane][2], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st->prev[lane][3], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (reloc) {
+        const double rcx = st->right_calc[0], rcy = st->right_calc[1];
         double sn, cs;
-        detm::det_sincos(-rotation, sn, cs);
-        double qx = x - tx - rcx, qy = y - ty - rcy;
+        detm::det_sincos(-st->rotation, sn, cs);
+        double qx = x - st->translation[0] - rcx, qy = y - st->translation[1] - rcy;
         o->path[lane][1] = blas_dot2(qx, cs, qy, -sn) + rcx;
         o->path[lane][2] = blas_dot2(qx, sn, qy, cs) + rcy;
       }
     }
-    if (lane == 0) st->index_along_path = new_index;
   } else if (lane < PATH_POINTS) {
     for (int q = 0; q < 4; q++) o->path[lane][q] = NAN;
   }
+  const int index_out = new_index;  // (the reference moves the index before the MPC step: it stays moved when the step raises)
   if (lane == 0) {
+    __hip_atomic_store(&st->index_along_path, index_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st->index_hist[g % SKID_HIST] = index_out;
     o->status = status;
     o->fallback = fallback;
     o->n_dense = n_dense;
     o->pad = 0;
-    SkidInfo* fi = &info[inst];
+    SkidInfo* fi = &me.info[inst];
     fi->relocalized = reloc ? 1 : 0;
-    fi->index_along_path = (status == ST_OK) ? new_index : st->index_along_path;
+    fi->index_along_path = index_out;
     fi->translation[0] = fi->translation[1] = fi->rotation = NAN;
     if (reloc) {
       // RelocalizationInformation.from_transform_function: images of (0,0) and (1,0)
+      const double tx = st->translation[0], ty = st->translation[1];
       double sn, cs;
-      detm::det_sincos(rotation, sn, cs);
+      detm::det_sincos(st->rotation, sn, cs);
       double ax0 = 0.0 + tx - T.ref_right[0], ay0 = 0.0 + ty - T.ref_right[1];
       double ax1 = 1.0 + tx - T.ref_right[0];
       double o0x = blas_dot2(ax0, cs, ay0, -sn) + T.ref_right[0], o0y = blas_dot2(ax0, sn, ay0, cs) + T.ref_right[1];
@@ -563,6 +687,12 @@ __global__ void __launch_bounds__(64, 1) skid_path_kernel(int n_inst, const doub
       fi->rotation = atan2(o1y - o0y, o1x - o0x);
     }
   }
+  __syncthreads();
+  // the state above has left the wavefront (its stores are acknowledged) before the flag goes out; no cache write-back:
+  // nothing else this wavefront wrote is anybody's before the launch ends
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0) __hip_atomic_store(&sync[1 + inst], (uint32_t)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace fsdp

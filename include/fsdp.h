@@ -50,7 +50,8 @@ enum {
   FSDP_OVERFLOW_ENDS = 202,  /* more than 4096 raw end configurations on one side */
   FSDP_OVERFLOW_PATH = 203,
   FSDP_OVERFLOW_KNOTS = 204, /* more than 64 knots (fits beyond the packed kernels' capacity are re-planned by the one-frame-per-wavefront kernel) */
-  FSDP_OVERFLOW_CLUSTERS = 205 /* skidpad relocalization: more than 64 centre clusters */
+  FSDP_OVERFLOW_CLUSTERS = 205, /* skidpad relocalization: more than 64 centre clusters */
+  FSDP_SYNC_LOST = 206 /* skidpad steps sharing a launch: a step never saw its predecessor's state (internal error) */
 };
 
 /* path_fallback bits */

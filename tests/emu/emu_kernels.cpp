@@ -192,10 +192,14 @@ void emu_match(int n_frames, const int32_t* offsets, const double* cones, const 
 int emu_sizeof_skid_state() { return (int)sizeof(fsdp::SkidState); }
 int emu_sizeof_skid_info() { return (int)sizeof(fsdp::SkidInfo); }
 
-// one skidpad step for n_inst planner instances (states updated in place)
-void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, const double* poses, fsdp::SkidState* states,
-                      const double* half_table, int n_path, const double* noise, int n_noise, const double* ref4,
-                      double mean_distance, fsdp::PathOut* out, fsdp::SkidInfo* info) {
+// n_steps consecutive skidpad steps for n_inst planner instances (states updated in place): the relocalization attempts
+// of all of them first, then ONE skid_path_kernel launch with a wavefront per (instance, step) — the order of commands
+// fsdp_skidpad_submit produces for a caller that submits ahead.  sync: n_inst + 1 words kept by the caller across calls
+// (zero at the planners' start), *ticket_base likewise; step0 = number of the first step since the start.
+void emu_skidpad_steps(int n_inst, int n_steps, int step0, const int32_t* const* offsets, const double* const* cones,
+                       const double* const* poses, fsdp::SkidState* states, const double* half_table, int n_path, const double* noise,
+                       int n_noise, const double* ref4, double mean_distance, fsdp::PathOut* const* out, fsdp::SkidInfo* const* info,
+                       uint32_t* sync, uint32_t* ticket_base) {
   std::call_once(g_once, build_default);
   fsdp::SkidTables T;
   T.path = half_table;
@@ -210,12 +214,21 @@ void emu_skidpad_step(int n_inst, const int32_t* offsets, const double* cones, c
   T.prm = &g_prm;
   double chord[fsdp::PATH_POINTS][2];
   fsdp::default_chord_points(chord);
-  AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_inst);
-  std::vector<int32_t> status(n_inst, 0);
-  emu::launch((unsigned)n_inst, 64, [&]() { fsdp::skid_reloc_kernel(n_inst, offsets, cones, poses, states, T, arena.data(), status.data()); });
-  emu::launch((unsigned)n_inst, 64, [&]() {
-    fsdp::skid_path_kernel(n_inst, poses, states, T, &chord[0][0], arena.data(), status.data(), out, info);
-  });
+  AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_inst * n_steps);
+  std::vector<int32_t> status((size_t)n_inst * n_steps, 0);
+  fsdp::SkidGroup G;
+  memset(&G, 0, sizeof(G));
+  for (int k = 0; k < n_steps; k++) {
+    double* ar = arena.data() + (size_t)fsdp::ARENA_DOUBLES * n_inst * k;
+    int32_t* stat = status.data() + (size_t)n_inst * k;
+    emu::launch((unsigned)n_inst, 64, [&]() { fsdp::skid_reloc_kernel(n_inst, offsets[k], cones[k], poses[k], states, T, ar, stat, step0 + k); });
+    G.step[k] = fsdp::SkidStep{poses[k], stat, ar, out[k], info[k]};
+  }
+  G.n_steps = n_steps;
+  G.step0 = step0;
+  G.ticket_base = *ticket_base;
+  *ticket_base += (uint32_t)n_inst * (uint32_t)n_steps;
+  emu::launch((unsigned)(n_inst * n_steps), 64, [&]() { fsdp::skid_path_kernel(n_inst, G, states, T, &chord[0][0], sync); });
 }
 
 // calculate_reference_centers_for_skidpad_path + table spacing as the device derives them (out5)

@@ -7,7 +7,7 @@
 //
 // Supported subset (what the kernels use): __global__/__device__/__shared__, threadIdx /
 // blockIdx / blockDim / gridDim (.x), __syncthreads, __ballot, __shfl/__shfl_xor/__shfl_down/
-// __shfl_up (int, unsigned, long long, double), __popcll, __ffsll, __clzll, atomicOr/atomicAdd
+// __shfl_up (int, unsigned, long long, double), __popcll, __ffsll, __clzll, atomicOr/atomicAdd, __hip_atomic_load/store, __threadfence
 // on shared ints.  Cross-lane operations are rendezvous of an aligned G-lane group (G = 64
 // by default; the path stage runs several frames per wavefront with G = 16): all lanes of a group must reach them
 // (group-uniform control flow) — the same discipline the kernels follow on hardware; groups may diverge.
@@ -51,6 +51,7 @@ struct Block {
   unsigned ggen[7][WAVE] = {{0}};
   Dim3 bid, bdim, gdim;
   uint64_t slots[WAVE];
+  int line[WAVE] = {0};  // source line of each lane's last __syncthreads (dead-lock report)
   std::function<void()> body;
 };
 
@@ -87,9 +88,23 @@ inline void gbarrier(int G) {
     b->ggen[lg][first]++;
     return;
   }
-  while (b->ggen[lg][first] == g) yield_lane();
+  // a rendezvous that never completes = lanes of one group took different paths to different rendezvous points (or left):
+  // report instead of spinning forever
+  for (unsigned long spins = 0; b->ggen[lg][first] == g; spins++) {
+    if (spins > 20000000ul) {
+      fprintf(stderr, "emu: dead-locked rendezvous of a %d-lane group (block %u); lane: last __syncthreads line / done\n", G, b->bid.x);
+      for (int l = 0; l < b->n_lanes; l++) fprintf(stderr, " %d:%d%s", l, b->line[l], b->lanes[l].done ? "/done" : "");
+      fprintf(stderr, "\n");
+      abort();
+    }
+    yield_lane();
+  }
 }
 inline void barrier() { gbarrier(WAVE); }
+inline void barrier_at(int line) {
+  B->line[B->cur] = line;
+  gbarrier(WAVE);
+}
 
 inline void lane_entry() {
   Block* b = B;
@@ -242,7 +257,7 @@ using std::isfinite;
 using std::isinf;
 using std::isnan;
 
-inline void __syncthreads() { emu::barrier(); }
+#define __syncthreads() emu::barrier_at(__LINE__)
 inline unsigned long long __ballot(int p) { return emu::ballot(p); }
 template <class T>
 inline T __shfl(T v, int src, int width = 64) {
@@ -282,3 +297,13 @@ inline T atomicAdd(T* p, T v) {
   *p = o + v;
   return o;
 }
+// scoped atomics / fences of kernels that hand data from one workgroup to another (csrc/skidpad_kernel.h): the emulator
+// runs the workgroups of a launch one after the other, in blockIdx order
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+inline void __threadfence() {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // (only ever applied to values all lanes hold)

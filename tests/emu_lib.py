@@ -128,7 +128,8 @@ def plan(offsets, cones, poses, group=8):
 
 
 SKID_STATE_DTYPE = np.dtype(
-    [("has_original", "<i4"), ("relocalized", "<i4"), ("index_along_path", "<i4"), ("pad", "<i4"), ("orig", "<f8", (4,)),
+    [("has_original", "<i4"), ("relocalized", "<i4"), ("index_along_path", "<i4"), ("reloc_step", "<i4"), ("index_hist", "<i4", (8,)),
+     ("orig", "<f8", (4,)),
      ("translation", "<f8", (2,)), ("right_calc", "<f8", (2,)), ("rotation", "<f8"), ("prev", "<f8", (PATH_POINTS, 4))],
     align=True,
 )
@@ -155,18 +156,31 @@ class SkidpadEmu:
         self.md = float(mean_distance)
         self.states = np.zeros(n, SKID_STATE_DTYPE)
         self.states["prev"] = default_path()
+        self.sync = np.zeros(n + 1, np.uint32)  # ticket counter + steps published per instance
+        self.ticket_base = np.zeros(1, np.uint32)
+        self.step_no = 0
 
     def step(self, offsets, cones, poses):
-        offsets = np.ascontiguousarray(offsets, np.int32)
-        cones = np.ascontiguousarray(cones, np.float64).reshape(-1, 3)
-        poses = np.ascontiguousarray(poses, np.float64)
-        out = np.zeros(self.n, PATH_DTYPE)
-        info = np.zeros(self.n, SKID_INFO_DTYPE)
-        lib().emu_skidpad_step(
-            ctypes.c_int(self.n), _p(offsets, ctypes.c_int32), _p(cones), _p(poses), ctypes.c_void_p(self.states.ctypes.data),
-            _p(self.half), ctypes.c_int(len(self.half)), _p(self.noise), ctypes.c_int(len(self.noise)), _p(self.ref),
-            ctypes.c_double(self.md), ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(info.ctypes.data))
-        return out, info
+        (res,) = self.steps([(offsets, cones, poses)])
+        return res
+
+    def steps(self, frames):
+        """len(frames) <= 4 consecutive steps [(offsets, cones, poses), ...] in one skid_path_kernel launch (one wavefront
+        per (instance, step): csrc/skidpad_kernel.h "Steps in flight") -> [(out, info), ...]."""
+        k = len(frames)
+        offs = [np.ascontiguousarray(f[0], np.int32) for f in frames]
+        cones = [np.ascontiguousarray(f[1], np.float64).reshape(-1, 3) for f in frames]
+        poses = [np.ascontiguousarray(f[2], np.float64) for f in frames]
+        outs = [np.zeros(self.n, PATH_DTYPE) for _ in range(k)]
+        infos = [np.zeros(self.n, SKID_INFO_DTYPE) for _ in range(k)]
+        ptrs = lambda arrs: (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrs])
+        lib().emu_skidpad_steps(
+            ctypes.c_int(self.n), ctypes.c_int(k), ctypes.c_int(self.step_no), ptrs(offs), ptrs(cones), ptrs(poses),
+            ctypes.c_void_p(self.states.ctypes.data), _p(self.half), ctypes.c_int(len(self.half)), _p(self.noise),
+            ctypes.c_int(len(self.noise)), _p(self.ref), ctypes.c_double(self.md), ptrs(outs), ptrs(infos),
+            ctypes.c_void_p(self.sync.ctypes.data), ctypes.c_void_p(self.ticket_base.ctypes.data))
+        self.step_no += k
+        return list(zip(outs, infos))
 
 
 class params:

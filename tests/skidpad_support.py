@@ -39,3 +39,29 @@ def batch_for_step(g, t, tf):
         poses.append(np.concatenate([R @ pose[:2] + tr, R @ pose[2:]]))
         off.append(off[-1] + len(c))
     return np.array(off, np.int32), np.concatenate(cones).reshape(-1, 3), np.array(poses)
+
+
+def awkward_frames(g, tf, n_frames=56):
+    """The first frames of the golden sequence for the instances tf, with the poses that break a planner's routine: a car
+    60 m off the track (the too-far check hands the step the previous path), positions / directions that are not finite
+    (the reference raises for the former and moves the window index first: skidpad_calculate_path.py:66-67), a car moved
+    15 m along the track (another window index than the recorded poses lead to)."""
+    frames = []
+    for t in range(n_frames):
+        off, cones, poses = batch_for_step(g, t, tf)
+        poses = poses.copy()
+        if t in (5, 30):
+            poses[:, 1] += 60.0
+        if t == 9:
+            poses[0, 0] = np.inf
+        if t == 35:
+            poses[1, 0] = np.nan
+        if t == 37:
+            poses[2, 1] = -np.inf
+        if t == 38:
+            poses[0, 2] = np.nan
+        if t in (41, 42):
+            poses[:, 0] += 15.0 * poses[:, 2]
+            poses[:, 1] += 15.0 * poses[:, 3]
+        frames.append((off, cones, poses))
+    return frames

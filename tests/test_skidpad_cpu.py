@@ -76,3 +76,51 @@ def test_emulated_kernels_equal_oracle_on_perturbed_instances(tables, golden_dir
                 assert int(info[i]["relocalized"]) == int(oi[0]) and int(info[i]["index_along_path"]) == int(oi[4])
                 assert np.array_equal(out[i]["path"], r["path"]), (t, i)
     assert info["relocalized"].all()
+
+
+def test_awkward_poses_equal_oracle(tables, golden_dir):
+    """Steps that fall back to the previous path or fail: statuses, window indices and paths of the emulated kernels are the
+    oracle's, and so is every later step (the states carry on identically)."""
+    table, noise, ref, md = tables
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, 3)
+    em = emu_lib.SkidpadEmu(3, table, noise, ref, md)
+    seen = set()
+    with oracle_lib.math_mode(1):
+        ops = [oracle_lib.SkidpadPlanner(table, noise) for _ in tf]
+        for t, (off, cones, poses) in enumerate(sk.awkward_frames(g, tf, 46)):
+            out, info = em.step(off, cones, poses)
+            for i, op in enumerate(ops):
+                r, oi = op.step(cones[off[i] : off[i + 1]], poses[i])
+                assert int(out[i]["status"]) == int(r["status"]), (t, i)
+                seen.add((int(r["status"]), int(out[i]["fallback"])))
+                if r["status"] == 0:
+                    assert int(info[i]["relocalized"]) == int(oi[0]) and int(info[i]["index_along_path"]) == int(oi[4]), (t, i)
+                    assert np.array_equal(out[i]["path"], r["path"], equal_nan=True), (t, i)
+                else:
+                    assert np.isnan(out[i]["path"]).all()
+    assert (103, 0) in seen and any(s == 0 and f & 4 for s, f in seen)
+
+
+def test_grouped_steps_equal_single_steps(tables, golden_dir):
+    """Steps in flight (csrc/skidpad_kernel.h): 1-4 consecutive steps planned by one skid_path_kernel launch, a wavefront
+    per (instance, step) working from the window index its predecessors' poses lead to, must give the bytes — results,
+    planner information, states — of one launch per step, also around the relocalization and through the steps of
+    _awkward_frames (a step that read the previous path is planned again behind its predecessor)."""
+    table, noise, ref, md = tables
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, 3)
+    frames = sk.awkward_frames(g, tf)
+    one = emu_lib.SkidpadEmu(3, table, noise, ref, md)
+    ref_res = [one.step(*f) for f in frames]
+    assert any(r[0]["fallback"].any() for r in ref_res) and any((r[0]["status"] != 0).any() for r in ref_res)
+    for sizes in ([2] * 28, [4] * 14, [3, 1, 4, 2, 2, 4, 1, 3, 4, 4, 2, 3, 1, 4, 2, 4, 4, 3, 3, 2]):
+        assert sum(sizes) == len(frames)
+        em = emu_lib.SkidpadEmu(3, table, noise, ref, md)
+        t = 0
+        for k in sizes:
+            for j, (out, info) in enumerate(em.steps(frames[t : t + k])):
+                assert out.tobytes() == ref_res[t + j][0].tobytes(), (sizes[:3], t + j)
+                assert info.tobytes() == ref_res[t + j][1].tobytes(), (sizes[:3], t + j)
+            t += k
+        assert em.states.tobytes() == one.states.tobytes()

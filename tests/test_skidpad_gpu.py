@@ -126,3 +126,46 @@ def test_full_size_config5(pkg, golden_dir):
     assert flips0 <= 0.03 * T
     assert (reloc_frame >= 0).mean() > 0.95, float((reloc_frame >= 0).mean())   # relocalization success count
     assert np.median(reloc_frame[reloc_frame >= 0]) <= 40
+
+
+def _same_fields(a, b):
+    """bit-equal field by field (the records' padding bytes are nobody's)"""
+    return a.dtype == b.dtype and all(np.ascontiguousarray(a[k]).tobytes() == np.ascontiguousarray(b[k]).tobytes() for k in a.dtype.names)
+
+
+@pytest.mark.parametrize("n,group", [(3, None), (64, "3"), (700, None), (1100, "4")])
+def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, n, group):
+    """Steps in flight (csrc/skidpad_kernel.h): a replay that submits ahead has 2-4 consecutive steps planned by one
+    skid_path_kernel launch (one wavefront per (instance, step), each working from the window index its predecessors'
+    poses lead to, waiting for its predecessor's published state before it keeps or repeats its result).  Results,
+    planner information and the states' further course must be those of one launch per step — byte for byte, through the
+    relocalization, through steps that read the previous path (a car 60 m off the track), steps that fail (positions that
+    are not finite) and jumps of the window index."""
+    if group:
+        monkeypatch.setenv("FSDP_SKID_GROUP", group)
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, n)
+    frames = sk.awkward_frames(g, tf, 64)
+    one = pkg.SkidpadBatch(n, device=0)
+    ref = []
+    for f in frames:
+        res, info = one.step(*f)
+        ref.append((res.copy(), info.copy()))
+    assert any(r["path_fallback"].any() for r, _ in ref) and any((r["status"] != 0).any() for r, _ in ref)
+    batch = pkg.SkidpadBatch(n, device=0)
+    for depth in (4, 3):
+        batch.reset()
+        batch.set_overlap(depth)
+        inflight, got = [], []
+        for f in frames:
+            if len(inflight) == depth:
+                got.append(batch.collect(inflight.pop(0)))
+            inflight.append(batch.submit(*f))
+        got += [batch.collect(t) for t in inflight]
+        for t, ((res, info), (r0, i0)) in enumerate(zip(got, ref)):
+            assert _same_fields(res, r0) and _same_fields(info, i0), (depth, t)
+    # and the states carry on identically: ten more steps, one at a time
+    for t in range(64, 74):
+        f = sk.batch_for_step(g, t, tf)
+        a, b = batch.step(*f), one.step(*f)
+        assert _same_fields(a[0], b[0]) and _same_fields(a[1], b[1]), t
