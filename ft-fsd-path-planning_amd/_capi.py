@@ -346,7 +346,7 @@ class Context:
         self._check(self._lib.fsdp_set_global_path(self._h, _dp(xy), ctypes.c_int(len(xy))), "fsdp_set_global_path")
 
     def set_overlap(self, depth: int):
-        """depth d (1..16): consecutive run() passes rotate through d HIP streams / buffer sets and overlap (a replay is a
+        """depth d (1..32): consecutive run() passes rotate through d HIP streams / buffer sets and overlap (a replay is a
         stream of batches); depth 1 (default): one pass after the other."""
         self._check(self._lib.fsdp_set_overlap(self._h, int(depth)), "fsdp_set_overlap")
 

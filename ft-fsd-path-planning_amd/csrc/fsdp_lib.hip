@@ -189,7 +189,15 @@ struct fsdp_ctx {
   uint32_t* d_skid_sync = nullptr;   // [0] ticket counter of skid_path_kernel, [1 + i] steps instance i has published
   uint32_t skid_ticket_base = 0;
   int skid_step_no = 0;              // steps submitted since fsdp_skidpad_reset
-  int skid_group = 1;                // steps per skid_path_kernel launch when the caller submits ahead
+  int skid_group_env = 0;            // FSDP_SKID_GROUP: steps per launch when the caller submits ahead (0: chosen from the instance count)
+  int skid_pack_min = 4096;          // (instance, step) pairs from which a group goes through the packed kernels
+  // workspace of a group that goes through the packed kernels, frame = step * n_instances + instance
+  double* d_g_arena = nullptr;
+  PathMid* d_g_mid = nullptr;
+  PathOut* d_g_out = nullptr;
+  int* d_g_retry = nullptr;
+  SkidSel* d_g_sel = nullptr;
+  size_t g_cap = 0;
   int skid_pending[SKID_GROUP_MAX] = {};  // slots whose step waits for its group's launch, oldest first
   int n_skid_pending = 0;
   int n_instances = 0;
@@ -428,6 +436,18 @@ template <int G>
 static void launch_finish(fsdp_ctx* c, Work& q, int n) {
   hipLaunchKernelGGL(path_finish_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, q.d_arena, q.d_mid, q.d_path,
                      q.d_retry, c->d_params);
+}
+
+// the same steps through the packed kernels (csrc/skidpad_kernel.h "steps in flight, many frames per wavefront")
+template <int G, int GF>
+static void launch_skid_packed_kernels(fsdp_ctx* c, int frames) {
+  hipStream_t xs = c->stream;
+  hipLaunchKernelGGL(skid_prep_kernel<G>, dim3((frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, xs, frames, c->d_g_sel, c->tables, c->d_chord,
+                     c->d_default_path, c->d_g_arena, c->d_g_mid);
+  hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid,
+                     c->d_g_retry, c->d_params);
+  hipLaunchKernelGGL(path_finish_kernel<G>, dim3((frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid, c->d_g_out,
+                     c->d_g_retry, c->d_params);
 }
 
 // Lanes per frame: a serial instruction costs its issue cycles whatever the number of active lanes, so the more frames
@@ -893,6 +913,11 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_skid);
   (void)hipFree(c->d_skid_backup);
   (void)hipFree(c->d_skid_sync);
+  (void)hipFree(c->d_g_arena);
+  (void)hipFree(c->d_g_mid);
+  (void)hipFree(c->d_g_out);
+  (void)hipFree(c->d_g_retry);
+  (void)hipFree(c->d_g_sel);
   (void)hipFree(c->d_default_path);
   (void)hipFree(c->d_params);
   if (c->h_sort) (void)hipHostFree(c->h_sort);
@@ -1731,18 +1756,28 @@ int fsdp_skidpad_reset(fsdp_ctx* c, int n_instances) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->skid_ticket_base = 0;
   c->skid_step_no = 0;
-  // steps per launch when the caller submits ahead: as many as put two wavefronts on every SIMD (256 CUs x 4 SIMDs; the
-  // kernel holds two per SIMD), FSDP_SKID_GROUP overrides
-  int group = 2048 / n_instances;
-  if (const char* e = getenv("FSDP_SKID_GROUP")) group = atoi(e);
-  c->skid_group = group < 1 ? 1 : group > SKID_GROUP_MAX ? SKID_GROUP_MAX : group;
+  c->skid_group_env = getenv("FSDP_SKID_GROUP") ? atoi(getenv("FSDP_SKID_GROUP")) : 0;
+  if (const char* e = getenv("FSDP_SKID_PACK_MIN")) c->skid_pack_min = atoi(e);
   return 0;
 }
 
-// skid_path_kernel for the steps whose inputs, relocalization status and output records sit in slots[0 .. n_steps): one
-// wavefront per (instance, step), csrc/skidpad_kernel.h "Steps in flight"
-static void launch_skid_path(fsdp_ctx* c, const int* slots, int n_steps, int step0) {
+// Steps per launch for a caller that submits ahead (half the slots at most, so that one group runs while the next one is
+// being submitted).  Thousands of (instance, step) pairs go through the packed kernels of the autocross path stage: the
+// group is made as large as gives them 16384 frames (the more steps share the launches the better: 1024 instances plan
+// 3.0 / 3.8 / 4.1 / 4.6 M frames/s in groups of 4 / 8 / 12 / 16); below that the steps get a wavefront each (skid_path_kernel) and the
+// group is what puts at least three wavefronts on every SIMD (256 CUs x 4 SIMDs; a partly filled second round costs less
+// than an unfilled first one: profiles/r03_skidpad_groups.txt).
+static int skid_group_size(const fsdp_ctx* c) {
   const int n = c->n_instances;
+  const int half = c->overlap / 2 > 1 ? c->overlap / 2 : 1;
+  auto clamp = [&](int g) { return g < 1 ? 1 : g > SKID_GROUP_MAX ? SKID_GROUP_MAX : g > half ? half : g; };
+  if (c->skid_group_env > 0) return c->skid_group_env > SKID_GROUP_MAX ? SKID_GROUP_MAX : c->skid_group_env > c->overlap ? c->overlap : c->skid_group_env;
+  const int packed = clamp((16384 + n - 1) / n);
+  if ((long long)packed * n >= c->skid_pack_min && c->params.max_deg == 3) return packed;
+  return clamp((3072 + n - 1) / n);
+}
+
+static SkidGroup skid_group_of(fsdp_ctx* c, const int* slots, int n_steps, int step0) {
   SkidGroup g;
   memset(&g, 0, sizeof(g));
   for (int k = 0; k < n_steps; k++) {
@@ -1752,9 +1787,47 @@ static void launch_skid_path(fsdp_ctx* c, const int* slots, int n_steps, int ste
   g.n_steps = n_steps;
   g.step0 = step0;
   g.ticket_base = c->skid_ticket_base;
+  return g;
+}
+
+// skid_path_kernel for the steps whose inputs, relocalization status and output records sit in slots[0 .. n_steps): one
+// wavefront per (instance, step), csrc/skidpad_kernel.h "steps in flight, a wavefront per (instance, step)"
+static void launch_skid_path(fsdp_ctx* c, const int* slots, int n_steps, int step0) {
+  const int n = c->n_instances;
+  const SkidGroup g = skid_group_of(c, slots, n_steps, step0);
   c->skid_ticket_base += (uint32_t)n * (uint32_t)n_steps;
   hipLaunchKernelGGL(skid_path_kernel, dim3((unsigned)n * (unsigned)n_steps), dim3(WAVE), 0, c->stream, n, g, c->d_skid, c->tables, c->d_chord,
                      c->d_skid_sync);
+}
+
+static int launch_skid_packed(fsdp_ctx* c, const int* slots, int n_steps, int step0) {
+  const int n = c->n_instances;
+  const int frames = n * n_steps;
+  if ((size_t)frames > c->g_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t m = (size_t)n * SKID_GROUP_MAX;
+    HIP_TRY(c, regrow(c->d_g_arena, (size_t)ARENA_DOUBLES * m));
+    HIP_TRY(c, regrow(c->d_g_mid, m));
+    HIP_TRY(c, regrow(c->d_g_out, m));
+    HIP_TRY(c, regrow(c->d_g_retry, m + 1));
+    HIP_TRY(c, regrow(c->d_g_sel, m));
+    c->g_cap = m;
+  }
+  const SkidGroup g = skid_group_of(c, slots, n_steps, step0);
+  hipStream_t xs = c->stream;
+  HIP_TRY(c, hipMemsetAsync(c->d_g_retry, 0, sizeof(int), xs));  // (the packed kernels' list of frames they hand on; the commit kernel goes by the frames' records)
+  hipLaunchKernelGGL(skid_select_kernel, dim3((unsigned)n), dim3(WAVE), 0, xs, n, g, c->d_skid, c->tables, c->d_g_sel);
+  if (frames >= PACK_FRAMES) {
+    if (c->fit_g == 4)
+      launch_skid_packed_kernels<8, 4>(c, frames);
+    else
+      launch_skid_packed_kernels<8, 8>(c, frames);
+  } else {
+    launch_skid_packed_kernels<16, 16>(c, frames);
+  }
+  hipLaunchKernelGGL(skid_commit_kernel, dim3((unsigned)n), dim3(WAVE), 0, xs, n, g, c->d_skid, c->tables, c->d_chord, c->d_g_sel, c->d_g_mid, c->d_g_out,
+                     c->d_g_arena, c->d_skid_sync);
+  return 0;
 }
 
 // The path kernel, result assembly and completion event of the steps submitted so far whose launch was put off
@@ -1766,7 +1839,11 @@ static int flush_skid(fsdp_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   const int n = c->n_instances;
   hipStream_t xs = c->stream;
-  launch_skid_path(c, c->skid_pending, n_steps, c->skid_step_no - n_steps);
+  if ((long long)n * n_steps >= c->skid_pack_min && c->params.max_deg == 3) {
+    if (int rc = launch_skid_packed(c, c->skid_pending, n_steps, c->skid_step_no - n_steps)) return rc;
+  } else {
+    launch_skid_path(c, c->skid_pending, n_steps, c->skid_step_no - n_steps);
+  }
   for (int k = 0; k < n_steps; k++) {
     Work& q = c->slot[c->skid_pending[k]];
     Work::Ticket& t = q.tk[0];
@@ -1811,11 +1888,7 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
     c->err = "fsdp_skidpad_submit: all " + std::to_string(c->overlap) + " slots hold a ticket; collect ticket " + std::to_string(t.id) + " first";
     return 4;
   }
-  // (buffers that must grow are replaced: not under the feet of the steps queued on the main stream)
-  if (n_instances > q.cap_frames || n_instances > q.in.cap_frames || total > q.in.cap_cones) {
-    if (int rc = flush_skid(c)) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-  }
+  // (the slot's ticket is free, i.e. collected: nothing queued uses its buffers any more, they may be replaced)
   if (int rc = ensure_work(c, q, n_instances)) return rc;
   hipStream_t xs = c->stream;
   const bool in_pinned = is_pinned(off) && is_pinned(poses) && (total == 0 || is_pinned(cones));
@@ -1859,8 +1932,7 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
   t.id = c->next_ticket++;
   c->outstanding++;
   *ticket = t.id;
-  const int group = c->skid_group < c->overlap ? c->skid_group : c->overlap;
-  if (c->n_skid_pending >= group) return flush_skid(c);
+  if (c->n_skid_pending >= skid_group_size(c)) return flush_skid(c);
   return 0;
 }
 

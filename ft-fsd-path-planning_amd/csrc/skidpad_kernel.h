@@ -24,7 +24,7 @@ constexpr int SKID_NEAR = 20;
 constexpr int ST_OVERFLOW_CLUSTERS = 205;
 constexpr int ST_SYNC_LOST = 206;  // internal: a step's wavefront never saw its predecessor's state published
 
-constexpr int SKID_HIST = 8;  // > SKID_GROUP_MAX
+constexpr int SKID_HIST = 32;  // > SKID_GROUP_MAX
 
 struct SkidState {
   int32_t has_original, relocalized, index_along_path;
@@ -435,24 +435,9 @@ __global__ void __launch_bounds__(64) skid_reloc_kernel(int n_inst, const int32_
   }
 }
 
-// Steps in flight.  A planner's steps chain through its state (window index, previous path), but almost all of a step —
-// the MPC refit of the window — depends on that state only through the window index, and the index a step leaves depends
-// on the poses alone (the reference moves it before the MPC step, skidpad_calculate_path.py:66-67: one 400-point arg-min
-// per step).  So one launch plans up to SKID_GROUP_MAX consecutive steps of every instance, one wavefront per (instance,
-// step): the wavefront of step g
-//   1. works out the index step g - 1 leaves from the index recorded before the launch (index_hist) and the poses of the
-//      launch's earlier steps,
-//   2. plans its step with it,
-//   3. waits until step g - 1 of its instance has published its state (sync[1 + inst] >= g), and
-//   4. keeps its result if the previous path was never read (fallback == 0: every read of it sets a bit) and the published
-//      index is the one it used — otherwise plans the step again from the published state, exactly as a launch of its
-//      own would;
-//   5. writes the state and publishes it (sync[1 + inst] = g + 1).
-// Results and states are therefore those of one launch per step, whatever the grouping.  Wavefronts take their
-// (step, instance) from a ticket counter in start order, step-major, so the wavefront a wait is for has always started:
-// no wait can be for work that is not resident or finished.  With 1024 instances two steps put two wavefronts on every
-// SIMD, where one issues an FP64 instruction every 8.7 cycles and two every 4.6.
-constexpr int SKID_GROUP_MAX = 4;
+// ---- the path step of a planner: pieces shared by the kernels below -------------------------------------------------------
+constexpr int SKID_GROUP_MAX = 16;  // steps of one planner that may share a launch
+constexpr int ST_SERIAL = 298;      // internal (PathMid::status): the step is planned by its planner's own wavefront, behind its predecessor
 
 struct SkidStep {
   const double* poses;       // (n_inst, 4) of this step
@@ -469,10 +454,199 @@ struct SkidGroup {
   uint32_t ticket_base;   // value of the ticket counter before this launch
 };
 
-__global__ void __launch_bounds__(64, 2) skid_path_kernel(int n_inst, SkidGroup G, SkidState* states, SkidTables T,
+// full_pipeline.py:126-134: pose into the known map frame (the transform is read where it is used rather than held in
+// registers across the path stage)
+__device__ __forceinline__ void skid_map_pose(const SkidState* st, const SkidTables& T, const double* pose, double& px, double& py,
+                                              double& dx, double& dy) {
+  px = pose[0], py = pose[1], dx = pose[2], dy = pose[3];
+  const double rotation = st->rotation;
+  double yaw = detm::det_atan2(dy, dx);
+  double sn, cs;
+  detm::det_sincos(rotation, sn, cs);
+  double qx = px + st->translation[0] - T.ref_right[0], qy = py + st->translation[1] - T.ref_right[1];
+  double rx = blas_dot2(qx, cs, qy, -sn), ry = blas_dot2(qx, sn, qy, cs);
+  px = rx + T.ref_right[0];
+  py = ry + T.ref_right[1];
+  yaw = yaw + rotation;
+  detm::det_sincos(yaw, dy, dx);
+  px = wave_uniform(px), py = wave_uniform(py), dx = wave_uniform(dx), dy = wave_uniform(dy);
+}
+
+// SkidpadCalculatePath.fit_matches_as_spline, skidpad_calculate_path.py:60-67: closest point of the known path within
+// +-max_change of the index, over the lanes of a wavefront; -1: empty window
+__device__ __forceinline__ int skid_closest_in_window(const SkidTables& T, int index, double px, double py) {
+  const int lane = lane_id();
+  const int max_change = (int)(20 / T.mean_distance);
+  int lo = index - max_change;
+  lo = lo < 0 ? 0 : lo;
+  int hi = index + max_change;
+  hi = hi > T.n_path ? T.n_path : hi;
+  if (hi <= lo) return -1;
+  double bv = 0.0;
+  int bi = -1;
+  for (int i = lo + lane; i < hi; i += WAVE) {
+    double d = norm_axis(px - T.path[2 * i], py - T.path[2 * i + 1]);
+    d = (d != d) ? -1.0 : d;  // np.argmin: the first NaN is the minimum (and every lane agrees on it); distances are >= 0
+    if (bi < 0 || d < bv) {
+      bv = d;
+      bi = i;
+    }
+  }
+  wave_argmin(bv, bi);
+  return wave_uniform(bi);
+}
+
+// the path update of a step into the arena polyline [1, 1 + n1), over the G lanes of a frame: the window of the known
+// path behind its closest point (skidpad_calculate_path.py:68-71) or, before relocalization, the trivial path
+// (calculate_trivial_path, core_calculate_path.py:127-134: chord[1:] rotated by the car yaw, + position); returns n1
+template <int G>
+__device__ __forceinline__ int skid_fill_update(const Arena& A, const SkidTables& T, const double* __restrict__ chord, bool reloc,
+                                                int first, double px, double py, double dx, double dy) {
+  using GR = Grp<G>;
+  const int lane = GR::lane();
+  int n1;
+  if (reloc) {
+    int fin = first + (int)(25 / T.mean_distance);
+    fin = fin > T.n_path ? T.n_path : fin;
+    n1 = fin - first;
+    for (int i = lane; i < n1; i += G) {
+      A.x[1 + i] = T.path[2 * (first + i)];
+      A.y[1 + i] = T.path[2 * (first + i) + 1];
+    }
+  } else {
+    double yaw = detm::det_atan2(dy, dx);
+    double sn, cs;
+    detm::det_sincos(yaw, sn, cs);
+    n1 = PATH_POINTS - 1;
+    for (int i = lane; i < n1; i += G) {
+      double cxp = chord[2 * (i + 1)], cyp = chord[2 * (i + 1) + 1];
+      A.x[1 + i] = blas_dot2(cxp, cs, cyp, -sn) + px;
+      A.y[1 + i] = blas_dot2(cxp, sn, cyp, cs) + py;
+    }
+  }
+  GR::sync();
+  return n1;
+}
+
+// One step of one planner on one wavefront, from the window index index_in and the previous path prev: window lookup, the
+// common MPC step (finish_path) with the shortened division / square-root sequences (spline_device.h: the same bits for
+// operands inside their exponent band) and, for a step that meets an operand outside the band (ST_RETRY), once more with
+// the plain ones.  Returns the step's status; *new_index = the index the step leaves (the reference moves it before the
+// MPC step, skidpad_calculate_path.py:66-67: it stays moved when the step raises).
+template <class PS>
+__device__ __forceinline__ int skid_plan_step(PS& S, const Arena& A, const SkidTables& T, const double* __restrict__ chord, int status_in,
+                                              bool reloc, int index_in, double px, double py, double dx, double dy, const double* prev,
+                                              double (*out)[4], int* fallback, int* n_dense, int* new_index) {
+  int status = status_in, n1 = 0;
+  *fallback = *n_dense = 0;
+  *new_index = index_in;
+  if (status != ST_OK) return status;
+  int first = 0;
+  if (reloc) {
+    first = skid_closest_in_window(T, index_in, px, py);
+    if (first < 0) return ST_REF_UNDEFINED_PATH;
+    *new_index = first;
+  }
+  // a car position that is not finite: the window index has moved (to the window's first point: np.argmin of NaNs), the
+  // MPC step raises whatever path it is given (the car position joins the path) — the reference's exception reaches the
+  // caller
+  if (!(fabs(px) < INFINITY && fabs(py) < INFINITY)) return ST_REF_UNDEFINED_PATH;
+  n1 = skid_fill_update<WAVE>(A, T, chord, reloc, first, px, py, dx, dy);
+  status = finish_path<WAVE, true>(S, A, n1, px, py, dx, dy, prev, out, fallback, n_dense);
+  if (status == ST_RETRY || status == ST_OVERFLOW_KNOTS) {
+    __syncthreads();
+    *fallback = *n_dense = 0;
+    n1 = skid_fill_update<WAVE>(A, T, chord, reloc, first, px, py, dx, dy);
+    status = finish_path<WAVE, false>(S, A, n1, px, py, dx, dy, prev, out, fallback, n_dense);
+  }
+  __syncthreads();
+  return status;
+}
+
+// What a finished step leaves behind: previous_paths[-1] <- the result (map frame), the path xy back in the original
+// frame (full_pipeline.py:178-194), the window index, the records of the step.  THROUGH: the state goes out with
+// agent-scope stores (written through to where another wavefront, on whatever XCD, reads it inside the same launch).
+template <bool THROUGH>
+__device__ __forceinline__ void skid_finish_step(SkidState* st, const SkidTables& T, PathOut* o, SkidInfo* fi, bool reloc, int status,
+                                                 int fallback, int n_dense, int index_out, int g) {
+  const int lane = lane_id();
+  if (status == ST_OK) {
+    if (lane < PATH_POINTS) {
+      double u = o->path[lane][0], x = o->path[lane][1], y = o->path[lane][2], k = o->path[lane][3];
+      if (THROUGH) {
+        __hip_atomic_store(&st->prev[lane][0], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->prev[lane][1], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->prev[lane][2], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->prev[lane][3], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        st->prev[lane][0] = u;
+        st->prev[lane][1] = x;
+        st->prev[lane][2] = y;
+        st->prev[lane][3] = k;
+      }
+      if (reloc) {
+        const double rcx = st->right_calc[0], rcy = st->right_calc[1];
+        double sn, cs;
+        detm::det_sincos(-st->rotation, sn, cs);
+        double qx = x - st->translation[0] - rcx, qy = y - st->translation[1] - rcy;
+        o->path[lane][1] = blas_dot2(qx, cs, qy, -sn) + rcx;
+        o->path[lane][2] = blas_dot2(qx, sn, qy, cs) + rcy;
+      }
+    }
+  } else if (lane < PATH_POINTS) {
+    for (int q = 0; q < 4; q++) o->path[lane][q] = NAN;
+  }
+  if (lane == 0) {
+    if (THROUGH)
+      __hip_atomic_store(&st->index_along_path, index_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      st->index_along_path = index_out;
+    st->index_hist[g % SKID_HIST] = index_out;
+    o->status = status;
+    o->fallback = fallback;
+    o->n_dense = n_dense;
+    o->pad = 0;
+    fi->relocalized = reloc ? 1 : 0;
+    fi->index_along_path = index_out;
+    fi->translation[0] = fi->translation[1] = fi->rotation = NAN;
+    if (reloc) {
+      // RelocalizationInformation.from_transform_function: images of (0,0) and (1,0)
+      const double tx = st->translation[0], ty = st->translation[1];
+      double sn, cs;
+      detm::det_sincos(st->rotation, sn, cs);
+      double ax0 = 0.0 + tx - T.ref_right[0], ay0 = 0.0 + ty - T.ref_right[1];
+      double ax1 = 1.0 + tx - T.ref_right[0];
+      double o0x = blas_dot2(ax0, cs, ay0, -sn) + T.ref_right[0], o0y = blas_dot2(ax0, sn, ay0, cs) + T.ref_right[1];
+      double o1x = blas_dot2(ax1, cs, ay0, -sn) + T.ref_right[0], o1y = blas_dot2(ax1, sn, ay0, cs) + T.ref_right[1];
+      fi->translation[0] = o0x;
+      fi->translation[1] = o0y;
+      fi->rotation = atan2(o1y - o0y, o1x - o0x);
+    }
+  }
+}
+
+// ---- steps in flight, a wavefront per (instance, step) --------------------------------------------------------------------
+// A planner's steps chain through its state (window index, previous path), but almost all of a step — the MPC refit of the
+// window — depends on that state only through the window index, and the index a step leaves depends on the poses alone
+// (one 400-point arg-min per step).  So one launch plans up to SKID_GROUP_MAX consecutive steps of every instance, one
+// wavefront per (instance, step): the wavefront of step g
+//   1. works out the index step g - 1 leaves from the index recorded before the launch (index_hist) and the poses of the
+//      launch's earlier steps,
+//   2. plans its step with it,
+//   3. waits until step g - 1 of its instance has published its state (sync[1 + inst] >= g), and
+//   4. keeps its result if the previous path was never read (fallback == 0: every read of it sets a bit) and the published
+//      index is the one it used — otherwise plans the step again from the published state, exactly as a launch of its
+//      own would;
+//   5. writes the state and publishes it (sync[1 + inst] = g + 1).
+// Results and states are therefore those of one launch per step, whatever the grouping.  Wavefronts take their
+// (step, instance) from a ticket counter in start order, step-major, so the wavefront a wait is for has always started:
+// no wait can be for work that is not resident or finished.  With 1024 instances three steps put three wavefronts on every
+// SIMD, where one alone issues an FP64 instruction every 8.7 cycles and four together one every 4.6; the
+// kernel is held to 168 registers for that (144 spilled: 1 % slower alone, 8 % faster three to a SIMD than two at 256).
+__global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, SkidGroup G, SkidState* states, SkidTables T,
                                                           const double* __restrict__ chord, uint32_t* sync) {
   __shared__ PathShared<WAVE> S;
-  __shared__ uint32_t s_ticket;
+  __shared__ uint32_t s_ticket, s_spins;
   __shared__ double s_prev[PATH_POINTS][4];
   const int lane = lane_id();
   if (lane == 0) s_ticket = atomicAdd(&sync[0], 1u) - G.ticket_base;
@@ -486,55 +660,16 @@ __global__ void __launch_bounds__(64, 2) skid_path_kernel(int n_inst, SkidGroup 
   SkidState* st = &states[inst];
   PathOut* o = &me.out[inst];
   // written by skid_reloc_kernel only, i.e. before this launch
-  // (the transform is read where it is used rather than held in registers across the path stage)
   const bool latched = wave_uniform(st->relocalized) != 0;
   const int reloc_step = wave_uniform(st->reloc_step);
-  const int max_change = (int)(20 / T.mean_distance);
 
-  // full_pipeline.py:126-134: pose into the known map frame
-  auto map_pose = [&](const double* pose, double& px, double& py, double& dx, double& dy) {
-    px = pose[0], py = pose[1], dx = pose[2], dy = pose[3];
-    const double rotation = st->rotation;
-    double yaw = detm::det_atan2(dy, dx);
-    double sn, cs;
-    detm::det_sincos(rotation, sn, cs);
-    double qx = px + st->translation[0] - T.ref_right[0], qy = py + st->translation[1] - T.ref_right[1];
-    double rx = blas_dot2(qx, cs, qy, -sn), ry = blas_dot2(qx, sn, qy, cs);
-    px = rx + T.ref_right[0];
-    py = ry + T.ref_right[1];
-    yaw = yaw + rotation;
-    detm::det_sincos(yaw, dy, dx);
-    px = wave_uniform(px), py = wave_uniform(py), dx = wave_uniform(dx), dy = wave_uniform(dy);
-  };
-  // SkidpadCalculatePath.fit_matches_as_spline, skidpad_calculate_path.py:60-67: closest point of the known path within
-  // +-max_change of the index; -1: empty window
-  auto closest_in_window = [&](int index, double px, double py) {
-    int lo = index - max_change;
-    lo = lo < 0 ? 0 : lo;
-    int hi = index + max_change;
-    hi = hi > T.n_path ? T.n_path : hi;
-    if (hi <= lo) return -1;
-    double bv = 0.0;
-    int bi = -1;
-    for (int i = lo + lane; i < hi; i += WAVE) {
-      double d = norm_axis(px - T.path[2 * i], py - T.path[2 * i + 1]);
-      d = (d != d) ? -1.0 : d;  // np.argmin: the first NaN is the minimum (and every lane agrees on it); distances are >= 0
-      if (bi < 0 || d < bv) {
-        bv = d;
-        bi = i;
-      }
-    }
-    wave_argmin(bv, bi);
-    return wave_uniform(bi);
-  };
-
-  // 1. the index step g - 1 is expected to leave
+  // 1. the index step g - 1 leaves
   int index_in = wave_uniform(st->index_hist[(G.step0 + SKID_HIST - 1) % SKID_HIST]);
   for (int j = 0; j < s; j++) {
     if (G.step[j].status_in[inst] != ST_OK || !(latched && reloc_step <= G.step0 + j)) continue;
     double qx, qy, qdx, qdy;
-    map_pose(G.step[j].poses + 4 * inst, qx, qy, qdx, qdy);
-    const int bi = closest_in_window(index_in, qx, qy);
+    skid_map_pose(st, T, G.step[j].poses + 4 * inst, qx, qy, qdx, qdy);
+    const int bi = skid_closest_in_window(T, index_in, qx, qy);
     if (bi >= 0) index_in = bi;
   }
 
@@ -542,67 +677,14 @@ __global__ void __launch_bounds__(64, 2) skid_path_kernel(int n_inst, SkidGroup 
   double px = wave_uniform(me.poses[4 * inst + 0]), py = wave_uniform(me.poses[4 * inst + 1]);
   double dx = wave_uniform(me.poses[4 * inst + 2]), dy = wave_uniform(me.poses[4 * inst + 3]);
   const int status_in = wave_uniform(me.status_in[inst]);
-  if (status_in == ST_OK && reloc) map_pose(me.poses + 4 * inst, px, py, dx, dy);
-  int status = ST_OK, fallback = 0, n_dense = 0, n1 = 0, new_index = index_in;
-  // the path update of this step into the arena polyline [1, 1 + n1): the window of the known path behind the closest
-  // point (skidpad_calculate_path.py:49-71) or, before relocalization, the trivial path (calculate_trivial_path,
-  // core_calculate_path.py:127-134: chord[1:] rotated by the car yaw, + position)
-  auto fill_update = [&]() {
-    if (reloc) {
-      const int bi = closest_in_window(index_in, px, py);
-      if (bi < 0) {
-        status = ST_REF_UNDEFINED_PATH;
-      } else {
-        new_index = bi;
-        int fin = bi + (int)(25 / T.mean_distance);
-        fin = fin > T.n_path ? T.n_path : fin;
-        n1 = fin - bi;
-        for (int i = lane; i < n1; i += WAVE) {
-          A.x[1 + i] = T.path[2 * (bi + i)];
-          A.y[1 + i] = T.path[2 * (bi + i) + 1];
-        }
-      }
-    } else {
-      double yaw = detm::det_atan2(dy, dx);
-      double sn, cs;
-      detm::det_sincos(yaw, sn, cs);
-      n1 = PATH_POINTS - 1;
-      if (lane < n1) {
-        double cxp = chord[2 * (lane + 1)], cyp = chord[2 * (lane + 1) + 1];
-        A.x[1 + lane] = blas_dot2(cxp, cs, cyp, -sn) + px;
-        A.y[1 + lane] = blas_dot2(cxp, sn, cyp, cs) + py;
-      }
-    }
-    __syncthreads();
-  };
+  if (status_in == ST_OK && reloc) skid_map_pose(st, T, me.poses + 4 * inst, px, py, dx, dy);
+  int status = ST_OK, fallback = 0, n_dense = 0, new_index = index_in;
   bool sync_lost = false;
   const double* prev = &st->prev[0][0];  // first round: whatever is there (a result that read it is not kept)
 #pragma unroll 1
   for (int round = 0; round < 2; round++) {
     // 2. (and 4.) the step from index_in
-    status = status_in;
-    fallback = n_dense = n1 = 0;
-    new_index = index_in;
-    if (status == ST_OK) fill_update();
-    // a car position that is not finite: the window index has moved (to the window's first point: np.argmin of NaNs), the
-    // MPC step raises whatever path it is given (the car position joins the path) — the reference's exception reaches
-    // the caller
-    if (status == ST_OK && !(fabs(px) < INFINITY && fabs(py) < INFINITY)) status = ST_REF_UNDEFINED_PATH;
-    // The path stage with the shortened division / square-root sequences (spline_device.h: the same bits for operands
-    // inside their exponent band); a step that meets an operand outside the band (ST_RETRY) is planned again with the
-    // plain ones.
-    if (status == ST_OK) {
-      status = finish_path<WAVE, true>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
-      if (status == ST_RETRY || status == ST_OVERFLOW_KNOTS) {
-        __syncthreads();
-        status = ST_OK;
-        fallback = 0;
-        n_dense = 0;
-        fill_update();
-        if (status == ST_OK) status = finish_path<WAVE, false>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
-      }
-    }
-    __syncthreads();
+    status = skid_plan_step(S, A, T, chord, status_in, reloc, index_in, px, py, dx, dy, prev, o->path, &fallback, &n_dense, &new_index);
     if (round == 1) break;
     // 3. step g - 1 of this instance has published its state
     // (bounded, seconds: a wait that ends this way means a broken launch order — the step reports ST_SYNC_LOST instead of
@@ -611,10 +693,10 @@ __global__ void __launch_bounds__(64, 2) skid_path_kernel(int n_inst, SkidGroup 
       uint32_t spins = 0;
       while (__hip_atomic_load(&sync[1 + inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)g && ++spins < (1u << 24))
         __builtin_amdgcn_s_sleep(8);
-      s_ticket = spins;
+      s_spins = spins;
     }
     __syncthreads();
-    if (s_ticket >= (1u << 24)) {
+    if (s_spins >= (1u << 24)) {
       sync_lost = true;
       break;
     }
@@ -640,59 +722,147 @@ __global__ void __launch_bounds__(64, 2) skid_path_kernel(int n_inst, SkidGroup 
     return;
   }
   // 5. state and results
-  if (status == ST_OK) {
-    // previous_paths[-1] <- this result (map frame); then path xy back to the original frame (full_pipeline.py:178-194)
-    if (lane < PATH_POINTS) {
-      double u = o->path[lane][0], x = o->path[lane][1], y = o->path[lane][2], k = o->path[lane][3];
-      // (agent-scope stores: written through to where the next step's wavefront, on whatever XCD, reads them)
-      __hip_atomic_store(&st->prev[lane][0], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&st->prev[lane][1], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&st->prev[lane][2], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&st->prev[lane][3], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (reloc) {
-        const double rcx = st->right_calc[0], rcy = st->right_calc[1];
-        double sn, cs;
-        detm::det_sincos(-st->rotation, sn, cs);
-        double qx = x - st->translation[0] - rcx, qy = y - st->translation[1] - rcy;
-        o->path[lane][1] = blas_dot2(qx, cs, qy, -sn) + rcx;
-        o->path[lane][2] = blas_dot2(qx, sn, qy, cs) + rcy;
-      }
-    }
-  } else if (lane < PATH_POINTS) {
-    for (int q = 0; q < 4; q++) o->path[lane][q] = NAN;
-  }
-  const int index_out = new_index;  // (the reference moves the index before the MPC step: it stays moved when the step raises)
-  if (lane == 0) {
-    __hip_atomic_store(&st->index_along_path, index_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    st->index_hist[g % SKID_HIST] = index_out;
-    o->status = status;
-    o->fallback = fallback;
-    o->n_dense = n_dense;
-    o->pad = 0;
-    SkidInfo* fi = &me.info[inst];
-    fi->relocalized = reloc ? 1 : 0;
-    fi->index_along_path = index_out;
-    fi->translation[0] = fi->translation[1] = fi->rotation = NAN;
-    if (reloc) {
-      // RelocalizationInformation.from_transform_function: images of (0,0) and (1,0)
-      const double tx = st->translation[0], ty = st->translation[1];
-      double sn, cs;
-      detm::det_sincos(st->rotation, sn, cs);
-      double ax0 = 0.0 + tx - T.ref_right[0], ay0 = 0.0 + ty - T.ref_right[1];
-      double ax1 = 1.0 + tx - T.ref_right[0];
-      double o0x = blas_dot2(ax0, cs, ay0, -sn) + T.ref_right[0], o0y = blas_dot2(ax0, sn, ay0, cs) + T.ref_right[1];
-      double o1x = blas_dot2(ax1, cs, ay0, -sn) + T.ref_right[0], o1y = blas_dot2(ax1, sn, ay0, cs) + T.ref_right[1];
-      fi->translation[0] = o0x;
-      fi->translation[1] = o0y;
-      fi->rotation = atan2(o1y - o0y, o1x - o0x);
-    }
-  }
+  skid_finish_step<true>(st, T, o, &me.info[inst], reloc, status, fallback, n_dense, new_index, g);
   __syncthreads();
   // the state above has left the wavefront (its stores are acknowledged) before the flag goes out; no cache write-back:
   // nothing else this wavefront wrote is anybody's before the launch ends
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   if (lane == 0) __hip_atomic_store(&sync[1 + inst], (uint32_t)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- steps in flight, many frames per wavefront ----------------------------------------------------------------------------
+// With thousands of (instance, step) pairs to plan — a replay submitted far ahead — the steps go through the packed
+// kernels of the autocross path stage instead (path_kernel.h: fit_kernel / path_finish_kernel, 4-16 lanes per frame, what
+// makes a frame 3-4 x cheaper than on a wavefront of its own), a frame being one step of one planner:
+//   skid_select_kernel  one wavefront per planner: the poses of the group's steps in the map frame and the window indices
+//                       they lead to, one after the other (they depend on the poses alone),
+//   skid_prep_kernel    per frame: window / trivial path into the workspace, too-far check, connect / extend / trim,
+//                       chord-length parameter (what path_prep_kernel does behind its own front end),
+//   fit_kernel, path_finish_kernel  as they are,
+//   skid_commit_kernel  one wavefront per planner, its steps in order: the packed result stands unless the step needs the
+//                       previous path (too far from the car, the ValueError retry), left the packed kernels' envelope
+//                       (knots, exponent bands) or failed there — such a step is planned here, by skid_plan_step with the
+//                       planner's state as the steps before it left it, exactly as skid_path_kernel would; then the
+//                       state moves on.  Results do not depend on the route a step took (the packed and the
+//                       one-wavefront forms of the path stage give the same bits: tests/test_gpu_parity.py).
+struct SkidSel {
+  int32_t status, reloc, index_in, first;  // first: the index the step leaves (a relocalized step's window starts there)
+  double px, py, dx, dy;                   // pose in the map frame
+};
+
+__global__ void __launch_bounds__(64) skid_select_kernel(int n_inst, SkidGroup G, const SkidState* __restrict__ states, SkidTables T,
+                                                         SkidSel* __restrict__ sel) {
+  const int inst = blockIdx.x;
+  if (inst >= n_inst) return;
+  const int lane = lane_id();
+  const SkidState* st = &states[inst];
+  const bool latched = wave_uniform(st->relocalized) != 0;
+  const int reloc_step = wave_uniform(st->reloc_step);
+  int index = wave_uniform(st->index_along_path);
+  for (int s = 0; s < G.n_steps; s++) {
+    const SkidStep& me = G.step[s];
+    int status = wave_uniform(me.status_in[inst]);
+    const bool reloc = latched && reloc_step <= G.step0 + s;
+    double px = wave_uniform(me.poses[4 * inst + 0]), py = wave_uniform(me.poses[4 * inst + 1]);
+    double dx = wave_uniform(me.poses[4 * inst + 2]), dy = wave_uniform(me.poses[4 * inst + 3]);
+    if (status == ST_OK && reloc) skid_map_pose(st, T, me.poses + 4 * inst, px, py, dx, dy);
+    const int index_in = index;
+    int first = 0;
+    if (status == ST_OK && reloc) {
+      first = skid_closest_in_window(T, index, px, py);
+      if (first < 0)
+        status = ST_REF_UNDEFINED_PATH;
+      else
+        index = first;
+    }
+    if (status == ST_OK && !(fabs(px) < INFINITY && fabs(py) < INFINITY)) status = ST_REF_UNDEFINED_PATH;
+    if (lane == 0) {
+      SkidSel r;
+      r.status = status;
+      r.reloc = reloc ? 1 : 0;
+      r.index_in = index_in;
+      r.first = index;
+      r.px = px, r.py = py, r.dx = dx, r.dy = dy;
+      sel[(size_t)s * n_inst + inst] = r;
+    }
+  }
+}
+
+template <int G>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) skid_prep_kernel(int n_frames, const SkidSel* __restrict__ sel, SkidTables T,
+                                                       const double* __restrict__ chord, const double* __restrict__ default_path,
+                                                       double* __restrict__ arena, PathMid* __restrict__ mid) {
+  using GR = Grp<G>;
+  __shared__ PathShared<G, true> S_all[WAVE / G];
+  const int frame = blockIdx.x * (WAVE / G) + GR::index();
+  if (frame < n_frames) {
+    PathShared<G, true>& S = S_all[GR::index()];
+    const Arena A = frame_arena(arena, frame, T.prm);
+    const SkidSel sl = sel[frame];
+    int fallback = 0, off = 0, n = 0;
+    bool plain = false;
+    if (sl.status == ST_OK) {
+      int n1 = skid_fill_update<G>(A, T, chord, sl.reloc != 0, sl.first, sl.px, sl.py, sl.dx, sl.dy);
+      // (a path too far from the car is replaced by the previous one, which only the planner's own wavefront knows: the
+      // constant initial path stands in here, and the fallback bit sends the step there)
+      n1 = overwrite_if_too_far<G>(A, n1, sl.px, sl.py, default_path, &fallback);
+      if (fallback == 0) {
+        const int rc = mpc_prepare<G>(S, A, n1, sl.px, sl.py, sl.dx, sl.dy, &fallback, &off, &n);
+        plain = rc == 0 && n >= 4 && fallback == 0;  // degree 3 needs 4 points
+        if (plain) build_parameter<G>(S, A, off, n);
+      }
+    }
+    if (GR::lane() == 0) {
+      PathMid m;
+      m.status = plain ? ST_OK : (sl.status != ST_OK ? sl.status : ST_SERIAL);
+      m.fallback = 0;
+      m.off = off;
+      m.n = n;
+      mid[frame] = m;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64, 1) skid_commit_kernel(int n_inst, SkidGroup G, SkidState* states, SkidTables T,
+                                                            const double* __restrict__ chord, const SkidSel* __restrict__ sel,
+                                                            const PathMid* __restrict__ mid, const PathOut* __restrict__ packed,
+                                                            double* __restrict__ arena, uint32_t* __restrict__ sync) {
+  __shared__ PathShared<WAVE> S;
+  const int inst = blockIdx.x;
+  if (inst >= n_inst) return;
+  const int lane = lane_id();
+  SkidState* st = &states[inst];
+#pragma unroll 1
+  for (int s = 0; s < G.n_steps; s++) {
+    const size_t frame = (size_t)s * n_inst + inst;
+    const SkidStep& me = G.step[s];
+    PathOut* o = &me.out[inst];
+    const int packed_status = wave_uniform(mid[frame].status);
+    const int sel_status = wave_uniform(sel[frame].status);
+    const bool reloc = wave_uniform(sel[frame].reloc) != 0;
+    int status, fallback = 0, n_dense = 0, new_index = wave_uniform(sel[frame].first);
+    if (packed_status == ST_OK) {
+      // the packed kernels' result stands
+      const PathOut* r = &packed[frame];
+      if (lane < PATH_POINTS)
+        for (int q = 0; q < 4; q++) o->path[lane][q] = r->path[lane][q];
+      status = ST_OK;
+      n_dense = wave_uniform(r->n_dense);
+      __syncthreads();
+    } else if (sel_status != ST_OK) {
+      status = sel_status;  // decided by the relocalization attempt, the window lookup or the car position
+    } else {
+      const double px = wave_uniform(sel[frame].px), py = wave_uniform(sel[frame].py);
+      const double dx = wave_uniform(sel[frame].dx), dy = wave_uniform(sel[frame].dy);
+      const Arena A = frame_arena(arena, (int)frame, T.prm);
+      status = skid_plan_step(S, A, T, chord, ST_OK, reloc, wave_uniform(sel[frame].index_in), px, py, dx, dy, &st->prev[0][0], o->path,
+                              &fallback, &n_dense, &new_index);
+    }
+    skid_finish_step<false>(st, T, o, &me.info[inst], reloc, status, fallback, n_dense, new_index, G.step0 + s);
+    __syncthreads();
+  }
+  if (lane == 0) sync[1 + inst] = (uint32_t)(G.step0 + G.n_steps);  // steps published, for a later skid_path_kernel launch
 }
 
 }  // namespace fsdp

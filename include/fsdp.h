@@ -202,7 +202,7 @@ int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
  * GPU_MAX_HW_QUEUES above the depth (bench.py sets 16 for its depth of 10).  Every extra depth costs one more set of
  * buffers (~0.1 MB per frame).  Measured at 4096 frames x 128 cones: the steady rate saturates at depth 8; a run of 20
  * passes is fastest with 10 in flight (two full rounds instead of 8 + 8 + 4). */
-#define FSDP_MAX_OVERLAP 16
+#define FSDP_MAX_OVERLAP 32
 int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
 
 /* The kernels that only serve frames the fast kernels hand on (sort_big_kernel: frames beyond the sorting kernel's LDS

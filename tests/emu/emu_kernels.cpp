@@ -107,6 +107,17 @@ static void emu_path_split_launch(int n_frames, const double* poses, const fsdp:
   });
 }
 
+// the same steps through the packed kernels (csrc/skidpad_kernel.h "steps in flight, many frames per wavefront"):
+// select -> prep -> fit -> finish -> commit; lanes = lanes per frame of prep / finish (16, or 8 with a 4-lane fit)
+template <int G, int GF>
+static void emu_skid_packed_kernels(int frames, const fsdp::SkidSel* sel, const fsdp::SkidTables& T, const double* chord, double* arena,
+                                    fsdp::PathMid* mid, fsdp::PathOut* pout, int* retry) {
+  const unsigned per = 64 / G, perf = 64 / GF;
+  emu::launch(((unsigned)frames + per - 1) / per, 64, [&]() { fsdp::skid_prep_kernel<G>(frames, sel, T, chord, g_default_path, arena, mid); });
+  emu::launch(((unsigned)frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, fsdp::FIT_KNOTS>(frames, arena, mid, retry, &g_prm); });
+  emu::launch(((unsigned)frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G>(frames, arena, mid, pout, retry, &g_prm); });
+}
+
 extern "C" {
 int emu_last_retries() { return g_last_retries; }
 // refit record of frame f of the last three-kernel launch: n knots, then knots (34), then coefficients (68); returns n
@@ -229,6 +240,55 @@ void emu_skidpad_steps(int n_inst, int n_steps, int step0, const int32_t* const*
   G.ticket_base = *ticket_base;
   *ticket_base += (uint32_t)n_inst * (uint32_t)n_steps;
   emu::launch((unsigned)(n_inst * n_steps), 64, [&]() { fsdp::skid_path_kernel(n_inst, G, states, T, &chord[0][0], sync); });
+}
+
+// n_steps consecutive skidpad steps through the packed kernels (emu_skid_packed_kernels); returns the number of steps the
+// planners' own wavefronts planned
+int emu_skidpad_steps_packed(int lanes, int n_inst, int n_steps, int step0, const int32_t* const* offsets, const double* const* cones,
+                             const double* const* poses, fsdp::SkidState* states, const double* half_table, int n_path, const double* noise,
+                             int n_noise, const double* ref4, double mean_distance, fsdp::PathOut* const* out, fsdp::SkidInfo* const* info, uint32_t* sync) {
+  std::call_once(g_once, build_default);
+  fsdp::SkidTables T;
+  T.path = half_table;
+  T.n_path = n_path;
+  T.noise = noise;
+  T.n_noise = n_noise;
+  T.ref_right[0] = ref4[0];
+  T.ref_right[1] = ref4[1];
+  T.ref_left[0] = ref4[2];
+  T.ref_left[1] = ref4[3];
+  T.mean_distance = mean_distance;
+  T.prm = &g_prm;
+  double chord[fsdp::PATH_POINTS][2];
+  fsdp::default_chord_points(chord);
+  const int frames = n_inst * n_steps;
+  AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * frames);
+  std::vector<int32_t> status((size_t)frames, 0);
+  std::vector<fsdp::PathMid> mid(frames);
+  std::vector<fsdp::PathOut> pout(frames);
+  std::vector<fsdp::SkidSel> sel(frames);
+  std::vector<int> retry((size_t)frames + 1, 0);
+  fsdp::SkidGroup G;
+  memset(&G, 0, sizeof(G));
+  for (int k = 0; k < n_steps; k++) {
+    double* ar = arena.data() + (size_t)fsdp::ARENA_DOUBLES * n_inst * k;
+    int32_t* stat = status.data() + (size_t)n_inst * k;
+    emu::launch((unsigned)n_inst, 64, [&]() { fsdp::skid_reloc_kernel(n_inst, offsets[k], cones[k], poses[k], states, T, ar, stat, step0 + k); });
+    G.step[k] = fsdp::SkidStep{poses[k], stat, ar, out[k], info[k]};
+  }
+  G.n_steps = n_steps;
+  G.step0 = step0;
+  emu::launch((unsigned)n_inst, 64, [&]() { fsdp::skid_select_kernel(n_inst, G, states, T, sel.data()); });
+  if (lanes == 8)
+    emu_skid_packed_kernels<8, 4>(frames, sel.data(), T, &chord[0][0], arena.data(), mid.data(), pout.data(), retry.data());
+  else
+    emu_skid_packed_kernels<16, 16>(frames, sel.data(), T, &chord[0][0], arena.data(), mid.data(), pout.data(), retry.data());
+  int serial = 0;
+  for (int f = 0; f < frames; f++) serial += mid[f].status != fsdp::ST_OK && sel[f].status == fsdp::ST_OK;
+  emu::launch((unsigned)n_inst, 64, [&]() {
+    fsdp::skid_commit_kernel(n_inst, G, states, T, &chord[0][0], sel.data(), mid.data(), pout.data(), arena.data(), sync);
+  });
+  return serial;  // steps the planners' own wavefronts planned
 }
 
 // calculate_reference_centers_for_skidpad_path + table spacing as the device derives them (out5)

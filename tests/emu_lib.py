@@ -128,7 +128,7 @@ def plan(offsets, cones, poses, group=8):
 
 
 SKID_STATE_DTYPE = np.dtype(
-    [("has_original", "<i4"), ("relocalized", "<i4"), ("index_along_path", "<i4"), ("reloc_step", "<i4"), ("index_hist", "<i4", (8,)),
+    [("has_original", "<i4"), ("relocalized", "<i4"), ("index_along_path", "<i4"), ("reloc_step", "<i4"), ("index_hist", "<i4", (32,)),
      ("orig", "<f8", (4,)),
      ("translation", "<f8", (2,)), ("right_calc", "<f8", (2,)), ("rotation", "<f8"), ("prev", "<f8", (PATH_POINTS, 4))],
     align=True,
@@ -164,8 +164,26 @@ class SkidpadEmu:
         (res,) = self.steps([(offsets, cones, poses)])
         return res
 
+    def steps_packed(self, frames, lanes=16):
+        """The same as ``steps`` through the packed kernels (select -> prep -> fit -> finish -> commit, lanes per frame 16
+        or 8 with a 4-lane fit) -> ([(out, info), ...], number of steps the planners' own wavefronts had to plan)."""
+        k = len(frames)
+        offs = [np.ascontiguousarray(f[0], np.int32) for f in frames]
+        cones = [np.ascontiguousarray(f[1], np.float64).reshape(-1, 3) for f in frames]
+        poses = [np.ascontiguousarray(f[2], np.float64) for f in frames]
+        outs = [np.zeros(self.n, PATH_DTYPE) for _ in range(k)]
+        infos = [np.zeros(self.n, SKID_INFO_DTYPE) for _ in range(k)]
+        ptrs = lambda arrs: (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrs])
+        serial = lib().emu_skidpad_steps_packed(
+            ctypes.c_int(lanes), ctypes.c_int(self.n), ctypes.c_int(k), ctypes.c_int(self.step_no), ptrs(offs), ptrs(cones), ptrs(poses),
+            ctypes.c_void_p(self.states.ctypes.data), _p(self.half), ctypes.c_int(len(self.half)), _p(self.noise),
+            ctypes.c_int(len(self.noise)), _p(self.ref), ctypes.c_double(self.md), ptrs(outs), ptrs(infos),
+            ctypes.c_void_p(self.sync.ctypes.data))
+        self.step_no += k
+        return list(zip(outs, infos)), int(serial)
+
     def steps(self, frames):
-        """len(frames) <= 4 consecutive steps [(offsets, cones, poses), ...] in one skid_path_kernel launch (one wavefront
+        """len(frames) <= 16 consecutive steps [(offsets, cones, poses), ...] in one skid_path_kernel launch (one wavefront
         per (instance, step): csrc/skidpad_kernel.h "Steps in flight") -> [(out, info), ...]."""
         k = len(frames)
         offs = [np.ascontiguousarray(f[0], np.int32) for f in frames]

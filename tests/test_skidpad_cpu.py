@@ -103,7 +103,7 @@ def test_awkward_poses_equal_oracle(tables, golden_dir):
 
 
 def test_grouped_steps_equal_single_steps(tables, golden_dir):
-    """Steps in flight (csrc/skidpad_kernel.h): 1-4 consecutive steps planned by one skid_path_kernel launch, a wavefront
+    """Steps in flight (csrc/skidpad_kernel.h): 1-8 consecutive steps planned by one skid_path_kernel launch, a wavefront
     per (instance, step) working from the window index its predecessors' poses lead to, must give the bytes — results,
     planner information, states — of one launch per step, also around the relocalization and through the steps of
     _awkward_frames (a step that read the previous path is planned again behind its predecessor)."""
@@ -114,7 +114,7 @@ def test_grouped_steps_equal_single_steps(tables, golden_dir):
     one = emu_lib.SkidpadEmu(3, table, noise, ref, md)
     ref_res = [one.step(*f) for f in frames]
     assert any(r[0]["fallback"].any() for r in ref_res) and any((r[0]["status"] != 0).any() for r in ref_res)
-    for sizes in ([2] * 28, [4] * 14, [3, 1, 4, 2, 2, 4, 1, 3, 4, 4, 2, 3, 1, 4, 2, 4, 4, 3, 3, 2]):
+    for sizes in ([2] * 28, [8] * 7, [3, 1, 4, 2, 7, 5, 1, 3, 8, 6, 2, 3, 1, 4, 6]):
         assert sum(sizes) == len(frames)
         em = emu_lib.SkidpadEmu(3, table, noise, ref, md)
         t = 0
@@ -124,3 +124,33 @@ def test_grouped_steps_equal_single_steps(tables, golden_dir):
                 assert info.tobytes() == ref_res[t + j][1].tobytes(), (sizes[:3], t + j)
             t += k
         assert em.states.tobytes() == one.states.tobytes()
+
+
+@pytest.mark.parametrize("lanes", [16, 8])
+def test_packed_steps_equal_single_steps(tables, golden_dir, lanes):
+    """Steps in flight, many frames per wavefront (csrc/skidpad_kernel.h): groups of up to 16 consecutive steps planned by
+    the packed kernels of the autocross path stage (a frame = one step of one planner) and committed by the planners' own
+    wavefronts in step order must give the bytes of one launch per step — through the relocalization and through the
+    steps of awkward_frames, which the commit kernel has to plan itself (previous path needed, failed steps)."""
+    table, noise, ref, md = tables
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, 3)
+    frames = sk.awkward_frames(g, tf)
+    one = emu_lib.SkidpadEmu(3, table, noise, ref, md)
+    ref_res = [one.step(*f) for f in frames]
+    em = emu_lib.SkidpadEmu(3, table, noise, ref, md)
+    t, serial_total = 0, 0
+    for k in [8, -3, 16, -1, 12, -2, 14]:  # (negative: a group through skid_path_kernel in between — the routes mix)
+        if k < 0:
+            k = -k
+            res = em.steps(frames[t : t + k])
+        else:
+            res, serial = em.steps_packed(frames[t : t + k], lanes)
+            serial_total += serial
+        for j, (out, info) in enumerate(res):
+            assert out.tobytes() == ref_res[t + j][0].tobytes(), (t + j)
+            assert info.tobytes() == ref_res[t + j][1].tobytes(), (t + j)
+        t += k
+    assert t == len(frames) and em.states.tobytes() == one.states.tobytes()
+    # the too-far step of the relocalized planners (3 instances) is the planners' own; the packed kernels keep nearly everything else
+    assert 3 <= serial_total <= 12, serial_total

@@ -133,16 +133,19 @@ def _same_fields(a, b):
     return a.dtype == b.dtype and all(np.ascontiguousarray(a[k]).tobytes() == np.ascontiguousarray(b[k]).tobytes() for k in a.dtype.names)
 
 
-@pytest.mark.parametrize("n,group", [(3, None), (64, "3"), (700, None), (1100, "4")])
-def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, n, group):
-    """Steps in flight (csrc/skidpad_kernel.h): a replay that submits ahead has 2-4 consecutive steps planned by one
-    skid_path_kernel launch (one wavefront per (instance, step), each working from the window index its predecessors'
-    poses lead to, waiting for its predecessor's published state before it keeps or repeats its result).  Results,
-    planner information and the states' further course must be those of one launch per step — byte for byte, through the
-    relocalization, through steps that read the previous path (a car 60 m off the track), steps that fail (positions that
-    are not finite) and jumps of the window index."""
+@pytest.mark.parametrize("n,group,pack_min", [(3, None, None), (64, "3", None), (700, None, None), (1100, "5", None), (40, "16", "1"), (1600, None, None), (24, "7", "100")])
+def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, n, group, pack_min):
+    """Steps in flight (csrc/skidpad_kernel.h): a replay that submits ahead has up to 16 consecutive steps planned by one
+    group of launches — a wavefront per (instance, step), each working from the window index its predecessors' poses lead
+    to and waiting for its predecessor's published state before it keeps or repeats its result; or, from 4096 (instance,
+    step) pairs (FSDP_SKID_PACK_MIN), the packed kernels of the autocross path stage with the planners' own wavefronts
+    committing the steps in order.  Results, planner information and the states' further course must be those of one
+    launch per step — bit for bit, through the relocalization, through steps that read the previous path (a car 60 m off
+    the track), steps that fail (positions that are not finite) and jumps of the window index."""
     if group:
         monkeypatch.setenv("FSDP_SKID_GROUP", group)
+    if pack_min:
+        monkeypatch.setenv("FSDP_SKID_PACK_MIN", pack_min)
     g = sk.load_sequence(golden_dir)
     tf = sk.perturbed_instances(g, n)
     frames = sk.awkward_frames(g, tf, 64)
@@ -153,7 +156,7 @@ def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, 
         ref.append((res.copy(), info.copy()))
     assert any(r["path_fallback"].any() for r, _ in ref) and any((r["status"] != 0).any() for r, _ in ref)
     batch = pkg.SkidpadBatch(n, device=0)
-    for depth in (4, 3):
+    for depth in (16, 3):
         batch.reset()
         batch.set_overlap(depth)
         inflight, got = [], []

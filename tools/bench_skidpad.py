@@ -36,7 +36,7 @@ T = len(g["poses"])
 batches = [sk.batch_for_step(g, t, tf) for t in range(T)]
 batch = pkg.SkidpadBatch(n, device=local_rank, table=table)
 assert np.array_equal(batch.tables[1], noise)
-DEPTH = int(os.environ.get("FSDP_SKID_DEPTH", "4"))
+DEPTH = int(os.environ.get("FSDP_SKID_DEPTH", "32"))
 batches = [tuple(pkg.pinned_copy(a, dt) for a, dt in zip(b, (np.int32, np.float64, np.float64))) for b in batches]
 outs = [pkg.pinned_empty(n, pkg.RESULT_DTYPE) for _ in range(DEPTH + 1)]
 batch.set_overlap(DEPTH)
@@ -55,8 +55,9 @@ for t in range(T):
 d.barrier()
 el_step = d.max_over_ranks(time.perf_counter() - t0)
 ref_last = res["path"].copy()
-# (b) the replay as a stream: up to DEPTH steps submitted ahead (fsdp_skidpad_submit): step k + 1's inputs go up and
-# step k - 1's results come down while step k's kernels run; the planner states chain on the device
+# (b) the replay as a stream: up to DEPTH steps submitted ahead (fsdp_skidpad_submit): consecutive steps share their launches
+# (csrc/skidpad_kernel.h "steps in flight"), the next group's inputs go up and the previous one's results come down while a
+# group's kernels run; the planner states chain on the device
 batch.reset()
 d.barrier()
 t0 = time.perf_counter()
@@ -81,6 +82,6 @@ if rank == 0:
                       "frames_per_s_incl_pcie": n_total * T / el, "seconds": el, "steps_in_flight": DEPTH,
                       "frames_per_s_incl_pcie_one_step_at_a_time": n_total * T / el_step, "relocalized": int(reloc),
                       "frames_with_nonzero_status": int(bad), "ms_per_step": el / T * 1e3, "skid_path_kernel_ms_on_the_last_frame": kms,
-                      "note": "GPU-bound: one wavefront per planner instance, a step is the latency of one path stage (rocprofv3: the stream is busy 99 % of the run, profiles/r03_skidpad.txt); the transfers are kernels of the same stream",
+                      "note": "submitted ahead, DEPTH / 2 consecutive steps share one group of launches (packed path-stage kernels from 4096 (instance, step) pairs, else a wavefront per pair); one step at a time = the latency of one path stage on a wavefront per planner",
                       "tables": ("rank 0 loads them, broadcast to the others; communicator " + d.describe()) if d.world > 1 or d._active else "single process"}))
 d.close()

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Debugging aid: replay the awkward skidpad sequence one step at a time and submitted ahead, report where they differ.
+   python tools/skid_group_check.py n_instances depth [n_frames]        (FSDP_SKID_GROUP / FSDP_SKID_PACK_MIN from the environment)"""
+import importlib, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import skidpad_support as sk
+pkg = importlib.import_module("ft-fsd-path-planning_amd")
+n, depth = int(sys.argv[1]), int(sys.argv[2])
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+g = sk.load_sequence(ROOT / "tests" / "golden")
+tf = sk.perturbed_instances(g, n)
+frames = sk.awkward_frames(g, tf, T) if T <= 64 else [sk.batch_for_step(g, t, tf) for t in range(T)]
+one = pkg.SkidpadBatch(n, device=0)
+ref = []
+for f in frames:
+    r, i = one.step(*f)
+    ref.append((r.copy(), i.copy()))
+b = pkg.SkidpadBatch(n, device=0)
+b.set_overlap(depth)
+inflight, got = [], []
+for f in frames:
+    if len(inflight) == depth:
+        got.append(b.collect(inflight.pop(0)))
+    inflight.append(b.submit(*f))
+got += [b.collect(t) for t in inflight]
+bad = 0
+for t, ((r, i), (r0, i0)) in enumerate(zip(got, ref)):
+    for k in r.dtype.names:
+        d = np.array([np.ascontiguousarray(r[k][j]).tobytes() != np.ascontiguousarray(r0[k][j]).tobytes() for j in range(n)])
+        if d.any():
+            j = int(np.argmax(d))
+            bad += 1
+            if bad <= 12:
+                print("step", t, "field", k, "instances", int(d.sum()), "first", j, "got", np.ravel(r[k][j])[:4], "want", np.ravel(r0[k][j])[:4],
+                      "status", r["status"][j], r0["status"][j], "fallback", r["path_fallback"][j], r0["path_fallback"][j])
+    for k in i.dtype.names:
+        d = np.array([np.ascontiguousarray(i[k][j]).tobytes() != np.ascontiguousarray(i0[k][j]).tobytes() for j in range(n)])
+        if d.any():
+            bad += 1
+            if bad <= 12:
+                j = int(np.argmax(d))
+                print("step", t, "info", k, "instances", int(d.sum()), "first", j, i[k][j], i0[k][j])
+print("n", n, "depth", depth, "differing (step, field) pairs:", bad)
