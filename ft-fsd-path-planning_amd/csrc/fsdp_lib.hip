@@ -91,6 +91,7 @@ struct Work {
   fsdp_frame_result* d_result = nullptr;  // the pass's results in the ABI's layout (assemble_kernel)
   SkidInfo* d_skid_info = nullptr;        // skidpad contexts
   int32_t* d_skid_status = nullptr;       // skid_reloc_kernel's status of the step this slot holds
+  bool skid_attempted = true;             // ... which ran for that step (not once every planner is relocalized)
   SortSharedBig* d_sort_big = nullptr;    // frame states of sort_big_kernel, allocated when the route is first needed
   int cap_frames = 0;
   // use_unknown_cones = False (filter_kernel.h): the batch without its UNKNOWN cones, and the way back for the indices
@@ -189,6 +190,7 @@ struct fsdp_ctx {
   uint32_t* d_skid_sync = nullptr;   // [0] ticket counter of skid_path_kernel, [1 + i] steps instance i has published
   uint32_t skid_ticket_base = 0;
   int skid_step_no = 0;              // steps submitted since fsdp_skidpad_reset
+  bool skid_all_reloc = false;       // a collected step reported every planner relocalized: cones have no reader any more
   int skid_group_env = 0;            // FSDP_SKID_GROUP: steps per launch when the caller submits ahead (0: chosen from the instance count)
   int skid_pack_min = 4096;          // (instance, step) pairs from which a group goes through the packed kernels
   // workspace of a group that goes through the packed kernels, frame = step * n_instances + instance
@@ -1294,7 +1296,12 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
   }
   if (rc == 0 && n > 0) {
     if (t.via_stage) memcpy(t.user_results, t.h_stage, sizeof(fsdp_frame_result) * (size_t)n);
-    if (t.user_info && t.h_info)
+    if (t.user_info && t.h_info) {
+      if (!c->skid_all_reloc) {
+        bool all = true;
+        for (int i = 0; i < n && all; i++) all = t.h_info[i].relocalized != 0;
+        c->skid_all_reloc = all;
+      }
       for (int i = 0; i < n; i++) {
         t.user_info[i].relocalized = t.h_info[i].relocalized;
         t.user_info[i].index_along_path = t.h_info[i].index_along_path;
@@ -1302,6 +1309,7 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
         t.user_info[i].translation[1] = t.h_info[i].translation[1];
         t.user_info[i].rotation = t.h_info[i].rotation;
       }
+    }
   }
   t.id = -1;
   t.user_results = nullptr;
@@ -1756,6 +1764,7 @@ int fsdp_skidpad_reset(fsdp_ctx* c, int n_instances) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->skid_ticket_base = 0;
   c->skid_step_no = 0;
+  c->skid_all_reloc = false;
   c->skid_group_env = getenv("FSDP_SKID_GROUP") ? atoi(getenv("FSDP_SKID_GROUP")) : 0;
   if (const char* e = getenv("FSDP_SKID_PACK_MIN")) c->skid_pack_min = atoi(e);
   return 0;
@@ -1782,7 +1791,7 @@ static SkidGroup skid_group_of(fsdp_ctx* c, const int* slots, int n_steps, int s
   memset(&g, 0, sizeof(g));
   for (int k = 0; k < n_steps; k++) {
     Work& q = c->slot[slots[k]];
-    g.step[k] = SkidStep{q.in.d_poses, q.d_skid_status, q.d_arena, q.d_path, q.d_skid_info};
+    g.step[k] = SkidStep{q.in.d_poses, q.skid_attempted ? q.d_skid_status : nullptr, q.d_arena, q.d_path, q.d_skid_info};
   }
   g.n_steps = n_steps;
   g.step0 = step0;
@@ -1891,12 +1900,18 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
   // (the slot's ticket is free, i.e. collected: nothing queued uses its buffers any more, they may be replaced)
   if (int rc = ensure_work(c, q, n_instances)) return rc;
   hipStream_t xs = c->stream;
+  // Once every planner is relocalized nobody reads cones any more (Relocalizer.attempt_relocalization_calculation returns
+  // at once, relocalization_base_class.py:56-57; the path comes from the known map): they stay on the host, and the
+  // relocalization kernel is not launched.  (Known from the planner information of a collected step.)
+  const bool attempt = !c->skid_all_reloc;
+  if (!attempt) total = 0;
   const bool in_pinned = is_pinned(off) && is_pinned(poses) && (total == 0 || is_pinned(cones));
   if (in_pinned) {
     if (int rc = stage_inputs(c, q.in, xs, n_instances, off, cones, poses, nullptr, total, max_cones)) return rc;
   } else if (int rc = upload_inputs(c, q.in, xs, n_instances, off, cones, poses, nullptr, total, max_cones)) {
     return rc;
   }
+  q.skid_attempted = attempt;
   if (info && n_instances > t.cap_info) {
     if (t.h_info) (void)hipHostFree(t.h_info);
     t.h_info = nullptr;
@@ -1913,8 +1928,9 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
     t.cap_stage = n_instances;
   }
   if (!t.done) HIP_TRY(c, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
-  hipLaunchKernelGGL(skid_reloc_kernel, dim3((unsigned)n_instances), dim3(WAVE), 0, xs, n_instances, q.in.d_off, q.in.d_cones, q.in.d_poses,
-                     c->d_skid, c->tables, q.d_arena, q.d_skid_status, c->skid_step_no);
+  if (attempt)
+    hipLaunchKernelGGL(skid_reloc_kernel, dim3((unsigned)n_instances), dim3(WAVE), 0, c->stream, n_instances, q.in.d_off, q.in.d_cones, q.in.d_poses,
+                       c->d_skid, c->tables, q.d_arena, q.d_skid_status, c->skid_step_no);
   HIP_TRY(c, hipGetLastError());
   c->skid_step_no++;
   q.pass_in = &q.in;

@@ -441,7 +441,7 @@ constexpr int ST_SERIAL = 298;      // internal (PathMid::status): the step is p
 
 struct SkidStep {
   const double* poses;       // (n_inst, 4) of this step
-  const int32_t* status_in;  // skid_reloc_kernel's status of this step
+  const int32_t* status_in;  // skid_reloc_kernel's status of this step; NULL: no attempt was due (every planner relocalized): ST_OK
   double* arena;             // workspace of this step's wavefronts
   PathOut* out;
   SkidInfo* info;
@@ -456,6 +456,7 @@ struct SkidGroup {
 
 // full_pipeline.py:126-134: pose into the known map frame (the transform is read where it is used rather than held in
 // registers across the path stage)
+template <bool UNIFORM = true>
 __device__ __forceinline__ void skid_map_pose(const SkidState* st, const SkidTables& T, const double* pose, double& px, double& py,
                                               double& dx, double& dy) {
   px = pose[0], py = pose[1], dx = pose[2], dy = pose[3];
@@ -469,7 +470,7 @@ __device__ __forceinline__ void skid_map_pose(const SkidState* st, const SkidTab
   py = ry + T.ref_right[1];
   yaw = yaw + rotation;
   detm::det_sincos(yaw, dy, dx);
-  px = wave_uniform(px), py = wave_uniform(py), dx = wave_uniform(dx), dy = wave_uniform(dy);
+  if (UNIFORM) px = wave_uniform(px), py = wave_uniform(py), dx = wave_uniform(dx), dy = wave_uniform(dy);
 }
 
 // SkidpadCalculatePath.fit_matches_as_spline, skidpad_calculate_path.py:60-67: closest point of the known path within
@@ -666,7 +667,7 @@ __global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, SkidGroup 
   // 1. the index step g - 1 leaves
   int index_in = wave_uniform(st->index_hist[(G.step0 + SKID_HIST - 1) % SKID_HIST]);
   for (int j = 0; j < s; j++) {
-    if (G.step[j].status_in[inst] != ST_OK || !(latched && reloc_step <= G.step0 + j)) continue;
+    if ((G.step[j].status_in && G.step[j].status_in[inst] != ST_OK) || !(latched && reloc_step <= G.step0 + j)) continue;
     double qx, qy, qdx, qdy;
     skid_map_pose(st, T, G.step[j].poses + 4 * inst, qx, qy, qdx, qdy);
     const int bi = skid_closest_in_window(T, index_in, qx, qy);
@@ -676,7 +677,7 @@ __global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, SkidGroup 
   const bool reloc = latched && reloc_step <= g;
   double px = wave_uniform(me.poses[4 * inst + 0]), py = wave_uniform(me.poses[4 * inst + 1]);
   double dx = wave_uniform(me.poses[4 * inst + 2]), dy = wave_uniform(me.poses[4 * inst + 3]);
-  const int status_in = wave_uniform(me.status_in[inst]);
+  const int status_in = me.status_in ? wave_uniform(me.status_in[inst]) : ST_OK;
   if (status_in == ST_OK && reloc) skid_map_pose(st, T, me.poses + 4 * inst, px, py, dx, dy);
   int status = ST_OK, fallback = 0, n_dense = 0, new_index = index_in;
   bool sync_lost = false;
@@ -759,34 +760,39 @@ __global__ void __launch_bounds__(64) skid_select_kernel(int n_inst, SkidGroup G
   const SkidState* st = &states[inst];
   const bool latched = wave_uniform(st->relocalized) != 0;
   const int reloc_step = wave_uniform(st->reloc_step);
+  // lane s: the pose of step s in the map frame (the steps' poses do not depend on each other) ...
+  SkidSel mine;
+  mine.status = ST_OK, mine.reloc = 0, mine.index_in = mine.first = 0;
+  mine.px = mine.py = mine.dx = mine.dy = 0.0;
+  if (lane < G.n_steps) {
+    const SkidStep& me = G.step[lane];
+    mine.status = me.status_in ? me.status_in[inst] : ST_OK;
+    mine.reloc = (latched && reloc_step <= G.step0 + lane) ? 1 : 0;
+    mine.px = me.poses[4 * inst + 0], mine.py = me.poses[4 * inst + 1], mine.dx = me.poses[4 * inst + 2], mine.dy = me.poses[4 * inst + 3];
+    if (mine.status == ST_OK && mine.reloc) skid_map_pose<false>(st, T, me.poses + 4 * inst, mine.px, mine.py, mine.dx, mine.dy);
+  }
+  // ... then the window index walks through the steps, one arg-min over the wavefront per step
   int index = wave_uniform(st->index_along_path);
   for (int s = 0; s < G.n_steps; s++) {
-    const SkidStep& me = G.step[s];
-    int status = wave_uniform(me.status_in[inst]);
-    const bool reloc = latched && reloc_step <= G.step0 + s;
-    double px = wave_uniform(me.poses[4 * inst + 0]), py = wave_uniform(me.poses[4 * inst + 1]);
-    double dx = wave_uniform(me.poses[4 * inst + 2]), dy = wave_uniform(me.poses[4 * inst + 3]);
-    if (status == ST_OK && reloc) skid_map_pose(st, T, me.poses + 4 * inst, px, py, dx, dy);
+    int status = wave_uniform(__shfl(mine.status, s, WAVE));
+    const bool reloc = wave_uniform(__shfl(mine.reloc, s, WAVE)) != 0;
+    const double px = wave_uniform(__shfl(mine.px, s, WAVE)), py = wave_uniform(__shfl(mine.py, s, WAVE));
     const int index_in = index;
-    int first = 0;
     if (status == ST_OK && reloc) {
-      first = skid_closest_in_window(T, index, px, py);
+      const int first = skid_closest_in_window(T, index, px, py);
       if (first < 0)
         status = ST_REF_UNDEFINED_PATH;
       else
         index = first;
     }
     if (status == ST_OK && !(fabs(px) < INFINITY && fabs(py) < INFINITY)) status = ST_REF_UNDEFINED_PATH;
-    if (lane == 0) {
-      SkidSel r;
-      r.status = status;
-      r.reloc = reloc ? 1 : 0;
-      r.index_in = index_in;
-      r.first = index;
-      r.px = px, r.py = py, r.dx = dx, r.dy = dy;
-      sel[(size_t)s * n_inst + inst] = r;
+    if (lane == s) {
+      mine.status = status;
+      mine.index_in = index_in;
+      mine.first = index;
     }
   }
+  if (lane < G.n_steps) sel[(size_t)lane * n_inst + inst] = mine;
 }
 
 template <int G>

@@ -199,7 +199,8 @@ int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
  * fsdp_sync waits for all passes in flight, fsdp_download returns the most recent one.  depth 1 (default) = strictly one
  * pass after the other.  Every stream takes one of the HIP runtime's hardware queues (environment variable
  * GPU_MAX_HW_QUEUES, default 4): with more streams than queues two passes share a queue and serialize — raise
- * GPU_MAX_HW_QUEUES above the depth (bench.py sets 16 for its depth of 10).  Every extra depth costs one more set of
+ * GPU_MAX_HW_QUEUES above the depth (bench.py sets 16 for its depth of 10; a skidpad context uses one stream whatever
+ * the depth: its slots only hold the steps' buffers).  Every extra depth costs one more set of
  * buffers (~0.1 MB per frame).  Measured at 4096 frames x 128 cones: the steady rate saturates at depth 8; a run of 20
  * passes is fastest with 10 in flight (two full rounds instead of 8 + 8 + 4). */
 #define FSDP_MAX_OVERLAP 32
@@ -275,13 +276,26 @@ int fsdp_skidpad_reset(fsdp_ctx* ctx, int n_instances);
 /* one frame for every instance; results[i].path is in the caller's (original) frame like the reference's return value */
 int fsdp_skidpad_step(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offsets, const double* cones_xyt,
                       const double* poses, fsdp_frame_result* results, fsdp_skidpad_info* info);
-/* The same as a ticket (fsdp_collect / fsdp_ticket_done as above): the steps' kernels run in submit order on the context's
- * main stream (the planner states chain step to step), step k + 1's inputs go up and step k - 1's results come down on the
- * slots' own streams meanwhile.  A replay knows the frames of the next steps ahead of the planner, which is what makes
- * submitting ahead meaningful; fsdp_skidpad_step = submit + collect. */
+/* The same as a ticket (fsdp_collect / fsdp_ticket_done as above; one ticket per pass slot, fsdp_set_overlap).  A replay
+ * knows the frames of the next steps ahead of the planner, which is what makes submitting ahead meaningful: consecutive
+ * steps of a planner then share their launches.  A step's inputs and its relocalization attempt are enqueued at once, its
+ * path stage when enough steps have been submitted (half the slots at most) or somebody asks for it (fsdp_collect,
+ * fsdp_ticket_done, any blocking call):
+ *   - from 4096 (instance, step) pairs (FSDP_SKID_PACK_MIN) the pairs are frames of the packed kernels of the autocross
+ *     path stage — a planner's window index depends on the poses alone (skidpad_calculate_path.py:60-67), so every step's
+ *     window is known up front — and one wavefront per planner then takes its steps in order, keeps the packed result or,
+ *     where the step needs the planner's previous path (too far from the car, the ValueError retry) or left the packed
+ *     kernels' envelope, plans it itself, and moves the state on;
+ *   - below that every (instance, step) pair gets a wavefront of its own in one launch: it plans from the window index
+ *     its predecessors' poses lead to, waits for its predecessor's published state and keeps its result unless it read
+ *     the previous path.
+ * Either way results, planner information and states are those of one launch per step, bit for bit
+ * (tests/test_skidpad_gpu.py, tests/test_skidpad_cpu.py).  A live car submits and collects one step at a time:
+ * fsdp_skidpad_step = submit + collect = one launch per step. */
 int fsdp_skidpad_submit(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offsets, const double* cones_xyt,
                         const double* poses, fsdp_frame_result* results, fsdp_skidpad_info* info, long long* ticket);
-/* time `iters` repetitions of the path kernel of the last step with HIP events (state is restored afterwards) */
+/* time `iters` repetitions of the one-wavefront-per-planner path kernel on the last step's inputs with HIP events (the
+ * states are restored afterwards) */
 int fsdp_skidpad_time_path(fsdp_ctx* ctx, int iters, float* ms_total);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------------------------------------------

@@ -42,19 +42,20 @@ outs = [pkg.pinned_empty(n, pkg.RESULT_DTYPE) for _ in range(DEPTH + 1)]
 batch.set_overlap(DEPTH)
 for t in range(3):  # warm-up on a throw-away state (reference demo does the same, json_demo.py:89-94)
     batch.step(*batches[t])
-for t in range(DEPTH):
-    batch.collect(batch.submit(*batches[t], out=outs[t]))
+for tk in [batch.submit(*batches[t], out=outs[t]) for t in range(DEPTH)]:  # (and on the group's kernels and workspace)
+    batch.collect(tk)
 # (a) one step at a time: submit + collect (what a live car does)
+ONLY_AHEAD = os.environ.get("FSDP_SKID_BENCH_LEGS") == "ahead"  # (kernel traces of the submitted-ahead leg alone)
 batch.reset()
 d.barrier()
 t0 = time.perf_counter()
 status = np.zeros(n, np.int64)
-for t in range(T):
+for t in range(0 if ONLY_AHEAD else T):
     res, info = batch.step(*batches[t])
     status += res["status"] != 0
 d.barrier()
 el_step = d.max_over_ranks(time.perf_counter() - t0)
-ref_last = res["path"].copy()
+ref_last = None if ONLY_AHEAD else res["path"].copy()
 # (b) the replay as a stream: up to DEPTH steps submitted ahead (fsdp_skidpad_submit): consecutive steps share their launches
 # (csrc/skidpad_kernel.h "steps in flight"), the next group's inputs go up and the previous one's results come down while a
 # group's kernels run; the planner states chain on the device
@@ -73,14 +74,14 @@ for tk in inflight:
     status += res["status"] != 0
 d.barrier()
 el = d.max_over_ranks(time.perf_counter() - t0)
-assert np.array_equal(res["path"], ref_last, equal_nan=True), "pipelined steps differ from one-at-a-time steps"
+assert ONLY_AHEAD or np.array_equal(res["path"], ref_last, equal_nan=True), "pipelined steps differ from one-at-a-time steps"
 kms = batch.time_path(10) / 10  # the path kernel repeated on the LAST frame of the replay (the car stands at the end of the track: the shortest path of the run)
 reloc = d.sum_over_ranks(float(info["relocalized"].sum()))
 bad = d.sum_over_ranks(float(status.sum()))
 if rank == 0:
     print(json.dumps({"config": "BASELINE configs[4]: skidpad, batch=%d perturbed starts x %d frames on %d GPU(s)" % (n_total, T, d.world),
                       "frames_per_s_incl_pcie": n_total * T / el, "seconds": el, "steps_in_flight": DEPTH,
-                      "frames_per_s_incl_pcie_one_step_at_a_time": n_total * T / el_step, "relocalized": int(reloc),
+                      "frames_per_s_incl_pcie_one_step_at_a_time": None if ONLY_AHEAD else n_total * T / el_step, "relocalized": int(reloc),
                       "frames_with_nonzero_status": int(bad), "ms_per_step": el / T * 1e3, "skid_path_kernel_ms_on_the_last_frame": kms,
                       "note": "submitted ahead, DEPTH / 2 consecutive steps share one group of launches (packed path-stage kernels from 4096 (instance, step) pairs, else a wavefront per pair); one step at a time = the latency of one path stage on a wavefront per planner",
                       "tables": ("rank 0 loads them, broadcast to the others; communicator " + d.describe()) if d.world > 1 or d._active else "single process"}))

@@ -16,6 +16,13 @@ FSDP_FORCE_DIST=1 $T python -m torch.distributed.run --nnodes=1 --nproc-per-node
 FSDP_SHARE_GPU=1 FSDP_RCCL_INIT_TIMEOUT=40 $T python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --no-latency --stream-batches 0 2>$R/bench_2ranks.err | grep '^{' | tail -1 > $R/bench_line_2ranks_one_gpu_tcp_fallback.json
 $T python tools/stream_probe.py > $R/streaming.jsonl 2>&1
 ( $T python tools/bench_skidpad.py 1024; $T python tools/bench_skidpad.py 4096 ) > $R/skidpad.jsonl 2>&1
+# skidpad by instance count and by steps per group (csrc/skidpad_kernel.h "steps in flight")
+( for n in 64 256 512 1024 2048 4096; do echo "instances $n"; $T python tools/bench_skidpad.py $n; done
+  for g in 1 2 4 8 12 16; do echo "1024 instances, groups of $g steps"; FSDP_SKID_GROUP=$g $T python tools/bench_skidpad.py 1024; done
+  for g in 1 2 3 4; do echo "1024 instances, a wavefront per (instance, step), groups of $g steps"; FSDP_SKID_PACK_MIN=100000000 FSDP_SKID_GROUP=$g $T python tools/bench_skidpad.py 1024; done
+  echo "4096 instances, a wavefront per (instance, step)"; FSDP_SKID_PACK_MIN=100000000 $T python tools/bench_skidpad.py 4096 ) > $R/skidpad_groups.txt 2>&1
+( export TMPDIR=/tmp; REPO=$(pwd); cd /tmp; FSDP_SKID_BENCH_LEGS=ahead timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03/skid -o trace -- python $REPO/tools/bench_skidpad.py 1024 > $REPO/$R/skid_trace.log 2>&1 )
+python tools/kernel_stats.py gpurun_out/prof_r03/skid "python tools/bench_skidpad.py 1024, the replay submitted ahead only" > $R/skidpad_rocprofv3_summary.txt 2>&1
 $T python tools/bench_configs.py > $R/bench_configs.jsonl 2>&1
 $T python tools/latency_breakdown.py > $R/latency_breakdown.txt 2>&1
 $T python tools/overlap_depths.py default > $R/overlap_depths.txt 2>&1
