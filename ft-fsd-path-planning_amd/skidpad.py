@@ -76,9 +76,27 @@ class SkidpadBatch:
             "fsdp_skidpad_step")
         return res, info
 
+    def replay(self, frames, depth: int = 32):
+        """A known sequence of frames [(cone_offsets, cones_xyt, poses), ...] for all planners, submitted ``depth`` steps
+        ahead (the counterpart of the reference's frame loop over a recording, demo/json_demo.py:103-131, for many planners
+        at once): consecutive steps share their launches (include/fsdp.h, fsdp_skidpad_submit).  Yields (results, info) per
+        step, in order — the bits of ``step`` called once per frame."""
+        self.set_overlap(depth)
+        ring = [_capi.pinned_empty(self.n, _capi.RESULT_DTYPE) for _ in range(depth + 1)]
+        inflight = []
+        for k, f in enumerate(frames):
+            if len(inflight) == depth:
+                res, info = self.collect(inflight.pop(0))
+                yield res.copy(), info
+            inflight.append(self.submit(*f, out=ring[k % (depth + 1)]))
+        for t in inflight:
+            res, info = self.collect(t)
+            yield res.copy(), info
+
     def submit(self, cone_offsets, cones_xyt, poses, out=None, info=None) -> "_capi.Ticket":
-        """One step as a ticket (fsdp_skidpad_submit): the steps' kernels run in submit order, their transfers overlap the
-        neighbouring steps' kernels.  Up to the context's overlap depth tickets may be outstanding (``set_overlap``)."""
+        """One step as a ticket (fsdp_skidpad_submit).  Up to the context's overlap depth tickets may be outstanding
+        (``set_overlap``, at most 32); steps submitted ahead share their launches, a step that is collected at once gets
+        launches of its own."""
         off, cones, poses, n = self._ctx._prep(cone_offsets, cones_xyt, poses)
         assert n == self.n
         if out is None:

@@ -156,15 +156,9 @@ def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, 
         ref.append((res.copy(), info.copy()))
     assert any(r["path_fallback"].any() for r, _ in ref) and any((r["status"] != 0).any() for r, _ in ref)
     batch = pkg.SkidpadBatch(n, device=0)
-    for depth in (16, 3):
+    for depth in (32, 3):
         batch.reset()
-        batch.set_overlap(depth)
-        inflight, got = [], []
-        for f in frames:
-            if len(inflight) == depth:
-                got.append(batch.collect(inflight.pop(0)))
-            inflight.append(batch.submit(*f))
-        got += [batch.collect(t) for t in inflight]
+        got = list(batch.replay(frames, depth))
         for t, ((res, info), (r0, i0)) in enumerate(zip(got, ref)):
             assert _same_fields(res, r0) and _same_fields(info, i0), (depth, t)
     # and the states carry on identically: ten more steps, one at a time
