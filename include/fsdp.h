@@ -281,7 +281,7 @@ int fsdp_skidpad_step(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offset
  * steps of a planner then share their launches.  A step's inputs and its relocalization attempt are enqueued at once, its
  * path stage when enough steps have been submitted (half the slots at most) or somebody asks for it (fsdp_collect,
  * fsdp_ticket_done, any blocking call):
- *   - from 4096 (instance, step) pairs (FSDP_SKID_PACK_MIN) the pairs are frames of the packed kernels of the autocross
+ *   - from 2048 (instance, step) pairs (FSDP_SKID_PACK_MIN) the pairs are frames of the packed kernels of the autocross
  *     path stage — a planner's window index depends on the poses alone (skidpad_calculate_path.py:60-67), so every step's
  *     window is known up front — and one wavefront per planner then takes its steps in order, keeps the packed result or,
  *     where the step needs the planner's previous path (too far from the car, the ValueError retry) or left the packed

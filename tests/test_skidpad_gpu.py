@@ -137,7 +137,7 @@ def _same_fields(a, b):
 def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, n, group, pack_min):
     """Steps in flight (csrc/skidpad_kernel.h): a replay that submits ahead has up to 16 consecutive steps planned by one
     group of launches — a wavefront per (instance, step), each working from the window index its predecessors' poses lead
-    to and waiting for its predecessor's published state before it keeps or repeats its result; or, from 4096 (instance,
+    to and waiting for its predecessor's published state before it keeps or repeats its result; or, from 2048 (instance,
     step) pairs (FSDP_SKID_PACK_MIN), the packed kernels of the autocross path stage with the planners' own wavefronts
     committing the steps in order.  Results, planner information and the states' further course must be those of one
     launch per step — bit for bit, through the relocalization, through steps that read the previous path (a car 60 m off

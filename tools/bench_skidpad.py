@@ -83,6 +83,6 @@ if rank == 0:
                       "frames_per_s_incl_pcie": n_total * T / el, "seconds": el, "steps_in_flight": DEPTH,
                       "frames_per_s_incl_pcie_one_step_at_a_time": None if ONLY_AHEAD else n_total * T / el_step, "relocalized": int(reloc),
                       "frames_with_nonzero_status": int(bad), "ms_per_step": el / T * 1e3, "skid_path_kernel_ms_on_the_last_frame": kms,
-                      "note": "submitted ahead, DEPTH / 2 consecutive steps share one group of launches (packed path-stage kernels from 4096 (instance, step) pairs, else a wavefront per pair); one step at a time = the latency of one path stage on a wavefront per planner",
+                      "note": "submitted ahead, DEPTH / 2 consecutive steps share one group of launches (packed path-stage kernels from 2048 (instance, step) pairs, else a wavefront per pair); one step at a time = the latency of one path stage on a wavefront per planner",
                       "tables": ("rank 0 loads them, broadcast to the others; communicator " + d.describe()) if d.world > 1 or d._active else "single process"}))
 d.close()
