@@ -289,6 +289,9 @@ int fsdp_skidpad_step(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offset
  *   - below that every (instance, step) pair gets a wavefront of its own in one launch: it plans from the window index
  *     its predecessors' poses lead to, waits for its predecessor's published state and keeps its result unless it read
  *     the previous path.
+ * Once a collected step's planner information (info != NULL) has shown every planner relocalized, later steps leave their
+ * cones on the host and skip the relocalization attempt: it would return at once (relocalization_base_class.py:56-57), and
+ * with a relocalizer the reference neither sorts nor matches (full_pipeline.py:122-140).
  * Either way results, planner information and states are those of one launch per step, bit for bit
  * (tests/test_skidpad_gpu.py, tests/test_skidpad_cpu.py).  A live car submits and collects one step at a time:
  * fsdp_skidpad_step = submit + collect = one launch per step. */
