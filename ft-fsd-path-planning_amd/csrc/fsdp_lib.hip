@@ -1815,7 +1815,8 @@ static int launch_skid_packed(fsdp_ctx* c, const int* slots, int n_steps, int st
   const int frames = n * n_steps;
   if ((size_t)frames > c->g_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const size_t m = (size_t)n * SKID_GROUP_MAX;
+    // (room for the groups this context forms: 16 384 frames with 1024 planners ~ 1.4 GB, most of it fit workspace)
+    const size_t m = std::max((size_t)frames, (size_t)n * (size_t)skid_group_size(c));
     HIP_TRY(c, regrow(c->d_g_arena, (size_t)ARENA_DOUBLES * m));
     HIP_TRY(c, regrow(c->d_g_mid, m));
     HIP_TRY(c, regrow(c->d_g_out, m));
@@ -1891,11 +1892,13 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
   size_t total;
   int max_cones;
   if (int rc = check_batch(c, n_instances, off, cones, poses, &total, &max_cones)) return rc;
-  const int si = (int)(c->next_ticket % c->overlap);
+  // one step per slot (the slots only hold the steps' buffers, every command goes to the main stream): the next free one
+  int si = (int)(c->next_ticket % c->overlap);
+  for (int k = 0; k < c->overlap && c->slot[si].tk[0].id >= 0; k++) si = (si + 1) % c->overlap;
   Work& q = c->slot[si];
-  Work::Ticket& t = q.tk[0];  // one step per slot: the slots only hold the steps' buffers, every command goes to the main stream
+  Work::Ticket& t = q.tk[0];
   if (t.id >= 0) {
-    c->err = "fsdp_skidpad_submit: all " + std::to_string(c->overlap) + " slots hold a ticket; collect ticket " + std::to_string(t.id) + " first";
+    c->err = "fsdp_skidpad_submit: all " + std::to_string(c->overlap) + " slots hold a ticket; collect one first, e.g. ticket " + std::to_string(t.id);
     return 4;
   }
   // (the slot's ticket is free, i.e. collected: nothing queued uses its buffers any more, they may be replaced)

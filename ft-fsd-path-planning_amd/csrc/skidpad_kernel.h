@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(64) skid_reloc_kernel(int n_inst, const int32_
 
 // ---- the path step of a planner: pieces shared by the kernels below -------------------------------------------------------
 constexpr int SKID_GROUP_MAX = 16;  // steps of one planner that may share a launch
+constexpr int FB_READ_PREVIOUS = 1 | 2 | 4 | 8;  // path_fallback bits whose branch reads previous_paths[-1] (16, 32: how the path was extended)
 constexpr int ST_SERIAL = 298;      // internal (PathMid::status): the step is planned by its planner's own wavefront, behind its predecessor
 
 struct SkidStep {
@@ -635,7 +636,7 @@ __device__ __forceinline__ void skid_finish_step(SkidState* st, const SkidTables
 //      launch's earlier steps,
 //   2. plans its step with it,
 //   3. waits until step g - 1 of its instance has published its state (sync[1 + inst] >= g), and
-//   4. keeps its result if the previous path was never read (fallback == 0: every read of it sets a bit) and the published
+//   4. keeps its result if the previous path was never read (every read of it sets a fallback bit) and the published
 //      index is the one it used — otherwise plans the step again from the published state, exactly as a launch of its
 //      own would;
 //   5. writes the state and publishes it (sync[1 + inst] = g + 1).
@@ -704,7 +705,7 @@ __global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, SkidGroup 
     // the state behind the flag is read past the caches (agent-scope loads): no cache invalidation, the workspace of the
     // path stage stays where it is
     const int index_now = wave_uniform(__hip_atomic_load(&st->index_along_path, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (s == 0 || (index_now == index_in && fallback == 0)) break;  // (s == 0: the state was final before the launch)
+    if (s == 0 || (index_now == index_in && (fallback & FB_READ_PREVIOUS) == 0)) break;  // (s == 0: the state was final before the launch)
     index_in = index_now;
     if (lane < PATH_POINTS)
       for (int q = 0; q < 4; q++) s_prev[lane][q] = __hip_atomic_load(&st->prev[lane][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -813,16 +814,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) sk
       // (a path too far from the car is replaced by the previous one, which only the planner's own wavefront knows: the
       // constant initial path stands in here, and the fallback bit sends the step there)
       n1 = overwrite_if_too_far<G>(A, n1, sl.px, sl.py, default_path, &fallback);
-      if (fallback == 0) {
+      if ((fallback & FB_READ_PREVIOUS) == 0) {
         const int rc = mpc_prepare<G>(S, A, n1, sl.px, sl.py, sl.dx, sl.dy, &fallback, &off, &n);
-        plain = rc == 0 && n >= 4 && fallback == 0;  // degree 3 needs 4 points
+        plain = rc == 0 && n >= 4 && (fallback & FB_READ_PREVIOUS) == 0;  // degree 3 needs 4 points
         if (plain) build_parameter<G>(S, A, off, n);
       }
     }
     if (GR::lane() == 0) {
       PathMid m;
       m.status = plain ? ST_OK : (sl.status != ST_OK ? sl.status : ST_SERIAL);
-      m.fallback = 0;
+      m.fallback = fallback;
       m.off = off;
       m.n = n;
       mid[frame] = m;
@@ -854,6 +855,7 @@ __global__ void __launch_bounds__(64, 1) skid_commit_kernel(int n_inst, SkidGrou
       if (lane < PATH_POINTS)
         for (int q = 0; q < 4; q++) o->path[lane][q] = r->path[lane][q];
       status = ST_OK;
+      fallback = wave_uniform(r->fallback);
       n_dense = wave_uniform(r->n_dense);
       __syncthreads();
     } else if (sel_status != ST_OK) {

@@ -8,7 +8,9 @@ Two replay modes:
   per-frame : one PathPlanner, one calculate_path_in_global_frame call per frame, wall-clock per call (what the
               reference's demo measures; for the skidpad mission this is the stateful sequence);
   --batched : the frames of the recording as a stream of batches of independent frames (fresh-planner semantics per
-              frame; trackdrive/autocross recordings only), several batches in flight (fsdp_submit / fsdp_collect).
+              frame; trackdrive/autocross recordings only), several batches in flight (fsdp_submit / fsdp_collect);
+              with --stateful the frames that read the previous path are planned again in order with the path their
+              predecessor left: the per-frame replay's results at the batched replay's speed.
 """
 from __future__ import annotations
 
@@ -97,11 +99,37 @@ def replay_batched(mission, positions, directions, observations, device=None, re
     return res, sec
 
 
+FB_READ_PREVIOUS = 1 | 2 | 4 | 8  # path_fallback bits of the branches that read previous_paths[-1] (include/fsdp.h)
+
+
+def replay_stateful_batched(mission, positions, directions, observations, device=None, batch_frames: int = 4096, depth: int = 4):
+    """The recording as ONE planner sees it — consecutive frames chain through previous_paths[-1] (core_calculate_path.py:
+    572-573), which the reference reads in its fallbacks only (:202-203, 218-221, 235-236, 531-536, 564-570) — at the speed
+    of the batched replay: all frames as independent frames first (every one with the fresh planner's previous path), then
+    the frames that did read the previous path (their path_fallback bits say so), in recording order, once more with the
+    path their predecessor really left (a frame the reference raises on leaves none).  Returns the results in recording
+    order, the seconds of the batched replay and the number of frames planned again."""
+    res, sec = replay_batched(mission, positions, directions, observations, device, repeats=1, batch_frames=batch_frames, depth=depth)
+    res = res.copy()
+    planner = PathPlanner(mission, device=device)
+    ctx = planner._ctx
+    prev, again = None, 0
+    for k in range(len(res)):
+        if (res["path_fallback"][k] & FB_READ_PREVIOUS) and prev is not None:
+            off, cones, poses = pack_frames([(observations[k], positions[k], directions[k])])
+            res[k] = ctx.plan_batch_sequential(off, cones, poses, prev[None])[0]
+            again += 1
+        if res["status"][k] == 0:
+            prev = np.array(res["path"][k][: ctx.horizon])
+    return res, sec, again
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--data-path", "-i", type=Path, required=True)
     ap.add_argument("--remove-color-info", action="store_true")
     ap.add_argument("--batched", action="store_true")
+    ap.add_argument("--stateful", action="store_true", help="--batched: one planner's view of the recording (frames chain through the previous path)")
     ap.add_argument("--output-path", "-o", type=Path, default=None)
     ap.add_argument("--device", type=int, default=None)
     ap.add_argument("--batch-frames", type=int, default=4096, help="--batched: frames per batch of the stream")
@@ -111,7 +139,11 @@ def main(argv=None):
     positions, directions, observations = load_data_json(a.data_path, a.remove_color_info)
     out = {"file": str(a.data_path), "mission": mission.name, "frames": len(positions)}
     if a.batched:
-        res, sec = replay_batched(mission, positions, directions, observations, a.device, batch_frames=a.batch_frames, depth=a.depth)
+        if a.stateful:
+            res, sec, again = replay_stateful_batched(mission, positions, directions, observations, a.device, batch_frames=a.batch_frames, depth=a.depth)
+            out.update(frames_planned_again_with_their_predecessors_path=again)
+        else:
+            res, sec = replay_batched(mission, positions, directions, observations, a.device, batch_frames=a.batch_frames, depth=a.depth)
         out.update(mode="batched", seconds_per_batch=sec, frames_per_s=len(res) / sec,
                    status_histogram={int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))})
         paths = res["path"]

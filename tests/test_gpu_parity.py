@@ -269,6 +269,32 @@ def test_replay_cli_roundtrip(pkg, golden_dir, tmp_path):
     assert np.abs(paths - g["path"][:16]).max() < 1e-5
 
 
+def test_stateful_batched_replay_equals_per_frame_replay(pkg, golden_dir, tmp_path):
+    """replay_stateful_batched: a recording whose frames 0, 7, 8, 9 and 20 show the planner fewer than three cones per
+    side (the reference falls back to previous_paths[-1], core_calculate_path.py:531-536 — frames 8 and 9 to a path that was
+    itself a fall-back) must give the per-frame replay's paths, bit for bit: batched first, the frames that read the
+    previous path again in order."""
+    import json
+
+    g = np.load(golden_dir / "cfg2_color.npz")
+    frames = []
+    for t in range(32):
+        xyt = g["cones"][g["offsets"][t] : g["offsets"][t + 1]]
+        if t in (0, 7, 8, 9, 20):
+            xyt = xyt[:2]
+        frames.append({"car_position": g["poses"][t, :2].tolist(), "car_direction": g["poses"][t, 2:].tolist(),
+                       "slam_cones": [xyt[xyt[:, 2] == k, :2].tolist() for k in range(5)]})
+    f = tmp_path / "replay.json"
+    f.write_text(json.dumps(frames))
+    pos, dirs, obs = pkg.replay.load_data_json(f)
+    paths, times, reloc, info = pkg.replay.replay_per_frame(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0)
+    res, sec, again = pkg.replay.replay_stateful_batched(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0, batch_frames=8, depth=3)
+    assert again == 4  # (frame 0 meets the fresh planner's path in both replays)
+    assert (res["status"] == 0).all() and np.array_equal(paths, res["path"])
+    independent, _ = pkg.replay.replay_batched(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0, repeats=1, batch_frames=8, depth=3)
+    assert not np.array_equal(independent["path"][8], res["path"][8])  # (the chain matters)
+
+
 def test_overlapped_passes_equal_serial_passes(pkg):
     """fsdp_set_overlap(2): consecutive passes alternate between two streams / buffer sets.  Every pass must return
     exactly what a single serial pass returns, whichever slot it ran in, also after a new upload."""

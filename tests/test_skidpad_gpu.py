@@ -166,3 +166,46 @@ def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, 
         f = sk.batch_for_step(g, t, tf)
         a, b = batch.step(*f), one.step(*f)
         assert _same_fields(a[0], b[0]) and _same_fields(a[1], b[1]), t
+
+
+def test_random_skidpad_traffic(pkg, golden_dir, monkeypatch):
+    """Stress of the deferred launches: 50 planners over 150 frames (the awkward ones first), steps submitted in bursts of
+    random length, collected in random order and at random times (a collect launches whatever group is pending, so groups
+    of every size 1 ... 16 occur and both routes — FSDP_SKID_PACK_MIN lowered to 300 pairs — alternate), single blocking
+    steps in between.  Every result must be the one-launch-per-step result, bit for bit."""
+    monkeypatch.setenv("FSDP_SKID_PACK_MIN", "300")
+    n = 50
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, n)
+    frames = sk.awkward_frames(g, tf, 64) + [sk.batch_for_step(g, t, tf) for t in range(64, 150)]
+    one = pkg.SkidpadBatch(n, device=0)
+    ref = []
+    for f in frames:
+        res, info = one.step(*f)
+        ref.append((res.copy(), info.copy()))
+    rng = np.random.default_rng(7)
+    for depth in (32, 5):
+        batch = pkg.SkidpadBatch(n, device=0)
+        batch.set_overlap(depth)
+        inflight, t, checked = [], 0, 0
+        while t < len(frames) or inflight:
+            r = rng.random()
+            if t < len(frames) and not inflight and r < 0.1:
+                res, info = batch.step(*frames[t])  # a blocking step (nothing outstanding)
+                assert _same_fields(res, ref[t][0]) and _same_fields(info, ref[t][1]), (depth, t)
+                t += 1
+                checked += 1
+            elif t < len(frames) and len(inflight) < depth and r < 0.7:
+                for _ in range(int(rng.integers(1, depth + 1))):
+                    if t == len(frames) or len(inflight) == depth:
+                        break
+                    inflight.append((t, batch.submit(*frames[t])))
+                    t += 1
+            elif inflight:
+                # tickets of one slot ring: the oldest first or any other one
+                k = 0 if rng.random() < 0.5 else int(rng.integers(len(inflight)))
+                j, tk = inflight.pop(k)
+                res, info = batch.collect(tk)
+                assert _same_fields(res, ref[j][0]) and _same_fields(info, ref[j][1]), (depth, j)
+                checked += 1
+        assert checked == len(frames)
