@@ -297,6 +297,9 @@ void fsdo_skidpad_step(void* h, const double* cones_xyt, int n, const double* po
   }
 }
 
+// SkidpadCalculatePath.index_along_path as it stands (a step that raised reports nothing, but may have moved it)
+int fsdo_skidpad_index(void* h) { return ((SkidpadPlanner*)h)->index_along_path; }
+
 void fsdo_skidpad_reference_centers(void* h, double* out4) {
   SkidpadPlanner* P = (SkidpadPlanner*)h;
   out4[0] = P->ref_right.x;

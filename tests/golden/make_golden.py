@@ -587,3 +587,42 @@ if __name__ == "__main__" and not any(a.endswith("-only") for a in sys.argv[1:])
     main()
     trackdrive_sequence_golden()
     global_path_golden()
+
+
+def skidpad_awkward_golden():
+    """tests/skidpad_support.py awkward_frames (46 frames of demo/skidpad.json for three rigidly perturbed planners, with a
+    car 60 m off the track, positions / directions that are not finite, a car moved 15 m along the track) through three
+    reference PathPlanner(MissionTypes.skidpad) objects, exceptions caught the way a caller would: what a step that falls
+    back or raises leaves behind (path, index_along_path — moved although the step raised —, the later steps)."""
+    sys.path.insert(0, str(HERE.parent))
+    import skidpad_support as sk
+
+    m = refharness.load()
+    g = np.load(HERE / "skidpad_sequence.npz")
+    tf = sk.perturbed_instances(g, 3)
+    frames = sk.awkward_frames(g, tf, 46)
+    planners = [m["PathPlanner"](m["MissionTypes"].skidpad) for _ in tf]
+    T, n = len(frames), len(tf)
+    ok = np.zeros((T, n), bool)
+    exc = np.zeros((T, n), "U24")
+    path = np.full((T, n, 40, 4), np.nan)
+    idx = np.zeros((T, n), np.int32)
+    reloc = np.zeros((T, n), bool)
+    for t, (off, cones, poses) in enumerate(frames):
+        for i, pp in enumerate(planners):
+            xyt = cones[off[i] : off[i + 1]]
+            by_type = [xyt[xyt[:, 2] == k, :2] for k in range(5)]
+            try:
+                with np.errstate(all="ignore"):
+                    path[t, i] = pp.calculate_path_in_global_frame(by_type, poses[i, :2], poses[i, 2:])
+                ok[t, i] = True
+            except Exception as e:  # noqa: BLE001
+                exc[t, i] = type(e).__name__
+            idx[t, i] = pp.pathing.index_along_path
+            reloc[t, i] = pp.relocalization_info is not None
+    np.savez_compressed(HERE / "skidpad_awkward.npz", ok=ok, exc=exc, path=path, index_along_path=idx, relocalized=reloc)
+    print("skidpad_awkward: raised", int((~ok).sum()), "of", ok.size, "steps:", sorted(set(exc[~ok].tolist())), "index after raising steps", idx[~ok].tolist())
+
+
+if __name__ == "__main__" and "--skidpad-awkward" in sys.argv:
+    skidpad_awkward_golden()
