@@ -858,6 +858,11 @@ __device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut*
   int fallback = 0;
   const int nl = mo->n_left_v, nr = mo->n_right_v;
   int nc = 0;  // centre points, written to the arena polyline [0, nc)
+  // A car position that is not finite: whatever branch the reference takes below, the position joins the path it fits
+  // (connect_path_to_car, :430-457), the fit raises ValueError, and so does the retry with the previous path (:564-570).
+  // Decided here, for all lanes alike, rather than by arg-mins over NaN distances (which lanes would not agree on).
+  // (Pinned by tests/golden/nonfinite_poses.npz; a direction that is not finite plans normally, as in the reference.)
+  if (status == ST_OK && !(fabs(px) < INFINITY && fabs(py) < INFINITY)) status = ST_REF_UNDEFINED_PATH;
   if (status == ST_OK && gpath != nullptr) {
     // PathPlanner.global_path is set (full_pipeline.py:81-82,181-183; core_calculate_path.py:514-529): the basis of the
     // path is the part of the global path within 30 m of the car, rolled so that it starts a third of the table before

@@ -133,7 +133,8 @@ static void create_adjacency(const Frame& f, int n_neighbors, int start_idx, int
   for (int i = 0; i < n; i++) {
     for (int j = 0; j < n; j++) order[j] = j;
     const double* row = &D[(size_t)i * n];
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return row[a] < row[b]; });
+    // (np.argsort: NaN distances — a cone with a coordinate that is not finite — go last, behind the infinities)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return row[a] < row[b] || (row[b] != row[b] && row[a] == row[a]); });
     for (int q = 0; q < n_neighbors && q < n; q++) {
       int j = order[q];
       if (!(row[j] > max_dist * max_dist)) adj[(size_t)i * n + j] = 1;

@@ -626,3 +626,58 @@ def skidpad_awkward_golden():
 
 if __name__ == "__main__" and "--skidpad-awkward" in sys.argv:
     skidpad_awkward_golden()
+
+
+def nonfinite_poses_golden():
+    """24 autocross frames (12 coloured, 12 without colour) whose pose has one component that is NaN / +inf / -inf: the
+    reference raises ValueError for a position that is not finite and plans normally for a direction that is not."""
+    refharness.load()
+    sets = []
+    for color in (True, False):
+        o, c, p = synth.make_replay_batch(12, 64, 0.15, seed=1, color=color)
+        p = p.copy()
+        for k in range(12):
+            p[k, k % 4] = [np.nan, np.inf, -np.inf][k // 4]
+        sets.append((o, c, p))
+    off = np.concatenate([sets[0][0], sets[0][0][-1] + sets[1][0][1:]]).astype(np.int32)
+    cones = np.concatenate([sets[0][1], sets[1][1]])
+    poses = np.concatenate([sets[0][2], sets[1][2]])
+    with np.errstate(all="ignore"):
+        d = capture(off, cones, poses)
+    np.savez_compressed(HERE / "nonfinite_poses.npz", **d)
+    print("nonfinite_poses frames", len(d["ok"]), "ok", int(d["ok"].sum()), "exc", sorted(set(d["exc"].tolist()) - {""}))
+
+
+if __name__ == "__main__" and "--nonfinite" in sys.argv:
+    nonfinite_poses_golden()
+
+
+def nonfinite_cones_golden():
+    """48 autocross frames (24 coloured, 24 without colour) in which one to three cones — the closest to the car, or any —
+    have a coordinate that is NaN / +inf / -inf: the reference plans around them (they end up with no neighbours:
+    np.argsort puts their distances last, adjacency_matrix.py:56)."""
+    refharness.load()
+    sets = []
+    rng = np.random.default_rng(0)
+    vals = [np.nan, np.inf, -np.inf]
+    for color in (True, False):
+        o, c, p = synth.make_replay_batch(24, 64, 0.15, seed=2, color=color)
+        c = c.copy()
+        for k in range(24):
+            lo, hi = o[k], o[k + 1]
+            d = np.hypot(c[lo:hi, 0] - p[k, 0], c[lo:hi, 1] - p[k, 1])
+            pick = np.argsort(d)[: 1 + k % 3] if k % 2 == 0 else rng.choice(hi - lo, 1 + k % 3, replace=False)
+            for j in pick:
+                c[lo + j, (k // 2) % 2] = vals[k % 3]
+        sets.append((o, c, p))
+    off = np.concatenate([sets[0][0], sets[0][0][-1] + sets[1][0][1:]]).astype(np.int32)
+    cones = np.concatenate([sets[0][1], sets[1][1]])
+    poses = np.concatenate([sets[0][2], sets[1][2]])
+    with np.errstate(all="ignore"):
+        d = capture(off, cones, poses)
+    np.savez_compressed(HERE / "nonfinite_cones.npz", **d)
+    print("nonfinite_cones frames", len(d["ok"]), "ok", int(d["ok"].sum()), "exc", sorted(set(d["exc"].tolist()) - {""}))
+
+
+if __name__ == "__main__" and "--nonfinite-cones" in sys.argv:
+    nonfinite_cones_golden()
