@@ -681,3 +681,53 @@ def nonfinite_cones_golden():
 
 if __name__ == "__main__" and "--nonfinite-cones" in sys.argv:
     nonfinite_cones_golden()
+
+
+def odd_inputs_golden():
+    """21 autocross frames with finite but unusual inputs: a zero / tiny / huge direction vector, coordinates offset by 1e7
+    and 1e12 (the reference raises IndexError there: the sorting search runs out of its buffers), 20 duplicated cones
+    (no-colour: no ties that NumPy's unstable argsort would decide), all cones on one point, collinear cones, a single
+    colour, a cone exactly at the car, the track scaled by 0.2 and by 1e-3, denormal coordinates, a pose of -0.0, and
+    frames of 0 / 1 / 2 / 3 / 5 cones."""
+    refharness.load()
+
+    def base(color=True):
+        o, c, p = synth.make_replay_batch(1, 64, 0.15, seed=1, color=color)
+        return c[o[0] : o[1]].copy(), p[0].copy()
+
+    frames, names = [], []
+
+    def add(name, c, p):
+        frames.append((c, p))
+        names.append(name)
+
+    c, p = base(); p[2:] = 0; add("direction zero", c, p)
+    c, p = base(); p[2:] *= 1e-300; add("direction 1e-300", c, p)
+    c, p = base(); p[2:] *= 1e150; add("direction 1e150", c, p)
+    c, p = base(); c[:, :2] += 1e7; p[:2] += 1e7; add("offset 1e7", c, p)
+    c, p = base(); c[:, :2] += 1e12; p[:2] += 1e12; add("offset 1e12", c, p)
+    c, p = base(False); c = np.concatenate([c, c[:20]]); add("20 duplicates, no colour", c, p)
+    c, p = base(); c[:, :2] = p[:2] + np.array([3.0, 1.0]); add("all cones on one point", c, p)
+    c, p = base(); t = np.linspace(1, 60, len(c)); c[:, 0] = p[0] + t * p[2]; c[:, 1] = p[1] + t * p[3]; add("collinear", c, p)
+    c, p = base(); c[:, 2] = 1; add("all right", c, p)
+    c, p = base(); c[:, 2] = 3; add("all orange small", c, p)
+    c, p = base(); c[0, :2] = p[:2]; add("cone at the car", c, p)
+    c, p = base(False); c[0, :2] = p[:2]; add("cone at the car, no colour", c, p)
+    c, p = base(); c[:, :2] = p[:2] + (c[:, :2] - p[:2]) * 1e-3; add("track scaled 1e-3", c, p)
+    c, p = base(); c[:, :2] = p[:2] + (c[:, :2] - p[:2]) * 0.2; add("track scaled 0.2", c, p)
+    c, p = base(); c[:5, 0] = 5e-324; add("denormal x", c, p)
+    c, p = base(); c[:, :2] -= p[:2]; p[:2] = -0.0; add("pose -0.0", c, p)
+    for k in (0, 1, 2, 3, 5):
+        c, p = base(); d = np.hypot(c[:, 0] - p[0], c[:, 1] - p[1]); add(f"{k} cones", c[np.argsort(d)[:k]], p)
+    off = np.concatenate([[0], np.cumsum([len(c) for c, _ in frames])]).astype(np.int32)
+    cones = np.concatenate([c.reshape(-1, 3) for c, _ in frames])
+    poses = np.array([p for _, p in frames])
+    with np.errstate(all="ignore"):
+        d = capture(off, cones, poses)
+    d["names"] = np.array(names)
+    np.savez_compressed(HERE / "odd_inputs.npz", **d)
+    print("odd_inputs frames", len(d["ok"]), "ok", int(d["ok"].sum()), "exc", sorted(set(d["exc"].tolist()) - {""}))
+
+
+if __name__ == "__main__" and "--odd-inputs" in sys.argv:
+    odd_inputs_golden()

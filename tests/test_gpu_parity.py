@@ -43,7 +43,7 @@ def test_default_previous_path_matches_reference(ctx, golden_dir):
     assert np.abs(ctx.default_path() - ref).max() < 1e-12
 
 
-@pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones"])
+@pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones", "odd_inputs"])
 def test_hip_matches_reference_golden(ctx, golden_dir, name):
     """Bar: sorted index arrays bit-equal, matching outputs bit-equal, path within 1e-5 (tests/parity.py)."""
     g = np.load(golden_dir / f"{name}.npz")
@@ -60,7 +60,7 @@ def test_hip_matches_reference_golden(ctx, golden_dir, name):
     assert cats["flip"] <= max(1, int(0.10 * n_arc)), (cats, n_arc)
 
 
-@pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones"])
+@pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones", "odd_inputs"])
 def test_hip_matches_oracle_on_golden_inputs(ctx, golden_dir, name):
     g = np.load(golden_dir / f"{name}.npz")
     res = ctx.plan_batch(g["offsets"], g["cones"], g["poses"])

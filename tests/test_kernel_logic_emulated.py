@@ -11,7 +11,7 @@ import parity
 
 
 @pytest.mark.parametrize("name,stride", [("scenarios", 1), ("cfg2_color", 4), ("cfg3_nocolor", 8), ("cfg4_200cones", 8),
-                                          ("cfg4_noisy_nocolor", 6), ("fuzz", 5), ("big_frames", 4), ("lattice", 2), ("nonfinite_poses", 1), ("nonfinite_cones", 2)])
+                                          ("cfg4_noisy_nocolor", 6), ("fuzz", 5), ("big_frames", 4), ("lattice", 2), ("nonfinite_poses", 1), ("nonfinite_cones", 2), ("odd_inputs", 1)])
 @pytest.mark.parametrize("group", emu_lib.PATH_GROUP_SIZES)
 def test_emulated_kernels_equal_oracle(golden_dir, name, stride, group):
     g = np.load(golden_dir / f"{name}.npz")

@@ -14,7 +14,7 @@ SETS = ["scenarios", "cfg2_color", "cfg3_nocolor", "cfg4_200cones", "cfg4_noisy_
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["libm", "detmath"])
-@pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones"])  # (a NaN / inf component in the pose: raises for positions, plans for directions; in cones: plans around them)
+@pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones", "odd_inputs"])  # (a NaN / inf component in the pose: raises for positions, plans for directions; in cones: plans around them)
 def test_oracle_matches_reference_golden(golden_dir, name, mode):
     """mode 0: libm sin/cos/atan2 (what NumPy calls); mode 1: det_math.h (what the HIP kernels use)."""
     g = np.load(golden_dir / f"{name}.npz")
