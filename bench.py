@@ -103,6 +103,23 @@ def cpu_baseline(off, cones, poses, budget_s: float = 12.0):
     }
 
 
+def skidpad_leg(n_instances: int = 1024, timeout: float = 120.0):
+    """BASELINE configs[4] (tools/bench_skidpad.py): frames/s of n_instances stateful skidpad planners over the 341-frame
+    recording, the replay submitted ahead and one step at a time; None-valued fields with the reason if it could not run."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "tools" / "bench_skidpad.py"), str(n_instances)], capture_output=True, text=True,
+                           timeout=timeout, env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"value": j["frames_per_s_incl_pcie"], "unit": "frames/s", "planner_instances": n_instances, "frames": 341,
+                "one_step_at_a_time_frames_per_s": j["frames_per_s_incl_pcie_one_step_at_a_time"], "steps_in_flight": j["steps_in_flight"],
+                "relocalized": j["relocalized"], "frames_with_nonzero_status": j["frames_with_nonzero_status"],
+                "what": "host buffers to host buffers, H2D + kernels + D2H of every step in the clock; consecutive steps of a planner share their launches (DESIGN.md, Skidpad)"}
+    except Exception as e:  # noqa: BLE001  (an extra of the line, never its failure)
+        return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def streaming_leg(pkg, ctx, per_gpu: int, depth: int, n_batches: int, seed0: int):
     """Host -> host: `n_batches` DIFFERENT batches (a different synthetic track each) through `depth` pass slots with
     fsdp_submit / fsdp_collect — every batch is copied to the GPU, planned and its results copied back inside the
@@ -220,6 +237,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override the frame count (per GPU for config 2, global for config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="(always measured at N = 1; kept for compatibility)")
+    ap.add_argument("--no-skidpad", action="store_true", help="skip the config-5 extra of the line (tools/bench_skidpad.py, ~10 s)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency loop and the golden flip count (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
     ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..16)")
@@ -399,6 +417,10 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(off, cones, poses)
                 out["p50_single_frame_vs_cpu_1thread"] = out["p50_single_frame_us"] / out["cpu_baseline"]["single_thread_us_per_frame"]
+            # BASELINE configs[4] next to the headline: 1024 stateful skidpad planners over the recording, host to host (a
+            # process of its own: tools/bench_skidpad.py; its own context on the same GPU, after everything timed above)
+            if not args.no_skidpad:
+                out["skidpad_config5"] = skidpad_leg()
         print(json.dumps(out), flush=True)
     # The line is out.  Tear-down (last barrier, ncclCommDestroy, hipHostFree of ~1 GB of page-locked buffers, the HIP
     # runtime's own exit handlers) has nothing left to report, and a benchmark process that hangs on its way out after a
