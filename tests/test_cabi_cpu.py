@@ -81,3 +81,15 @@ def test_replay_loader_matches_reference_schema(pkg, golden_dir, tmp_path):
     assert pkg.replay.select_mission_by_filename(f.name) == pkg.MissionTypes.skidpad
     assert pkg.replay.select_mission_by_filename("accel_run.json") == pkg.MissionTypes.acceleration
     assert pkg.replay.select_mission_by_filename("fsg_19_2_laps.json") == pkg.MissionTypes.trackdrive
+
+
+def test_bench_extras_never_fail_the_line():
+    """bench.py's config-5 extra runs tools/bench_skidpad.py as a child process; without a GPU (here) the child fails, and
+    the extra reports that instead of raising — the headline line must come out whatever happens to its extras."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.skidpad_leg(n_instances=8, timeout=120)
+    assert r["value"] is None and "error" in r
