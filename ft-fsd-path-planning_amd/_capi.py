@@ -143,7 +143,7 @@ def load() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_default_params", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
     "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_time_reserve", "fsdp_time_results", "fsdp_time_detail", "fsdp_stage_names", "fsdp_resident_frames",
-    "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_default_path",
+    "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_path_batch_centers", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
@@ -294,6 +294,22 @@ class Context:
         prev = None if prev_paths is None else _dp(self.pad_paths(prev_paths))
         self._check(self._lib.fsdp_path_batch(self._h, len(poses), _dp(poses), prev, ctypes.c_void_p(results.ctypes.data)), "fsdp_path_batch")
         return results
+
+    def path_batch_centers(self, poses, results: np.ndarray, prev_paths=None, cap: int = 1408):
+        """path_batch + the second value of CalculatePath.run_path_calculation (core_calculate_path.py:575): a list of
+        (n_i, 2) arrays, the points every frame's first spline fit was given."""
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 4)
+        results = np.ascontiguousarray(results)
+        assert results.dtype == RESULT_DTYPE and len(results) == len(poses)
+        prev = None if prev_paths is None else _dp(self.pad_paths(prev_paths))
+        n = len(poses)
+        centers = np.zeros((n, cap, 2))
+        counts = np.zeros(n, np.int32)
+        self._check(self._lib.fsdp_path_batch_centers(self._h, n, _dp(poses), prev, ctypes.c_void_p(results.ctypes.data), _dp(centers), _ip(counts),
+                                                      ctypes.c_int(cap)), "fsdp_path_batch_centers")
+        if (counts > cap).any():
+            raise FsdpError(f"centre points beyond the buffer ({int(counts.max())} > {cap})")
+        return results, [centers[i, : counts[i]].copy() for i in range(n)]
 
     # streams of batches: several different batches in flight (fsdp_submit / fsdp_collect)
     def submit(self, offsets, cones, poses, prev_paths=None, out=None) -> Ticket:

@@ -59,6 +59,11 @@ struct Params {
   int32_t horizon;                      // config.py:58 mpc_prediction_horizon: rows of a path (<= PATH_POINTS, the stride of every path array)
   int32_t matches_should_be_monotonic;  // config.py:124-146, functional_cone_matching.py:164-171
   int32_t use_unknown_cones;            // config.py:40, core_cone_sorting.py:114 (0: cones of type UNKNOWN are dropped before sorting)
+  // Optional side output of the path stage: the second value CalculatePath.run_path_calculation returns
+  // (core_calculate_path.py:575 center_along_match_connection).  Null except during fsdp_path_batch_centers.
+  int32_t centers_cap;   // points per frame the buffer holds
+  double* centers;       // (n_frames, centers_cap, 2)
+  int32_t* n_centers;    // (n_frames,) points the reference's array holds (may exceed centers_cap: only the first cap are stored)
 };
 
 #define FSDP_PI 3.14159265358979323846

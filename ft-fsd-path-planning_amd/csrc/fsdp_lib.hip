@@ -869,6 +869,9 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   c->params.horizon = pp.mpc_prediction_horizon;
   c->params.matches_should_be_monotonic = pp.matches_should_be_monotonic ? 1 : 0;
   c->params.use_unknown_cones = pp.use_unknown_cones ? 1 : 0;
+  c->params.centers_cap = 0;
+  c->params.centers = nullptr;
+  c->params.n_centers = nullptr;
   if (e == hipSuccess) e = hipMalloc(&c->d_params, sizeof(Params));
   if (e == hipSuccess) e = hipMemcpyAsync(c->d_params, &c->params, sizeof(Params), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMalloc(&c->d_default_path, sizeof(double) * PATH_POINTS * 4);
@@ -1611,12 +1614,38 @@ int fsdp_match_batch(fsdp_ctx* c, int n_frames, const double* sorted_left, const
   return 0;
 }
 
-int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, const double* prev_paths, fsdp_frame_result* results) {
+// centers / n_centers / centers_cap: optional side output (fsdp_path_batch_centers)
+static int path_batch_impl(fsdp_ctx* c, int n_frames, const double* poses, const double* prev_paths, fsdp_frame_result* results,
+                           double* centers, int32_t* n_centers, int centers_cap) {
   if (!c || n_frames < 0) return 1;
   if (c->outstanding) return busy_error(c, "fsdp_path_batch");
   if (n_frames == 0) return 0;
   HIP_TRY(c, hipSetDevice(c->device));
   if (int rc = sync_all(c)) return rc;  // passes in flight still use the buffers ensure_work may replace
+  // the centre points leave the kernels through a buffer the device copy of the parameters points to for this one call
+  struct CentersScope {
+    fsdp_ctx* c;
+    double* d_xy = nullptr;
+    int32_t* d_n = nullptr;
+    ~CentersScope() {
+      if (!d_xy && !d_n) return;
+      c->params.centers = nullptr;
+      c->params.n_centers = nullptr;
+      c->params.centers_cap = 0;
+      (void)hipMemcpy(c->d_params, &c->params, sizeof(Params), hipMemcpyHostToDevice);
+      (void)hipFree(d_xy);
+      (void)hipFree(d_n);
+    }
+  } cs{c};
+  if (centers) {
+    HIP_TRY(c, hipMalloc(&cs.d_xy, sizeof(double) * 2 * (size_t)centers_cap * (size_t)n_frames));
+    HIP_TRY(c, hipMalloc(&cs.d_n, sizeof(int32_t) * (size_t)n_frames));
+    HIP_TRY(c, hipMemset(cs.d_n, 0, sizeof(int32_t) * (size_t)n_frames));
+    c->params.centers = cs.d_xy;
+    c->params.n_centers = cs.d_n;
+    c->params.centers_cap = centers_cap;
+    HIP_TRY(c, hipMemcpy(c->d_params, &c->params, sizeof(Params), hipMemcpyHostToDevice));
+  }
   Work& q = c->slot[0];
   if (int rc = ensure_work(c, q, n_frames)) return rc;
   if (int rc = ensure_inputs(c, q.in, n_frames, 1, prev_paths != nullptr)) return rc;
@@ -1654,7 +1683,25 @@ int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, const double
     results[i].status = 0;
     assemble(nullptr, nullptr, &c->h_path[i], &results[i]);
   }
+  if (centers) {
+    HIP_TRY(c, hipMemcpy(centers, cs.d_xy, sizeof(double) * 2 * (size_t)centers_cap * (size_t)n_frames, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(n_centers, cs.d_n, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost));
+  }
   return 0;
+}
+
+int fsdp_path_batch(fsdp_ctx* c, int n_frames, const double* poses, const double* prev_paths, fsdp_frame_result* results) {
+  return path_batch_impl(c, n_frames, poses, prev_paths, results, nullptr, nullptr, 0);
+}
+
+int fsdp_path_batch_centers(fsdp_ctx* c, int n_frames, const double* poses, const double* prev_paths, fsdp_frame_result* results,
+                            double* centers, int32_t* n_centers, int centers_cap) {
+  if (!c) return 1;
+  if (!centers || !n_centers || centers_cap <= 0) {
+    c->err = "fsdp_path_batch_centers: centers, n_centers and a positive centers_cap are required";
+    return 1;
+  }
+  return path_batch_impl(c, n_frames, poses, prev_paths, results, centers, n_centers, centers_cap);
 }
 
 #ifdef FSDP_PROFILE
@@ -1984,6 +2031,9 @@ int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
   float t = 0;
   HIP_TRY(c, hipEventElapsedTime(&t, c->ev[4], c->ev[5]));
   HIP_TRY(c, hipMemcpyAsync(c->d_skid, c->d_skid_backup, bytes, hipMemcpyDeviceToDevice, c->stream));
+  // the timed launches published step skid_step_no + 1 for every planner while the restored state is that of step
+  // skid_step_no: put the publish counters back too, or the second step of the next group launch would not wait for the first
+  HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)(c->d_skid_sync + 1), c->skid_step_no, (size_t)c->n_instances, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (ms_total) *ms_total = t;
   return 0;

@@ -65,6 +65,7 @@ struct Arena {
   FitRec* fit;
   double* band;  // fit_kernel's band triangle between observation passes (FitWS)
   const Params* prm;  // the context's configuration constants
+  int frame;          // index of the frame within its batch
 };
 
 // Per-frame LDS = the spline workspace; while no fit is running the path stage uses its bytes for segment lengths (before
@@ -804,6 +805,7 @@ __device__ __forceinline__ Arena frame_arena(double* arena, int frame, const Par
   A.fit = (FitRec*)(A.filt + DENSE_CAP);
   A.band = A.filt + DENSE_CAP + FITREC_DOUBLES;
   A.prm = prm;
+  A.frame = frame;
   return A;
 }
 
@@ -967,6 +969,16 @@ __device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut*
       nc = A.prm->horizon;
     }
     GR::sync();
+  }
+  if (A.prm->centers != nullptr) {
+    // run_path_calculation's second return value (:575): the points the first fit is given, whichever branch chose them
+    const int nk = status == ST_OK ? nc : 0, cap = A.prm->centers_cap;
+    double* co = A.prm->centers + (size_t)A.frame * 2 * (size_t)cap;
+    for (int i = lane; i < nk && i < cap; i += G) {
+      co[2 * i] = A.x[i];
+      co[2 * i + 1] = A.y[i];
+    }
+    if (lane == 0) A.prm->n_centers[A.frame] = nk;
   }
   // fit_matches_as_spline :207-223 -> dense path update in arena [1, 1+n1)
   int n1 = 0;

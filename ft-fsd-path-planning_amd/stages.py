@@ -163,7 +163,8 @@ class CalculatePath:
         if i.global_path is not None:  # core_calculate_path.py:514-529: the path is drawn from the global path
             ctx.set_global_path(i.global_path)
         try:
-            out = ctx.path_batch(pose[None], res, None if self._prev is None else self._prev[None])[0]
+            outs, centers = ctx.path_batch_centers(pose[None], res, None if self._prev is None else self._prev[None])
+            out = outs[0]
         finally:
             if i.global_path is not None:
                 ctx.set_global_path(None)
@@ -172,4 +173,5 @@ class CalculatePath:
         path = np.array(out["path"][: ctx.horizon])
         if self.stateful:
             self._prev = path.copy()
-        return path, None
+        # second value (core_calculate_path.py:575): the points the first fit was given, from the device
+        return path, centers[0]

@@ -249,6 +249,14 @@ int fsdp_match_batch(fsdp_ctx* ctx, int n_frames, const double* sorted_left, con
  * counts) and poses; prev_paths (n_frames,40,4) = CalculatePath.previous_paths[-1] of every frame's planner, or NULL for
  * fresh planners; fills path, path_fallback, n_dense, status. */
 int fsdp_path_batch(fsdp_ctx* ctx, int n_frames, const double* poses, const double* prev_paths, fsdp_frame_result* results);
+/* The same call with the SECOND value run_path_calculation returns (calculate_path/core_calculate_path.py:575,
+ * `center_along_match_connection`): the points the first spline fit is given — centres of the matched cone pairs
+ * (:185-205), the previous path's xy when fewer than two matches exist (:203) or both sides hold fewer than three cones
+ * (:531-536), or the slice of the global path within 30 m of the car (:514-529).  centers: (n_frames, centers_cap, 2);
+ * n_centers[f] = the number of points of frame f's array (0 when the frame's status is not 0 before the first fit); when
+ * it exceeds centers_cap only the first centers_cap points were stored (a global path slice holds up to 1408). */
+int fsdp_path_batch_centers(fsdp_ctx* ctx, int n_frames, const double* poses, const double* prev_paths,
+                            fsdp_frame_result* results, double* centers, int32_t* n_centers, int centers_cap);
 
 /* ---- skidpad mission (BASELINE config 5): stateful planner instances ------------------------------------------------
  * PathPlanner(MissionTypes.skidpad) keeps state across calls (relocalizer transform, SkidpadCalculatePath.index_along_path,

@@ -731,3 +731,67 @@ def odd_inputs_golden():
 
 if __name__ == "__main__" and "--odd-inputs" in sys.argv:
     odd_inputs_golden()
+
+
+def stage_centers_golden():
+    """The reference's CalculatePath stage class on its own (README.md:78-79): run_path_calculation returns
+    (path, center_along_match_connection) — core_calculate_path.py:575.  Inputs: the matching outputs the reference produced
+    for the frames of fuzz.npz and scenarios.npz (every branch that picks the centre points: matches of the better side,
+    < 2 matches -> previous path, < 3 cones on both sides -> previous path), a fresh stage object per frame, plus 12 frames
+    with a global path (the slice within 30 m, rolled).  Stored: the inputs' frame indices, the centre points (padded) and
+    the path."""
+    m = refharness.load()
+    from fsd_path_planning.calculate_path.core_calculate_path import PathCalculationInput
+    from fsd_path_planning import config as cfg
+
+    mission = m["MissionTypes"].trackdrive
+    rows = []
+    for name in ("fuzz", "scenarios", "odd_inputs"):
+        g = np.load(HERE / f"{name}.npz")
+        idx = np.flatnonzero(g["ok"])
+        if name == "fuzz":
+            idx = idx[::4]
+        for f in idx:
+            nl, nr = int(g["n_left_v"][f]), int(g["n_right_v"][f])
+            rows.append((name, int(f), g["left_v"][f, :nl], g["right_v"][f, :nr], g["l2r"][f, :nl].astype(np.int64),
+                         g["r2l"][f, :nr].astype(np.int64), g["poses"][f], None))
+    left, right, centre_fn = synth.closed_track(40, 33)
+    gp = np.array([centre_fn(s)[0] for s in np.linspace(0, 1, 600, endpoint=False)])
+    rng = np.random.default_rng(9)
+    for t in range(12):
+        pos, tan = centre_fn(0.03 + t * 0.07)
+        rows.append(("global", t, np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0, np.int64), np.zeros(0, np.int64),
+                     np.concatenate([np.array(pos) + rng.normal(0, 0.3, 2), tan]), gp))
+    F = len(rows)
+    CAP = 640
+    out = dict(set=np.array([r[0] for r in rows]), frame=np.array([r[1] for r in rows], np.int32), ok=np.zeros(F, bool),
+               exc=np.array([""] * F, dtype="U24"), poses=np.array([r[6] for r in rows]), n_left_v=np.zeros(F, np.int32),
+               n_right_v=np.zeros(F, np.int32), left_v=np.zeros((F, MAX_MATCH, 2)), right_v=np.zeros((F, MAX_MATCH, 2)),
+               l2r=np.full((F, MAX_MATCH), -1, np.int32), r2l=np.full((F, MAX_MATCH), -1, np.int32),
+               uses_global=np.zeros(F, bool), global_path=gp, n_centers=np.zeros(F, np.int32), centers=np.zeros((F, CAP, 2)),
+               path=np.full((F, 40, 4), np.nan))
+    for k, (name, f, lv, rv, l2r, r2l, pose, gpath) in enumerate(rows):
+        out["n_left_v"][k], out["n_right_v"][k] = len(lv), len(rv)
+        out["left_v"][k, : len(lv)], out["right_v"][k, : len(rv)] = lv, rv
+        out["l2r"][k, : len(lv)], out["r2l"][k, : len(rv)] = l2r, r2l
+        out["uses_global"][k] = gpath is not None
+        stage = cfg.create_default_pathing(mission)
+        stage.set_new_input(PathCalculationInput(lv, rv, l2r, r2l, pose[:2], pose[2:], gpath))
+        try:
+            with np.errstate(all="ignore"):
+                path, centers = stage.run_path_calculation()
+        except Exception as e:  # noqa: BLE001 (which class is part of the fixture)
+            out["exc"][k] = type(e).__name__
+            continue
+        out["ok"][k] = True
+        assert len(centers) <= CAP
+        out["n_centers"][k] = len(centers)
+        out["centers"][k, : len(centers)] = centers
+        out["path"][k] = path
+    np.savez_compressed(HERE / "stage_centers.npz", **out)
+    print("stage_centers frames", F, "ok", int(out["ok"].sum()), "exc", sorted(set(out["exc"].tolist()) - {""}),
+          "centre counts", sorted(set(out["n_centers"].tolist()))[:12], "...")
+
+
+if __name__ == "__main__" and "--stage-centers-only" in sys.argv:
+    stage_centers_golden()

@@ -251,6 +251,35 @@ def test_stage_classes_mirror_reference_protocol(pkg, golden_dir):
         cs.run_cone_sorting()
 
 
+def test_calculate_path_stage_returns_the_centre_points(pkg, golden_dir):
+    """CalculatePath.run_path_calculation returns (path, center_along_match_connection) like the reference
+    (core_calculate_path.py:575).  156 captures of the reference's own stage object (tests/golden/make_golden.py
+    --stage-centers-only): centres of the matched pairs, the previous path's xy (fewer than two matches / fewer than three
+    cones on both sides), the rolled slice of a global path within 30 m.  The centre points are plain (a + b) / 2 of the
+    inputs or copies: bit-equal; the path within 1e-5 (arc frames: the counted sample-count flip)."""
+    g = np.load(golden_dir / "stage_centers.npz")
+    flips = []
+    seen = set()
+    for k in range(len(g["ok"])):
+        assert g["ok"][k]
+        nl, nr = int(g["n_left_v"][k]), int(g["n_right_v"][k])
+        cp = pkg.CalculatePath(device=0, stateful=False)
+        gp = g["global_path"] if g["uses_global"][k] else None
+        cp.set_new_input(pkg.PathCalculationInput(g["left_v"][k, :nl], g["right_v"][k, :nr], g["l2r"][k, :nl], g["r2l"][k, :nr],
+                                                  g["poses"][k, :2], g["poses"][k, 2:], gp))
+        path, centers = cp.run_path_calculation()
+        n = int(g["n_centers"][k])
+        assert centers.shape == (n, 2), (k, centers.shape, n)
+        assert np.array_equal(centers, g["centers"][k, :n]), k
+        seen.add("global" if gp is not None else ("previous" if n == 40 else "matches"))
+        e = np.abs(path - g["path"][k]).max()
+        if e > 1e-5:
+            assert parity.is_sample_count_flip(path, g["path"][k]) and int(cp.last_result["path_fallback"]) & parity.ARC_FLAG, (k, e)
+            flips.append(k)
+    assert seen == {"global", "previous", "matches"}
+    assert len(flips) <= 2, flips
+
+
 def test_replay_cli_roundtrip(pkg, golden_dir, tmp_path):
     import json
 

@@ -209,3 +209,38 @@ def test_random_skidpad_traffic(pkg, golden_dir, monkeypatch):
                 assert _same_fields(res, ref[j][0]) and _same_fields(info, ref[j][1]), (depth, j)
                 checked += 1
         assert checked == len(frames)
+
+
+def test_timing_launches_leave_no_trace(pkg, golden_dir, monkeypatch):
+    """fsdp_skidpad_time_path repeats the last step's path kernel and restores the planners' state — and the publish
+    counters the wavefronts of grouped launches wait on (round-3 advisor: with stale counters the second step of the next
+    group did not wait for the first one's state).  Steps, timing launches, then a replay submitted ahead through the
+    wavefront-per-(instance, step) kernel: every result must equal the one-launch-per-step planners that were never timed."""
+    monkeypatch.setenv("FSDP_SKID_GROUP", "5")
+    monkeypatch.setenv("FSDP_SKID_PACK_MIN", "1000000")  # keep the groups on skid_path_kernel (the kernel that waits)
+    n = 48
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, n)
+    frames = sk.awkward_frames(g, tf, 64)
+    one = pkg.SkidpadBatch(n, device=0)
+    ref = []
+    for f in frames:
+        res, info = one.step(*f)
+        ref.append((res.copy(), info.copy()))
+    batch = pkg.SkidpadBatch(n, device=0)
+    for t in range(30):
+        res, info = batch.step(*frames[t])
+        assert _same_fields(res, ref[t][0]) and _same_fields(info, ref[t][1]), t
+    assert batch.time_path(7) > 0.0
+    got = list(batch.replay(frames[30:], 16))
+    for t, (res, info) in enumerate(got, start=30):
+        assert _same_fields(res, ref[t][0]) and _same_fields(info, ref[t][1]), t
+    with oracle_lib.math_mode(1):
+        table, noise = batch.tables
+        op = oracle_lib.SkidpadPlanner(table, noise)
+        for t, f in enumerate(frames):
+            off, cones, poses = f
+            r, oi = op.step(cones[off[0] : off[1]], poses[0])
+            assert int(ref[t][0][0]["status"]) == int(r["status"]), t
+            if int(r["status"]) == 0:
+                assert np.abs(ref[t][0][0]["path"] - r["path"]).max() <= 1e-9, t
