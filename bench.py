@@ -174,6 +174,75 @@ def streaming_leg(pkg, ctx, per_gpu: int, depth: int, n_batches: int, seed0: int
     }
 
 
+
+class InProcess:
+    """--single-process: every GPU of the node driven from THIS process (multi.py's form of the product: one context per
+    device, no launcher, no socket, no RCCL).  Context 0 plays rank 0 (all the extras of the line are measured on it); the
+    timed region runs `steps` passes on every context at once, one host thread per context around the blocking
+    fsdp_time_runs call (ctypes releases the GIL), and the clock spans the slowest of them.  Interface of dist.Dist."""
+
+    transport = "in-process"
+
+    def __init__(self, pkg, n: int, n_dev: int, share: bool):
+        if n_dev < n and not share:
+            sys.exit(f"bench.py: --gpus {n} but only {n_dev} GPU(s) visible (FSDP_SHARE_GPU=1 puts several contexts on one GPU: testing only)")
+        self.world, self.rank = n, 0
+        self.devices = [g % max(n_dev, 1) for g in range(n)]
+        self.ctxs = [pkg.Context(device=dv, mission=int(pkg.MissionTypes.trackdrive)) for dv in self.devices]
+
+    def describe(self):
+        return f"in-process, {self.world} context(s) on device(s) {self.devices} driven by one process (multi.py), no collective at all"
+
+    def shard_seed(self, base_seed, g=0):
+        return base_seed + g
+
+    def frame_range(self, n_total, g=0):
+        return g * n_total // self.world, (g + 1) * n_total // self.world
+
+    def broadcast_check_table(self, table):
+        ref = np.ascontiguousarray(table).view(np.uint64)
+        return all(np.array_equal(np.ascontiguousarray(c.default_path()).view(np.uint64), ref) for c in self.ctxs[1:])
+
+    def barrier(self):
+        for c in self.ctxs:
+            c.sync()
+
+    def max_over_ranks(self, v):
+        return v
+
+    def timed_region(self, steps):
+        """EXACTLY `steps` passes on every context, started together; returns the wall clock over all of them."""
+        import threading
+
+        gate = threading.Barrier(len(self.ctxs) + 1)
+        errs = []
+
+        def work(c):
+            gate.wait()
+            try:
+                c.time_runs(steps, collect=False)
+                c.sync()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(c,)) for c in self.ctxs]
+        for t in th:
+            t.start()
+        self.barrier()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        if errs:
+            raise errs[0]
+        return el
+
+    def close(self):
+        for c in self.ctxs[1:]:
+            c.close()
+
+
 def _lib_hash(pkg) -> str:
     import hashlib
 
@@ -242,6 +311,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
     ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..16)")
     ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic track (config 2; rank r replays seed + r)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 without a launcher, sockets or RCCL: one context per GPU, all driven from this process (multi.py); "
+                         "also what --gpus N falls back to when its own launch of N ranks fails")
     ap.add_argument("--stream-batches", type=int, default=100, help="different batches of the host -> host streaming leg (0: skip)")
     args = ap.parse_args()
     if os.environ.get("FSDP_HANG_DUMP"):  # diagnostics: Python stacks of all threads after N seconds, then exit
@@ -252,17 +324,29 @@ def main():
     pkg = importlib.import_module("ft-fsd-path-planning_amd")
     n_dev = pkg._capi.load().fsdp_device_count()
     share = os.environ.get("FSDP_SHARE_GPU") == "1"  # testing only: several ranks on one GPU (RCCL refuses that -> tcp-fallback)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    single = args.single_process and args.gpus > 1
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not single:
         # started without a launcher: be the launcher — one rank per GPU with the launch contract's environment
         if n_dev < args.gpus and not share:
             sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible")
-        sys.exit(pkg.dist.spawn_ranks([str(Path(__file__).resolve()), *sys.argv[1:]], args.gpus))
+        rc, text = pkg.dist.spawn_ranks([str(Path(__file__).resolve()), *sys.argv[1:]], args.gpus, capture=True,
+                                        timeout=float(os.environ.get("FSDP_SPAWN_TIMEOUT", "900")))
+        lines = [l for l in text.splitlines() if l.startswith("{") and '"metric"' in l]
+        if lines:
+            print(lines[-1], flush=True)
+            sys.exit(0)
+        print(f"bench.py: the {args.gpus} ranks produced no line (exit status {rc}); planning on the {args.gpus} GPUs from this process instead", file=sys.stderr)
+        single = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    ctx = pkg.Context(device=local_rank % max(n_dev, 1) if share else local_rank, mission=int(pkg.MissionTypes.trackdrive))
-    # WORLD_SIZE > 1: ncclCommInitRank on this rank's GPU (RCCL over xGMI; its id travels over the TCP star of dist.py, which
-    # also carries the collectives if RCCL fails on any rank)
-    d = pkg.dist.Dist(ctx)
+    if single:
+        d = InProcess(pkg, args.gpus, n_dev, share)
+        ctx = d.ctxs[0]
+    else:
+        ctx = pkg.Context(device=local_rank % max(n_dev, 1) if share else local_rank, mission=int(pkg.MissionTypes.trackdrive))
+        # WORLD_SIZE > 1: ncclCommInitRank on this rank's GPU (RCCL over xGMI; its id travels over the TCP star of dist.py, which
+        # also carries the collectives if RCCL fails on any rank)
+        d = pkg.dist.Dist(ctx)
     world = d.world
     assert "torch" not in sys.modules, "the product path must not pull in PyTorch"
     if args.gpus != world and rank == 0:
@@ -290,6 +374,13 @@ def main():
                     f"contiguous shards of {hi - lo} frames per GPU")
         scaling = "strong"
     n_local = len(off) - 1
+    peer_batches = []
+    if single:  # the other contexts' shards: what ranks 1 .. N-1 would build
+        for g in range(1, world):
+            if args.config == 2:
+                peer_batches.append(pkg.synth.make_replay_batch(per_gpu, CONES_PER_SIDE, 0.15, seed=d.shard_seed(args.seed, g), color=True))
+            else:
+                peer_batches.append(pkg.synth.make_config4_shard(*d.frame_range(frames_global, g), CFG4_CONES_PER_SIDE, 0.1, seed=7))
     algo_bytes = algo_bytes_per_frame(cones_per_frame)
     # a replay is a stream of batches: consecutive passes rotate through `overlap` HIP streams / buffer sets so that the
     # next passes fill the compute units the slowest frames of the previous ones no longer occupy (fsdp_set_overlap)
@@ -298,6 +389,13 @@ def main():
         overlap = max(1, 131072 // n_local)
     ctx.set_overlap(overlap)
     ctx.upload(off, cones, poses)
+    for c, b in zip(d.ctxs[1:] if single else [], peer_batches):
+        c.set_overlap(overlap)
+        c.upload(*b)
+        for _ in range(args.warmup):
+            c.run()
+        c.time_reserve(args.steps)
+        c.time_detail(False)
 
     for _ in range(args.warmup):
         ctx.run()
@@ -309,13 +407,16 @@ def main():
     ctx.time_detail(False)
     ctx.sync()
     d.barrier()
-    t0 = time.perf_counter()
-    # EXACTLY `steps` passes, enqueued back to back; returns after the last pass has finished.  The events are read after
-    # the clock has stopped.
-    ctx.time_runs(args.steps, collect=False)
-    ctx.sync()
-    d.barrier()
-    elapsed = d.max_over_ranks(time.perf_counter() - t0)
+    if single:
+        elapsed = d.timed_region(args.steps)
+    else:
+        t0 = time.perf_counter()
+        # EXACTLY `steps` passes, enqueued back to back; returns after the last pass has finished.  The events are read after
+        # the clock has stopped.
+        ctx.time_runs(args.steps, collect=False)
+        ctx.sync()
+        d.barrier()
+        elapsed = d.max_over_ranks(time.perf_counter() - t0)
     ev_total_ms, ev_main_ms = ctx.time_results()
     names = ctx.stage_names()
     main_ms = [x / args.steps for x in ev_main_ms]  # non-zero for the bracketed kernel only
@@ -362,6 +463,7 @@ def main():
                 "cones_per_frame": cones_per_frame,
                 "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; communicator: "
                                + d.describe(),
+                "processes": 1 if single else world,
                 "communicator": d.transport,
                 "pass_overlap": overlap,
             },

@@ -792,7 +792,14 @@ inline void default_chord_points(double (*chord)[2]) {
 }
 
 __device__ __forceinline__ Arena frame_arena(double* arena, int frame, const Params* prm) {
+#ifdef FSDP_ARENA_ALIAS
+  // experiment builds only (tools/build_variant.sh -DFSDP_ARENA_ALIAS=64 with a batch whose frames repeat with that
+  // period): frames share scratch arenas, so the path stage's scratch stream stays in the L2 — what the kernels would
+  // take if that stream cost nothing (profiles/r04_fit_memory_bound.txt)
+  double* b = arena + (size_t)(frame % FSDP_ARENA_ALIAS) * ARENA_DOUBLES;
+#else
   double* b = arena + (size_t)frame * ARENA_DOUBLES;
+#endif
   Arena A;
   A.x = b;
   A.y = b + PATH_CAP;
@@ -1108,10 +1115,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
 #ifndef FSDP_FIT_WAVES
 #define FSDP_FIT_WAVES 3
 #endif
+#ifdef FSDP_EMU
+#define FSDP_WAVES_PER_EU(n)  // (the host emulator's compiler does not parse an expression in an attribute it does not know)
+#else
+#define FSDP_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
 // the refit: utils/spline_fit.py:95-128 (splprep, k = 3, s = 0.2) of the arena polyline [off, off + n), G lanes per frame
 template <int G, int NKC>
-// (three wavefronts per SIMD: 168 registers, measured +2 % frames/s over two)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FSDP_FIT_WAVES))) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
+// (8 / 16 lanes per frame: three wavefronts per SIMD at 168 registers, measured +2 % frames/s over two; 4 lanes per frame:
+// sixteen frames' workspaces are 19.2 KB, i.e. two wavefronts per SIMD — a third one at 14.2 KB / 168 registers was measured
+// to change nothing, profiles/r04_ab_variants.txt 1)
+__global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? 2 : FSDP_FIT_WAVES) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                  int* __restrict__ retry, const Params* __restrict__ prm) {
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;

@@ -71,6 +71,7 @@ struct SplineWS {
     };
   };
   static constexpr bool BAND_GLOBAL = false;
+  static constexpr bool RECOMPUTE = false;  // basis values travel through the BasisCache records
   __device__ __forceinline__ double& A(int i, int j) { return a_[i][j - 1]; }
   __device__ __forceinline__ double& Z(int i) { return z[i]; }
   __device__ __forceinline__ double& Gm(int i, int j) { return g_[i][j - 1]; }
@@ -87,24 +88,39 @@ template <int G, int NKC>
 struct FitWS {
   static constexpr int GRP = G;
   static constexpr int NK = NKC;
-  static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : (G >= 8 ? FSDP_FIT_CH8 : 8));
+#ifndef FSDP_FIT_CH4
+#define FSDP_FIT_CH4 4
+#endif
+  static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : (G >= 8 ? FSDP_FIT_CH8 : FSDP_FIT_CH4));
   static constexpr bool BAND_GLOBAL = true;
-  double t[NK + 2];
-  double c[2 * (NK + 2)];
+  // 1-based arrays sized for what a fit of NK knots touches: t(1..n), c(1..2n), fpint / nrdata(1..n), and the rows
+  // 1..n-4 of the extended triangle.  At four lanes per frame (CH = 4) a frame is 888 bytes.
+  double t[NK + 1];
+  double c[2 * NK + 1];
   double* band;
   union {
     struct {
       double hq[CH][4];
       double xq[CH], yq[CH];
       int32_t lq[CH];
-      double fpint[NK + 2];
-      int32_t nrdata[NK + 2];
+      double fpint[NK + 1];
+      int16_t nrdata[NK + 2];  // data points inside a knot interval (< PATH_CAP)
+      // refined reciprocals of the knot differences t(a + j) - t(a), j = 1..3, a = 1..n, of the current knot set
+      // (knot_reciprocals): what the six divisions of a point's basis values (fpbspl3_rd) divide by.  Outside the
+      // bookkeeping arrays, so that it survives the residual pass; the rows of g_ overwrite its head in the smoothing
+      // iteration, which therefore rebuilds it before every f(p) pass.
+      double rd[3 * (NK + 1)];
     };
-    double g_[NK + 2][5];
+    double g_[NK - 4][5];
   };
+  // The basis values of a data point are computed again in every pass over the data (observation, residual, f(p)) from
+  // its parameter value and the reciprocal table instead of being written to / read from the frame's scratch (BasisCache
+  // records): 25 instead of 49 bytes per point and pass through HBM — the fit kernel is bound by that stream
+  // (profiles/r04_fit_memory_bound.txt) — for ~45 more FP64 instructions per point and pass.
+  static constexpr bool RECOMPUTE = true;
   __device__ __forceinline__ double& A(int i, int j) { return band[4 * i + j - 1]; }
   __device__ __forceinline__ double& Z(int i) { return band[4 * (NK + 2) + i]; }
-  __device__ __forceinline__ double& Gm(int i, int j) { return g_[i][j - 1]; }
+  __device__ __forceinline__ double& Gm(int i, int j) { return g_[i - 1][j - 1]; }
 };
 
 // Per-point basis cache in the frame's HBM/L2 scratch: one 32-byte record per data point — the K+1 non-zero B-spline
@@ -422,6 +438,88 @@ __device__ __forceinline__ bool knot_differences_safe(const double* t, int n) {
   return Grp<G>::ballot(badk) == 0ull;
 }
 
+// ---- basis values from the reciprocal table (workspaces with RECOMPUTE) ---------------------------------------
+// rd(a, j) = rcp_refined(t(a + j) - t(a)) at rd[3 a + j - 1].  The six denominators of a point in knot interval l are
+// t(l+1)-t(l), t(l+1)-t(l-1), t(l+2)-t(l), t(l+1)-t(l-2), t(l+2)-t(l-1), t(l+3)-t(l): each spans [t(l), t(l+1)], which
+// is not empty for an interval that holds a data point — so none of them is zero and fpbspl's "coincident knots" branch
+// (the selects of fpbspl3) is never taken; knot_reciprocals checks exactly that once per knot set, and that every one of
+// them lies in the exponent band of the scaling-free division.
+template <int G>
+__device__ __forceinline__ bool knot_reciprocals(const double* t, int n, double* rd) {
+  bool badk = false;
+  for (int idx = Grp<G>::lane(); idx < 3 * n; idx += G) {
+    const int a = 1 + idx / 3, j = 1 + idx % 3;
+    const int b = a + j <= n ? a + j : n;
+    const double d = t[b] - t[a];
+    const bool zero = d == 0.0;
+    badk |= !(zero | ((d >= 0x1p-255) & (d <= 0x1p255)));
+    // interior knot intervals must not be empty: a = k1 .. nk1 = 4 .. n - 4 (then all six spans of fpbspl3_rd are > 0)
+    if (j == 1 && a >= 4 && a <= n - 4) badk |= zero;
+    rd[3 * a + j - 1] = zero ? 0.0 : rcp_refined(d);
+  }
+  return Grp<G>::ballot(badk) == 0ull;
+}
+
+// fpbspl3 without the coincident-knot selects and with the denominators' reciprocals from the table: the operations on
+// the operands of fpbspl3<true> in its order — same bits (the quotients are div_rcp(num, den, rcp_refined(den))).
+// CHECK: the numerators' exponent band (once per point and knot set is enough: the observation pass).
+template <bool CHECK>
+__device__ __forceinline__ void fpbspl3_rd(const double* t, const double* rd, double x, int l, double* h /*[0..3]*/, int& bad) {
+  const double tm2 = t[l - 2], tm1 = t[l - 1], t0 = t[l], tp1 = t[l + 1], tp2 = t[l + 2], tp3 = t[l + 3];
+  const double r01 = rd[3 * l], r02 = rd[3 * l + 1], r03 = rd[3 * l + 2];              // t(l+1..3) - t(l)
+  const double rm12 = rd[3 * (l - 1) + 1], rm13 = rd[3 * (l - 1) + 2];                  // t(l+1..2) - t(l-1)
+  const double rm23 = rd[3 * (l - 2) + 2];                                              // t(l+1) - t(l-2)
+  bool ok = true;
+  auto quot = [&](double num, double den, double r) {
+    if constexpr (CHECK) ok = ok & ((num == 0.0) | ((num >= 0x1p-255) & (num <= 0x1p255)));
+    return div_rcp(num, den, r);
+  };
+  double h1, h2, h3, h4;
+  {
+    const double f = quot(1.0, tp1 - t0, r01);
+    h1 = 0.0 + f * (tp1 - x);
+    h2 = f * (x - t0);
+  }
+  {
+    const double a1 = h1, a2 = h2;
+    h1 = 0.0;
+    {
+      const double f = quot(a1, tp1 - tm1, rm12);
+      h1 = h1 + f * (tp1 - x);
+      h2 = f * (x - tm1);
+    }
+    {
+      const double f = quot(a2, tp2 - t0, r02);
+      h2 = h2 + f * (tp2 - x);
+      h3 = f * (x - t0);
+    }
+  }
+  {
+    const double a1 = h1, a2 = h2, a3 = h3;
+    h1 = 0.0;
+    {
+      const double f = quot(a1, tp1 - tm2, rm23);
+      h1 = h1 + f * (tp1 - x);
+      h2 = f * (x - tm2);
+    }
+    {
+      const double f = quot(a2, tp2 - tm1, rm13);
+      h2 = h2 + f * (tp2 - x);
+      h3 = f * (x - tm1);
+    }
+    {
+      const double f = quot(a3, tp3 - t0, r03);
+      h3 = h3 + f * (tp3 - x);
+      h4 = f * (x - t0);
+    }
+  }
+  h[0] = h1;
+  h[1] = h2;
+  h[2] = h3;
+  h[3] = h4;
+  if constexpr (CHECK) bad |= (int)!ok;
+}
+
 // ---- 4-stage systolic Givens pipeline (degree 3) ------------------------------------------------------
 // A data row of knot interval l touches the 4 consecutive band rows l-3..l, one rotation each, in that order;
 // consecutive data rows fall (almost always) into the same interval.  Lane p of the group's first quad owns the band
@@ -616,29 +714,36 @@ __device__ __forceinline__ void giv_feed(WS& ws, GivLane& st, int r0, int r1) {
 #ifndef RB_MAX_ROUNDS
 #define RB_MAX_ROUNDS 2  // rounds of a residual super-chunk held in registers (2: fit_kernel fits three wavefronts per SIMD)
 #endif
-template <int K, int G, bool FLAGS, int CHV>
+template <int K, int G, bool FLAGS, int CHV, bool RC = false>  // RC: basis values from the parameter value and the workspace's reciprocal table
 struct ResidualBatch {
   // (4 lanes per frame: fit_kernel<4> runs at two wavefronts per SIMD and has the registers for four rounds in flight)
-  static constexpr int RB_CAP = (G == 4) ? 2 * RB_MAX_ROUNDS : RB_MAX_ROUNDS;
+#ifndef FSDP_RB_G4
+#define FSDP_RB_G4 (2 * RB_MAX_ROUNDS)
+#endif
+  static constexpr int RB_CAP = (G == 4) ? FSDP_RB_G4 : RB_MAX_ROUNDS;
   static constexpr int ROUNDS = (4 * CHV / G > RB_CAP) ? RB_CAP : 4 * CHV / G;
   static constexpr int k1 = K + 1, k2 = K + 2;
-  double hv[ROUNDS][K + 1], xv[ROUNDS], yv[ROUNDS];
+  double hv[ROUNDS][RC ? 1 : K + 1], xv[ROUNDS], yv[ROUNDS];
   int lv[ROUNDS], lpv[ROUNDS];
 
   // Loads are unconditional (rows past the end re-read the last record, index clamped) so that all of a super-chunk's
   // loads sit in one basic block and fly together; only the stores of compute() are predicated.
-  __device__ __forceinline__ void load(const BasisCache& bc, const double* X, const double* Y, int base, int cnt, int m) {
+  __device__ __forceinline__ void load(const BasisCache& bc, const double* U, const double* X, const double* Y, int base, int cnt, int m) {
     (void)cnt;
     const int lane = Grp<G>::lane();
 #pragma unroll
     for (int q = 0; q < ROUNDS; q++) {
       int it = base + q * G + lane;
       it = it < m ? it : m - 1;
-      const BRec* p = &bc.rec[it];
-      const D2 a = p->h01, b = p->h23;
-      const double hh[4] = {a.a, a.b, b.a, b.b};
+      if constexpr (RC) {
+        hv[q][0] = U[it];  // (the parameter value; compute() turns it into the basis values)
+      } else {
+        const BRec* p = &bc.rec[it];
+        const D2 a = p->h01, b = p->h23;
+        const double hh[4] = {a.a, a.b, b.a, b.b};
 #pragma unroll
-      for (int j = 0; j < k1; j++) hv[q][j] = hh[j];
+        for (int j = 0; j < k1; j++) hv[q][j] = hh[j];
+      }
       // FITPACK tracks l sequentially (one step per data point); with knots at data points this is
       // l = k2 + #{interior knots <= u(it)} = (interval of u(it)) + 1, "new" when it grew at this point
       lv[q] = (int)bc.l[it] + 1;
@@ -648,6 +753,12 @@ struct ResidualBatch {
       }
       xv[q] = X[it];
       yv[q] = Y[it];
+#ifdef FSDP_PAD_LOADS
+      {  // experiment: 32 more bytes per point and pass from lines nobody else touches (is the kernel bound by its scratch stream?)
+        const D2 e0 = bc.rec[it + 704].h01, e1 = bc.rec[it + 704].h23;
+        asm volatile("" ::"v"(e0.a), "v"(e0.b), "v"(e1.a), "v"(e1.b));
+      }
+#endif
     }
   }
 
@@ -658,6 +769,14 @@ struct ResidualBatch {
     for (int q = 0; q < ROUNDS; q++) {
       const int r = q * G + lane;
       const int l0 = lv[q] - k2;
+      double hb[K + 1];
+      if constexpr (RC) {
+        int unused = 0;
+        fpbspl3_rd<false>(ws.t, ws.rd, hv[q][0], lv[q] - 1, hb, unused);  // (lv = FITPACK's l = interval + 1)
+      } else {
+#pragma unroll
+        for (int j = 0; j < k1; j++) hb[j] = hv[q][j];
+      }
       double term = 0.0;
 #pragma unroll
       for (int d = 0; d < 2; d++) {
@@ -666,7 +785,7 @@ struct ResidualBatch {
 #pragma unroll
         for (int j = 1; j <= k1; j++) {
           j1++;
-          fac = fac + ws.c[j1] * hv[q][j - 1];
+          fac = fac + ws.c[j1] * hb[j - 1];
         }
         double dv = 1.0 * (fac - (d == 0 ? xv[q] : yv[q]));  // w = 1
         term = term + dv * dv;
@@ -762,7 +881,11 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       fp = 0.0;
       GivLane gst;
       giv_init(gst);
-      if constexpr (FAST && K == 3) {
+      if constexpr (WS::RECOMPUTE) {
+        static_assert(!WS::RECOMPUTE || (FAST && K == 3), "the reciprocal table serves the scaling-free cubic fit only");
+        if (!knot_reciprocals<G>(ws.t, n, ws.rd)) gst.bad = 1;
+        GR::sync();
+      } else if constexpr (FAST && K == 3) {
         if (!knot_differences_safe<G>(ws.t, n)) gst.bad = 1;
       }
       int lvq[CH / G] = {};  // knot intervals of this lane's rows of the current chunk
@@ -796,7 +919,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
               int l = find_interval_from(ws.t, lres, nk1, ui);
               lres = l;
               double h[K + 2];
-              if constexpr (K == 3)
+              if constexpr (WS::RECOMPUTE)
+                fpbspl3_rd<true>(ws.t, ws.rd, ui, l, &h[1], gst.bad);
+              else if constexpr (K == 3)
                 fpbspl3<FAST>(ws.t, ui, l, &h[1], gst.bad);
               else
                 fpbspl<K>(ws.t, ui, l, h);
@@ -810,10 +935,12 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
               lvq[q] = l;
               ws.xq[r] = pxv[q];
               ws.yq[r] = pyv[q];
-              BRec* p = &bc.rec[it];
-              p->h01 = D2{hf[0], hf[1]};
-              p->h23 = D2{hf[2], hf[3]};
-              bc.l[it] = (uint8_t)l;
+              if constexpr (!WS::RECOMPUTE) {
+                BRec* p = &bc.rec[it];
+                p->h01 = D2{hf[0], hf[1]};
+                p->h23 = D2{hf[2], hf[3]};
+              }
+              bc.l[it] = (uint8_t)l;  // (RECOMPUTE: the interval is all a later pass reads back, one byte per point)
             }
           }
           GR::sync();
@@ -970,16 +1097,16 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         int ii = 1;
         double* const tbuf = &ws.hq[0][0];     // 4 * CH terms
         int32_t* const fbuf = (int32_t*)ws.xq;  // xq | yq: 4 * CH flags
-        ResidualBatch<K, G, true, CH> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
+        ResidualBatch<K, G, true, CH, WS::RECOMPUTE> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
         auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
-        ra.load(bc, X, Y, 0, clampc(m), m);
+        ra.load(bc, U, X, Y, 0, clampc(m), m);
         for (int base = 0; base < m; base += HALVES * SC) {
           const int cnt_a = clampc(m - base);
           const int cnt_b = (HALVES == 2) ? clampc(m - base - SC) : 0;
           const int cnt = cnt_a + cnt_b;
-          if constexpr (HALVES == 2) rb.load(bc, X, Y, base + SC, cnt_b, m);
+          if constexpr (HALVES == 2) rb.load(bc, U, X, Y, base + SC, cnt_b, m);
           ra.compute(ws, cnt_a, n, tbuf, fbuf);
-          ra.load(bc, X, Y, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
+          ra.load(bc, U, X, Y, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
           if constexpr (HALVES == 2) rb.compute(ws, cnt_b, n, tbuf + SC, fbuf + SC);
           GR::sync();
           for (int r0 = 0; r0 < cnt; r0 += 8) {  // operands eight at a time (one LDS round trip), order kept
@@ -1222,22 +1349,26 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         fpback(gel, &ws.c[n], nk1, k2, &ws.c[n]);
       }
       GR::sync();
+      if constexpr (WS::RECOMPUTE) {
+        (void)knot_reciprocals<G>(ws.t, n, ws.rd);  // (checked when this knot set's observation pass built it)
+        GR::sync();
+      }
       // f(p): terms per lane, accumulation in data order
       PROF(17);
       fp = 0.;
       {
         double* const tbuf = &ws.hq[0][0];  // 4 * CH terms
-        ResidualBatch<K, G, false, CH> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
+        ResidualBatch<K, G, false, CH, WS::RECOMPUTE> ra, rb;  // two half super-chunks: one is computed while the other's loads fly
         auto clampc = [&](int left) { return left < 0 ? 0 : (left < SC ? left : SC); };
-        ra.load(bc, X, Y, 0, clampc(m), m);
+        ra.load(bc, U, X, Y, 0, clampc(m), m);
         for (int base = 0; base < m; base += HALVES * SC) {
           const int cnt_a = clampc(m - base);
           const int cnt_b = (HALVES == 2) ? clampc(m - base - SC) : 0;
           {
             PROF(28);
-            if constexpr (HALVES == 2) rb.load(bc, X, Y, base + SC, cnt_b, m);
+            if constexpr (HALVES == 2) rb.load(bc, U, X, Y, base + SC, cnt_b, m);
             ra.compute(ws, cnt_a, n, tbuf, nullptr);
-            ra.load(bc, X, Y, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
+            ra.load(bc, U, X, Y, base + HALVES * SC, 0, m);  // (clamped: harmless past the end)
             if constexpr (HALVES == 2) rb.compute(ws, cnt_b, n, tbuf + SC, nullptr);
             GR::sync();
           }

@@ -397,10 +397,10 @@ class Dist:
             self._star = None
 
 
-def spawn_ranks(argv, n: int, env_extra=None, timeout: float | None = None) -> int:
+def spawn_ranks(argv, n: int, env_extra=None, timeout: float | None = None, capture: bool = False):
     """Launcher-less multi-GPU start: run ``python argv...`` as n ranks of one node (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR=127.0.0.1 / a free MASTER_PORT / a fresh FSDP_LAUNCH_KEY), rank 0's stdout passed through.  Returns the
-    worst exit code.  What ``python -m torch.distributed.run --nproc-per-node n`` does for this package, without torch."""
+    worst exit code — with capture=True (worst exit code, rank 0's stdout) instead of passing it through.  What ``python -m torch.distributed.run --nproc-per-node n`` does for this package, without torch."""
     import secrets
     import subprocess
     import sys
@@ -419,8 +419,19 @@ def spawn_ranks(argv, n: int, env_extra=None, timeout: float | None = None) -> i
             key = env["FSDP_LAUNCH_KEY"]
         env["FSDP_LAUNCH_KEY"] = key
         env.update(env_extra or {})
-        procs.append(subprocess.Popen([sys.executable, *argv], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env,
+                                      stdout=(subprocess.PIPE if capture else None) if r == 0 else subprocess.DEVNULL, text=True if capture and r == 0 else None))
     rc = 0
+    text = ""
+    if capture:  # rank 0's stdout is read while the ranks run (a full pipe would block it)
+        import threading
+
+        def drain():
+            nonlocal text
+            text = procs[0].stdout.read()
+
+        reader = threading.Thread(target=drain, daemon=True)
+        reader.start()
     deadline = None if timeout is None else time.monotonic() + timeout
     for p in procs:
         try:
@@ -430,4 +441,7 @@ def spawn_ranks(argv, n: int, env_extra=None, timeout: float | None = None) -> i
     for p in procs:
         if p.poll() is None:
             p.kill()
+    if capture:
+        reader.join(5.0)
+        return rc, text
     return rc

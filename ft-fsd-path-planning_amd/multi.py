@@ -1,0 +1,225 @@
+"""Several GPUs from ONE process and ONE host thread ("one handle + stream per GPU ... inputs H2D and
+outputs D2H per GPU").
+
+``MultiPlanner(devices=None)`` owns one context (= ``fsdp_ctx``: streams, pass slots, device buffers, the constant
+tables) per device, cuts a batch of independent frames into contiguous ranges ``[g*B/G, (g+1)*B/G)``, hands every range
+to its context with the asynchronous ``fsdp_submit`` and collects the tickets in order.  No launcher, no socket, no RCCL:
+frames never talk to each other, so the only thing the GPUs share is the host thread that feeds them.  Results are the
+bytes of one ``plan_batch`` over the whole batch (a frame's result does not depend on the batch it travels in:
+tests/test_gpu_parity.py::test_batch_composition_invariance, tests/test_multi_gpu.py).
+
+``MultiSkidpadBatch`` shards stateful skidpad planner INSTANCES the same way (BASELINE config 5): instance i lives on
+one GPU for its whole life.
+
+The process-per-GPU mode of bench.py / dist.py (RANK / LOCAL_RANK / WORLD_SIZE, RCCL for the start-up table broadcast)
+stays what it is; this is the form a user of the Python API calls.
+
+Reference: there is none — full_pipeline/full_pipeline.py:84-207 plans one frame per call on one CPU thread.  The
+semantics mirrored here are those of ``PathPlanner.plan_batch`` (planner.py): independent frames, fresh-planner
+previous path unless ``prev_paths`` is given.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+
+
+def shard_ranges(n: int, parts: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges [g*n/G, (g+1)*n/G) — the same cut as dist.Dist.frame_range for ranks."""
+    return [(g * n // parts, (g + 1) * n // parts) for g in range(parts)]
+
+
+def visible_devices() -> List[int]:
+    return list(range(int(_capi.load().fsdp_device_count())))
+
+
+class _Staging:
+    """Page-locked input buffers of one shard: fsdp_submit reads page-locked memory from inside the slot's own kernels
+    (no blocking copy), pageable memory is staged by the runtime and blocks the host thread — which would serialise the
+    GPUs behind one another."""
+
+    def __init__(self):
+        self.off = self.cones = self.poses = self.prev = None
+
+    @staticmethod
+    def _fit(buf, shape, dtype):
+        n = int(np.prod(shape))
+        if buf is None or buf.size < n:
+            buf = _capi.pinned_empty(max(n, 1) * 5 // 4 + 16, dtype)
+        return buf, buf[:n].reshape(shape)
+
+    def load(self, off, cones, poses, prev):
+        self.off, o = self._fit(self.off, off.shape, np.int32)
+        self.cones, c = self._fit(self.cones, cones.shape, np.float64)
+        self.poses, p = self._fit(self.poses, poses.shape, np.float64)
+        np.subtract(off, off[0], out=o)
+        c[...] = cones
+        p[...] = poses
+        q = None
+        if prev is not None:
+            self.prev, q = self._fit(self.prev, prev.shape, np.float64)
+            q[...] = prev
+        return o, c, p, q
+
+
+class MultiTicket:
+    __slots__ = ("parts", "out")
+
+    def __init__(self, parts, out):
+        self.parts, self.out = parts, out
+
+
+class MultiPlanner:
+    """plan_batch over every visible GPU (or the given ``devices``; a device may appear more than once — two contexts
+    on one GPU is how the 1-GPU test box exercises this class)."""
+
+    def __init__(self, devices: Sequence[int] | None = None, params: dict | None = None, mission: int = 4, overlap: int = 2):
+        devices = visible_devices() if devices is None else [int(d) for d in devices]
+        if not devices:
+            raise _capi.FsdpError("MultiPlanner: no GPU visible (this package has no CPU fallback)")
+        self.devices = devices
+        self.ctx = [_capi.Context(device=d, mission=mission, params=params) for d in devices]
+        # staging sets per context: a batch's inputs must stay untouched until its ticket is collected, and `overlap`
+        # batches per context may be in flight
+        self._overlap = 0
+        self.set_overlap(overlap)
+
+    def set_overlap(self, depth: int):
+        """Batches in flight per context (fsdp_set_overlap): a stream of batches keeps `depth` of them on every GPU."""
+        depth = max(1, int(depth))
+        for c in self.ctx:
+            c.set_overlap(depth)
+        self._overlap = depth
+        self._stage = [[_Staging() for _ in range(2 * depth)] for _ in self.ctx]
+        self._turn = [0] * len(self.ctx)
+
+    @property
+    def horizon(self) -> int:
+        return self.ctx[0].horizon
+
+    def set_global_path(self, xy):
+        for c in self.ctx:
+            c.set_global_path(xy)
+
+    def close(self):
+        for c in self.ctx:
+            c.close()
+
+    # ---- one batch --------------------------------------------------------------------------------------------------
+    def submit(self, offsets, cones, poses, prev_paths=None, out: np.ndarray | None = None) -> MultiTicket:
+        """Cut the batch, enqueue every shard on its GPU, return at once.  ``out``: page-locked RESULT_DTYPE array of the
+        whole batch (``pinned_empty``); every GPU writes its range of it."""
+        offsets, cones, poses, n = _capi.Context._prep(offsets, cones, poses)
+        prev = None if prev_paths is None else self.ctx[0].pad_paths(prev_paths)
+        if prev is not None and len(prev) != n:
+            raise ValueError("prev_paths: one (horizon, 4) path per frame")
+        if out is None:
+            out = _capi.pinned_empty(n, _capi.RESULT_DTYPE)
+        assert out.dtype == _capi.RESULT_DTYPE and len(out) == n and out.flags.c_contiguous
+        parts = []
+        for g, (lo, hi) in enumerate(shard_ranges(n, len(self.ctx))):
+            if hi == lo:
+                continue
+            st = self._stage[g][self._turn[g] % len(self._stage[g])]
+            self._turn[g] += 1
+            o, c, p, q = st.load(offsets[lo : hi + 1], cones[offsets[lo] : offsets[hi]], poses[lo:hi], None if prev is None else prev[lo:hi])
+            parts.append((g, self.ctx[g].submit(o, c, p, q, out=out[lo:hi])))
+        return MultiTicket(parts, out)
+
+    def collect(self, ticket: MultiTicket) -> np.ndarray:
+        for g, t in ticket.parts:
+            self.ctx[g].collect(t)
+        return ticket.out
+
+    def plan_batch(self, offsets, cones, poses, prev_paths=None) -> np.ndarray:
+        """The bytes of ``Context.plan_batch`` / ``plan_batch_sequential`` over the whole batch, planned on all GPUs."""
+        return np.array(self.collect(self.submit(offsets, cones, poses, prev_paths)))
+
+    # ---- a stream of batches ----------------------------------------------------------------------------------------
+    def plan_stream(self, batches, depth: int | None = None):
+        """Yield the results of an iterable of batches ``(offsets, cones, poses)`` in order, `depth` batches in flight on
+        every GPU (default: the overlap depth)."""
+        depth = self._overlap if depth is None else max(1, min(int(depth), self._overlap))
+        inflight = []
+        for b in batches:
+            if len(inflight) == depth:
+                yield np.array(self.collect(inflight.pop(0)))
+            inflight.append(self.submit(*b))
+        for t in inflight:
+            yield np.array(self.collect(t))
+
+
+class MultiSkidpadBatch:
+    """n stateful skidpad planners (BASELINE config 5) sharded over GPUs by instance: planner i lives in context
+    ``g`` with ``lo_g <= i < hi_g``.  Same methods as ``SkidpadBatch``; results are those of one ``SkidpadBatch`` holding
+    all n planners."""
+
+    def __init__(self, n_instances: int, devices: Sequence[int] | None = None, table: np.ndarray | None = None, params: dict | None = None):
+        from .skidpad import INFO_DTYPE, SkidpadBatch
+
+        devices = visible_devices() if devices is None else [int(d) for d in devices]
+        self.n = int(n_instances)
+        self.devices = devices
+        self._info_dtype = INFO_DTYPE
+        self.ranges = [(lo, hi) for lo, hi in shard_ranges(self.n, len(devices)) if hi > lo]
+        self.parts = [SkidpadBatch(hi - lo, device=d, table=table, params=params) for (lo, hi), d in zip(self.ranges, devices)]
+        self.tables = self.parts[0].tables
+        self._depth = 1
+        self._stage, self._turn = None, 0
+
+    @property
+    def constants(self):
+        return self.parts[0].constants
+
+    def reset(self):
+        for p in self.parts:
+            p.reset()
+
+    def set_overlap(self, depth: int):
+        self._depth = max(1, int(depth))
+        for p in self.parts:
+            p.set_overlap(depth)
+        self._stage = [[_Staging() for _ in range(self._depth + 1)] for _ in self.parts]
+        self._turn = 0
+
+    def submit(self, cone_offsets, cones_xyt, poses, out=None, info=None):
+        off, cones, poses, n = _capi.Context._prep(cone_offsets, cones_xyt, poses)
+        assert n == self.n
+        if out is None:
+            out = _capi.pinned_empty(n, _capi.RESULT_DTYPE)
+        if info is None:
+            info = np.zeros(n, dtype=self._info_dtype)
+        if self._stage is None:
+            self.set_overlap(self._depth)
+        k = self._turn % len(self._stage[0])
+        self._turn += 1
+        tickets = []
+        for g, ((lo, hi), part) in enumerate(zip(self.ranges, self.parts)):
+            o, c, p, _ = self._stage[g][k].load(off[lo : hi + 1], cones[off[lo] : off[hi]], poses[lo:hi], None)
+            tickets.append(part.submit(o, c, p, out=out[lo:hi], info=info[lo:hi]))
+        return MultiTicket(tickets, (out, info))
+
+    def collect(self, ticket: MultiTicket):
+        for part, t in zip(self.parts, ticket.parts):
+            part.collect(t)
+        return ticket.out
+
+    def step(self, cone_offsets, cones_xyt, poses):
+        out, info = self.collect(self.submit(cone_offsets, cones_xyt, poses))
+        return np.array(out), info
+
+    def replay(self, frames, depth: int = 32):
+        """SkidpadBatch.replay over all GPUs: `depth` steps submitted ahead on every context."""
+        self.set_overlap(depth)
+        inflight = []
+        for f in frames:
+            if len(inflight) == depth:
+                res, info = self.collect(inflight.pop(0))
+                yield np.array(res), info
+            inflight.append(self.submit(*f))
+        for t in inflight:
+            res, info = self.collect(t)
+            yield np.array(res), info

@@ -122,7 +122,11 @@ class PathPlanner:
     """
 
     def __init__(self, mission: MissionTypes, experimental_performance_improvements: bool = False, device: int | None = None,
-                 stateful: bool = True, relocalization_seed: int | None = 0, params: dict | None = None):
+                 stateful: bool = True, relocalization_seed: int | None = 0, params: dict | None = None,
+                 devices: Sequence[int] | str | None = None):
+        """devices: GPUs ``plan_batch`` shards its frames over from this one process (multi.MultiPlanner): a list of
+        device indices, or "all" for every visible GPU; None (default) = the single GPU ``device``.  The single-frame
+        call always runs on the first of them."""
         if experimental_performance_improvements:
             # reference README.md:24-27: off by default, changes results, meaningless for independent frames
             raise NotImplementedError("the experimental sorting cache is out of scope (SURVEY.md §2 row 15)")
@@ -139,7 +143,13 @@ class PathPlanner:
         self._prev = None
         self._skid = None
         self._skid_info = None
-        if self.mission == MissionTypes.skidpad:
+        self._multi = None
+        if devices is not None and self.mission != MissionTypes.skidpad:
+            from .multi import MultiPlanner
+
+            self._multi = MultiPlanner(None if devices == "all" else devices, params=params, mission=int(self.mission))
+            self._ctx = self._multi.ctx[0]
+        elif self.mission == MissionTypes.skidpad:
             from .skidpad import SkidpadBatch
 
             self._skid = SkidpadBatch(1, device=device, params=params)  # stateful, like the reference's skidpad planner
@@ -171,7 +181,7 @@ class PathPlanner:
         if self._skid is not None:
             raise RuntimeError("the skidpad mission plans along its own known path")
         self.global_path = None if global_path is None else np.ascontiguousarray(global_path, dtype=np.float64).reshape(-1, 2)
-        self._ctx.set_global_path(self.global_path)
+        (self._multi or self._ctx).set_global_path(self.global_path)
 
     def _accelerate(self, cones, xyt, pose, return_intermediate_results):
         """acceleration / ebs_test (full_pipeline.py:118-140,178-194): relocalize once on the host, then plan along the
@@ -211,6 +221,8 @@ class PathPlanner:
         """Structured array (one row per frame, dtype _capi.RESULT_DTYPE)."""
         if self._skid is not None:
             raise RuntimeError("the skidpad mission is stateful: use skidpad.SkidpadBatch.step for batches of planner instances")
+        if self._multi is not None:  # contiguous frame ranges, one per GPU, from this thread (multi.py)
+            return self._multi.plan_batch(cone_offsets, cones_xyt, poses)
         return self._ctx.plan_batch(cone_offsets, cones_xyt, poses)
 
     # ---- reference-shaped single-frame call ---------------------------------------------

@@ -42,9 +42,20 @@ class RelocalizationInformation:
 
 
 class SkidpadBatch:
-    """n independent skidpad planners advanced in lock-step (one frame of every instance per step)."""
+    """n independent skidpad planners advanced in lock-step (one frame of every instance per step).
+    ``devices`` (a list of GPU indices or "all"): the instances are sharded over those GPUs from this one process and the
+    object is a ``multi.MultiSkidpadBatch`` with the same methods."""
 
-    def __init__(self, n_instances: int = 1, device: int | None = None, table: np.ndarray | None = None, params: dict | None = None):
+    def __new__(cls, n_instances: int = 1, device: int | None = None, table: np.ndarray | None = None, params: dict | None = None,
+                devices=None):
+        if devices is not None:
+            from .multi import MultiSkidpadBatch
+
+            return MultiSkidpadBatch(n_instances, None if devices == "all" else devices, table=table, params=params)
+        return super().__new__(cls)
+
+    def __init__(self, n_instances: int = 1, device: int | None = None, table: np.ndarray | None = None, params: dict | None = None,
+                 devices=None):
         self._ctx = _capi.Context(device=device, mission=2, params=params)
         self.n = int(n_instances)
         table, noise = load_tables(table)

@@ -9,9 +9,22 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+import os
+if os.environ.get("AB_LIB"):  # an experiment build (tools/build_variant.sh)
+    pkg._capi.LIB_PATH = Path(os.environ["AB_LIB"])
 ctx = pkg.Context(device=0)
 sizes = [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 1536, 2048, 2560, 3072, 4096, 5120, 6144, 8192, 16384]
 off, cones, poses = pkg.synth.make_replay_batch(max(sizes), 64, 0.15, seed=1, color=True)
+if os.environ.get("AB_REPEAT"):  # a batch whose frames repeat with this period (experiments with aliased scratch arenas)
+    import numpy as np
+    per = int(os.environ["AB_REPEAT"])
+    n = max(sizes)
+    counts = np.diff(off)[:per]
+    reps = -(-n // per)
+    cones = np.tile(cones[: off[per]], (reps, 1))
+    poses = np.tile(poses[:per], (reps, 1))[:n]
+    off = np.concatenate([[0], np.cumsum(np.tile(counts, reps))]).astype(np.int32)[: n + 1]
+    cones = cones[: off[n]]
 for n in sizes:
     ctx.upload(off[: n + 1], cones[: off[n]], poses[:n])
     ctx.time_runs(2)
