@@ -21,9 +21,56 @@ PATH_TOL = 1e-5
 ARC_FLAG = 16
 
 
-def compare_frame(res, g, k, require_exact_match=True):
+class ArcLibm:
+    """tests/golden/arc_libm_level.npz (arc_libm_golden.py): the reference's paths on the arc-extension frames of a golden set
+    with NumPy's SIMD sin / cos / arctan2 kernels disabled (libm level), and the frames on which that run differs from the
+    AVX-512 run the goldens were captured with — i.e. on which the REFERENCE is not reproducible across machines."""
+
+    def __init__(self, golden_dir, name):
+        f = np.load(golden_dir / "arc_libm_level.npz")
+        self.name = name
+        self.frames = f[f"{name}__frames"].tolist() if f"{name}__frames" in f else []
+        self._path = f[f"{name}__path"] if self.frames else None
+        self._differs = f[f"{name}__differs"] if self.frames else None
+        # expected differences (> 1e-5) of a result computed with `math` = "libm" (the oracle's default mode: host libm) or "det"
+        # (det_math.h: kernels, emulator, oracle in det mode) from the two captures
+        self._exp = {(m, lvl): (f[f"{name}__{m}_vs_{lvl}"] if self.frames else None) for m in ("libm", "det") for lvl in ("libm_level", "avx512")}
+        self._idx = {fr: i for i, fr in enumerate(self.frames)}
+
+    def __contains__(self, k):
+        return int(k) in self._idx
+
+    def path(self, k):
+        return self._path[self._idx[int(k)]]
+
+    def differs(self, k):
+        return bool(self._differs[self._idx[int(k)]])
+
+    def expected(self, k, math, level):
+        return bool(self._exp[(math, level)][self._idx[int(k)]])
+
+    def flips(self, math):
+        """Frames on which a result computed with this math differs from the AVX-512 golden (the committed <set>.npz)."""
+        return sorted(fr for fr in self.frames if self.expected(fr, math, "avx512"))
+
+    @property
+    def reference_differs_from_itself(self):
+        return sorted(fr for fr in self.frames if self.differs(fr))
+
+
+def _linf(p, q):
+    e = np.abs(p - q)
+    return 0.0 if np.isnan(e).all() else float(np.nanmax(e))
+
+
+def compare_frame(res, g, k, require_exact_match=True, arc=None, math="det"):
     """res: one structured result row (oracle_lib.RESULT_DTYPE-like); g: golden dict; k: frame.
-    Returns (category, detail).  category in {'ok','ref_undefined','flip','IDX','MATCH','PATH','STATUS'}"""
+    Returns (category, detail).  category in {'ok','ref_undefined','flip','IDX','MATCH','PATH','STATUS'}
+    arc (ArcLibm of the set): on arc-extension frames the result is held against BOTH captures of the reference (libm level and
+    AVX-512) and must differ from each (by the sample-count flip) on exactly the frames recorded for its `math` ("libm": host
+    libm — none against the libm level, the reference's own self-differences against AVX-512; "det": det_math.h — additionally the
+    two frames on which the correctly rounded sin / cos / atan2 differ from glibc's last bit).  'flip' = differs from the AVX-512
+    golden as recorded; any unrecorded difference, or a recorded one that is missing, is 'PATH'."""
     ref_ok = bool(g["ok"][k])
     st = int(res["status"])
     if not ref_ok:
@@ -63,6 +110,16 @@ def compare_frame(res, g, k, require_exact_match=True):
     if not np.array_equal(np.isnan(p), np.isnan(q)):
         return "PATH", "nan pattern differs"
     e = np.nanmax(np.abs(p - q)) if not np.isnan(q).all() else 0.0
+    is_arc = bool(int(res["path_fallback"]) & ARC_FLAG)
+    if arc is not None and (is_arc or k in arc):
+        if not (is_arc and k in arc):
+            return "PATH", f"arc-extension frame according to {'the result' if is_arc else 'the fixture'} only"
+        for level, ref_path, err in (("libm_level", arc.path(k), _linf(p, arc.path(k))), ("avx512", q, e)):
+            if arc.expected(k, math, level) != (err > PATH_TOL):
+                return "PATH", f"arc frame: L-inf {err} against the reference at the {level} level, recorded for {math} math: {'differs' if arc.expected(k, math, level) else 'equal'}"
+            if err > PATH_TOL and not is_sample_count_flip(p, ref_path):
+                return "PATH", f"arc frame: L-inf {err} against the {level} capture is not the sample-count flip"
+        return ("flip", e) if e > PATH_TOL else ("ok", e)
     if e <= PATH_TOL:
         return "ok", e
     if int(res["path_fallback"]) & ARC_FLAG and is_sample_count_flip(p, q):

@@ -50,14 +50,17 @@ def test_hip_matches_reference_golden(ctx, golden_dir, name):
     res = _as_oracle_rows(ctx.plan_batch(g["offsets"], g["cones"], g["poses"]))
     cats = collections.Counter()
     bad, n_arc = [], 0
+    arc = parity.ArcLibm(golden_dir, name)
     for k in range(len(res)):
-        cat, detail = parity.compare_frame(res[k], g, k)
+        cat, detail = parity.compare_frame(res[k], g, k, arc=arc)
         cats[cat] += 1
         n_arc += bool(int(res[k]["path_fallback"]) & parity.ARC_FLAG)
         if cat in ("IDX", "MATCH", "PATH", "STATUS"):
             bad.append((k, cat, detail))
     assert not bad, bad[:5]
-    assert cats["flip"] <= max(1, int(0.10 * n_arc)), (cats, n_arc)
+    # arc frames: within 1e-5 of the reference at the libm level (compare_frame); a difference from the AVX-512 golden exactly
+    # on the frames on which the reference differs from itself (fuzz: 339 and 347), nowhere else
+    assert n_arc == len(arc.frames) and cats["flip"] == len(arc.flips("det")), (cats, n_arc, arc.flips("det"))
 
 
 @pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones", "odd_inputs"])
@@ -483,11 +486,12 @@ def test_non_default_parameters(pkg, golden_dir, name):
     res = c.plan_batch(g["offsets"], g["cones"], g["poses"])
     rows = _as_oracle_rows(res)
     cats = collections.Counter()
+    arc = parity.ArcLibm(golden_dir, name)
     for k in range(len(rows)):
-        cat, detail = parity.compare_frame(rows[k], g, k)
+        cat, detail = parity.compare_frame(rows[k], g, k, arc=arc)
         cats[cat] += 1
         assert cat in ("ok", "ref_undefined", "flip"), (k, cat, detail)
-    assert cats["flip"] <= 3, cats
+    assert cats["flip"] == len(arc.flips("det")), (cats, arc.flips("det"))  # (params_sort: 98; params_no_unknown: 6 and 97)
     with oracle_lib.params(prm), oracle_lib.math_mode(1):
         ref = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=os.cpu_count() or 1)
     _assert_equal_to_oracle(res, ref)

@@ -60,9 +60,13 @@ def test_emulated_kernels_with_non_default_parameters(golden_dir, name):
         assert np.array_equal(res[f][ok], ref[f][ok]), f
     parity.assert_intermediates_equal(res, ref, ok)
     assert np.array_equal(res["path"][ok], ref["path"][ok], equal_nan=True)  # (rows beyond a shorter horizon are NaN on both sides)
+    arc = parity.ArcLibm(golden_dir, name)
+    flips = []
     for j, k in enumerate(idx):
-        cat, detail = parity.compare_frame(res[j], g, int(k))
+        cat, detail = parity.compare_frame(res[j], g, int(k), arc=arc)
         assert cat in ("ok", "ref_undefined", "flip"), (k, cat, detail)
+        flips += [int(k)] if cat == "flip" else []
+    assert flips == [f for f in arc.flips("det") if f in set(idx.tolist())], flips
 
 
 @pytest.mark.parametrize("group", [1004, 1008, 1016])

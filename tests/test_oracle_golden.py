@@ -23,15 +23,18 @@ def test_oracle_matches_reference_golden(golden_dir, name, mode):
     cats = collections.Counter()
     bad = []
     n_arc = 0
+    arc = parity.ArcLibm(golden_dir, name)
     for k in range(len(res)):
-        cat, detail = parity.compare_frame(res[k], g, k)
+        cat, detail = parity.compare_frame(res[k], g, k, arc=arc, math="det" if mode else "libm")
         cats[cat] += 1
         n_arc += bool(int(res[k]["path_fallback"]) & parity.ARC_FLAG)
         if cat in ("IDX", "MATCH", "PATH", "STATUS"):
             bad.append((k, cat, detail))
     assert not bad, bad[:5]
     # sample-count flips only on arc-extension frames, and only a small share of those
-    assert cats["flip"] <= max(1, int(0.10 * n_arc)), (cats, n_arc)
+    # arc frames: within 1e-5 of the reference at the libm level (compare_frame); a difference from the AVX-512 golden exactly
+    # on the frames on which the reference differs from itself (fuzz: 339 and 347), nowhere else
+    assert n_arc == len(arc.frames) and cats["flip"] == len(arc.flips("det" if mode else "libm")), (cats, n_arc, arc.flips("det" if mode else "libm"))
 
 
 def test_default_previous_path(golden_dir):
@@ -61,13 +64,14 @@ def test_oracle_with_non_default_parameters(golden_dir, name):
         res = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=4)
     cats = collections.Counter()
     bad = []
+    arc = parity.ArcLibm(golden_dir, name)
     for k in range(len(res)):
-        cat, detail = parity.compare_frame(res[k], g, k)
+        cat, detail = parity.compare_frame(res[k], g, k, arc=arc, math="libm")
         cats[cat] += 1
         if cat in ("IDX", "MATCH", "PATH", "STATUS"):
             bad.append((k, cat, detail))
     assert not bad, bad[:5]
-    assert cats["flip"] <= 3, cats
+    assert cats["flip"] == len(arc.flips("libm")), (cats, arc.flips("libm"))  # (params_no_unknown: frame 97, where the reference differs from itself)
     # and the defaults are back afterwards
     d = np.load(golden_dir / "cfg2_color.npz")
     r = oracle_lib.plan_batch(d["offsets"][:3], d["cones"][: d["offsets"][2]], d["poses"][:2])
