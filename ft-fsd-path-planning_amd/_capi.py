@@ -147,9 +147,9 @@ EXPORTED_SYMBOLS = [
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
-    "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path",
+    "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path", "fsdp_skidpad_time_groups", "fsdp_skidpad_group_times",
     "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
-    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena", "fsdp_selftest_absminmax",
+    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena", "fsdp_selftest_absminmax", "fsdp_selftest_libm",
 ]
 
 
@@ -433,6 +433,13 @@ class Context:
         a, b = (np.ascontiguousarray(v, np.float64) for v in (a, b))
         out = np.zeros((2, len(a)))
         self._check(self._lib.fsdp_selftest_absminmax(self._h, len(a), _dp(a), _dp(b), _dp(out)), "fsdp_selftest_absminmax")
+        return out
+
+    def selftest_libm(self, y, x, cs) -> np.ndarray:
+        """(3, n): the device library's atan2(y, x), det_atan2(y, x) (correctly rounded), the device library's acos(cs)."""
+        y, x, cs = (np.ascontiguousarray(v, np.float64) for v in (y, x, cs))
+        out = np.zeros((3, len(y)))
+        self._check(self._lib.fsdp_selftest_libm(self._h, len(y), _dp(y), _dp(x), _dp(cs), _dp(out)), "fsdp_selftest_libm")
         return out
 
     def selftest_det3(self, xy6) -> np.ndarray:

@@ -107,6 +107,10 @@ __device__ __forceinline__ double blas_dot2(double a0, double b0, double a1, dou
   // np.dot / BLAS inner product of length 2 as OpenBLAS evaluates it: acc = a0*b0; acc = fma(a1,b1,acc)
   return fma(a1, b1, a0 * b0);
 }
+// np.dot of ONE point (a 1-D vector) with a 2 x 2 matrix goes to gemv, whose OpenBLAS kernel forms the products in the other
+// order; from two rows on it is gemm, i.e. blas_dot2 (oracle/np_compat.h blas_dot2_single_row; pinned against NumPy by
+// tests/test_oracle_numpy_semantics.py).  The skidpad mission rotates the car's position as a single point.
+__device__ __forceinline__ double blas_dot2_single_row(double a0, double b0, double a1, double b1) { return fma(a0, b0, a1 * b1); }
 __device__ __forceinline__ double norm_blas(double x, double y) { return sqrt(blas_dot2(x, x, y, y)); }
 __device__ __forceinline__ double norm_axis(double x, double y) { return sqrt(x * x + y * y); }
 

@@ -192,6 +192,11 @@ struct fsdp_ctx {
   int skid_step_no = 0;              // steps submitted since fsdp_skidpad_reset
   bool skid_all_reloc = false;       // a collected step reported every planner relocalized: cones have no reader any more
   int skid_group_env = 0;            // FSDP_SKID_GROUP: steps per launch when the caller submits ahead (0: chosen from the instance count)
+  // fsdp_skidpad_time_groups: HIP events around the packed kernels of every group of steps (select | prep | fit | finish | commit)
+  bool skid_time_groups = false;
+  std::vector<hipEvent_t> skid_group_ev;  // six per group
+  std::vector<int> skid_group_frames;     // (instance, step) pairs per group
+  std::string skid_group_names;
   int skid_pack_min = 2048;          // (instance, step) pairs from which a group goes through the packed kernels (one step of
                                      // 2048 planners: 1.49 M frames/s packed, 1.40 M a wavefront each; 1024: 0.98 / 1.08 M)
   // workspace of a group that goes through the packed kernels, frame = step * n_instances + instance
@@ -442,15 +447,29 @@ static void launch_finish(fsdp_ctx* c, Work& q, int n) {
 }
 
 // the same steps through the packed kernels (csrc/skidpad_kernel.h "steps in flight, many frames per wavefront")
+static void skid_group_mark(fsdp_ctx* c) {  // (timing of the groups' kernels on request: fsdp_skidpad_time_groups)
+  if (!c->skid_time_groups) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, c->stream);
+  c->skid_group_ev.push_back(e);
+}
 template <int G, int GF>
 static void launch_skid_packed_kernels(fsdp_ctx* c, int frames) {
   hipStream_t xs = c->stream;
+  if (c->skid_time_groups && c->skid_group_names.empty())  // (the first group's instantiations: a replay's last, shorter group may take the 16-lane ones)
+    c->skid_group_names = "skid_select_kernel,skid_prep_kernel<" + std::to_string(G) + ">,fit_kernel<" + std::to_string(GF) + ">,path_finish_kernel<" +
+                          std::to_string(G) + ">,skid_commit_kernel";
+  skid_group_mark(c);
   hipLaunchKernelGGL(skid_prep_kernel<G>, dim3((frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, xs, frames, c->d_g_sel, c->tables, c->d_chord,
                      c->d_default_path, c->d_g_arena, c->d_g_mid);
+  skid_group_mark(c);
   hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid,
                      c->d_g_retry, c->d_params);
+  skid_group_mark(c);
   hipLaunchKernelGGL(path_finish_kernel<G>, dim3((frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid, c->d_g_out,
                      c->d_g_retry, c->d_params);
+  skid_group_mark(c);
 }
 
 // Lanes per frame: a serial instruction costs its issue cycles whatever the number of active lanes, so the more frames
@@ -917,6 +936,7 @@ void fsdp_destroy(fsdp_ctx* c) {
   (void)hipFree(c->d_table);
   (void)hipFree(c->d_noise);
   (void)hipFree(c->d_skid);
+  for (hipEvent_t e : c->skid_group_ev) (void)hipEventDestroy(e);
   (void)hipFree(c->d_skid_backup);
   (void)hipFree(c->d_skid_sync);
   (void)hipFree(c->d_g_arena);
@@ -1874,6 +1894,7 @@ static int launch_skid_packed(fsdp_ctx* c, const int* slots, int n_steps, int st
   const SkidGroup g = skid_group_of(c, slots, n_steps, step0);
   hipStream_t xs = c->stream;
   HIP_TRY(c, hipMemsetAsync(c->d_g_retry, 0, sizeof(int), xs));  // (the packed kernels' list of frames they hand on; the commit kernel goes by the frames' records)
+  skid_group_mark(c);
   hipLaunchKernelGGL(skid_select_kernel, dim3((unsigned)n), dim3(WAVE), 0, xs, n, g, c->d_skid, c->tables, c->d_g_sel);
   if (frames >= PACK_FRAMES) {
     if (c->fit_g == 4)
@@ -1885,6 +1906,8 @@ static int launch_skid_packed(fsdp_ctx* c, const int* slots, int n_steps, int st
   }
   hipLaunchKernelGGL(skid_commit_kernel, dim3((unsigned)n), dim3(WAVE), 0, xs, n, g, c->d_skid, c->tables, c->d_chord, c->d_g_sel, c->d_g_mid, c->d_g_out,
                      c->d_g_arena, c->d_skid_sync);
+  skid_group_mark(c);
+  if (c->skid_time_groups) c->skid_group_frames.push_back(frames);
   return 0;
 }
 
@@ -2010,6 +2033,41 @@ int fsdp_skidpad_step(fsdp_ctx* c, int n_instances, const int32_t* off, const do
   long long t;
   if (int rc = fsdp_skidpad_submit(c, n_instances, off, cones, poses, results, info, &t)) return rc;
   return fsdp_collect(c, t);
+}
+
+// Timing of the packed path-stage kernels of the groups of steps a replay forms (fsdp_skidpad_submit): enable, replay, read.
+int fsdp_skidpad_time_groups(fsdp_ctx* c, int enable) {
+  if (!c) return 1;
+  for (hipEvent_t e : c->skid_group_ev) (void)hipEventDestroy(e);
+  c->skid_group_ev.clear();
+  c->skid_group_frames.clear();
+  c->skid_group_names.clear();
+  c->skid_time_groups = enable != 0;
+  return 0;
+}
+int fsdp_skidpad_group_times(fsdp_ctx* c, float* ms5, int* n_groups, long long* n_frames, char* names, int names_cap) {
+  if (!c || !ms5 || !n_groups || !n_frames) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 5; k++) ms5[k] = 0.f;
+  const size_t groups = c->skid_group_frames.size();
+  if (c->skid_group_ev.size() != 6 * groups) {
+    c->err = "fsdp_skidpad_group_times: incomplete event set";
+    return 1;
+  }
+  long long frames = 0;
+  for (size_t gidx = 0; gidx < groups; gidx++) {
+    for (int k = 0; k < 5; k++) {
+      float t = 0.f;
+      HIP_TRY(c, hipEventElapsedTime(&t, c->skid_group_ev[6 * gidx + k], c->skid_group_ev[6 * gidx + k + 1]));
+      ms5[k] += t;
+    }
+    frames += c->skid_group_frames[gidx];
+  }
+  *n_groups = (int)groups;
+  *n_frames = frames;
+  if (names && names_cap > 0) snprintf(names, (size_t)names_cap, "%s", c->skid_group_names.c_str());
+  return 0;
 }
 
 int fsdp_skidpad_time_path(fsdp_ctx* c, int iters, float* ms_total) {
@@ -2162,6 +2220,37 @@ extern "C" int fsdp_selftest_det3(fsdp_ctx* c, int n, const double* xy6, double*
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(dx);
+  (void)hipFree(dout);
+  HIP_TRY(c, e);
+  return 0;
+}
+
+// The device libm values the sorting stage's discrete decisions hang on (atan2 of the search predicates, start-cone bearings and
+// cost terms; acos where a cosine sits within 1e-9 of a threshold) next to the correctly rounded det_atan2 (det_math.h)
+__global__ void libm_selftest_kernel(int n, const double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ cs,
+                                     double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = atan2(y[i], x[i]);
+  out[(size_t)n + i] = detm::det_atan2(y[i], x[i]);
+  out[2 * (size_t)n + i] = acos(cs[i]);
+}
+extern "C" int fsdp_selftest_libm(fsdp_ctx* c, int n, const double* y, const double* x, const double* cs, double* out3n) {
+  if (!c || n <= 0 || !y || !x || !cs || !out3n) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *din = nullptr, *dout = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  HIP_TRY(c, hipMalloc(&din, 3 * bytes));
+  HIP_TRY(c, hipMalloc(&dout, 3 * bytes));
+  hipError_t e = hipMemcpyAsync(din, y, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(din + n, x, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(din + 2 * (size_t)n, cs, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(libm_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, din, din + n, din + 2 * (size_t)n, dout);
+    e = hipMemcpyAsync(out3n, dout, 3 * bytes, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(din);
   (void)hipFree(dout);
   HIP_TRY(c, e);
   return 0;

@@ -466,7 +466,7 @@ __device__ __forceinline__ void skid_map_pose(const SkidState* st, const SkidTab
   double sn, cs;
   detm::det_sincos(rotation, sn, cs);
   double qx = px + st->translation[0] - T.ref_right[0], qy = py + st->translation[1] - T.ref_right[1];
-  double rx = blas_dot2(qx, cs, qy, -sn), ry = blas_dot2(qx, sn, qy, cs);
+  double rx = blas_dot2_single_row(qx, cs, qy, -sn), ry = blas_dot2_single_row(qx, sn, qy, cs);  // (one point: gemv order)
   px = rx + T.ref_right[0];
   py = ry + T.ref_right[1];
   yaw = yaw + rotation;
@@ -618,8 +618,8 @@ __device__ __forceinline__ void skid_finish_step(SkidState* st, const SkidTables
       detm::det_sincos(st->rotation, sn, cs);
       double ax0 = 0.0 + tx - T.ref_right[0], ay0 = 0.0 + ty - T.ref_right[1];
       double ax1 = 1.0 + tx - T.ref_right[0];
-      double o0x = blas_dot2(ax0, cs, ay0, -sn) + T.ref_right[0], o0y = blas_dot2(ax0, sn, ay0, cs) + T.ref_right[1];
-      double o1x = blas_dot2(ax1, cs, ay0, -sn) + T.ref_right[0], o1y = blas_dot2(ax1, sn, ay0, cs) + T.ref_right[1];
+      double o0x = blas_dot2_single_row(ax0, cs, ay0, -sn) + T.ref_right[0], o0y = blas_dot2_single_row(ax0, sn, ay0, cs) + T.ref_right[1];
+      double o1x = blas_dot2_single_row(ax1, cs, ay0, -sn) + T.ref_right[0], o1y = blas_dot2_single_row(ax1, sn, ay0, cs) + T.ref_right[1];
       fi->translation[0] = o0x;
       fi->translation[1] = o0y;
       fi->rotation = atan2(o1y - o0y, o1x - o0x);

@@ -129,6 +129,18 @@ class SkidpadBatch:
     def set_overlap(self, depth: int):
         self._ctx.set_overlap(depth)
 
+    def time_groups(self, enable: bool = True):
+        """HIP events around the packed kernels of every group of steps of the replays that follow (fsdp_skidpad_time_groups)."""
+        self._ctx._check(self._ctx._lib.fsdp_skidpad_time_groups(self._ctx._h, ctypes.c_int(1 if enable else 0)), "fsdp_skidpad_time_groups")
+
+    def group_times(self):
+        """({kernel name: summed ms}, groups, (instance, step) pairs) since time_groups(True)."""
+        ms = (ctypes.c_float * 5)()
+        ng, nf = ctypes.c_int(), ctypes.c_longlong()
+        names = ctypes.create_string_buffer(256)
+        self._ctx._check(self._ctx._lib.fsdp_skidpad_group_times(self._ctx._h, ms, ctypes.byref(ng), ctypes.byref(nf), names, 256), "fsdp_skidpad_group_times")
+        return dict(zip(names.value.decode().split(","), [float(x) for x in ms])), int(ng.value), int(nf.value)
+
     def time_path(self, iters: int) -> float:
         t = ctypes.c_float()
         self._ctx._check(self._ctx._lib.fsdp_skidpad_time_path(self._ctx._h, ctypes.c_int(iters), ctypes.byref(t)), "fsdp_skidpad_time_path")

@@ -308,6 +308,12 @@ int fsdp_skidpad_submit(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offs
 /* time `iters` repetitions of the one-wavefront-per-planner path kernel on the last step's inputs with HIP events (the
  * states are restored afterwards) */
 int fsdp_skidpad_time_path(fsdp_ctx* ctx, int iters, float* ms_total);
+/* Measurement of a replay submitted ahead: with enable != 0 every group of steps that goes through the packed path-stage
+ * kernels is bracketed by HIP events on the context's stream (six per group); fsdp_skidpad_group_times waits for the stream
+ * and returns the summed durations ms5 = [select | prep | fit | finish | commit], the number of groups, the (instance, step)
+ * pairs they held and the kernels' names (comma separated).  enable = 0 / a new enable drops the events. */
+int fsdp_skidpad_time_groups(fsdp_ctx* ctx, int enable);
+int fsdp_skidpad_group_times(fsdp_ctx* ctx, float* ms5, int* n_groups, long long* n_frames, char* names, int names_cap);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------------------------------------------
  * The reference is single-process Python with no distributed layer ("distributed communication backend: none");
@@ -349,6 +355,13 @@ int fsdp_selftest_absminmax(fsdp_ctx* ctx, int n, const double* a, const double*
 /* The device's restatement of numpy.linalg.det for three homogeneous points (calculate_path/path_parameterization.py:86-92
  * takes the curvature's sign from it): xy6 = (n,6) rows x0,y0,x1,y1,x2,y2 -> out (n) determinants whose SIGN is NumPy's. */
 int fsdp_selftest_det3(fsdp_ctx* ctx, int n, const double* xy6, double* out);
+
+/* The device's libm where discrete decisions of the sorting stage take its values (the reference compares angles from
+ * np.arctan2 / np.arccos: sorting_cones/trace_sorter/end_configurations.py:108-223, cost_function.py:40-120,
+ * core_trace_sorter.py:344-377): out3n = [atan2(y, x) of the ROCm device library | det_atan2(y, x), the correctly rounded
+ * value (csrc/det_math.h) | acos(cs)].  A test holds the first to within 1 ulp of the second on 10^6 arguments and the third to
+ * within 2 ulp of the host's, so that a ROCm release that moves them cannot move a sorted index silently. */
+int fsdp_selftest_libm(fsdp_ctx* ctx, int n, const double* y, const double* x, const double* cs, double* out3n);
 
 /* The constant initial previous path (core_calculate_path.py:103-107), (40,4), as computed on the device. */
 int fsdp_default_path(fsdp_ctx* ctx, double* out40x4);

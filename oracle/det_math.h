@@ -163,8 +163,12 @@ DETM_FN double det_cos(double x) {
 // atan2 for finite arguments (not both zero): crude polynomial start, two Newton steps on
 // f(a) = x sin a - y cos a in double-double (a <- a - f(a) / (x cos a + y sin a)).
 DETM_FN double det_atan2(double y, double x) {
-  if (x == 0.0 && y == 0.0) return 0.0;
   const double PI_HI = 0x1.921fb54442d18p+1;
+  if (y == 0.0) {
+    // C99 / IEEE 754 (what np.arctan2 returns): atan2(+-0, x) = +-0 for x > 0 or x = +0, +-pi for x < 0 or x = -0
+    const bool x_neg = x < 0.0 || (x == 0.0 && copysign(1.0, x) < 0.0);
+    return x_neg ? copysign(PI_HI, y) : y;
+  }
   double ax = fabs(x), ay = fabs(y);
   double mn = ax < ay ? ax : ay, mx = ax < ay ? ay : ax;
   double t = mn / mx;

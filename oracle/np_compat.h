@@ -91,6 +91,12 @@ inline double np_sign(double v) { return (v > 0) ? 1.0 : ((v < 0) ? -1.0 : (v ==
 // tests/test_oracle_numpy_semantics.py).  fma() is exact by IEEE-754, so the restatement is
 // portable; on a BLAS without FMA the reference itself would differ in the last bit.
 inline double blas_dot2(double a0, double b0, double a1, double b1) { return std::fma(a1, b1, a0 * b0); }
+// np.dot of ONE point with a 2 x 2 matrix (a 1-D vector, or a (1, 2) array): NumPy hands that to gemv, whose OpenBLAS kernel
+// forms the products in the other order — fma(a0, b0, a1 * b1); from two rows on it is gemm: blas_dot2.  Measured on the
+// build container's NumPy (tests/test_oracle_numpy_semantics.py::test_dot_of_a_single_point_is_gemv_order); where it matters:
+// the skidpad mission rotates the car's position as a single point (skidpad_relocalizer.py:140-153, math_utils.py:103-117)
+// — round 3 attributed the 2 / 341 sample-count flips of the skidpad replay to glibc's sin / cos; they were this.
+inline double blas_dot2_single_row(double a0, double b0, double a1, double b1) { return std::fma(a0, b0, a1 * b1); }
 
 // np.linalg.norm of a 1-D 2-vector: sqrt(x.dot(x))  (BLAS ddot)
 inline double norm2(double x, double y) { return std::sqrt(blas_dot2(x, x, y, y)); }

@@ -31,6 +31,10 @@ struct SkidpadPlanner {
 static Vec2 rot_point(double theta_cos, double theta_sin, double x, double y) {
   return Vec2{blas_dot2(x, theta_cos, y, -theta_sin), blas_dot2(x, theta_sin, y, theta_cos)};
 }
+// rotate() of a single point: np.dot(1-D, 2 x 2) is gemv (np_compat.h blas_dot2_single_row)
+static Vec2 rot_single_point(double theta_cos, double theta_sin, double x, double y) {
+  return Vec2{blas_dot2_single_row(x, theta_cos, y, -theta_sin), blas_dot2_single_row(x, theta_sin, y, theta_cos)};
+}
 
 // skidpad_relocalizer.py:198-240 do_relocalization_once; true on success
 static bool relocalize(SkidpadPlanner& P, const double* xyt, int n, Vec2 pos) {
@@ -180,7 +184,7 @@ static void skidpad_step(SkidpadPlanner& P, const double* xyt, int n, const doub
     double yaw = m_atan2(dir.y, dir.x);
     double c = m_cos(P.rotation), s = m_sin(P.rotation);
     Vec2 t{pos.x + P.translation.x - P.ref_right.x, pos.y + P.translation.y - P.ref_right.y};
-    Vec2 r = rot_point(c, s, t.x, t.y);
+    Vec2 r = rot_single_point(c, s, t.x, t.y);  // (position_2d is one point: skidpad_relocalizer.py:140-147)
     pos = Vec2{r.x + P.ref_right.x, r.y + P.ref_right.y};
     yaw = yaw + P.rotation;
     dir = Vec2{m_cos(yaw), m_sin(yaw)};
@@ -241,7 +245,7 @@ static void skidpad_step(SkidpadPlanner& P, const double* xyt, int n, const doub
       double c = m_cos(P.rotation), s = m_sin(P.rotation);
       auto tf = [&](double x, double y) {
         Vec2 t{x + P.translation.x - P.ref_right.x, y + P.translation.y - P.ref_right.y};
-        Vec2 r = rot_point(c, s, t.x, t.y);
+        Vec2 r = rot_single_point(c, s, t.x, t.y);  // (relocalization_information.py:21-27 transforms single points)
         return Vec2{r.x + P.ref_right.x, r.y + P.ref_right.y};
       };
       Vec2 o0 = tf(0.0, 0.0), o1 = tf(1.0, 0.0);
@@ -299,6 +303,16 @@ void fsdo_skidpad_step(void* h, const double* cones_xyt, int n, const double* po
 
 // SkidpadCalculatePath.index_along_path as it stands (a step that raised reports nothing, but may have moved it)
 int fsdo_skidpad_index(void* h) { return ((SkidpadPlanner*)h)->index_along_path; }
+
+// the relocalization transform as the planner holds it: translation x, y, rotation, calculated right centre x, y
+void fsdo_skidpad_transform(void* h, double* out5) {
+  SkidpadPlanner* P = (SkidpadPlanner*)h;
+  out5[0] = P->translation.x;
+  out5[1] = P->translation.y;
+  out5[2] = P->rotation;
+  out5[3] = P->right_calc.x;
+  out5[4] = P->right_calc.y;
+}
 
 void fsdo_skidpad_reference_centers(void* h, double* out4) {
   SkidpadPlanner* P = (SkidpadPlanner*)h;

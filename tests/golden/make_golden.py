@@ -795,3 +795,26 @@ def stage_centers_golden():
 
 if __name__ == "__main__" and "--stage-centers-only" in sys.argv:
     stage_centers_golden()
+
+
+def gemv_semantics_golden():
+    """np.dot of ONE point with a 2 x 2 matrix (gemv) versus rows of a 2-D array (gemm), as this NumPy / OpenBLAS build
+    evaluates them — what utils/math_utils.py:103-117 rotate() returns for a single position (the skidpad mission's pose
+    transform, skidpad_relocalizer.py:140-153) and for arrays of points.  Values only."""
+    rng = np.random.default_rng(21)
+    v = rng.uniform(-700, 700, (300, 2))
+    th = rng.uniform(-3.2, 3.2, 300)
+    from fsd_path_planning.utils.math_utils import rotate
+
+    single = np.array([rotate(v[i], th[i]) for i in range(300)])             # 1-D point
+    one_row = np.array([rotate(v[i : i + 1], th[i])[0] for i in range(300)])  # (1, 2) array
+    two_rows = np.array([rotate(v[i : i + 2], th[i])[0] for i in range(299)])  # first row of a (2, 2) array
+    many = rotate(v, 0.7)
+    np.savez_compressed(HERE / "numpy_semantics_gemv.npz", v=v, th=th, cos=np.cos(th), sin=np.sin(th), single=single, one_row=one_row,
+                        two_rows=two_rows, many=many, cos07=np.cos(0.7), sin07=np.sin(0.7))
+    print("gemv semantics: 300 single points, 300 one-row arrays, 299 two-row arrays, one 300-row array")
+
+
+if __name__ == "__main__" and "--gemv-only" in sys.argv:
+    refharness.load()
+    gemv_semantics_golden()

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Skidpad replay under rigid perturbations: the REFERENCE (imported, build container only) against the oracle in its two
+math modes, frame by frame.  Answers VERDICT r3 next-round 4b: does the correctly rounded sin / cos / atan2 of det_math.h
+(what the kernels use: the device cannot call glibc) ever flip a skidpad frame against the reference?
+
+    python tests/golden/skidpad_sweep.py [n_replays=64] [n_procs=8]   ->  table on stdout (profiles/r04_skidpad_reference_sweep.txt)
+"""
+import json
+import sys
+from multiprocessing import Pool
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent))
+sys.path.insert(0, str(HERE.parent.parent))
+
+
+def one(k):
+    import importlib
+
+    import oracle_lib
+    import refharness
+    import skidpad_support as sk
+
+    m = refharness.load()
+    g = sk.load_sequence(HERE)
+    tf = sk.perturbed_instances(g, k + 1, seed=100 + k, max_shift=2.0, max_rot_deg=180.0)[-1] if k else (np.eye(2), np.zeros(2))
+    R, tr = tf
+    pkgsk = importlib.import_module("ft-fsd-path-planning_amd.skidpad")
+    table, noise = pkgsk.load_tables()
+    pp = m["PathPlanner"](m["MissionTypes"].skidpad)
+    ops = {}
+    for mode in (0, 1):
+        with oracle_lib.math_mode(mode):
+            ops[mode] = oracle_lib.SkidpadPlanner(table, noise)
+    out = {0: [0, 0, 0, 0], 1: [0, 0, 0, 0]}  # frames compared, > 1e-5, any bit in u/x/y, any bit in curvature
+    raised = 0
+    T = len(g["poses"])
+    for t in range(T):
+        xyt, pose = sk.frame(g, t)
+        c = xyt.copy()
+        c[:, :2] = xyt[:, :2] @ R.T + tr
+        p = np.concatenate([R @ pose[:2] + tr, R @ pose[2:]])
+        try:
+            with np.errstate(all="ignore"):
+                ref = np.array(pp.calculate_path_in_global_frame([c[c[:, 2] == q, :2] for q in range(5)], p[:2], p[2:]))
+        except Exception:  # noqa: BLE001
+            ref = None
+            raised += 1
+        for mode in (0, 1):
+            with oracle_lib.math_mode(mode):
+                r, info = ops[mode].step(c, p)
+            if ref is None or int(r["status"]) != 0:
+                assert (ref is None) == (int(r["status"]) != 0), (k, t, mode)
+                continue
+            d = np.abs(r["path"] - ref)
+            o = out[mode]
+            o[0] += 1
+            o[1] += bool(d.max() > 1e-5)
+            o[2] += bool(d[:, :3].max() > 0)
+            o[3] += bool(d[:, 3].max() > 0)
+    return k, out, raised
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    procs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    with Pool(procs) as pool:
+        rows = pool.map(one, range(n))
+    tot = {0: np.zeros(4, int), 1: np.zeros(4, int)}
+    worst = []
+    for k, out, raised in rows:
+        for mode in (0, 1):
+            tot[mode] += np.array(out[mode])
+        if out[0][1] or out[1][1]:
+            worst.append((k, out[0][1], out[1][1]))
+    print(f"{n} replays of the 341-frame skidpad recording, each under its own rigid transform (rotation up to +-180 deg, shift up to 2 m; replay 0 = the recording),")
+    print("reference (this container's NumPy, default dispatch) vs the oracle, stateful planners on both sides, every frame:")
+    for mode, name in ((0, "oracle, host libm (glibc sin / cos / atan2)"), (1, "oracle, det_math.h (= the kernels)      ")):
+        a = tot[mode]
+        print(f"  {name}: {a[0]} frames compared, {a[1]} differ by > 1e-5, {a[2]} differ in a bit of u / x / y, {a[3]} in a bit of the curvature")
+    print("  replays with a frame > 1e-5 (replay, libm mode, det mode):", worst)
+    print("  frames on which the reference raised (and the oracle reported a 1xx status):", sum(r for _, _, r in rows))
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,11 @@ def test_agrees_with_glibc_almost_everywhere(lib):
     ys, x2 = rng.uniform(-60, 60, 5000), rng.uniform(-60, 60, 5000)
     assert sum(lib.t_atan2(a, b) != math.atan2(a, b) for a, b in zip(ys, x2)) < 25
     assert lib.t_atan2(0.0, 1.0) == 0.0 and lib.t_atan2(1.0, 0.0) == math.pi / 2 and lib.t_atan2(0.0, -1.0) == math.pi
+    # signed zeros as C99 / np.arctan2 have them (a direction vector (-1, -0.0) is a yaw of -pi, not +pi)
+    for y, x in [(0.0, 1.0), (-0.0, 1.0), (0.0, -1.0), (-0.0, -1.0), (0.0, 0.0), (-0.0, 0.0), (0.0, -0.0), (-0.0, -0.0), (1.0, 0.0), (-1.0, 0.0),
+                 (1.0, -0.0), (-1.0, -0.0), (-0.0, 5e-324), (-0.0, -5e-324)]:
+        a, b = lib.t_atan2(y, x), math.atan2(y, x)
+        assert a == b and math.copysign(1.0, a) == math.copysign(1.0, b), (y, x, a, b)
 
 
 def test_correctly_rounded_against_mpmath(lib):

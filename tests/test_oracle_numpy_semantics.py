@@ -93,3 +93,27 @@ def test_det3_sign_is_numpy_linalg_det_sign():
         zeros += ref == 0
     assert bad == 0, (bad, n)
     assert zeros > n // 10  # exact zeros are part of the contract (the reference then returns curvature 0)
+
+
+def test_dot_of_a_single_point_is_gemv_order(golden_dir):
+    """rotate() of the reference (utils/math_utils.py:103-117) is np.dot(points, R).  For ONE point — a 1-D vector or a (1, 2)
+    array — NumPy calls gemv and OpenBLAS forms fma(x, R0j, y * R1j); from two rows on it is gemm: fma(y, R1j, x * R0j)
+    (np_compat.h blas_dot2_single_row / blas_dot2).  The skidpad mission transforms the car's position as a single point
+    (skidpad_relocalizer.py:140-153): with the gemm order there, 2 of the 341 frames of the replay flipped their sample count
+    (rounds 1-3: attributed to libm; tests/test_skidpad_cpu.py now asserts none)."""
+    z = np.load(golden_dir / "numpy_semantics_gemv.npz")
+    v, c, s = z["v"].tolist(), z["cos"].tolist(), z["sin"].tolist()
+    c07, s07 = float(z["cos07"]), float(z["sin07"])
+    differ = 0
+    for i in range(len(v)):
+        R = ((c[i], s[i]), (-s[i], c[i]))  # rotation_matrix = [[c, -s], [s, c]].T
+        R07 = ((c07, s07), (-s07, c07))
+        for j in range(2):
+            gemv = _fma(v[i][0], R[0][j], v[i][1] * R[1][j])
+            gemm = _fma(v[i][1], R[1][j], v[i][0] * R[0][j])
+            differ += gemv != gemm
+            assert z["single"][i, j] == gemv and z["one_row"][i, j] == gemv
+            if i < len(z["two_rows"]):
+                assert z["two_rows"][i, j] == gemm
+            assert z["many"][i, j] == _fma(v[i][1], R07[1][j], v[i][0] * R07[0][j])
+    assert differ > 60  # the two orders do differ on these inputs (the fixture can tell them apart)

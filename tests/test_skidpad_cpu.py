@@ -37,10 +37,12 @@ def test_device_constants_match_reference(tables, golden_dir):
 @pytest.mark.parametrize("mode", [0, 1], ids=["libm", "detmath"])
 def test_oracle_replays_reference_sequence(tables, golden_dir, mode):
     """One stateful planner over all 341 frames of demo/skidpad.json: relocalization frame, transform, window index
-    identical; paths within 1e-5 except sample-count flips (libm-dependent yaw/rotation feed the float chain)."""
+    identical; every path within 1e-5 of the reference's — in both math modes, all 341 frames, no allowance (until round 4 two
+    frames, 116 and 167, differed by a sample-count flip: the car's position is rotated as a single point, which NumPy hands
+    to gemv, not gemm — np_compat.h blas_dot2_single_row); x, y and the arc length are the reference's bits on every frame,
+    the relocalization information too."""
     table, noise, ref, md = tables
     g = sk.load_sequence(golden_dir)
-    flips = 0
     with oracle_lib.math_mode(mode):
         op = oracle_lib.SkidpadPlanner(table, noise)
         for t in range(len(g["poses"])):
@@ -50,12 +52,11 @@ def test_oracle_replays_reference_sequence(tables, golden_dir, mode):
             assert bool(info[0]) == bool(g["relocalized"][t]), t
             if g["relocalized"][t]:
                 assert int(info[4]) == int(g["index_along_path"][t]), t
-                assert np.abs(info[1:4] - g["info"][t]).max() < 1e-9
-            e = np.abs(r["path"] - g["path"][t]).max()
-            if e > 1e-5:
-                assert 0.1 < e < 0.2, (t, e)  # one dense-sample step: the 120/121 sample-count flip
-                flips += 1
-    assert flips <= 0.03 * len(g["poses"]), flips
+                assert np.array_equal(info[1:4], g["info"][t]) if mode == 0 else np.abs(info[1:4] - g["info"][t]).max() < 1e-12, t
+            assert np.abs(r["path"] - g["path"][t]).max() <= 1e-5, t
+            if mode == 0:  # host libm: u, x, y bit for bit (the curvature column differs in its last bit on 4 frames)
+                assert np.array_equal(r["path"][:, :3], g["path"][t][:, :3]), t
+                assert np.abs(r["path"][:, 3] - g["path"][t][:, 3]).max() < 1e-15, t
 
 
 def test_emulated_kernels_equal_oracle_on_perturbed_instances(tables, golden_dir):
@@ -167,7 +168,6 @@ def test_oracle_equals_reference_on_awkward_steps(tables, golden_dir):
     tf = sk.perturbed_instances(g, 3)
     frames = sk.awkward_frames(g, tf, len(a["ok"]))
     assert (~a["ok"]).sum() == 3 and set(a["exc"][~a["ok"]]) == {"ValueError"}
-    flips = 0
     with oracle_lib.math_mode(0):
         ops = [oracle_lib.SkidpadPlanner(table, noise) for _ in tf]
         for t, (off, cones, poses) in enumerate(frames):
@@ -180,10 +180,7 @@ def test_oracle_equals_reference_on_awkward_steps(tables, golden_dir):
                     assert bool(oi[0]) == bool(a["relocalized"][t, i])
                     e = np.nanmax(np.abs(r["path"] - a["path"][t, i]))
                     assert np.array_equal(np.isnan(r["path"]), np.isnan(a["path"][t, i]))
-                    if e > 1e-5:
-                        assert 0.1 < e < 0.2, (t, i, e)  # one dense-sample step: the 120/121 sample-count flip
-                        flips += 1
-    assert flips <= 4
+                    assert e <= 1e-5, (t, i, e)
 
 
 def op_index(op):

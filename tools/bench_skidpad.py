@@ -59,22 +59,54 @@ ref_last = None if ONLY_AHEAD else res["path"].copy()
 # (b) the replay as a stream: up to DEPTH steps submitted ahead (fsdp_skidpad_submit): consecutive steps share their launches
 # (csrc/skidpad_kernel.h "steps in flight"), the next group's inputs go up and the previous one's results come down while a
 # group's kernels run; the planner states chain on the device
+def replay_ahead(keep0=None):
+    status = np.zeros(n, np.int64)
+    inflight = []
+    done = 0
+    for t in range(T):
+        if len(inflight) == DEPTH:
+            res, info = batch.collect(inflight.pop(0))
+            status += res["status"] != 0
+            if keep0 is not None:
+                keep0.append(res["path"][0].copy())
+        inflight.append(batch.submit(*batches[t], out=outs[t % (DEPTH + 1)]))
+    for tk in inflight:
+        res, info = batch.collect(tk)
+        status += res["status"] != 0
+        if keep0 is not None:
+            keep0.append(res["path"][0].copy())
+    return status, res, info
+
+
 batch.reset()
 d.barrier()
 t0 = time.perf_counter()
-status = np.zeros(n, np.int64)
-inflight = []
-for t in range(T):
-    if len(inflight) == DEPTH:
-        res, info = batch.collect(inflight.pop(0))
-        status += res["status"] != 0
-    inflight.append(batch.submit(*batches[t], out=outs[t % (DEPTH + 1)]))
-for tk in inflight:
-    res, info = batch.collect(tk)
-    status += res["status"] != 0
+status, res, info = replay_ahead()
 d.barrier()
 el = d.max_over_ranks(time.perf_counter() - t0)
 assert ONLY_AHEAD or np.array_equal(res["path"], ref_last, equal_nan=True), "pipelined steps differ from one-at-a-time steps"
+# the same replay once more, untimed, with HIP events around every group's packed kernels (dominant kernel -> roofline) and
+# planner 0 — the unperturbed recording — held against the reference's golden sequence (flip count)
+paths0 = []
+extra = {}
+if rank == 0:
+    batch.reset()
+    batch.time_groups(True)
+    replay_ahead(paths0)
+    kernel_ms, n_groups, n_pairs = batch.group_times()
+    batch.time_groups(False)
+    err0 = np.array([np.abs(p - g["path"][t]).max() for t, p in enumerate(paths0)])
+    extra["flip_count"] = {"frames": int(T), "flips": int((err0 > 1e-5).sum()), "max_err": float(err0.max()),
+                           "set": "planner 0 = the recording, against tests/golden/skidpad_sequence.npz (the reference's outputs)"}
+    if n_groups:
+        dom = max(kernel_ms, key=kernel_ms.get)
+        # algorithmic bytes per (planner, step) once relocalized: pose in (32 B) + path out (1280 B) + relocalization information out (40 B)
+        algo = 32 + 1280 + 40
+        achieved = algo * n_pairs / (kernel_ms[dom] * 1e-3) / 1e9
+        extra["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                             "kernel_ms_per_group": {k: v / n_groups for k, v in kernel_ms.items()}, "groups": n_groups, "instance_step_pairs": n_pairs,
+                             "note": f"algorithmic bytes per (planner, step) = {algo} x pairs / summed duration of the dominant kernel's launches "
+                                     "(HIP events on the context's stream around the packed kernels of every group of steps; untimed repeat of the replay)"}
 kms = batch.time_path(10) / 10  # the path kernel repeated on the LAST frame of the replay (the car stands at the end of the track: the shortest path of the run)
 reloc = d.sum_over_ranks(float(info["relocalized"].sum()))
 bad = d.sum_over_ranks(float(status.sum()))
@@ -84,5 +116,6 @@ if rank == 0:
                       "frames_per_s_incl_pcie_one_step_at_a_time": None if ONLY_AHEAD else n_total * T / el_step, "relocalized": int(reloc),
                       "frames_with_nonzero_status": int(bad), "ms_per_step": el / T * 1e3, "skid_path_kernel_ms_on_the_last_frame": kms,
                       "note": "submitted ahead, DEPTH / 2 consecutive steps share one group of launches (packed path-stage kernels from 2048 (instance, step) pairs, else a wavefront per pair); one step at a time = the latency of one path stage on a wavefront per planner",
+                      **extra,
                       "tables": ("rank 0 loads them, broadcast to the others; communicator " + d.describe()) if d.world > 1 or d._active else "single process"}))
 d.close()
