@@ -54,6 +54,21 @@ enum {
   FSDP_SYNC_LOST = 206 /* skidpad steps sharing a launch: a step never saw its predecessor's state (internal error) */
 };
 
+/* Defined behaviour where the reference's is not (stated here because it is part of the contract, not an implementation detail):
+ *
+ * Exact ties.  The reference orders start-cone candidates and a cone's nearest neighbours with np.argsort, NumPy's unstable
+ * default sort (trace_sorter/adjacency_matrix.py:55, core_trace_sorter.py:344-377): on an EXACT distance tie — mirror-symmetric
+ * tracks, exactly duplicated cones — which cone it takes depends on the NumPy build and CPU (AVX-512 / AVX2 / scalar sort
+ * kernels).  This library orders ties by the cones' position in the input: the LOWEST INDEX first (a stable sort), the same on
+ * every route and batch composition.  On all tied demo scenarios the final sorted configurations equal the reference's
+ * (tests/golden/scenarios.npz); where only intermediates are compared the tied frames are flagged in the fixtures.
+ *
+ * Capacities refused at fsdp_create (the reference takes any value; its buffers grow by doubling,
+ * trace_sorter/end_configurations.py:74-105): max_n_neighbors > 5, max_length > 12 (register / result-struct shapes),
+ * mpc_prediction_horizon > 40 (rows of a result path).  Refused per frame, with a status and never truncated:
+ * more than 8192 cones (201), more than 4096 raw end configurations on a side (202), a working polyline beyond 1408 points
+ * (203), more than 64 knots in a spline (204), more than 64 skidpad centre clusters (205). */
+
 /* path_fallback bits */
 enum {
   FSDP_FB_PREVIOUS_CENTER = 1, /* < 2 centre points / < 3 cones both sides: previous path (core_calculate_path.py:202-203,531-536) */
