@@ -64,6 +64,10 @@ struct Params {
   int32_t centers_cap;   // points per frame the buffer holds
   double* centers;       // (n_frames, centers_cap, 2)
   int32_t* n_centers;    // (n_frames,) points the reference's array holds (may exceed centers_cap: only the first cap are stored)
+  // path_retry_kernel: list length above which the frames of the exact route share wavefronts (four per wavefront); up to it a
+  // frame has a wavefront to itself (path_kernel.h).  512 in the library (FSDP_RETRY_PACK_MIN); 0 in the host emulator's
+  // parameter block, so that the CPU tests run the shared form.
+  int32_t retry_pack_min;
 };
 
 #define FSDP_PI 3.14159265358979323846

@@ -888,6 +888,8 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   c->params.horizon = pp.mpc_prediction_horizon;
   c->params.matches_should_be_monotonic = pp.matches_should_be_monotonic ? 1 : 0;
   c->params.use_unknown_cones = pp.use_unknown_cones ? 1 : 0;
+  c->params.retry_pack_min = 512;
+  if (const char* e = getenv("FSDP_RETRY_PACK_MIN")) c->params.retry_pack_min = atoi(e);
   c->params.centers_cap = 0;
   c->params.centers = nullptr;
   c->params.n_centers = nullptr;

@@ -71,10 +71,10 @@ struct Arena {
 // Per-frame LDS = the spline workspace; while no fit is running the path stage uses its bytes for segment lengths (before
 // fit #3), the <= 20 tail points of the extension, and after fit #3 the dense samples x | y (and, unless LEAN, the raw
 // curvature; LEAN keeps that in the frame's scratch, Arena::curv).
-template <int G, bool LEAN_ = false>
+template <int G, bool LEAN_ = false, int NKC = 0>  // NKC: knots per fit (0: the group size's default — 16 lean, 32 packed, 64 for a whole wavefront)
 struct PathShared {
   static constexpr bool LEAN = LEAN_;
-  using WS = SplineWS<G, LEAN_ ? FIT_KNOTS : knot_capacity<G>(), DENSE_CAP, LEAN_>;
+  using WS = SplineWS<G, NKC ? NKC : (LEAN_ ? FIT_KNOTS : knot_capacity<G>()), DENSE_CAP, LEAN_>;
   static constexpr int SEG_CAP = WS::DENSE_ARRAYS * DENSE_CAP;  // segment-length scratch in LDS
   WS ws;
   __device__ __forceinline__ double* seg() { return ws.dxyu; }
@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void write_path_status(PathOut* o, int status, int fa
 
 // the whole path stage of one frame on one lane group
 template <int G, bool FAST, class PS>
-__device__ __forceinline__ void path_frame(PS& S, int frame, const double* __restrict__ poses,
+__device__ __forceinline__ int path_frame(PS& S, int frame, const double* __restrict__ poses,
                                   const MatchOut* __restrict__ matched, const double* __restrict__ default_path,
                                   const double* __restrict__ prev_paths, const double* __restrict__ gpath, int n_gpath,
                                   double* __restrict__ arena, PathOut* __restrict__ out, const Params* __restrict__ prm) {
@@ -1059,6 +1059,7 @@ __device__ __forceinline__ void path_frame(PS& S, int frame, const double* __res
   int status = path_front<G, FAST>(S, A, &matched[frame], px, py, prev, gpath, n_gpath, &fallback, &n1);
   if (status == ST_OK) status = finish_path<G, FAST>(S, A, n1, px, py, dx, dy, prev, o->path, &fallback, &n_dense);
   write_path_status<G>(o, status, fallback, n_dense);
+  return status;
 }
 
 // ---- the path stage as three kernels (large batches) --------------------------------------------------------------------
@@ -1228,18 +1229,54 @@ __global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames,
   PROF_FLUSH();
 }
 
-// the host's list of frames a packed launch left at ST_OVERFLOW_KNOTS (fsdp_lib.hip finish_knot_overflow)
-__global__ void __launch_bounds__(64, 1) path_retry_kernel(const double* __restrict__ poses, const MatchOut* __restrict__ matched,
+// The frames the packed kernels handed on (device list: more than 16 knots in a fit, a degree below 3, the ValueError retry,
+// an operand outside the fast division's exponent band, a global-path slice): the whole path stage of such a frame from
+// scratch.  Two levels inside one kernel: first FOUR frames per wavefront with 16 lanes each (64 knots per fit like the
+// whole-wavefront form — with 32 most frames of a noisy batch came back for the second level — and the scaling-free divisions) — a frame then costs a quarter of a wavefront instead of a whole SIMD (round 3: one frame per
+// wavefront at one wavefront per SIMD: 3 % of the frames of a noisy batch took 60 % of the chip's time); what that form
+// cannot finish (an exponent outside the fast division's band) is planned once more by the whole wavefront with plain IEEE
+// divisions.  The route never changes a result (tests: test_every_path_kernel_instantiation_equals_oracle).
+#ifndef FSDP_RETRY_WAVES
+#define FSDP_RETRY_WAVES 1  // (two per SIMD: 107 registers spilled to scratch, slower: profiles/r04_ab_variants.txt 4)
+#endif
+__global__ void __launch_bounds__(64, FSDP_RETRY_WAVES) path_retry_kernel(const double* __restrict__ poses, const MatchOut* __restrict__ matched,
                                                            const double* __restrict__ default_path,
                                                            const double* __restrict__ prev_paths,
                                                            const double* __restrict__ gpath, int n_gpath,
                                                            double* __restrict__ arena, PathOut* __restrict__ out,
                                                            const int* __restrict__ retry, const Params* __restrict__ prm) {
-  __shared__ PathShared<WAVE> S;
+  constexpr int G1 = 16, PER = WAVE / G1;
+  union Shared {
+    PathShared<G1, false, NK_MAX> quad[PER];
+    PathShared<WAVE> whole;
+    __device__ Shared() {}
+  };
+  __shared__ Shared S;
   const int n = retry[0];
-  for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    path_frame<WAVE, false>(S, retry[1 + i], poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out, prm);
+  // A short list (a few frames of a noisy batch): the chip is idle next to them and the pass waits for the slowest one —
+  // a whole wavefront per frame is the quickest way through (config 4r: 60 frames, 4.9 ms instead of 5.8).  A long one (every
+  // frame of a global-path / acceleration batch): chip time counts — four frames per wavefront (+ 90 % frames/s there).
+  if (n <= prm->retry_pack_min) {
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+      path_frame<WAVE, false>(S.whole, retry[1 + i], poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out, prm);
+      __syncthreads();
+    }
+    return;
+  }
+  const int g = Grp<G1>::index();
+  for (int base = blockIdx.x * PER; base < n; base += gridDim.x * PER) {
+    const int i = base + g;
+    const int frame = i < n ? retry[1 + i] : -1;
+    int st = ST_OK;
+    if (frame >= 0) st = path_frame<G1, true>(S.quad[g], frame, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out, prm);
     __syncthreads();
+    for (int q = 0; q < PER; q++) {
+      const int fq = __shfl(frame, q * G1), sq = __shfl(st, q * G1);
+      if (fq >= 0 && (sq == ST_OVERFLOW_KNOTS || sq == ST_RETRY)) {
+        path_frame<WAVE, false>(S.whole, fq, poses, matched, default_path, prev_paths, gpath, n_gpath, arena, out, prm);
+        __syncthreads();
+      }
+    }
   }
 }
 

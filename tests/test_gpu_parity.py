@@ -666,7 +666,7 @@ def test_device_libm_values_the_sorting_stage_decides_with(ctx):
     """The sorting stage keeps the ROCm device library's atan2 / acos where the reference compares np.arctan2 / np.arccos values
     (search predicates, start-cone bearings, cost terms -> arg-min).  The closest such decision of 8.2 M recorded ones sits
     3.9e-7 from its tie (profiles/r03_sort_decision_margins.txt), nine orders of magnitude above an ulp — as long as the
-    library's atan2 stays within an ulp of the true value.  Pinned here: against the correctly rounded det_atan2 (computed on
+    library's atan2 stays within an ulp or two of the true value.  Pinned here: against the correctly rounded det_atan2 (computed on
     the device next to it; bit-identical to the host copy that tests/test_det_math.py holds to mpmath) on 10^6 arguments —
     track-scale vectors, near-axis and near-diagonal directions, tiny and huge magnitudes — and acos against the host's on
     10^6 cosines incl. the neighbourhood of the thresholds' cosines and of +-1."""
@@ -694,10 +694,37 @@ def test_device_libm_values_the_sorting_stage_decides_with(ctx):
         return np.abs(ia - ib)
 
     d = ulps(out[0], out[1])
-    assert d.max() <= 1, (int(d.max()), y[d.argmax()], x[d.argmax()])
+    # measured on ROCm 7.2: 2 ulp at most (the device library's documented bound for atan2).  A release that goes beyond that
+    # moves this assertion, not a sorted index unnoticed.
+    assert d.max() <= 2, (int(d.max()), y[d.argmax()], x[d.argmax()])
+    assert (d == 2).mean() < 0.01
     assert np.array_equal(np.signbit(out[0]), np.signbit(out[1]))
     # det_atan2 on the device == the host's glibc within an ulp too (a second, independent witness)
     assert ulps(out[1], np.arctan2(y, x)).max() <= 1
     a = ulps(out[2], np.arccos(cs))
     assert a.max() <= 2, (int(a.max()), cs[a.argmax()])
-    print(f"device atan2 vs det_atan2: {int((d == 0).sum())} of {n} bit-equal, max {int(d.max())} ulp; acos vs host: {int((a == 0).sum())} bit-equal, max {int(a.max())} ulp")
+    print(f"device atan2 vs det_atan2: {int((d == 0).sum())} of {n} bit-equal, {int((d == 1).sum())} off by 1 ulp, {int((d == 2).sum())} by 2 ulp; acos vs host: {int((a == 0).sum())} bit-equal, max {int(a.max())} ulp")
+
+
+def test_both_forms_of_the_exact_route_return_the_same_bytes(pkg, monkeypatch):
+    """path_retry_kernel plans a short list of handed-on frames with a wavefront per frame (64 lanes, plain divisions) and a
+    long one with four frames per wavefront (16 lanes each, 64 knots, the scaling-free divisions; a frame outside their
+    exponent band once more by the whole wavefront).  Same bytes either way, on a noisy colourless batch (knot overflows of
+    the packed kernels), on a global-path batch (every frame takes the route) and with a non-cubic context."""
+    noisy = pkg.synth.make_replay_batch(1536, 100, 0.0, seed=8, frame_noise=0.3, random_pose=True, color=False, lateral_noise=0.5, heading_noise=0.2)
+    left, right, centre_fn = pkg.synth.closed_track(40, 33)
+    gp = np.array([centre_fn(s)[0] for s in np.linspace(0, 1, 600, endpoint=False)])
+    smooth = pkg.synth.make_replay_batch(1300, 40, 0.15, seed=33, color=True)
+    got = {}
+    for form, env in (("whole", "1000000"), ("shared", "0")):
+        monkeypatch.setenv("FSDP_RETRY_PACK_MIN", env)
+        c = pkg.Context(device=0)
+        r1 = c.plan_batch(*noisy)
+        assert c.route_stats()[1]  # the exact route was needed
+        c.set_global_path(gp)
+        r2 = c.plan_batch(*smooth)
+        c.close()
+        got[form] = (r1, r2)
+    for a, b in zip(got["whole"], got["shared"]):
+        assert a.tobytes() == b.tobytes()
+    assert (got["whole"][1]["status"] == 0).mean() > 0.99
