@@ -116,6 +116,7 @@ def skidpad_leg(n_instances: int = 1024, timeout: float = 120.0):
                 "one_step_at_a_time_frames_per_s": j["frames_per_s_incl_pcie_one_step_at_a_time"], "steps_in_flight": j["steps_in_flight"],
                 "relocalized": j["relocalized"], "frames_with_nonzero_status": j["frames_with_nonzero_status"],
                 "flip_count": j.get("flip_count"), "roofline": j.get("roofline"),
+                "compact_results_frames_per_s": j.get("frames_per_s_incl_pcie_compact_results"),
                 "what": "host buffers to host buffers, H2D + kernels + D2H of every step in the clock; consecutive steps of a planner share their launches (DESIGN.md, Skidpad)"}
     except Exception as e:  # noqa: BLE001  (an extra of the line, never its failure)
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}

@@ -10,4 +10,4 @@ from . import dist, multi, replay, skidpad, stages, synth  # noqa: F401
 from .stages import CalculatePath, ConeMatching, ConeSorting, ConeMatchingInput, ConeSortingInput, PathCalculationInput  # noqa: F401
 from .skidpad import SkidpadBatch  # noqa: F401
 from .multi import MultiPlanner, MultiSkidpadBatch  # noqa: F401
-from ._capi import Context, FsdpError, RESULT_DTYPE, pinned_copy, pinned_empty  # noqa: F401
+from ._capi import Context, FsdpError, PATH_RESULT_DTYPE, RESULT_DTYPE, pinned_copy, pinned_empty  # noqa: F401

@@ -53,6 +53,10 @@ RESULT_DTYPE = np.dtype(
 )
 
 
+# fsdp_path_result (include/fsdp.h): a skidpad step's compact result
+PATH_RESULT_DTYPE = np.dtype([("path", "<f8", (PATH_POINTS, 4)), ("status", "<i4"), ("path_fallback", "<i4"), ("n_dense", "<i4"), ("pad", "<i4")], align=True)
+
+
 class FsdpError(RuntimeError):
     pass
 
@@ -131,6 +135,8 @@ def load() -> ctypes.CDLL:
     lib.fsdp_collect.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
     lib.fsdp_ticket_done.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
     lib.fsdp_ticket_capacity.argtypes = [ctypes.c_void_p]
+    lib.fsdp_skidpad_submit_compact.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     lib.fsdp_skidpad_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     lib.fsdp_route_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong)]
@@ -147,7 +153,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
-    "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path", "fsdp_skidpad_time_groups", "fsdp_skidpad_group_times",
+    "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path", "fsdp_skidpad_time_groups", "fsdp_skidpad_group_times", "fsdp_skidpad_submit_compact",
     "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
     "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena", "fsdp_selftest_absminmax", "fsdp_selftest_libm",
 ]

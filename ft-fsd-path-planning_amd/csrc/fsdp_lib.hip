@@ -128,6 +128,7 @@ struct Work {
     fsdp_frame_result* user_results = nullptr;
     fsdp_skidpad_info* user_info = nullptr;
     bool via_stage = false;                // results go through h_stage (the caller's buffer is pageable)
+    bool compact = false;                  // skidpad step: user_results holds fsdp_path_result records (path + status only)
     fsdp_frame_result* h_stage = nullptr;  // pinned
     SkidInfo* h_info = nullptr;            // pinned
     int cap_stage = 0, cap_info = 0;
@@ -1321,7 +1322,7 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
     }
   }
   if (rc == 0 && n > 0) {
-    if (t.via_stage) memcpy(t.user_results, t.h_stage, sizeof(fsdp_frame_result) * (size_t)n);
+    if (t.via_stage) memcpy(t.user_results, t.h_stage, (t.compact ? sizeof(PathOut) : sizeof(fsdp_frame_result)) * (size_t)n);
     if (t.user_info && t.h_info) {
       if (!c->skid_all_reloc) {
         bool all = true;
@@ -1340,6 +1341,7 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
   t.id = -1;
   t.user_results = nullptr;
   t.user_info = nullptr;
+  t.compact = false;
   c->outstanding--;
   return rc;
 }
@@ -1934,6 +1936,19 @@ static int flush_skid(fsdp_ctx* c) {
     // page-locked results: assemble_kernel writes them into the caller's buffer (over PCIe); the planners' information
     // records ride along into the ticket's pinned block
     fsdp_frame_result* direct = t.user_results ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
+    if (t.compact) {
+      // compact results = the path stage's own records: one plain copy (and the information records) instead of the assembly of
+      // 2.4 KB results whose sorting / matching fields a skidpad step leaves empty anyway
+      CopySegs segs;
+      segs.n = 0;
+      if (direct) segs.seg[segs.n++] = CopySeg{q.d_path, direct, sizeof(PathOut) * (unsigned long long)n};
+      if (t.user_info) segs.seg[segs.n++] = CopySeg{q.d_skid_info, device_view(t.h_info), sizeof(SkidInfo) * (unsigned long long)n};
+      if (segs.n) hipLaunchKernelGGL(stage_in_kernel, dim3(128), dim3(256), 0, xs, segs);
+      HIP_TRY(c, hipGetLastError());
+      if (t.via_stage) HIP_TRY(c, hipMemcpyAsync(t.h_stage, q.d_path, sizeof(PathOut) * (size_t)n, hipMemcpyDeviceToHost, xs));
+      HIP_TRY(c, hipEventRecord(t.done, xs));
+      continue;
+    }
     if (t.user_results || t.user_info)
       launch_assemble(c, q, t.user_results ? n : 0, true, direct, xs, t.user_info ? q.d_skid_info : nullptr,
                       t.user_info ? (SkidInfo*)device_view(t.h_info) : nullptr);
@@ -1952,8 +1967,8 @@ static int flush_skid(fsdp_ctx* c) {
 // kernel is put off until `skid_group` steps have been submitted — they share one launch, with one wavefront per
 // (instance, step) — or until somebody asks for the step (fsdp_collect, fsdp_ticket_done, any blocking call), so a live
 // car that submits and collects one step at a time (fsdp_skidpad_step) gets one launch per step.
-int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const double* cones, const double* poses,
-                        fsdp_frame_result* results, fsdp_skidpad_info* info, long long* ticket) {
+static int skidpad_submit_impl(fsdp_ctx* c, int n_instances, const int32_t* off, const double* cones, const double* poses,
+                               fsdp_frame_result* results, fsdp_skidpad_info* info, long long* ticket, bool compact) {
   if (!c || !ticket) return 1;
   *ticket = -1;
   if (!c->have_tables || n_instances != c->n_instances || !c->d_skid) {
@@ -2018,6 +2033,7 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
   t.user_results = results;
   t.user_info = info;
   t.via_stage = results && !direct;
+  t.compact = compact;
   c->skid_pending[c->n_skid_pending++] = si;
   c->last_slot = si;
   c->last_n = n_instances;
@@ -2026,6 +2042,18 @@ int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const 
   *ticket = t.id;
   if (c->n_skid_pending >= skid_group_size(c)) return flush_skid(c);
   return 0;
+}
+
+int fsdp_skidpad_submit(fsdp_ctx* c, int n_instances, const int32_t* off, const double* cones, const double* poses,
+                        fsdp_frame_result* results, fsdp_skidpad_info* info, long long* ticket) {
+  return skidpad_submit_impl(c, n_instances, off, cones, poses, results, info, ticket, false);
+}
+static_assert(sizeof(fsdp_path_result) == sizeof(PathOut) && offsetof(fsdp_path_result, status) == offsetof(PathOut, status) &&
+                  offsetof(fsdp_path_result, path_fallback) == offsetof(PathOut, fallback) && offsetof(fsdp_path_result, n_dense) == offsetof(PathOut, n_dense),
+              "fsdp_path_result is the path stage's record");
+int fsdp_skidpad_submit_compact(fsdp_ctx* c, int n_instances, const int32_t* off, const double* cones, const double* poses,
+                                fsdp_path_result* results, fsdp_skidpad_info* info, long long* ticket) {
+  return skidpad_submit_impl(c, n_instances, off, cones, poses, (fsdp_frame_result*)results, info, ticket, true);
 }
 
 int fsdp_skidpad_step(fsdp_ctx* c, int n_instances, const int32_t* off, const double* cones, const double* poses,

@@ -185,11 +185,11 @@ class MultiSkidpadBatch:
         self._stage = [[_Staging() for _ in range(self._depth + 1)] for _ in self.parts]
         self._turn = 0
 
-    def submit(self, cone_offsets, cones_xyt, poses, out=None, info=None):
+    def submit(self, cone_offsets, cones_xyt, poses, out=None, info=None, compact: bool = False):
         off, cones, poses, n = _capi.Context._prep(cone_offsets, cones_xyt, poses)
         assert n == self.n
         if out is None:
-            out = _capi.pinned_empty(n, _capi.RESULT_DTYPE)
+            out = _capi.pinned_empty(n, _capi.PATH_RESULT_DTYPE if compact else _capi.RESULT_DTYPE)
         if info is None:
             info = np.zeros(n, dtype=self._info_dtype)
         if self._stage is None:
@@ -211,7 +211,7 @@ class MultiSkidpadBatch:
         out, info = self.collect(self.submit(cone_offsets, cones_xyt, poses))
         return np.array(out), info
 
-    def replay(self, frames, depth: int = 32):
+    def replay(self, frames, depth: int = 32, compact: bool = False):
         """SkidpadBatch.replay over all GPUs: `depth` steps submitted ahead on every context."""
         self.set_overlap(depth)
         inflight = []
@@ -219,7 +219,7 @@ class MultiSkidpadBatch:
             if len(inflight) == depth:
                 res, info = self.collect(inflight.pop(0))
                 yield np.array(res), info
-            inflight.append(self.submit(*f))
+            inflight.append(self.submit(*f, compact=compact))
         for t in inflight:
             res, info = self.collect(t)
             yield np.array(res), info

@@ -87,13 +87,13 @@ class SkidpadBatch:
             "fsdp_skidpad_step")
         return res, info
 
-    def replay(self, frames, depth: int = 32):
+    def replay(self, frames, depth: int = 32, compact: bool = False):
         """A known sequence of frames [(cone_offsets, cones_xyt, poses), ...] for all planners, submitted ``depth`` steps
         ahead (the counterpart of the reference's frame loop over a recording, demo/json_demo.py:103-131, for many planners
         at once): consecutive steps share their launches (include/fsdp.h, fsdp_skidpad_submit).  Yields (results, info) per
         step, in order — the bits of ``step`` called once per frame."""
         self.set_overlap(depth)
-        ring = [_capi.pinned_empty(self.n, _capi.RESULT_DTYPE) for _ in range(depth + 1)]
+        ring = [_capi.pinned_empty(self.n, _capi.PATH_RESULT_DTYPE if compact else _capi.RESULT_DTYPE) for _ in range(depth + 1)]
         inflight = []
         for k, f in enumerate(frames):
             if len(inflight) == depth:
@@ -104,21 +104,24 @@ class SkidpadBatch:
             res, info = self.collect(t)
             yield res.copy(), info
 
-    def submit(self, cone_offsets, cones_xyt, poses, out=None, info=None) -> "_capi.Ticket":
-        """One step as a ticket (fsdp_skidpad_submit).  Up to the context's overlap depth tickets may be outstanding
+    def submit(self, cone_offsets, cones_xyt, poses, out=None, info=None, compact: bool = False) -> "_capi.Ticket":
+        """One step as a ticket (fsdp_skidpad_submit).  compact=True (or an ``out`` array of PATH_RESULT_DTYPE): results as
+        fsdp_path_result records — path, status, fallback bits: everything a skidpad step produces — 1.3 KB instead of 2.4 KB
+        per planner and step (fsdp_skidpad_submit_compact).  Up to the context's overlap depth tickets may be outstanding
         (``set_overlap``, at most 32); steps submitted ahead share their launches, a step that is collected at once gets
         launches of its own."""
         off, cones, poses, n = self._ctx._prep(cone_offsets, cones_xyt, poses)
         assert n == self.n
         if out is None:
-            out = _capi.pinned_empty(n, _capi.RESULT_DTYPE)
+            out = _capi.pinned_empty(n, _capi.PATH_RESULT_DTYPE if compact else _capi.RESULT_DTYPE)
+        compact = out.dtype == _capi.PATH_RESULT_DTYPE
+        assert compact or out.dtype == _capi.RESULT_DTYPE
         if info is None:
             info = np.zeros(n, dtype=INFO_DTYPE)
         t = ctypes.c_longlong(-1)
-        self._ctx._check(
-            self._ctx._lib.fsdp_skidpad_submit(self._ctx._h, ctypes.c_int(n), off.ctypes.data, cones.ctypes.data if len(cones) else None,
-                                               poses.ctypes.data, out.ctypes.data, info.ctypes.data, ctypes.byref(t)),
-            "fsdp_skidpad_submit")
+        fn = self._ctx._lib.fsdp_skidpad_submit_compact if compact else self._ctx._lib.fsdp_skidpad_submit
+        self._ctx._check(fn(self._ctx._h, ctypes.c_int(n), off.ctypes.data, cones.ctypes.data if len(cones) else None, poses.ctypes.data,
+                            out.ctypes.data, info.ctypes.data, ctypes.byref(t)), "fsdp_skidpad_submit")
         return _capi.Ticket(int(t.value), out, info, (off, cones, poses))
 
     def collect(self, ticket):

@@ -320,6 +320,19 @@ int fsdp_skidpad_step(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offset
  * fsdp_skidpad_step = submit + collect = one launch per step. */
 int fsdp_skidpad_submit(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offsets, const double* cones_xyt,
                         const double* poses, fsdp_frame_result* results, fsdp_skidpad_info* info, long long* ticket);
+/* The same step with COMPACT results: what a skidpad step produces is its path and status — sorting and matching are skipped
+ * (full_pipeline.py:138-140: the intermediates are empty arrays) — so a replay may ask for fsdp_path_result records (1296 bytes
+ * per planner and step instead of the 2408 of fsdp_frame_result: the result block is what a step moves over PCIe).  Same
+ * tickets, same fsdp_collect; results may be page-locked (written by a kernel of the context's stream) or pageable. */
+typedef struct {
+  double path[FSDP_PATH_POINTS][4]; /* [spline parameter, x, y, curvature], rows beyond the horizon NaN */
+  int32_t status;
+  int32_t path_fallback;
+  int32_t n_dense;
+  int32_t pad;
+} fsdp_path_result;
+int fsdp_skidpad_submit_compact(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offsets, const double* cones_xyt,
+                                const double* poses, fsdp_path_result* results, fsdp_skidpad_info* info, long long* ticket);
 /* time `iters` repetitions of the one-wavefront-per-planner path kernel on the last step's inputs with HIP events (the
  * states are restored afterwards) */
 int fsdp_skidpad_time_path(fsdp_ctx* ctx, int iters, float* ms_total);

@@ -234,3 +234,33 @@ def test_timing_launches_leave_no_trace(pkg, golden_dir, monkeypatch):
             assert int(ref[t][0][0]["status"]) == int(r["status"]), t
             if int(r["status"]) == 0:
                 assert np.abs(ref[t][0][0]["path"] - r["path"]).max() <= 1e-9, t
+
+
+@pytest.mark.parametrize("n,pinned", [(40, True), (40, False), (1100, True)])
+def test_compact_results_are_the_path_fields_of_the_full_ones(pkg, golden_dir, n, pinned):
+    """fsdp_skidpad_submit_compact: path, status, fallback bits and dense-sample count of every planner and step — what a
+    skidpad step produces (sorting and matching are skipped, full_pipeline.py:138-140) — in 1296-byte records, into page-locked
+    or pageable memory, for groups on both routes; equal to those fields of the full 2408-byte results, information included."""
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, n)
+    frames = sk.awkward_frames(g, tf, 48)
+    full = pkg.SkidpadBatch(n, device=0)
+    ref = [(r.copy(), i.copy()) for r, i in full.replay(frames, 16)]
+    batch = pkg.SkidpadBatch(n, device=0)
+    batch.set_overlap(16)
+    inflight, got = [], []
+    for f in frames:
+        if len(inflight) == 16:
+            r, i = batch.collect(inflight.pop(0))
+            got.append((r.copy(), i.copy()))
+        out = pkg.pinned_empty(n, pkg.PATH_RESULT_DTYPE) if pinned else np.zeros(n, pkg.PATH_RESULT_DTYPE)
+        inflight.append(batch.submit(*f, out=out))
+    for tk in inflight:
+        r, i = batch.collect(tk)
+        got.append((r.copy(), i.copy()))
+    assert len(got) == len(ref)
+    for t, ((r, i), (r0, i0)) in enumerate(zip(got, ref)):
+        assert r.dtype == pkg.PATH_RESULT_DTYPE and r.itemsize == 1296
+        for k in ("path", "status", "path_fallback", "n_dense"):
+            assert np.ascontiguousarray(r[k]).tobytes() == np.ascontiguousarray(r0[k]).tobytes(), (t, k)
+        assert _same_fields(i, i0), t

@@ -85,6 +85,27 @@ status, res, info = replay_ahead()
 d.barrier()
 el = d.max_over_ranks(time.perf_counter() - t0)
 assert ONLY_AHEAD or np.array_equal(res["path"], ref_last, equal_nan=True), "pipelined steps differ from one-at-a-time steps"
+# (c) the same stream with compact results (fsdp_skidpad_submit_compact: 1296-byte records — a skidpad step has no sorting /
+# matching outputs — instead of the 2408-byte fsdp_frame_result)
+outs_c = [pkg.pinned_empty(n, pkg.PATH_RESULT_DTYPE) for _ in range(DEPTH + 1)]
+def replay_compact():
+    inflight = []
+    for t in range(T):
+        if len(inflight) == DEPTH:
+            res_c, _ = batch.collect(inflight.pop(0))
+        inflight.append(batch.submit(*batches[t], out=outs_c[t % (DEPTH + 1)]))
+    for tk in inflight:
+        res_c, _ = batch.collect(tk)
+    return res_c
+batch.reset()
+replay_compact()  # (the copy kernel's first launches)
+batch.reset()
+d.barrier()
+t0 = time.perf_counter()
+res_c = replay_compact()
+d.barrier()
+el_c = d.max_over_ranks(time.perf_counter() - t0)
+assert np.array_equal(res_c["path"], res["path"], equal_nan=True), "compact results differ"
 # the same replay once more, untimed, with HIP events around every group's packed kernels (dominant kernel -> roofline) and
 # planner 0 — the unperturbed recording — held against the reference's golden sequence (flip count)
 paths0 = []
@@ -113,6 +134,7 @@ bad = d.sum_over_ranks(float(status.sum()))
 if rank == 0:
     print(json.dumps({"config": "BASELINE configs[4]: skidpad, batch=%d perturbed starts x %d frames on %d GPU(s)" % (n_total, T, d.world),
                       "frames_per_s_incl_pcie": n_total * T / el, "seconds": el, "steps_in_flight": DEPTH,
+                      "frames_per_s_incl_pcie_compact_results": n_total * T / el_c,
                       "frames_per_s_incl_pcie_one_step_at_a_time": None if ONLY_AHEAD else n_total * T / el_step, "relocalized": int(reloc),
                       "frames_with_nonzero_status": int(bad), "ms_per_step": el / T * 1e3, "skid_path_kernel_ms_on_the_last_frame": kms,
                       "note": "submitted ahead, DEPTH / 2 consecutive steps share one group of launches (packed path-stage kernels from 2048 (instance, step) pairs, else a wavefront per pair); one step at a time = the latency of one path stage on a wavefront per planner",

@@ -1,14 +1,14 @@
 #!/bin/bash
-# evidence pass of round 3: everything profiles/ holds for the round, taken with the library build of this snapshot.
+# evidence pass of round 4: everything profiles/ holds for the round, taken with the library build of this snapshot.
 # Every command runs under `timeout` (a hung process would cost the box's whole limit).
 set -u
-R=gpurun_out/r03
+R=gpurun_out/r04
 mkdir -p $R
 T="timeout 600"
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $R/gpu_tests.txt
 $T python __graft_entry__.py smoke >> $R/gpu_tests.txt 2>&1
-timeout 2400 bash tools/profile_gpu.sh r03 > $R/profile.log 2>&1
-cp gpurun_out/prof_r03/pmc_traffic.json profiles/pmc_traffic.json   # so that the bench lines below carry traffic / insts
+timeout 2400 bash tools/profile_gpu.sh r04 > $R/profile.log 2>&1
+cp gpurun_out/prof_r04/pmc_traffic.json profiles/pmc_traffic.json   # so that the bench lines below carry traffic / insts
 $T python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $R/bench_line.json
 $T python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-latency 2>/dev/null | tail -1 > $R/bench_line_100steps.json
 $T python bench.py --config 4 --frames 8192 --no-cpu-baseline --no-latency 2>/dev/null | tail -1 > $R/bench_cfg4_shard.json
@@ -21,9 +21,16 @@ $T python tools/stream_probe.py > $R/streaming.jsonl 2>&1
   for g in 1 2 4 8 12 16; do echo "1024 instances, groups of $g steps"; FSDP_SKID_GROUP=$g $T python tools/bench_skidpad.py 1024; done
   for g in 1 2 3 4; do echo "1024 instances, a wavefront per (instance, step), groups of $g steps"; FSDP_SKID_PACK_MIN=100000000 FSDP_SKID_GROUP=$g $T python tools/bench_skidpad.py 1024; done
   echo "4096 instances, a wavefront per (instance, step)"; FSDP_SKID_PACK_MIN=100000000 $T python tools/bench_skidpad.py 4096 ) > $R/skidpad_groups.txt 2>&1
-( export TMPDIR=/tmp; REPO=$(pwd); cd /tmp; FSDP_SKID_BENCH_LEGS=ahead timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03/skid -o trace -- python $REPO/tools/bench_skidpad.py 1024 > $REPO/$R/skid_trace.log 2>&1 )
-python tools/kernel_stats.py gpurun_out/prof_r03/skid "python tools/bench_skidpad.py 1024, the replay submitted ahead only" > $R/skidpad_rocprofv3_summary.txt 2>&1
+( export TMPDIR=/tmp; REPO=$(pwd); cd /tmp; FSDP_SKID_BENCH_LEGS=ahead timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r04/skid -o trace -- python $REPO/tools/bench_skidpad.py 1024 > $REPO/$R/skid_trace.log 2>&1 )
+python tools/kernel_stats.py gpurun_out/prof_r04/skid "python tools/bench_skidpad.py 1024, the replay submitted ahead only" > $R/skidpad_rocprofv3_summary.txt 2>&1
 $T python tools/bench_configs.py > $R/bench_configs.jsonl 2>&1
+# one process, two contexts on the one GPU (multi.py; the form the driver's 8-GPU node can run without a launcher)
+FSDP_SHARE_GPU=1 $T python bench.py --gpus 2 --single-process --steps 20 --warmup 3 --no-cpu-baseline --no-latency --stream-batches 0 2>$R/bench_single_process.err | grep '^{' | tail -1 > $R/bench_line_2contexts_one_process.json
+$T python tools/ab_routes.py > $R/routes.txt 2>&1
+python tools/kernel_resources.py > $R/kernel_resources.txt 2>&1
+$T tools/ubench/mfma_f64_order > $R/mfma_f64_order.txt 2>&1
+$T python tools/batch_sweep.py 1024 2048 4096 8192 16384 32768 65536 98304 > $R/batch_sweep.jsonl 2>&1
+FSDP_PACK=1 $T python tools/batch_sweep.py 2048 4096 8192 16384 32768 98304 > $R/batch_sweep_packed_kernels.jsonl 2>&1
 $T python tools/latency_breakdown.py > $R/latency_breakdown.txt 2>&1
 $T python tools/overlap_depths.py default > $R/overlap_depths.txt 2>&1
 timeout 1500 python tests/fuzz_gpu_vs_oracle.py 2048 > $R/fuzz_gpu_vs_oracle.txt 2>&1

@@ -7,6 +7,9 @@ import hashlib
 import json
 import re
 import sqlite3
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sys
 from pathlib import Path
 
@@ -38,13 +41,37 @@ for sub, label in (("trace", "python bench.py --steps 20 --warmup 5 --no-cpu-bas
         print(f"{'kernel':<30}{'calls':>6}{'avg_us':>12}{'total_ms':>11}{'pct':>7}")
         for name, calls, tot, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
             print(f"{short(name):<30}{calls:>6}{avg:>12.1f}{tot / 1e3:>11.2f}{pct:>7.2f}")
-        print("-- per-kernel resources (4096-frame launches) --")
+        # Registers / spills / LDS / scratch come from the code object of the library that ran (tools/kernel_resources.py: the
+        # AMDGPU metadata of the gfx950 ELF inside the .so), NOT from rocprofv3's kernel records — their VGPR field saturates at
+        # 128 on this stack (fit_kernel<4> printed 128, the compiler says 256).  Only the launch geometry
+        # is taken from the trace.
+        print("-- per-kernel resources (code object metadata of lib/libfsdp_hip.so; launch geometry of the 4096-frame launches from the trace) --")
+        try:
+            import kernel_resources as kr
+            meta = {k["short"]: k for k in kr.kernels(kr.ROOT / "ft-fsd-path-planning_amd" / "lib" / "libfsdp_hip.so")}
+        except Exception as e:  # noqa: BLE001
+            meta = {}
+            print("(code object metadata unavailable:", e, ")")
+
+        def lookup(nm):
+            base = nm.split("<")[0]
+            for k, v in meta.items():
+                if k == nm or (k.split("<")[0] == base and nm.split("<")[-1].rstrip(">").split(",")[0] == k.split("<")[-1].rstrip(">").split(",")[0].strip()):
+                    return v
+            return None
         seen = set()
-        for r in con.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x from kernels order by grid_x desc"):
+        for r in con.execute("select name, workgroup_x, grid_x from kernels order by grid_x desc"):
             if r[0] in seen:
                 continue
             seen.add(r[0])
-            print(f"{short(r[0]):<30} vgpr={r[1]} agpr={r[2]} sgpr={r[3]} lds={r[4]}B scratch={r[5]}B/lane wg={r[6]} grid={r[7]}")
+            m = lookup(short(r[0]))
+            if m:
+                regs, by_lds = kr.occupancy(int(m["vgpr_count"]), int(m.get("agpr_count", 0)), int(m["group_segment_fixed_size"]), int(r[1]))
+                print(f"{short(r[0]):<30} regs={m['vgpr_count']} (agpr {m.get('agpr_count', 0)}) sgpr={m['sgpr_count']} vgpr_spill={m.get('vgpr_spill_count', 0)} "
+                      f"sgpr_spill={m.get('sgpr_spill_count', 0)} lds={m['group_segment_fixed_size']}B scratch={m['private_segment_fixed_size']}B/lane "
+                      f"waves/SIMD: {regs} by registers, {by_lds:.2f} by LDS   wg={r[1]} grid={r[2]}")
+            else:
+                print(f"{short(r[0]):<30} (not one of the library's kernels) wg={r[1]} grid={r[2]}")
         for name, avg, cnt in con.execute("select name, avg(duration), count(*) from kernels where grid_x >= 4096 group by name"):
             if "fsdp::" in name and "default" not in name:
                 gbs = ALGO_BYTES * FRAMES / (avg * 1e-9) / 1e9
