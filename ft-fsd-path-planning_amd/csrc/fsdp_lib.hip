@@ -357,6 +357,16 @@ static void* device_view(const void* p) {
   return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
 }
 static bool is_pinned(const void* p) { return device_view(p) != nullptr; }
+// the whole extent [p, p + bytes) is page-locked and one mapping: a view that starts inside a registered range and runs past
+// its end would let a kernel read / write unmapped host memory (a device fault instead of an error code) — such a buffer
+// takes the pageable path (round-3 advisor)
+static bool is_pinned(const void* p, size_t bytes) {
+  const char* dv = (const char*)device_view(p);
+  if (!dv) return false;
+  if (bytes <= 1) return true;
+  const char* de = (const char*)device_view((const char*)p + bytes - 1);
+  return de != nullptr && de - dv == (ptrdiff_t)(bytes - 1);
+}
 
 #ifdef FSDP_LDS_KNOBS
 // experiment builds only: extra dynamic LDS per workgroup (bytes) from the environment, to probe occupancy sensitivity
@@ -1127,9 +1137,10 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
   // a bigger batch than the slot has seen: its buffers are replaced — not under the feet of the passes queued on the stream
   if (n > q.cap_frames || n > q.in.cap_frames || t.total > q.in.cap_cones || (t.prev && n > q.in.cap_prev)) HIP_TRY(c, hipStreamSynchronize(q.stream));
   if (int rc = ensure_work(c, q, n > 0 ? n : 1)) return rc;
-  const bool in_pinned = !force_sdma && n > 0 && is_pinned(t.off) && is_pinned(t.poses) && (t.total == 0 || is_pinned(t.cones)) &&
-                         (!t.prev || is_pinned(t.prev));
-  const bool out_pinned = n > 0 && is_pinned(t.user_results);
+  const bool in_pinned = !force_sdma && n > 0 && is_pinned(t.off, sizeof(int32_t) * ((size_t)n + 1)) && is_pinned(t.poses, sizeof(double) * 4 * (size_t)n) &&
+                         (t.total == 0 || is_pinned(t.cones, sizeof(double) * 3 * t.total)) &&
+                         (!t.prev || is_pinned(t.prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n));
+  const bool out_pinned = n > 0 && is_pinned(t.user_results, sizeof(fsdp_frame_result) * (size_t)n);
   static const bool no_fuse = getenv("FSDP_STAGE_KERNEL") != nullptr;  // experiments: a separate stage_in_kernel in front of the pass
   q.in.h_off = nullptr;
   {
@@ -1250,7 +1261,15 @@ int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
   t->max_cones = max_cones;
   t->user_results = results;
   t->user_info = nullptr;
-  if (int rc = enqueue_ticket(c, q, *t, false)) return rc;
+  if (int rc = enqueue_ticket(c, q, *t, false)) {
+    // Part of the batch may already be queued on the slot's stream — kernels that read the caller's buffers or write his
+    // page-locked results — and no ticket goes out that he could wait on: wait here, so that an error return means the
+    // buffers are his again (round-3 advisor).
+    (void)hipStreamSynchronize(q.stream);
+    (void)hipGetLastError();
+    t->user_results = nullptr;
+    return rc;
+  }
   t->id = c->next_ticket++;
   c->outstanding++;
   c->last_slot = si;
@@ -1314,6 +1333,7 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
         // caller's buffers are still his to leave alone: the batch is read again from them)
         c->reruns++;
         rc = enqueue_ticket(c, q, t, true);
+        if (rc != 0) (void)hipStreamSynchronize(q.stream);  // (nothing of the repeated pass is left running over the caller's buffers)
         if (rc == 0 && (e = hipEventSynchronize(t.done)) != hipSuccess) {
           c->err = std::string("fsdp_collect: ") + hipGetErrorString(e);
           rc = 2;
@@ -1996,7 +2016,8 @@ static int skidpad_submit_impl(fsdp_ctx* c, int n_instances, const int32_t* off,
   // relocalization kernel is not launched.  (Known from the planner information of a collected step.)
   const bool attempt = !c->skid_all_reloc;
   if (!attempt) total = 0;
-  const bool in_pinned = is_pinned(off) && is_pinned(poses) && (total == 0 || is_pinned(cones));
+  const bool in_pinned = is_pinned(off, sizeof(int32_t) * ((size_t)n_instances + 1)) && is_pinned(poses, sizeof(double) * 4 * (size_t)n_instances) &&
+                         (total == 0 || is_pinned(cones, sizeof(double) * 3 * total));
   if (in_pinned) {
     if (int rc = stage_inputs(c, q.in, xs, n_instances, off, cones, poses, nullptr, total, max_cones)) return rc;
   } else if (int rc = upload_inputs(c, q.in, xs, n_instances, off, cones, poses, nullptr, total, max_cones)) {
@@ -2010,7 +2031,7 @@ static int skidpad_submit_impl(fsdp_ctx* c, int n_instances, const int32_t* off,
     HIP_TRY(c, hipHostMalloc((void**)&t.h_info, sizeof(SkidInfo) * (size_t)n_instances, hipHostMallocDefault));
     t.cap_info = n_instances;
   }
-  const bool direct = results && device_view(results);
+  const bool direct = results && is_pinned(results, (compact ? sizeof(PathOut) : sizeof(fsdp_frame_result)) * (size_t)n_instances);
   if (results && !direct && n_instances > t.cap_stage) {
     if (t.h_stage) (void)hipHostFree(t.h_stage);
     t.h_stage = nullptr;

@@ -67,8 +67,13 @@ def _send_msg(sock: socket.socket, payload: bytes) -> None:
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
 
+MAX_MESSAGE = 4 << 20  # the collectives of this path move a 128-byte id, scalars and two tables of <= 100 KB
+
+
 def _recv_msg(sock: socket.socket) -> bytes:
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > MAX_MESSAGE:  # a foreign or broken peer must not make this rank buffer whatever length it announces
+        raise ConnectionError(f"peer announced a {n}-byte message (limit {MAX_MESSAGE})")
     return _recv_exact(sock, n)
 
 
@@ -103,7 +108,7 @@ class Star:
                         conn, _ = srv.accept()
                     except socket.timeout:
                         raise TimeoutError(f"rank rendezvous: only ranks {sorted(self.peers)} of {world - 1} connected within {connect_timeout:.0f} s") from None
-                    conn.settimeout(10.0)
+                    conn.settimeout(1.0)  # a rank sends its hello at once; a stranger must not hold the rendezvous window
                     try:
                         hello = _recv_exact(conn, len(_MAGIC) + 16 + 4)
                     except (ConnectionError, socket.timeout, OSError):
@@ -170,8 +175,12 @@ class Star:
         if self.world == 1:
             return bytes(payload)
         if self.rank == 0:
-            data = bytes(payload) if src == 0 else _recv_msg(self.peers[src])
-            self._root_send_all(data)
+            try:
+                data = bytes(payload) if src == 0 else _recv_msg(self.peers[src])
+                self._root_send_all(data)
+            except BaseException:
+                self.close()
+                raise
             return data
         if self.rank == src:
             _send_msg(self.sock, bytes(payload))
@@ -182,9 +191,15 @@ class Star:
         if self.world == 1:
             return v.copy()
         if self.rank == 0:
-            parts = [np.frombuffer(b, dtype=np.float64) for b in self._root_collect(v.tobytes())]
-            res = _OPS[op](np.stack(parts), axis=0)
-            self._root_send_all(res.tobytes())
+            try:
+                parts = [np.frombuffer(b, dtype=np.float64) for b in self._root_collect(v.tobytes())]
+                if any(p.shape != parts[0].shape for p in parts):
+                    raise RuntimeError(f"allreduce: the ranks sent {[p.size for p in parts]} values")
+                res = _OPS[op](np.stack(parts), axis=0)
+                self._root_send_all(res.tobytes())
+            except BaseException:
+                self.close()  # the other ranks fail at once on the closed sockets instead of waiting out their i/o timeout
+                raise
             return res.reshape(v.shape)
         _send_msg(self.sock, v.tobytes())
         return np.frombuffer(_recv_msg(self.sock), dtype=np.float64).reshape(v.shape).copy()
@@ -241,6 +256,7 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self._ctx = None
+        self._comm = None          # the context that owns the RCCL communicator (its own: see _try_rccl)
         self._active = False       # an RCCL communicator carries the collectives
         self.transport = "none"    # "none" (single process) | "rccl" | "tcp-fallback"
         self.fallback_reason = None
@@ -258,6 +274,14 @@ class Dist:
 
     # -- RCCL ---------------------------------------------------------------------------------------------------------------
     def _try_rccl(self, ctx):
+        # The communicator lives on a context of ITS OWN on the same GPU, never on the planning context: if the bootstrap
+        # hangs, the helper thread that is abandoned below keeps poking at a context nobody else ever touches (the planning
+        # context has no locking: round-3 advisor), and a communicator that comes up late is simply never used.
+        from . import _capi
+
+        self._comm = _capi.Context(device=ctx.device, mission=4)
+        planning = ctx
+        ctx = self._comm
         lib = ctx._lib
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
         uid = None
@@ -306,11 +330,14 @@ class Dist:
             self._active = True
             self.transport = "rccl"
             self.fallback_reason = None
-            assert self.comm_size == self.world and int(ctx._lib.fsdp_comm_rank(ctx._h)) == self.rank
+            assert self.comm_size == self.world and int(self._comm._lib.fsdp_comm_rank(self._comm._h)) == self.rank
             return
         if why is None:
-            ctx._lib.fsdp_comm_destroy(ctx._h)  # mine works, another rank's does not
+            # mine works, another rank's does not: tear it down — under a deadline, its peers may never answer — and leave the
+            # communication context alone from here on
+            _call_with_deadline(lambda: self._comm._lib.fsdp_comm_destroy(self._comm._h), 20.0)
             why = "RCCL failed on another rank"
+        self._comm = None  # (not closed: an abandoned bootstrap thread may still be inside it)
         if want == "rccl" or self._star is None:
             raise RuntimeError(f"RCCL communicator unavailable: {why}")
         self.fallback_reason = why
@@ -323,7 +350,7 @@ class Dist:
     def comm_size(self) -> int:
         """Rank count of the communicator in use (ncclCommCount for RCCL)."""
         if self._active:
-            return int(self._ctx._lib.fsdp_comm_size(self._ctx._h))
+            return int(self._comm._lib.fsdp_comm_size(self._comm._h))
         return self.world if self._star is not None else 1
 
     def describe(self) -> str:
@@ -349,8 +376,8 @@ class Dist:
         else:
             buf = np.zeros(shape, dtype=dtype)
         if self._active:
-            self._ctx._check(self._ctx._lib.fsdp_comm_broadcast(self._ctx._h, ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf.nbytes), src),
-                             "fsdp_comm_broadcast")
+            self._comm._check(self._comm._lib.fsdp_comm_broadcast(self._comm._h, ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf.nbytes), src),
+                              "fsdp_comm_broadcast")
         elif self._star is not None:
             data = self._star.broadcast(buf.tobytes() if self.rank == src else b"", src)
             buf = np.frombuffer(data, dtype=dtype).reshape(shape).copy()
@@ -366,7 +393,7 @@ class Dist:
     def _reduce(self, value: float, op: int) -> float:
         if self._active:
             v = np.array([value], dtype=np.float64)
-            self._ctx._check(self._ctx._lib.fsdp_comm_allreduce(self._ctx._h, v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1, op), "fsdp_comm_allreduce")
+            self._comm._check(self._comm._lib.fsdp_comm_allreduce(self._comm._h, v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1, op), "fsdp_comm_allreduce")
             return float(v[0])
         if self._star is not None:
             return float(self._star.allreduce(np.array([value], dtype=np.float64), op)[0])
@@ -375,7 +402,9 @@ class Dist:
     def barrier(self):
         """Waits for this rank's passes in flight, then for every rank."""
         if self._active:
-            self._ctx._check(self._ctx._lib.fsdp_comm_barrier(self._ctx._h), "fsdp_comm_barrier")
+            if self._ctx is not None:
+                self._ctx.sync()
+            self._comm._check(self._comm._lib.fsdp_comm_barrier(self._comm._h), "fsdp_comm_barrier")
             return
         if self._ctx is not None:
             self._ctx.sync()
@@ -390,7 +419,9 @@ class Dist:
 
     def close(self):
         if self._active:
-            self._ctx._lib.fsdp_comm_destroy(self._ctx._h)
+            self._comm._lib.fsdp_comm_destroy(self._comm._h)
+            self._comm.close()
+            self._comm = None
             self._active = False
         if self._star is not None:
             self._star.close()
