@@ -93,3 +93,20 @@ def test_bench_extras_never_fail_the_line():
     spec.loader.exec_module(bench)
     r = bench.skidpad_leg(n_instances=8, timeout=120)
     assert r["value"] is None and "error" in r
+
+
+def test_in_process_shards_are_the_ranks_shards():
+    """multi.shard_ranges (one process, a context per GPU) cuts a batch exactly where dist.frame_range cuts it for ranks when
+    the counts divide, and always into contiguous ranges that cover the batch with sizes differing by at most one."""
+    import importlib
+
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    for n in (0, 1, 7, 4096, 65536, 65537):
+        for g in (1, 2, 3, 4, 8):
+            r = pkg.multi.shard_ranges(n, g)
+            assert len(r) == g and r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+            if n % g == 0:
+                assert r == [pkg.dist.frame_range(k, g, n) for k in range(g)]
