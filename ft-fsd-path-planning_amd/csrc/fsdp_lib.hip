@@ -976,7 +976,9 @@ void fsdp_destroy(fsdp_ctx* c) {
 // ---- page-locked host memory for the asynchronous entry points ----------------------------------------------------------
 void* fsdp_host_alloc(size_t bytes) {
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+  // portable + mapped: a buffer allocated while one GPU is current is read and written by the kernels of any context's GPU
+  // (multi.py drives every GPU of a node from one process and stages all shards in buffers of this kind)
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
@@ -987,7 +989,7 @@ void fsdp_host_free(void* p) {
 }
 int fsdp_host_register(void* p, size_t bytes) {
   if (!p || !bytes) return 1;
-  if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+  if (hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
     (void)hipGetLastError();
     return 2;
   }
