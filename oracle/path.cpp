@@ -73,7 +73,12 @@ void circle_fit(const Pts& p, double& ocx, double& ocy, double& orad) {
   double Yc = (Myz * (Mxx - x) - Mxz * Mxy) / det / 2.0;
   ocx = Xc + xm;
   ocy = Yc + ym;
-  orad = std::sqrt(std::fabs(Xc * Xc + Yc * Yc + Mz));
+  // `X_center**2` of a NumPy scalar is C pow(x, 2.0), and glibc's pow is not correctly rounded for every argument (nor the
+  // same in its FMA and non-FMA variants): on ~1 % of frames one window's radius — hence one curvature sample — differs from
+  // the product x * x in its last bit.  Host-libm mode follows the reference on this machine; det mode (what the kernels
+  // compute) takes the correctly rounded product.
+  volatile double two = 2.0;  // (a literal exponent would be folded into x * x by the compiler: this must be libm's pow)
+  orad = g_math_mode ? std::sqrt(std::fabs(Xc * Xc + Yc * Yc + Mz)) : std::sqrt(std::fabs(std::pow(Xc, two) + std::pow(Yc, two) + Mz));
 }
 
 // utils/spline_fit.py:95-128 fit + :46-63 predict(der=0, max_u).  Throws PyValueError where

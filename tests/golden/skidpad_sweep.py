@@ -78,8 +78,10 @@ def main():
         if out[0][1] or out[1][1]:
             worst.append((k, out[0][1], out[1][1]))
     print(f"{n} replays of the 341-frame skidpad recording, each under its own rigid transform (rotation up to +-180 deg, shift up to 2 m; replay 0 = the recording),")
-    print("reference (this container's NumPy, default dispatch) vs the oracle, stateful planners on both sides, every frame:")
-    for mode, name in ((0, "oracle, host libm (glibc sin / cos / atan2)"), (1, "oracle, det_math.h (= the kernels)      ")):
+    import os
+    lvl = "NPY_DISABLE_CPU_FEATURES=" + os.environ["NPY_DISABLE_CPU_FEATURES"] if os.environ.get("NPY_DISABLE_CPU_FEATURES") else "default dispatch"
+    print(f"reference (this container's NumPy, {lvl}) vs the oracle, stateful planners on both sides, every frame:")
+    for mode, name in ((0, "oracle, host libm (glibc sin / cos / atan2 / pow)"), (1, "oracle, det_math.h (= the kernels)      ")):
         a = tot[mode]
         print(f"  {name}: {a[0]} frames compared, {a[1]} differ by > 1e-5, {a[2]} differ in a bit of u / x / y, {a[3]} in a bit of the curvature")
     print("  replays with a frame > 1e-5 (replay, libm mode, det mode):", worst)

@@ -148,3 +148,15 @@ def assert_intermediates_equal(res, ref, ok, cost_rtol=0.0):
         has = ok & (ref[f"n_configs_{side}"] > 0)
         a_, b_ = res[f"best_cost_{side}"][has], ref[f"best_cost_{side}"][has]
         assert (np.abs(a_ - b_) <= cost_rtol * np.maximum(1.0, np.abs(b_))).all(), f"best_cost_{side}"
+
+
+def host_libm_is_the_fixture_machines(golden_dir):
+    """Bit-for-bit comparisons of host-libm results with the reference hold where libm returns what it returned when the goldens
+    were captured (glibc's sin / cos / atan2 / pow differ in a last bit between its FMA and non-FMA variants): probe values
+    recorded with the captures (arc_libm_level.npz) + one argument on which glibc's pow(x, 2) is not the rounded product."""
+    import math
+
+    f = np.load(golden_dir / "arc_libm_level.npz")
+    here = np.array([math.atan2(0.3, 1.7), math.sin(1.234567), math.cos(2.3456789), math.atan2(-2.5, 0.11)])
+    pow_probe = math.pow(float.fromhex("-0x1.b504fa57a4d82p+2"), 2.0) == float.fromhex("0x1.7504ff64002b3p+5")  # (x * x ends in ...2b2)
+    return bool(np.array_equal(here, f["probe_libm"]) and pow_probe)

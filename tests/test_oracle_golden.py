@@ -105,3 +105,34 @@ def test_oracle_splines_match_reference_per_frame(golden_dir, name):
                 n_fits += 1
             n_frames += 1
     assert n_frames > 5 and n_fits >= 3 * n_frames - 3
+
+
+@pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones", "odd_inputs", "params_sort", "params_path", "params_monotonic",
+                                         "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"])
+def test_oracle_with_host_libm_is_the_reference_bit_for_bit(golden_dir, name):
+    """Every value of every path — arc length, x, y AND curvature, 40 x 4 doubles — of every frame the reference plans, in all
+    eighteen golden sets (1 774 frames): the oracle in host-libm mode returns the reference's bits.  On arc-extension frames the
+    reference is taken at the libm level of its NumPy (arc_libm_level.npz), elsewhere from the committed goldens (no libm value
+    in their float chain but one: the circle fit squares its centre with C pow(), np.float64 ** 2, which host-libm mode
+    follows).  What separates the kernels (det mode) from this is therefore libm alone: correctly rounded sin / cos / atan2 and
+    x * x where glibc is one bit off."""
+    if not parity.host_libm_is_the_fixture_machines(golden_dir):
+        pytest.skip("this host's libm returns other last bits than the machine the goldens were captured on")
+    g = np.load(golden_dir / f"{name}.npz")
+    prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist())) if "param_names" in g else None
+    with oracle_lib.math_mode(0):
+        if prm:
+            with oracle_lib.params(prm):
+                res = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=4)
+        else:
+            res = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=4)
+    arc = parity.ArcLibm(golden_dir, name)
+    n = 0
+    for k in range(len(res)):
+        if not g["ok"][k]:
+            continue
+        assert int(res[k]["status"]) == 0, k
+        ref = arc.path(k) if k in arc else g["path"][k]
+        assert np.array_equal(res[k]["path"], ref, equal_nan=True), (k, np.nanmax(np.abs(res[k]["path"] - ref)))
+        n += 1
+    assert n == int(g["ok"].sum())
