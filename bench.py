@@ -24,7 +24,7 @@ import os
 
 # several passes in flight = one HIP stream each; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
 # RCCL / the null stream take queues too — must be set before the HIP runtime starts in this process
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")
 
 import argparse
 import importlib
@@ -46,8 +46,12 @@ CFG4_FRAMES, CFG4_CONES_PER_SIDE = 65536, 100  # config 4 (global batch)
 def algo_bytes_per_frame(cones_per_frame: int) -> int:
     """read N*24 + 32 (cones, pose) + write 1280 + 96 + 8: 4488 at N = 128, 6216 at N = 200."""
     return cones_per_frame * 24 + 32 + 1280 + 96 + 8
-PASS_OVERLAP = 10  # passes in flight in the timed region (fsdp_set_overlap); measured 4..20 (profiles/README.md): the steady rate
-# saturates at 8, a 20-pass run is fastest with 10 (two full rounds of passes instead of 8 + 8 + 4)
+PASS_OVERLAP = 20  # passes in flight in the timed region (fsdp_set_overlap).  Round 4 (profiles/r04_ab_variants.txt 7): every pass in
+# flight has its own HIP stream, and streams beyond the runtime's hardware queues share one and serialise (20 in flight on 16
+# queues: 5.0 M); with 20-32 queues twenty passes in flight give 5.7-5.9 M frames/s over 20 passes and 6.3-6.4 M over 100, against
+# 5.4 / 6.1-6.2 M with ten; 24 or more passes collapse (0.7-3.6 M).  22 queues, not 32: the queues of all processes on a GPU add up,
+# and a second process next to 24+ of them crawls (the skidpad child of this script: 5.3 -> 0.5 M; it gets 8 of its own).
+STREAM_DEPTH = 10  # pass slots of the host -> host streaming leg (two tickets queue on each)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -110,7 +114,8 @@ def skidpad_leg(n_instances: int = 1024, timeout: float = 120.0):
 
     try:
         r = subprocess.run([sys.executable, str(ROOT / "tools" / "bench_skidpad.py"), str(n_instances)], capture_output=True, text=True,
-                           timeout=timeout, env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+                           timeout=timeout, env={**{k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")},
+                                                 "GPU_MAX_HW_QUEUES": "8"})  # (one stream; this process still holds its 22 queues)
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         return {"value": j["frames_per_s_incl_pcie"], "unit": "frames/s", "planner_instances": n_instances, "frames": 341,
                 "one_step_at_a_time_frames_per_s": j["frames_per_s_incl_pcie_one_step_at_a_time"], "steps_in_flight": j["steps_in_flight"],
@@ -311,7 +316,7 @@ def main():
     ap.add_argument("--no-skidpad", action="store_true", help="skip the config-5 extra of the line (tools/bench_skidpad.py, ~10 s)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency loop and the golden flip count (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="one pass strictly after the other (single stream)")
-    ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..16)")
+    ap.add_argument("--overlap", type=int, default=PASS_OVERLAP, help="passes in flight (1..32)")
     ap.add_argument("--seed", type=int, default=1, help="seed of the synthetic track (config 2; rank r replays seed + r)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without a launcher, sockets or RCCL: one context per GPU, all driven from this process (multi.py); "
@@ -506,7 +511,7 @@ def main():
             "lib_sha256_16": _lib_hash(pkg),
         }
         if args.config == 2 and args.stream_batches > 0:
-            out["streaming"] = streaming_leg(pkg, ctx, n_local, overlap, args.stream_batches, d.shard_seed(args.seed))
+            out["streaming"] = streaming_leg(pkg, ctx, n_local, min(overlap, STREAM_DEPTH), args.stream_batches, d.shard_seed(args.seed))
         if world == 1 and not args.no_latency:
             # sample-count flips against the reference, measured on the committed golden fuzz set
             out["flip_count"] = golden_flip_count(pkg, ctx)

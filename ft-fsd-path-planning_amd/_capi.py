@@ -14,8 +14,9 @@ from pathlib import Path
 # runtime starts in this process
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # every pass in flight (Context.set_overlap) runs on its own HIP stream; streams beyond the runtime's hardware queues
-# (default 4) share a queue and serialize — also read when the HIP runtime starts
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (default 4) share a queue and serialize (20 passes in flight on 16 queues: 5.0 M frames/s, on 20-32: 5.8 M; the queues of all processes
+# on one GPU add up: two processes with 24 each crawl, profiles/r04_ab_variants.txt 7) — also read when the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")
 
 import numpy as np
 
