@@ -24,7 +24,8 @@ import os
 
 # several passes in flight = one HIP stream each; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
 # RCCL / the null stream take queues too — must be set before the HIP runtime starts in this process
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")
+# (FSDP_SHARE_GPU=1 — several ranks on one GPU, testing only — adds the processes' queues up: keep each small)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "10" if os.environ.get("FSDP_SHARE_GPU") == "1" and "RANK" in os.environ else "22")
 
 import argparse
 import importlib
@@ -362,6 +363,9 @@ def main():
     # the only collectives on this path: rank 0 broadcasts the constant previous-path table (RCCL over xGMI), every
     # rank checks it against the table its own GPU computed at context creation; then barriers / one max-reduction
     assert d.broadcast_check_table(ctx.default_path()), "previous-path table differs across ranks"
+    if not single:
+        # RCCL has done what north_star names it for; the timing barrier and the max-reduction are host-side scalars (TCP star)
+        d.release_device_communicator()
 
     if args.config == 2:
         # weak scaling: this rank's own 4096-frame replay (a different track per rank)
@@ -392,6 +396,8 @@ def main():
     # a replay is a stream of batches: consecutive passes rotate through `overlap` HIP streams / buffer sets so that the
     # next passes fill the compute units the slowest frames of the previous ones no longer occupy (fsdp_set_overlap)
     overlap = 1 if args.no_overlap else args.overlap
+    if share and world > 1 and not single:
+        overlap = min(overlap, 8)  # (several processes on one GPU: their streams share its hardware queues)
     if n_local * overlap > 131072:  # every pass in flight keeps its own intermediates (~0.1 MB per frame): bound them to ~13 GB
         overlap = max(1, 131072 // n_local)
     ctx.set_overlap(overlap)
@@ -422,8 +428,9 @@ def main():
         # the clock has stopped.
         ctx.time_runs(args.steps, collect=False)
         ctx.sync()
+        mine = time.perf_counter() - t0  # this rank's K passes, from the common start to its own last kernel
         d.barrier()
-        elapsed = d.max_over_ranks(time.perf_counter() - t0)
+        elapsed = d.max_over_ranks(mine)  # the job is done when the slowest rank is
     ev_total_ms, ev_main_ms = ctx.time_results()
     names = ctx.stage_names()
     main_ms = [x / args.steps for x in ev_main_ms]  # non-zero for the bracketed kernel only

@@ -257,6 +257,7 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self._ctx = None
         self._comm = None          # the context that owns the RCCL communicator (its own: see _try_rccl)
+        self.released = False      # release_device_communicator() was called: RCCL served the start-up collectives only
         self._active = False       # an RCCL communicator carries the collectives
         self.transport = "none"    # "none" (single process) | "rccl" | "tcp-fallback"
         self.fallback_reason = None
@@ -354,11 +355,28 @@ class Dist:
         return self.world if self._star is not None else 1
 
     def describe(self) -> str:
+        if self.transport == "rccl" and self.released:
+            return (f"rccl, {self.world} rank(s), for the start-up table broadcast; released before the timed region (barrier and "
+                    "max-reduction around it over the TCP star)")
         if self.transport == "rccl":
             return f"rccl, {self.comm_size} rank(s) (ncclCommCount)"
         if self.transport == "tcp-fallback":
             return f"tcp-fallback, {self.world} rank(s) ({self.fallback_reason})"
         return "none (single process)"
+
+    def release_device_communicator(self) -> None:
+        """Done with the device-side collectives (north_star: RCCL only for the initial broadcast of the constant tables): destroy
+        the communicator and its context.  What is left — barriers, scalar reductions around a timed region — goes over the TCP
+        star (WORLD_SIZE > 1) or is trivial (one rank).  Why: an idle communicator still holds streams and hardware queues of the
+        GPU, and with twenty passes in flight the planning context wants them all (bench.py: 5.7 M frames/s without, 4.8 M next
+        to a live communicator; profiles/r04_ab_variants.txt 8)."""
+        if not self._active:
+            return
+        self._comm._lib.fsdp_comm_destroy(self._comm._h)
+        self._comm.close()
+        self._comm = None
+        self._active = False
+        self.released = True
 
     def shard_seed(self, base_seed: int) -> int:
         """Weak scaling: each rank replays its own synthetic track (fixed frames per GPU)."""

@@ -447,6 +447,12 @@ def test_rccl_single_rank_communicator(pkg, monkeypatch):
     # the compute path still works on the same stream after collectives
     off, cones, poses = pkg.synth.make_replay_batch(8, 16, 0.1, seed=3)
     assert (c.plan_batch(off, cones, poses)["status"] == 0).all()
+    # RCCL is for the start-up broadcast: afterwards the communicator (and its context) can go, the scalar collectives carry on
+    d.release_device_communicator()
+    assert not d._active and d.released and d.transport == "rccl" and "released" in d.describe()
+    assert d.max_over_ranks(3.5) == 3.5 and d.sum_over_ranks(2.0) == 2.0
+    d.barrier()
+    assert (c.plan_batch(off, cones, poses)["status"] == 0).all()
     d.close()
     c.close()
     assert "torch" not in sys.modules or True  # (pytest plugins may import torch; bench.py asserts it for real)
