@@ -63,12 +63,28 @@ def replay_per_frame(mission, positions, directions, observations, device=None):
     return np.array(paths), np.array(times), reloc_frame, planner.relocalization_info
 
 
-def replay_batched(mission, positions, directions, observations, device=None, repeats: int = 5, batch_frames: int = 4096, depth: int = 4):
+def replay_batched(mission, positions, directions, observations, device=None, repeats: int = 5, batch_frames: int = 4096, depth: int = 4,
+                   devices=None):
     """The recording as a stream of batches of `batch_frames` frames, `depth` of them in flight (fsdp_submit /
     fsdp_collect: a batch's transfers run under the other batches' kernels; page-locked buffers).  Returns the results of
-    all frames in recording order and the seconds one replay of the whole recording took (host buffers to host buffers)."""
+    all frames in recording order and the seconds one replay of the whole recording took (host buffers to host buffers).
+    devices (a list of GPU indices or "all"): every batch is cut into contiguous frame ranges, one per GPU, all driven from
+    this process (multi.MultiPlanner.plan_stream) — the same bytes."""
     from . import _capi
 
+    if devices is not None:
+        from .multi import MultiPlanner
+
+        mp = MultiPlanner(None if devices == "all" else devices, mission=int(mission), overlap=depth)
+        frames = list(zip(observations, positions, directions))
+        chunks = [pack_frames(frames[lo:lo + batch_frames]) for lo in range(0, len(frames), batch_frames)]
+        got = list(mp.plan_stream(chunks))  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            got = list(mp.plan_stream(chunks))
+        sec = (time.perf_counter() - t0) / repeats
+        mp.close()
+        return (np.concatenate(got) if got else np.zeros(0, _capi.RESULT_DTYPE)), sec
     planner = PathPlanner(mission, device=device)
     ctx = planner._ctx
     frames = list(zip(observations, positions, directions))
@@ -132,6 +148,7 @@ def main(argv=None):
     ap.add_argument("--stateful", action="store_true", help="--batched: one planner's view of the recording (frames chain through the previous path)")
     ap.add_argument("--output-path", "-o", type=Path, default=None)
     ap.add_argument("--device", type=int, default=None)
+    ap.add_argument("--devices", type=str, default=None, help='--batched: GPUs the stream is sharded over from this process, e.g. "0,1,2,3" or "all"')
     ap.add_argument("--batch-frames", type=int, default=4096, help="--batched: frames per batch of the stream")
     ap.add_argument("--depth", type=int, default=4, help="--batched: batches in flight")
     a = ap.parse_args(argv)
@@ -143,7 +160,8 @@ def main(argv=None):
             res, sec, again = replay_stateful_batched(mission, positions, directions, observations, a.device, batch_frames=a.batch_frames, depth=a.depth)
             out.update(frames_planned_again_with_their_predecessors_path=again)
         else:
-            res, sec = replay_batched(mission, positions, directions, observations, a.device, batch_frames=a.batch_frames, depth=a.depth)
+            devs = None if a.devices is None else ("all" if a.devices == "all" else [int(x) for x in a.devices.split(",")])
+            res, sec = replay_batched(mission, positions, directions, observations, a.device, batch_frames=a.batch_frames, depth=a.depth, devices=devs)
         out.update(mode="batched", seconds_per_batch=sec, frames_per_s=len(res) / sec,
                    status_histogram={int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))})
         paths = res["path"]

@@ -299,6 +299,9 @@ def test_replay_cli_roundtrip(pkg, golden_dir, tmp_path):
     res, sec = pkg.replay.replay_batched(pkg.MissionTypes.trackdrive, pos, dirs, obs, device=0, repeats=1, batch_frames=5, depth=3)
     assert np.array_equal(paths, res["path"]) and reloc is None and info is None
     assert np.abs(paths - g["path"][:16]).max() < 1e-5
+    # the same stream sharded over two contexts from this process (replay --devices 0,0): the same bytes
+    multi, _ = pkg.replay.replay_batched(pkg.MissionTypes.trackdrive, pos, dirs, obs, repeats=1, batch_frames=5, depth=3, devices=[0, 0])
+    assert all(np.ascontiguousarray(multi[k]).tobytes() == np.ascontiguousarray(res[k]).tobytes() for k in res.dtype.names)  # (field by field: the records' padding is nobody's)
 
 
 def test_stateful_batched_replay_equals_per_frame_replay(pkg, golden_dir, tmp_path):
