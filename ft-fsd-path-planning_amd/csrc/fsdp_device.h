@@ -244,6 +244,13 @@ struct ProfScope {
   }
 };
 #define PROF(slot) ProfScope prof_scope_##slot(slot)
+// (a section that is not a scope of its own: PROF_T0(slot) ... PROF_T1(slot))
+#define PROF_T0(slot) long long prof_t0_##slot = clock64()
+#define PROF_T1(slot)                                                                        \
+  do {                                                                                       \
+    long long prof_t1_ = clock64();                                                          \
+    if (g_prof && (threadIdx.x & 63) == 0) prof_lds()[slot] += (prof_t1_ - prof_t0_##slot); \
+  } while (0)
 // per-frame counters of the profiling build: slot + (group index of the frame inside its wavefront), lane 0 of the group
 #define PROF_COUNT(slot, G, value)                                                                              \
   do {                                                                                                          \
@@ -262,6 +269,8 @@ struct ProfScope {
   } while (0)
 #else
 #define PROF(slot)
+#define PROF_T0(slot)
+#define PROF_T1(slot)
 #define PROF_COUNT(slot, G, value)
 #define PROF_INIT()
 #define PROF_FLUSH()

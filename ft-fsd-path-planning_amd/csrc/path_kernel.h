@@ -257,38 +257,108 @@ __device__ inline double det3_lu(double x0, double y0, double x1, double y1, dou
 __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
 __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
 
+// The lane-parallel passes over a polyline in the frame's scratch are bound by the round trip of their loads (the prep
+// and finish kernels run two wavefronts per SIMD, nothing else hides it): they fetch PASS_BATCH points per round — each
+// lane its PASS_BATCH / G points, all loads in flight together — instead of one point per lane and round trip
+// (profiles/r04_prep_finish_sections.txt).
+constexpr int PASS_BATCH = 64;
+
+// first closest point of the polyline (X, Y)[0, n) to (px, py) by norm_axis, "first smallest" (np.argmin): bi = -1 if n = 0
+template <int G>
+__device__ __forceinline__ void closest_point(const double* X, const double* Y, int n, double px, double py, double& bv, int& bi) {
+  using GR = Grp<G>;
+  constexpr int UN = PASS_BATCH / G;
+  const int lane = GR::lane();
+  bv = 0.0;
+  bi = -1;
+  for (int base = lane; base < n; base += PASS_BATCH) {
+    double vx[UN], vy[UN];
+#pragma unroll
+    for (int q = 0; q < UN; q++) {
+      int i = base + q * G;  // unconditional loads (index clamped): the round's fetches fly together
+      i = i < n ? i : n - 1;
+      vx[q] = X[i];
+      vy[q] = Y[i];
+    }
+#pragma unroll
+    for (int q = 0; q < UN; q++) {
+      const int i = base + q * G;
+      if (i < n) {
+        double d = norm_axis(px - vx[q], py - vy[q]);
+        if (bi < 0 || d < bv) {
+          bv = d;
+          bi = i;
+        }
+      }
+    }
+  }
+  GR::argmin(bv, bi);
+}
+
+// segment lengths of the polyline (X, Y)[0, ns + 1) of one round: this lane's segments base + q * G + lane, q < UN
+template <int G>
+struct SegmentFetch {
+  static constexpr int UN = PASS_BATCH / G;
+  double ax[UN], ay[UN], bx[UN], by[UN];
+  __device__ __forceinline__ void load(const double* X, const double* Y, int base, int ns) {
+    const int lane = Grp<G>::lane();
+#pragma unroll
+    for (int q = 0; q < UN; q++) {
+      int i = base + q * G + lane;  // (clamped: harmless past the end; ns >= 1)
+      i = i < ns ? i : ns - 1;
+      ax[q] = X[i];
+      ay[q] = Y[i];
+      bx[q] = X[i + 1];
+      by[q] = Y[i + 1];
+    }
+  }
+  __device__ __forceinline__ double length(int q) const {
+    const double dx = bx[q] - ax[q], dy = by[q] - ay[q];
+    return sqrt(dx * dx + dy * dy);
+  }
+};
+
 // chord lengths -> parameter values: A.u[off + i] = cumulative length (np.cumsum: sequential order); returns max_u.
+// PASS_BATCH segments per round: lengths lane-parallel into LDS (the dense-sample bytes: no fit is running), the next
+// round's points fetched while every lane walks the sum in order and keeps the values of its own elements.
 template <int G, class PS>
 __device__ __forceinline__ double build_parameter(PS& S, const Arena& A, int off, int m) {
   PROF(19);
   using GR = Grp<G>;
-  constexpr int CH = PS::WS::CH;
-  constexpr int NR = CH / G;
+  constexpr int NR = PASS_BATCH / G;
+  static_assert(PASS_BATCH <= PS::SEG_CAP && G % 8 == 0 && PASS_BATCH % G == 0, "round buffer");
+  double* const term = S.seg();
   const int lane = GR::lane();
+  const double *X = A.x + off, *Y = A.y + off;
+  const int ns = m - 1;
   double acc = 0.0;
   if (lane == 0) A.u[off] = 0.0;
-  for (int base = 0; base < m - 1; base += CH) {
-    const int cnt = (m - 1 - base) < CH ? (m - 1 - base) : CH;
-    for (int r = lane; r < cnt; r += G) {
-      int i = base + r;
-      double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
-      S.ws.term[r] = sqrt(dx * dx + dy * dy);
-    }
+  if (ns <= 0) return acc;
+  SegmentFetch<G> sf;
+  sf.load(X, Y, 0, ns);
+  for (int base = 0; base < ns; base += PASS_BATCH) {
+    const int cnt = (ns - base) < PASS_BATCH ? (ns - base) : PASS_BATCH;
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+      if (q * G + lane < cnt) term[q * G + lane] = sf.length(q);
     GR::sync();
+    if (base + PASS_BATCH < ns) sf.load(X, Y, base + PASS_BATCH, ns);
     double mine[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++) {
       mine[q] = 0.0;
-      for (int r0 = 0; r0 < G; r0 += 8) {  // operands eight at a time, additions in order
-        double v[8];
+      if (q * G < cnt) {  // (group-uniform: the last round is short)
+        for (int r0 = 0; r0 < G; r0 += 8) {  // operands eight at a time, additions in order
+          double v[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = S.ws.term[q * G + r0 + e];
+          for (int e = 0; e < 8; e++) v[e] = term[q * G + r0 + e];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int rr = r0 + e;
-          if (q * G + rr < cnt) {
-            acc += v[e];
-            if (lane == rr) mine[q] = acc;  // lane rr keeps element q*G + rr
+          for (int e = 0; e < 8; e++) {
+            const int rr = r0 + e;
+            if (q * G + rr < cnt) {
+              acc += v[e];
+              if (lane == rr) mine[q] = acc;  // lane rr keeps element q*G + rr
+            }
           }
         }
       }
@@ -342,9 +412,16 @@ __device__ __forceinline__ int parameterize_path(PS& S, const Arena& A, int off,
   if (n < 2) return ST_REF_UNDEFINED_PATH;
   // _refit_spline :125-161 — segment lengths (LDS when they fit, else the arena's parameter array)
   double* seg = (n - 1 <= PS::SEG_CAP) ? S.seg() : (A.u + off);
-  for (int i = lane; i < n - 1; i += G) {
-    double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
-    seg[i] = sqrt(dx * dx + dy * dy);
+  {
+    SegmentFetch<G> sf;
+    for (int base = 0; base < n - 1; base += PASS_BATCH) {
+      sf.load(A.x + off, A.y + off, base, n - 1);
+#pragma unroll
+      for (int q = 0; q < SegmentFetch<G>::UN; q++) {
+        const int i = base + q * G + lane;
+        if (i < n - 1) seg[i] = sf.length(q);
+      }
+    }
   }
   GR::sync();
   double path_length = np_sum_run(seg, n - 1);
@@ -452,17 +529,28 @@ __device__ __forceinline__ int parameterize_path(PS& S, const Arena& A, int off,
     double tmp = 0.0;
     for (int j = -s1; j <= s2; j++) tmp += curv[clampi(j)];
     if (lane == 0) filt[0] = tmp / size;
-    for (int base = 1; base < L; base += G) {
-      const int i = base + lane;
-      double d = 0.0;
-      if (i < L) d = curv[clampi(i + s2)] - curv[clampi(i - 1 - s1)];
-      double mine = 0.0;
-      const int cnt = (L - base) < G ? (L - base) : G;
-      for (int r = 0; r < cnt; r++) {
-        tmp += GR::bcast(d, r);
-        if (lane == r) mine = tmp;
+    constexpr int UN = PASS_BATCH / G;
+    for (int base0 = 1; base0 < L; base0 += PASS_BATCH) {
+      double dq[UN];  // the differences of UN rounds, fetched together (indices clamped: values past L are not used)
+#pragma unroll
+      for (int q = 0; q < UN; q++) {
+        const int i = base0 + q * G + lane;
+        dq[q] = curv[clampi(i + s2)] - curv[clampi(i - 1 - s1)];
       }
-      if (i < L) filt[i] = mine / size;
+#pragma unroll
+      for (int q = 0; q < UN; q++) {
+        const int base = base0 + q * G;
+        if (base < L) {
+          const int i = base + lane;
+          double mine = 0.0;
+          const int cnt = (L - base) < G ? (L - base) : G;
+          for (int r = 0; r < cnt; r++) {
+            tmp += GR::bcast(dq[q], r);
+            if (lane == r) mine = tmp;
+          }
+          if (i < L) filt[i] = mine / size;
+        }
+      }
     }
   }
   GR::sync();
@@ -507,39 +595,46 @@ __device__ __forceinline__ int parameterize_path(PS& S, const Arena& A, int off,
 
 // sequential sum of segment lengths of the arena polyline [off, off+n) with optional early stop:
 // returns the running total; *first_over = index of the first segment whose cumulative length exceeds
-// `limit` (or n-1 if none).  Chunks of segments are staged in LDS; the additions keep np.cumsum's order.
+// `limit` (or n-1 if none).  Rounds of PASS_BATCH segments staged in LDS (as build_parameter); the additions keep
+// np.cumsum's order.
 template <int G, class PS>
 __device__ __forceinline__ double cumulative_length(PS& S, const Arena& A, int off, int n, double limit, int* first_over) {
   using GR = Grp<G>;
-  constexpr int CH = PS::WS::CH;
+  constexpr int NR = PASS_BATCH / G;
+  double* const term = S.seg();
   const int lane = GR::lane();
+  const double *X = A.x + off, *Y = A.y + off;
+  const int ns = n - 1;
   double acc = 0.0;
   int first = n - 1;
   bool stop = false;
-  for (int base = 0; base < n - 1 && !stop; base += CH) {
-    const int cnt = (n - 1 - base) < CH ? (n - 1 - base) : CH;
-    for (int r = lane; r < cnt; r += G) {
-      int i = base + r;
-      double dx = A.x[off + i + 1] - A.x[off + i], dy = A.y[off + i + 1] - A.y[off + i];
-      S.ws.term[r] = sqrt(dx * dx + dy * dy);
-    }
-    GR::sync();
-    for (int r0 = 0; r0 < cnt && !stop; r0 += 8) {  // operands eight at a time, additions in order
-      double v[8];
+  if (ns > 0) {
+    SegmentFetch<G> sf;
+    sf.load(X, Y, 0, ns);
+    for (int base = 0; base < ns && !stop; base += PASS_BATCH) {
+      const int cnt = (ns - base) < PASS_BATCH ? (ns - base) : PASS_BATCH;
 #pragma unroll
-      for (int q = 0; q < 8; q++) v[q] = S.ws.term[r0 + q];  // r0 + q < CH
+      for (int q = 0; q < NR; q++)
+        if (q * G + lane < cnt) term[q * G + lane] = sf.length(q);
+      GR::sync();
+      if (base + PASS_BATCH < ns) sf.load(X, Y, base + PASS_BATCH, ns);
+      for (int r0 = 0; r0 < cnt && !stop; r0 += 8) {  // operands eight at a time, additions in order
+        double v[8];
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        if (!stop && r0 + q < cnt) {
-          acc += v[q];
-          if (acc > limit) {
-            first = base + r0 + q;
-            stop = true;
+        for (int q = 0; q < 8; q++) v[q] = term[r0 + q];  // r0 + q < PASS_BATCH
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          if (!stop && r0 + q < cnt) {
+            acc += v[q];
+            if (acc > limit) {
+              first = base + r0 + q;
+              stop = true;
+            }
           }
         }
       }
+      GR::sync();
     }
-    GR::sync();
   }
   if (first_over) *first_over = first;
   return acc;
@@ -657,16 +752,9 @@ __device__ __forceinline__ int mpc_prepare(PS& S, const Arena& A, int n, double 
   }
   // remove_path_behind_car :459-465
   {
-    double bv = 0.0;
-    int bi = -1;
-    for (int i = lane; i < n; i += G) {
-      double d = norm_axis(px - A.x[off + i], py - A.y[off + i]);
-      if (bi < 0 || d < bv) {
-        bv = d;
-        bi = i;
-      }
-    }
-    GR::argmin(bv, bi);
+    double bv;
+    int bi;
+    closest_point<G>(A.x + off, A.y + off, n, px, py, bv, bi);
     off += bi;
     n -= bi;
   }
@@ -723,16 +811,9 @@ template <int G>
 __device__ __forceinline__ int overwrite_if_too_far(const Arena& A, int n1, double px, double py, const double* prev, int* fallback) {
   using GR = Grp<G>;
   const int lane = GR::lane();
-  double bv = 0.0;
-  int bi = -1;
-  for (int i = lane; i < n1; i += G) {
-    double d = norm_axis(px - A.x[1 + i], py - A.y[1 + i]);
-    if (bi < 0 || d < bv) {
-      bv = d;
-      bi = i;
-    }
-  }
-  GR::argmin(bv, bi);
+  double bv;
+  int bi;
+  closest_point<G>(A.x + 1, A.y + 1, n1, px, py, bv, bi);
   if (bv > A.prm->maximal_distance_for_valid_path) {
     *fallback |= 4;
     GR::sync();
@@ -863,6 +944,7 @@ __device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut*
                                           int* n1_out) {
   using GR = Grp<G>;
   const int lane = GR::lane();
+  PROF_T0(2);
   int status = mo->status;
   int fallback = 0;
   const int nl = mo->n_left_v, nr = mo->n_right_v;
@@ -987,6 +1069,7 @@ __device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut*
     }
     if (lane == 0) A.prm->n_centers[A.frame] = nk;
   }
+  PROF_T1(2);
   // fit_matches_as_spline :207-223 -> dense path update in arena [1, 1+n1)
   int n1 = 0;
   if (status == ST_OK) {
@@ -1000,7 +1083,9 @@ __device__ __forceinline__ int path_front(PS& S, const Arena& A, const MatchOut*
         if (n1 + 1 + 50 > PATH_CAP) {
           status = ST_OVERFLOW_PATH;
         } else {
+          PROF_T0(3);
           eval_spline<CUBIC>(S.ws, f, A.prm->predict_every, n1, A.x + 1, A.y + 1, nullptr);
+          PROF_T1(3);
         }
         break;
       }
@@ -1093,8 +1178,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
   int status = path_front<G, true, true>(S, A, &matched[frame], px, py, prev, gpath, n_gpath, &fallback, &n1);
   bool plain = false;
   if (status == ST_OK && n1 > 0) {
+    PROF_T0(6);
     n1 = overwrite_if_too_far<G>(A, n1, px, py, prev, &fallback);
+    PROF_T1(6);
+    PROF_T0(30);
     const int rc = mpc_prepare<G>(S, A, n1, px, py, dx, dy, &fallback, &off, &n);
+    PROF_T1(30);
     plain = rc == 0 && n >= 4;  // degree 3 needs 4 points; everything else takes the exact route
     if (plain) build_parameter<G>(S, A, off, n);
   }

@@ -17,7 +17,11 @@ so.parent.mkdir(exist_ok=True)
 KERNELS = {"fit": 1, "prep": 2, "finish": 3}
 which = next((a[len("--kernel="):] for a in sys.argv[1:] if a.startswith("--kernel=")), "fit")
 sys.argv = [a for a in sys.argv if not a.startswith("--kernel=")]
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-sink-insts-to-avoid-spills=1", "-fPIC", "-shared",
+prebuilt = PKG / "lib" / "variants" / f"prof_{which}.so"   # tools/build_variant.sh prof_<kernel> -DFSDP_PROFILE -DFSDP_PROFILE_KERNEL=<k>
+if prebuilt.exists():
+    so = prebuilt
+else:
+  subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-sink-insts-to-avoid-spills=1", "-fPIC", "-shared",
                 "-DFSDP_PROFILE", f"-DFSDP_PROFILE_KERNEL={KERNELS[which]}", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so), "-ldl"], check=True, capture_output=True)
 import os
 
@@ -58,10 +62,10 @@ for q in (0, len(order) // 2, len(order) - 1):
 
 print(f"{N} frames, {len(out)} wavefronts; cycles per wavefront: min {tot.min()}, median {int(np.median(tot))}, "
       f"p90 {int(np.percentile(tot, 90))}, p99 {int(np.percentile(tot, 99))}, max {tot.max()}")
-names = {0: "whole kernel", 1: "fit#1 (incl. parameter)", 4: "fit#2", 5: "eval#2 + cut", 7: "fit#3", 8: "eval#3", 9: "curvature windows",
+names = {0: "whole kernel", 2: "centre points (select side, match loop)", 3: "eval#1 (dense path update)", 6: "overwrite_if_too_far", 30: "mpc_prepare", 1: "fit#1 (incl. parameter)", 4: "fit#2", 5: "eval#2 + cut", 7: "fit#3", 8: "eval#3", 9: "curvature windows",
          18: "filter + sample", 19: "build_parameter (all fits)", 10: "fit: basis prep (lanes)", 11: "fit: Givens pipeline", 12: "fit: fp serial sum",
          13: "fit: back substitution", 14: "fit: residual pass", 15: "fit: fpknot", 16: "fit: part-2 Givens+back", 17: "fit: f(p) pass", 28: "  f(p): terms (lanes)", 29: "  f(p): serial sum"}
 m = out.mean(axis=0)
-print(f"{'section':<28}{'mean cycles/wave ':>20}{'% of kernel':>14}")
+print(f"{'section':<42}{'mean cycles/wave ':>20}{'% of kernel':>14}")
 for k in sorted(names):
-    print(f"{names[k]:<28}{m[k]:>20.0f}{100 * m[k] / m[0]:>13.1f}%")
+    print(f"{names[k]:<42}{m[k]:>20.0f}{100 * m[k] / m[0]:>13.1f}%")
