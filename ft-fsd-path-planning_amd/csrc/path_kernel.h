@@ -34,7 +34,7 @@ constexpr int FIT_KNOTS = 16;  // knots the kernels of the three-kernel path sta
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
 constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
 constexpr int FITREC_DOUBLES = 112;  // >= sizeof(FitRec) / 8
-constexpr int BAND_DOUBLES = 112;    // >= 6 * (FIT_KNOTS + 2): band triangle + right-hand sides of fit_kernel's fit
+constexpr int BAND_DOUBLES = 128;    // >= 7 * (FIT_KNOTS + 2): band triangle + right-hand sides + fpint of fit_kernel's fit
 constexpr int ARENA_REC = 3 * PATH_CAP;                  // basis records (32 bytes per point), then one interval byte per point
 constexpr int ARENA_BMAT = ARENA_REC + 4 * PATH_CAP + PATH_CAP / 8;  // rows of the smoothness matrix
 constexpr int ARENA_FIT = ARENA_BMAT + ARENA_B + DENSE_CAP;          // FitRec
@@ -1205,6 +1205,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
 #ifndef FSDP_FIT_WAVES
 #define FSDP_FIT_WAVES 3
 #endif
+#ifndef FSDP_FIT4_WAVES
+#define FSDP_FIT4_WAVES 2
+#endif
 #ifdef FSDP_EMU
 #define FSDP_WAVES_PER_EU(n)  // (the host emulator's compiler does not parse an expression in an attribute it does not know)
 #else
@@ -1215,11 +1218,11 @@ template <int G, int NKC>
 // (8 / 16 lanes per frame: three wavefronts per SIMD at 168 registers, measured +2 % frames/s over two; 4 lanes per frame:
 // sixteen frames' workspaces are 19.2 KB, i.e. two wavefronts per SIMD — a third one at 14.2 KB / 168 registers was measured
 // to change nothing, profiles/r04_ab_variants.txt 1)
-__global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? 2 : FSDP_FIT_WAVES) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
+__global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES : FSDP_FIT_WAVES) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                  int* __restrict__ retry, const Params* __restrict__ prm) {
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;
-  static_assert(6 * (NKC + 2) <= BAND_DOUBLES, "band region of the arena");
+  static_assert(7 * (NKC + 2) <= BAND_DOUBLES, "band region of the arena");
   __shared__ WS ws_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
   PROF_INIT_K(1);

@@ -72,6 +72,10 @@ struct SplineWS {
   };
   static constexpr bool BAND_GLOBAL = false;
   static constexpr bool RECOMPUTE = false;  // basis values travel through the BasisCache records
+  __device__ __forceinline__ double& FPI(int i) { return fpint[i]; }
+  __device__ __forceinline__ double& FPI_W(int i) { return fpint[i]; }  // (where the residual pass writes it)
+  __device__ __forceinline__ void fpint_commit(int) {}
+  __device__ __forceinline__ int32_t& NRD(int i) { return nrdata[i]; }
   __device__ __forceinline__ double& A(int i, int j) { return a_[i][j - 1]; }
   __device__ __forceinline__ double& Z(int i) { return z[i]; }
   __device__ __forceinline__ double& Gm(int i, int j) { return g_[i][j - 1]; }
@@ -93,31 +97,43 @@ struct FitWS {
 #endif
   static constexpr int CH = (G >= 32) ? G : (G >= 16 ? 32 : (G >= 8 ? FSDP_FIT_CH8 : FSDP_FIT_CH4));
   static constexpr bool BAND_GLOBAL = true;
-  // 1-based arrays sized for what a fit of NK knots touches: t(1..n), c(1..2n), fpint / nrdata(1..n), and the rows
-  // 1..n-4 of the extended triangle.  At four lanes per frame (CH = 4) a frame is 888 bytes.
+  // 1-based arrays sized for what a fit of NK knots touches: t(1..n), c(1..2n), nrdata(1..n), and the rows 1..n-4 of the
+  // extended triangle.  At four lanes per frame (CH = 4) a frame is 928 bytes: sixteen of them are 14 848 bytes, eleven
+  // workgroups per CU.
   double t[NK + 1];
   double c[2 * NK + 1];
-  double* band;
+  double* band;             // the frame's scratch: band triangle | right-hand sides | fpint(1..n)
+  int16_t nrdata[NK + 4];   // data points inside a knot interval (< PATH_CAP); lives across the passes of a fit
   union {
     struct {
       double hq[CH][4];
       double xq[CH], yq[CH];
       int32_t lq[CH];
-      double fpint[NK + 1];
-      int16_t nrdata[NK + 2];  // data points inside a knot interval (< PATH_CAP)
-      // refined reciprocals of the knot differences t(a + j) - t(a), j = 1..3, a = 1..n, of the current knot set
-      // (knot_reciprocals): what the six divisions of a point's basis values (fpbspl3_rd) divide by.  Outside the
-      // bookkeeping arrays, so that it survives the residual pass; the rows of g_ overwrite its head in the smoothing
+      // refined reciprocals of the knot differences t(a + j) - t(a), j = 1..3, of the current knot set (knot_reciprocals):
+      // what the six divisions of a point's basis values (fpbspl3_rd) divide by — a = l-2 .. l for a point in knot
+      // interval l = 4 .. n-4, so rows a = RD_A0 .. n-4 are kept.  The rows of g_ overwrite its head in the smoothing
       // iteration, which therefore rebuilds it before every f(p) pass.
-      double rd[3 * (NK + 1)];
+      double rd[3 * (NK - 5)];
     };
     double g_[NK - 4][5];
   };
+  static constexpr int RD_A0 = 2;  // first row of rd
   // The basis values of a data point are computed again in every pass over the data (observation, residual, f(p)) from
   // its parameter value and the reciprocal table instead of being written to / read from the frame's scratch (BasisCache
-  // records): 25 instead of 49 bytes per point and pass through HBM — the fit kernel is bound by that stream
+  // records): 25 instead of 49 bytes per point and pass through HBM — the fit kernel was bound by that stream
   // (profiles/r04_fit_memory_bound.txt) — for ~45 more FP64 instructions per point and pass.
   static constexpr bool RECOMPUTE = true;
+  // fpint (residual sum per knot interval: written once per interval by the residual pass, read and updated by the knot
+  // selection that follows it) has no bytes of its own: the residual pass — whose term / flag buffers are hq | xq | yq —
+  // writes it behind the band in the frame's scratch, fpint_commit() fetches it into the then dead chunk buffers.
+  __device__ __forceinline__ double& FPI_W(int i) { return band[6 * (NK + 2) + i]; }
+  __device__ __forceinline__ double& FPI(int i) { return (&hq[0][0])[i]; }
+  __device__ __forceinline__ void fpint_commit(int nrint) {  // (after a group sync that follows the last FPI_W)
+    static_assert(sizeof(hq) + sizeof(xq) + sizeof(yq) + sizeof(lq) >= sizeof(double) * (NK + 1), "fpint over the chunk buffers");
+    for (int i = 1 + Grp<G>::lane(); i <= nrint; i += G) FPI(i) = FPI_W(i);
+    Grp<G>::sync();
+  }
+  __device__ __forceinline__ int16_t& NRD(int i) { return nrdata[i]; }
   __device__ __forceinline__ double& A(int i, int j) { return band[4 * i + j - 1]; }
   __device__ __forceinline__ double& Z(int i) { return band[4 * (NK + 2) + i]; }
   __device__ __forceinline__ double& Gm(int i, int j) { return g_[i - 1][j - 1]; }
@@ -444,7 +460,7 @@ __device__ __forceinline__ bool knot_differences_safe(const double* t, int n) {
 // is not empty for an interval that holds a data point — so none of them is zero and fpbspl's "coincident knots" branch
 // (the selects of fpbspl3) is never taken; knot_reciprocals checks exactly that once per knot set, and that every one of
 // them lies in the exponent band of the scaling-free division.
-template <int G>
+template <int G, int A0 = 1>  // A0: first row the table keeps (rows A0 .. n-4 at rd[3 (a - A0) + j - 1])
 __device__ __forceinline__ bool knot_reciprocals(const double* t, int n, double* rd) {
   bool badk = false;
   for (int idx = Grp<G>::lane(); idx < 3 * n; idx += G) {
@@ -455,7 +471,8 @@ __device__ __forceinline__ bool knot_reciprocals(const double* t, int n, double*
     badk |= !(zero | ((d >= 0x1p-255) & (d <= 0x1p255)));
     // interior knot intervals must not be empty: a = k1 .. nk1 = 4 .. n - 4 (then all six spans of fpbspl3_rd are > 0)
     if (j == 1 && a >= 4 && a <= n - 4) badk |= zero;
-    rd[3 * a + j - 1] = zero ? 0.0 : rcp_refined(d);
+    // (fpbspl3_rd reads rows l-2 .. l of a point in knot interval l = 4 .. n-4)
+    if (a >= A0 && a <= n - 4) rd[3 * (a - A0) + j - 1] = zero ? 0.0 : rcp_refined(d);
   }
   return Grp<G>::ballot(badk) == 0ull;
 }
@@ -463,12 +480,13 @@ __device__ __forceinline__ bool knot_reciprocals(const double* t, int n, double*
 // fpbspl3 without the coincident-knot selects and with the denominators' reciprocals from the table: the operations on
 // the operands of fpbspl3<true> in its order — same bits (the quotients are div_rcp(num, den, rcp_refined(den))).
 // CHECK: the numerators' exponent band (once per point and knot set is enough: the observation pass).
-template <bool CHECK>
-__device__ __forceinline__ void fpbspl3_rd(const double* t, const double* rd, double x, int l, double* h /*[0..3]*/, int& bad) {
+template <bool CHECK, int A0 = 1>
+__device__ __forceinline__ void fpbspl3_rd(const double* t, const double* rdt, double x, int l, double* h /*[0..3]*/, int& bad) {
   const double tm2 = t[l - 2], tm1 = t[l - 1], t0 = t[l], tp1 = t[l + 1], tp2 = t[l + 2], tp3 = t[l + 3];
-  const double r01 = rd[3 * l], r02 = rd[3 * l + 1], r03 = rd[3 * l + 2];              // t(l+1..3) - t(l)
-  const double rm12 = rd[3 * (l - 1) + 1], rm13 = rd[3 * (l - 1) + 2];                  // t(l+1..2) - t(l-1)
-  const double rm23 = rd[3 * (l - 2) + 2];                                              // t(l+1) - t(l-2)
+  const double* const rd = rdt + 3 * (l - A0) - 1;  // rd[3 (a - l) + j] = row a, span j
+  const double r01 = rd[1], r02 = rd[2], r03 = rd[3];  // t(l+1..3) - t(l)
+  const double rm12 = rd[-3 + 2], rm13 = rd[-3 + 3];   // t(l+1..2) - t(l-1)
+  const double rm23 = rd[-6 + 3];                      // t(l+1) - t(l-2)
   bool ok = true;
   auto quot = [&](double num, double den, double r) {
     if constexpr (CHECK) ok = ok & ((num == 0.0) | ((num >= 0x1p-255) & (num <= 0x1p255)));
@@ -772,7 +790,7 @@ struct ResidualBatch {
       double hb[K + 1];
       if constexpr (RC) {
         int unused = 0;
-        fpbspl3_rd<false>(ws.t, ws.rd, hv[q][0], lv[q] - 1, hb, unused);  // (lv = FITPACK's l = interval + 1)
+        fpbspl3_rd<false, WS::RD_A0>(ws.t, ws.rd, hv[q][0], lv[q] - 1, hb, unused);  // (lv = FITPACK's l = interval + 1)
       } else {
 #pragma unroll
         for (int j = 0; j < k1; j++) hb[j] = hv[q][j];
@@ -844,7 +862,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
   const int nmax = m + k1;
   int n = nmin, ier = 0, nplus = 0, nrint = 0, nk1 = 0;
   double fp = 0, fpold = 0, fp0 = 0, fpms = 0;
-  if (lane == 0) ws.nrdata[1] = m - 2;
+  if (lane == 0) ws.NRD(1) = m - 2;
   GR::sync();
 
   bool done = false, to_part2 = false, interp_knots = false;
@@ -883,7 +901,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       giv_init(gst);
       if constexpr (WS::RECOMPUTE) {
         static_assert(!WS::RECOMPUTE || (FAST && K == 3), "the reciprocal table serves the scaling-free cubic fit only");
-        if (!knot_reciprocals<G>(ws.t, n, ws.rd)) gst.bad = 1;
+        if (!knot_reciprocals<G, WS::RD_A0>(ws.t, n, ws.rd)) gst.bad = 1;
         GR::sync();
       } else if constexpr (FAST && K == 3) {
         if (!knot_differences_safe<G>(ws.t, n)) gst.bad = 1;
@@ -920,7 +938,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
               lres = l;
               double h[K + 2];
               if constexpr (WS::RECOMPUTE)
-                fpbspl3_rd<true>(ws.t, ws.rd, ui, l, &h[1], gst.bad);
+                fpbspl3_rd<true, WS::RD_A0>(ws.t, ws.rd, ui, l, &h[1], gst.bad);
               else if constexpr (K == 3)
                 fpbspl3<FAST>(ws.t, ui, l, &h[1], gst.bad);
               else
@@ -1053,9 +1071,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       GR::sync();
       if (ier == -2) fp0 = fp;
       if (lane == 0) {
-        ws.fpint[n] = fp0;
-        ws.fpint[n - 1] = fpold;
-        ws.nrdata[n] = nplus;
+        ws.FPI(n) = fp0;
+        ws.FPI(n - 1) = fpold;
+        ws.NRD(n) = nplus;
       }
       GR::sync();
       fpms = fp - s;
@@ -1126,7 +1144,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
                 fpart = fpart + term;
                 if (fl[q]) {
                   double store = term * half;
-                  if (lane == 0) ws.fpint[ii] = fpart - store;
+                  if (lane == 0) ws.FPI_W(ii) = fpart - store;
                   ii++;
                   fpart = store;
                 }
@@ -1135,8 +1153,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
           }
           GR::sync();
         }
-        if (lane == 0) ws.fpint[nrint] = fpart;
+        if (lane == 0) ws.FPI_W(nrint) = fpart;
         GR::sync();
+        ws.fpint_commit(nrint);
       }
       // ---- add nplus knots (fpknot), group-uniform ----
       for (int lq = 1; lq <= nplus; lq++) {
@@ -1147,9 +1166,9 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
           int jbegin = 1;
           int number = 0, maxpt = 0, maxbeg = 0;
           for (int j = 1; j <= nrint; j++) {
-            int jpoint = ws.nrdata[j];
-            if (!(fpmax >= ws.fpint[j] || jpoint == 0)) {
-              fpmax = ws.fpint[j];
+            int jpoint = ws.NRD(j);
+            if (!(fpmax >= ws.FPI(j) || jpoint == 0)) {
+              fpmax = ws.FPI(j);
               number = j;
               maxpt = jpoint;
               maxbeg = jbegin;
@@ -1164,19 +1183,19 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
             if (next <= nrint) {
               for (int j = next; j <= nrint; j++) {
                 int jj = next + nrint - j;
-                ws.fpint[jj + 1] = ws.fpint[jj];
-                ws.nrdata[jj + 1] = ws.nrdata[jj];
+                ws.FPI(jj + 1) = ws.FPI(jj);
+                ws.NRD(jj + 1) = ws.NRD(jj);
                 int jk = jj + kk;
                 ws.t[jk + 1] = ws.t[jk];
               }
             }
-            ws.nrdata[number] = ihalf - 1;
-            ws.nrdata[next] = maxpt - ihalf;
+            ws.NRD(number) = ihalf - 1;
+            ws.NRD(next) = maxpt - ihalf;
             double am = maxpt;
-            double an = ws.nrdata[number];
-            ws.fpint[number] = fpmax * an / am;
-            an = ws.nrdata[next];
-            ws.fpint[next] = fpmax * an / am;
+            double an = ws.NRD(number);
+            ws.FPI(number) = fpmax * an / am;
+            an = ws.NRD(next);
+            ws.FPI(next) = fpmax * an / am;
             int jk = next + kk;
             ws.t[jk] = U[nrx - 1];
           }
@@ -1350,7 +1369,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       }
       GR::sync();
       if constexpr (WS::RECOMPUTE) {
-        (void)knot_reciprocals<G>(ws.t, n, ws.rd);  // (checked when this knot set's observation pass built it)
+        (void)knot_reciprocals<G, WS::RD_A0>(ws.t, n, ws.rd);  // (checked when this knot set's observation pass built it)
         GR::sync();
       }
       // f(p): terms per lane, accumulation in data order
