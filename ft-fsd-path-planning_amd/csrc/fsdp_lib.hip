@@ -271,9 +271,23 @@ static void free_inputs(Inputs& in) {
   in = Inputs();
 }
 
+// A slot's stream.  Experiments only (FSDP_SLOT_PRIO = K): slots K, K + 1, ... get the device's highest stream priority
+// (K < 0: the slots below |K|) — how the hardware queues' arbitration shapes the fill and drain of a burst of passes
+// (profiles/r04_ab_variants.txt 10).
+static hipError_t create_slot_stream(hipStream_t* s, int index) {
+  static const int k = getenv("FSDP_SLOT_PRIO") ? atoi(getenv("FSDP_SLOT_PRIO")) : 0;
+  static const bool on = getenv("FSDP_SLOT_PRIO") != nullptr;
+  if (on && ((k >= 0 && index >= k) || (k < 0 && index < -k))) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 // stream, trailer and intermediates of slot w for passes of up to n frames
 static int ensure_work(fsdp_ctx* c, Work& w, int n) {
-  if (!w.stream) HIP_TRY(c, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+  if (!w.stream) HIP_TRY(c, create_slot_stream(&w.stream, w.index));
   if (!w.h_trailer) {
     HIP_TRY(c, hipHostMalloc((void**)&w.h_trailer, sizeof(PassTrailer) * N_TRAILERS, hipHostMallocMapped | hipHostMallocCoherent));
     memset(w.h_trailer, 0, sizeof(PassTrailer) * N_TRAILERS);
@@ -879,7 +893,7 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   if (const char* e = getenv("FSDP_FIT_G")) c->fit_g = atoi(e) == 8 ? 8 : 4;
   if (const char* e = getenv("FSDP_PACK")) c->force_pack = atoi(e) ? 2 : 1;
   hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->slot[0].stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = create_slot_stream(&c->slot[0].stream, 0);
   c->stream = c->slot[0].stream;
   for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
   c->params.max_n_neighbors = pp.max_n_neighbors;
