@@ -432,6 +432,8 @@ def main():
         d.barrier()
         elapsed = d.max_over_ranks(mine)  # the job is done when the slowest rank is
     ev_total_ms, ev_main_ms = ctx.time_results()
+    # the refit kernel by its own clock (first wavefront's start to last wavefront's end of every launch of the timed region)
+    kclock_ms, kclock_n = ctx.time_kernel_clock() if hasattr(ctx, "time_kernel_clock") else (0.0, 0)
     names = ctx.stage_names()
     main_ms = [x / args.steps for x in ev_main_ms]  # non-zero for the bracketed kernel only
     ctx.time_detail(True)
@@ -491,6 +493,13 @@ def main():
                 "traffic": pk.get("hbm_bytes_per_launch", 0) / 1e9 if pk.get("hbm_bytes_per_launch") else None,
                 "kernel_ms_timed_region": main_ms[dom] if main_ms[dom] > 0 else None,
                 "kernel_bracketed_in_timed_region": names[int(np.argmax(main_ms))],
+                # the same launches by the kernel's own clock readings (s_memrealtime: first wavefront's start to last
+                # wavefront's end = what a kernel trace calls the duration).  The event bracket above starts when the previous
+                # kernel of the stream ends, so it also holds the time the launch waits in its hardware queue — with twenty
+                # streams on the command processor that wait is of the order of the kernel itself.
+                "kernel_ms_device_clock": (kclock_ms / kclock_n) if kclock_n else None,
+                "achieved_by_device_clock": (algo_bytes * n_local / (kclock_ms / kclock_n * 1e-3) / 1e9) if kclock_n else None,
+                "frac_by_device_clock": (algo_bytes * n_local / (kclock_ms / kclock_n * 1e-3) / 1e9 / HBM_PEAK_GBS) if kclock_n else None,
                 "kernel_ms": {n: m for n, m in zip(names, stage_ms)},
                 "kernel_ms_serial": {n: m for n, m in zip(names_serial, serial_ms)},
                 "ms_per_step_serial": ser_total_ms / n_ser,

@@ -120,6 +120,7 @@ def load() -> ctypes.CDLL:
     lib.fsdp_time_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.fsdp_time_detail.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.fsdp_time_results.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fsdp_time_kernel_clock.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.fsdp_comm_unique_id.argtypes = [ctypes.c_void_p]
     lib.fsdp_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     lib.fsdp_comm_broadcast.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
@@ -149,7 +150,7 @@ def load() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = [
     "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_default_params", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
-    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_time_reserve", "fsdp_time_results", "fsdp_time_detail", "fsdp_stage_names", "fsdp_resident_frames",
+    "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_time_reserve", "fsdp_time_results", "fsdp_time_kernel_clock", "fsdp_time_detail", "fsdp_stage_names", "fsdp_resident_frames",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_path_batch_centers", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
@@ -413,6 +414,14 @@ class Context:
         self._check(self._lib.fsdp_time_results(self._h, ctypes.byref(tot), st), "fsdp_time_results")
         n = len(self.stage_names())
         return float(tot.value), [float(x) for x in st][:n]
+
+    def time_kernel_clock(self):
+        """(summed ms, launches) of the refit kernel in the most recent time_runs by the kernel's own clock readings: first
+        wavefront's start to last wavefront's end, what a kernel trace reports (fsdp_time_kernel_clock)."""
+        ms = ctypes.c_double()
+        n = ctypes.c_int()
+        self._check(self._lib.fsdp_time_kernel_clock(self._h, ctypes.byref(ms), ctypes.byref(n)), "fsdp_time_kernel_clock")
+        return float(ms.value), int(n.value)
 
     def stage_names(self):
         """Kernel names behind the per-stage times of the most recent time_runs (the path kernel's lane-group

@@ -178,6 +178,8 @@ struct fsdp_ctx {
   int timed_iters = 0, timed_stages = 0;  // the most recent fsdp_time_runs (fsdp_time_results reads its events)
   bool time_main_only = false;            // fsdp_time_detail: events only around the path stage's main kernel
   std::vector<unsigned> tev_recorded;     // per pass of the most recent fsdp_time_runs: which of its events were recorded
+  unsigned long long* d_kclock = nullptr;  // [2 * kclock_cap]: first-wavefront-start | last-wavefront-end of the refit kernel, per timed pass
+  int kclock_cap = 0;
   bool primed[FSDP_MAX_OVERLAP] = {};     // slot i has executed a pass of the current packing (its stream / hardware queue is set up)
   // skidpad mission
   double* d_table = nullptr;
@@ -407,6 +409,8 @@ struct StageEvents {  // optional timing: ev[k] is recorded before stage k, ev[n
   int n = 0;
   bool main_only = false;   // record only the events around the path stage's main kernel (and the last one of the pass)
   unsigned recorded = 0;    // bit k: ev[k] was recorded
+  unsigned long long* clock_first = nullptr;  // device words for the refit kernel's own clock readings (fit_kernel)
+  unsigned long long* clock_last = nullptr;
 };
 enum MarkKind { MARK_PLAIN = 0, MARK_MAIN = 1, MARK_LAST = 2 };
 static void mark(const Work& q, StageEvents* t, MarkKind kind = MARK_PLAIN) {
@@ -455,9 +459,9 @@ static void launch_match(fsdp_ctx* c, Work& q, const Inputs& in) {
 // Large batches: three kernels (path_kernel.h: path_prep_kernel -> fit_kernel -> path_finish_kernel).  Either way the
 // frames the fast kernels hand on (retry list on the device) are planned by the exact kernel in the same stream.
 template <int GF>
-static void launch_fit(fsdp_ctx* c, Work& q, int n) {
+static void launch_fit(fsdp_ctx* c, Work& q, int n, const StageEvents* t = nullptr) {
   hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((n + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), DYN_LDS("FSDP_LDS_FIT"), q.stream, n,
-                     q.d_arena, q.d_mid, q.d_retry, c->d_params);
+                     q.d_arena, q.d_mid, q.d_retry, c->d_params, t ? t->clock_first : nullptr, t ? t->clock_last : nullptr);
 }
 template <int G>
 static void launch_prep(fsdp_ctx* c, Work& q, const Inputs& in, const double* prev) {
@@ -490,7 +494,7 @@ static void launch_skid_packed_kernels(fsdp_ctx* c, int frames) {
                      c->d_default_path, c->d_g_arena, c->d_g_mid);
   skid_group_mark(c);
   hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid,
-                     c->d_g_retry, c->d_params);
+                     c->d_g_retry, c->d_params, (unsigned long long*)nullptr, (unsigned long long*)nullptr);
   skid_group_mark(c);
   hipLaunchKernelGGL(path_finish_kernel<G>, dim3((frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid, c->d_g_out,
                      c->d_g_retry, c->d_params);
@@ -530,11 +534,11 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
       launch_prep<16>(c, q, in, prev);
     mark(q, t, MARK_MAIN);
     if (gf == 4)
-      launch_fit<4>(c, q, n);
+      launch_fit<4>(c, q, n, t);
     else if (gf == 8)
-      launch_fit<8>(c, q, n);
+      launch_fit<8>(c, q, n, t);
     else
-      launch_fit<16>(c, q, n);
+      launch_fit<16>(c, q, n, t);
     mark(q, t, MARK_MAIN);
     if (packed)
       launch_finish<8>(c, q, n);
@@ -1441,6 +1445,13 @@ static int reserve_timing(fsdp_ctx* c, int iters) {
     HIP_TRY(c, hipEventCreate(&e));
     c->tev.push_back(e);
   }
+  if (iters > c->kclock_cap) {
+    (void)hipFree(c->d_kclock);
+    c->d_kclock = nullptr;
+    c->kclock_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_kclock, sizeof(unsigned long long) * 2 * (size_t)iters));
+    c->kclock_cap = iters;
+  }
   return 0;
 }
 
@@ -1518,6 +1529,9 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
   rc = reserve_timing(c, iters);
   if (rc) return rc;
   hipEvent_t ev_begin = c->tev[need - 2], ev_end = c->tev[need - 1];
+  // the refit kernel's own clock readings: atomicMin over "all ones", atomicMax over zero (set before the region begins)
+  HIP_TRY(c, hipMemsetAsync(c->d_kclock, 0xff, sizeof(unsigned long long) * (size_t)c->kclock_cap, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_kclock + c->kclock_cap, 0, sizeof(unsigned long long) * (size_t)c->kclock_cap, c->stream));
   HIP_TRY(c, hipEventRecord(ev_begin, c->stream));
   int last_of_slot[FSDP_MAX_OVERLAP];
   bool started[FSDP_MAX_OVERLAP];
@@ -1536,6 +1550,8 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
     StageEvents t;
     t.ev = &c->tev[(size_t)EPP * (size_t)it];
     t.main_only = c->time_main_only;
+    t.clock_first = c->d_kclock + it;
+    t.clock_last = c->d_kclock + c->kclock_cap + it;
     if ((rc = launch_pass(c, q, c->res, &t))) return rc;
     n_stages = t.n - 1;
     c->tev_recorded[it] = t.recorded;
@@ -1557,6 +1573,26 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
   c->timed_iters = iters;
   c->timed_stages = n_stages;
   if (ms_total || ms_stage) return fsdp_time_results(c, ms_total, ms_stage);
+  return 0;
+}
+
+int fsdp_time_kernel_clock(fsdp_ctx* c, double* ms_sum, int* launches) {
+  if (!c || !ms_sum || !launches) return 1;
+  *ms_sum = 0.0;
+  *launches = 0;
+  if (c->timed_iters <= 0 || !c->d_kclock) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int khz = 0;
+  HIP_TRY(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+  if (khz <= 0) return 0;
+  std::vector<unsigned long long> h(2 * (size_t)c->kclock_cap);
+  HIP_TRY(c, hipMemcpy(h.data(), c->d_kclock, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+  for (int it = 0; it < c->timed_iters && it < c->kclock_cap; it++) {
+    const unsigned long long a = h[(size_t)it], b = h[(size_t)c->kclock_cap + (size_t)it];
+    if (a == ~0ull || b == 0ull || b < a) continue;  // (a pass whose path stage was not the three-kernel form)
+    *ms_sum += (double)(b - a) / (double)khz;
+    (*launches)++;
+  }
   return 0;
 }
 

@@ -1219,9 +1219,15 @@ template <int G, int NKC>
 // sixteen frames' workspaces are 19.2 KB, i.e. two wavefronts per SIMD — a third one at 14.2 KB / 168 registers was measured
 // to change nothing, profiles/r04_ab_variants.txt 1)
 __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES : FSDP_FIT_WAVES) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
-                                                 int* __restrict__ retry, const Params* __restrict__ prm) {
+                                                 int* __restrict__ retry, const Params* __restrict__ prm,
+                                                 unsigned long long* __restrict__ clock_first, unsigned long long* __restrict__ clock_last) {
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;
+#ifndef FSDP_EMU
+  // optional (fsdp_time_runs): when did the launch's first wavefront start and its last one end, on the device's constant-rate
+  // clock — the kernel's duration as a kernel trace reports it, without the wait of its queue that an event bracket includes
+  if (clock_first && threadIdx.x == 0) atomicMin(clock_first, (unsigned long long)wall_clock64());
+#endif
   static_assert(7 * (NKC + 2) <= BAND_DOUBLES, "band region of the arena");
   __shared__ WS ws_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
@@ -1256,6 +1262,9 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES
     }
   }
   PROF_FLUSH_K(1);
+#ifndef FSDP_EMU
+  if (clock_last && threadIdx.x == 0) atomicMax(clock_last, (unsigned long long)wall_clock64());
+#endif
 }
 
 template <int G>

@@ -248,6 +248,12 @@ int fsdp_time_reserve(fsdp_ctx* ctx, int iters);
  * stages on the host; they are switched off in the reference's own benchmark runs.) */
 int fsdp_time_detail(fsdp_ctx* ctx, int every_kernel);
 int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
+/* The refit kernel (fit_kernel, the dominant kernel of a large batch) by its own clock: every launch of the most recent timed
+ * region notes when its first wavefront started and its last one ended (the device's constant-rate counter, s_memrealtime),
+ * i.e. the duration a kernel trace reports — without the time the launch waited in its hardware queue, which an event bracket
+ * on the stream includes when twenty streams share the command processor.  *ms_sum = summed duration, *launches = how many
+ * launches it covers (0 when the region ran the one-kernel path stage).  No counterpart in the reference (measurement only). */
+int fsdp_time_kernel_clock(fsdp_ctx* ctx, double* ms_sum, int* launches);
 /* comma-separated kernel names behind ms_stage of the most recent pass, e.g.
  * "sort_kernel_128,match_kernel<32>,path_prep_kernel<8>,fit_kernel<4>,path_finish_kernel<8>,assemble_kernel" */
 int fsdp_stage_names(fsdp_ctx* ctx, char* out, int cap);

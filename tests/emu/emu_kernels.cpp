@@ -93,7 +93,7 @@ static void emu_path_split_launch(int n_frames, const double* poses, const fsdp:
     fsdp::path_prep_kernel<G>(n_frames, poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out,
                               mid.data(), retry.data(), &g_prm);
   });
-  emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data(), &g_prm); });
+  emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data(), &g_prm, nullptr, nullptr); });
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G>(n_frames, arena.data(), mid.data(), out, retry.data(), &g_prm); });
   g_last_retries = retry[0];
   // the refit records (knots / coefficients fit_kernel handed to path_finish_kernel), kept for emu_last_refit
@@ -114,7 +114,7 @@ static void emu_skid_packed_kernels(int frames, const fsdp::SkidSel* sel, const 
                                     fsdp::PathMid* mid, fsdp::PathOut* pout, int* retry) {
   const unsigned per = 64 / G, perf = 64 / GF;
   emu::launch(((unsigned)frames + per - 1) / per, 64, [&]() { fsdp::skid_prep_kernel<G>(frames, sel, T, chord, g_default_path, arena, mid); });
-  emu::launch(((unsigned)frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, fsdp::FIT_KNOTS>(frames, arena, mid, retry, &g_prm); });
+  emu::launch(((unsigned)frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, fsdp::FIT_KNOTS>(frames, arena, mid, retry, &g_prm, nullptr, nullptr); });
   emu::launch(((unsigned)frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G>(frames, arena, mid, pout, retry, &g_prm); });
 }
 

@@ -365,8 +365,17 @@ def test_overlapped_passes_equal_serial_passes(pkg):
     main = [n.startswith(("fit_kernel", "path_kernel<64>")) for n in ctx.stage_names()]
     assert tot4 > 0 and sum(main) == 1 and st4[main.index(True)] > 0 and st4[0] == 0 and st4[1] == 0, (ctx.stage_names(), st4)
     assert ctx.download()["path"].tobytes() == ref["path"].tobytes()
+    # the refit kernel by its own clock (first wavefront's start to last wavefront's end of every launch): all seven launches
+    # are covered, and the duration lies inside the event bracket (which starts when the previous kernel of the stream ends)
+    kms, kn = ctx.time_kernel_clock()
+    fit = [n.startswith("fit_kernel") for n in ctx.stage_names()]
+    if any(fit):
+        assert kn == 7 and 0 < kms <= st4[fit.index(True)] * 1.05, (kms, kn, st4)
+    else:
+        assert kn == 0 and kms == 0.0
     ctx.time_detail(True)
     assert all(x > 0 for x in ctx.time_runs(3)[1])
+    assert ctx.time_kernel_clock()[1] == (3 if any(fit) else 0)
     ctx.set_overlap(2)
     # a different batch through the same overlapped context
     off2, cones2, poses2 = pkg.synth.make_replay_batch(700, 64, 0.15, seed=12, color=False)

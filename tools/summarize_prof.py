@@ -90,7 +90,9 @@ for sub, label in (("trace", "python bench.py --steps 20 --warmup 5 --no-cpu-bas
                         line = [l for l in open(f"{out}/trace.log") if l.startswith("{")][-1]
                         bj = json.loads(line)
                         print(f"bench.py in this run: value {bj['value']:.0f} frames/s, roofline.kernel {bj['roofline']['kernel']}, "
-                              f"kernel_ms_timed_region {1e3 * bj['roofline']['kernel_ms_timed_region']:.1f} us (HIP events, launches 11-30)")
+                              f"kernel_ms_timed_region {1e3 * bj['roofline']['kernel_ms_timed_region']:.1f} us (HIP events, launches 11-30)"
+                              + (f", kernel_ms_device_clock {1e3 * bj['roofline']['kernel_ms_device_clock']:.1f} us (the kernel's own clock, same launches)"
+                                 if bj['roofline'].get('kernel_ms_device_clock') else ""))
                     except Exception as e:  # noqa: BLE001
                         print("(no bench line in trace.log:", e, ")")
                 if len(d) >= 50:
