@@ -275,6 +275,15 @@ struct ProfScope {
 #define PROF_INIT()
 #define PROF_FLUSH()
 #endif
+// finer sections of the fit itself (profiling builds of the fit kernel with -DFSDP_PROFILE_FIT_DETAIL: slots 1-6, which
+// belong to the path stage in the prep / finish profiles)
+#if defined(FSDP_PROFILE_FIT_DETAIL)
+#define PROFX_T0(slot) PROF_T0(slot)
+#define PROFX_T1(slot) PROF_T1(slot)
+#else
+#define PROFX_T0(slot)
+#define PROFX_T1(slot)
+#endif
 // which kernel of the three-kernel path stage the profiling build accounts: 1 fit_kernel (default), 2 prep, 3 finish
 #ifndef FSDP_PROFILE_KERNEL
 #define FSDP_PROFILE_KERNEL 1

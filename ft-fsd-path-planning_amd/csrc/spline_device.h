@@ -885,6 +885,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
     }
     bool restart = false;
     for (int iter = 1; iter <= m && !restart; iter++) {
+      PROFX_T0(1);
       if (n == nmin) ier = -2;
       nrint = n - nmin + 1;
       nk1 = n - k1;
@@ -924,6 +925,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         }
       };
       fetch_chunk(0);
+      PROFX_T1(1);
       for (int base = 0; base < m; base += CH) {
         const int cnt = m - base < CH ? m - base : CH;
         {
@@ -1023,6 +1025,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         }
         GR::sync();
       }
+      PROFX_T0(2);
       if constexpr (K == 3) {
         PROF(12);
         giv_end_run<G, FAST>(gst);
@@ -1076,6 +1079,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         ws.NRD(n) = nplus;
       }
       GR::sync();
+      PROFX_T1(2);
       fpms = fp - s;
       if (fabs(fpms) < acc) {
         done = true;
@@ -1227,6 +1231,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
   if (to_part2 && ier != -2) {
     // ---- part 2: smoothing spline, root of f(p) = s ----
     // fpdisc: discontinuity jumps of the k-th derivative at the interior knots (lane = knot)
+    PROFX_T0(4);
     {
       int nrint2 = nk1 - k;
       double an = nrint2;
@@ -1259,8 +1264,11 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
       }
       GR::sync();
     }
+    PROFX_T1(4);
+    PROFX_T0(3);
     double p1 = 0., f1 = fp0 - s, p3 = -one, f3 = fpms, p = 0.;
     for (int i = 1; i <= nk1; i++) p = p + ws.A(i, 1);
+    PROFX_T1(3);
     double rn = nk1;
     p = rn / p;
     int ich1 = 0, ich3 = 0;
@@ -1268,13 +1276,47 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
     for (int iter = 1; iter <= maxit; iter++) {
       double pinv = one / p;
       PROF_COUNT(24, G, 1);
+      PROFX_T0(5);
       GR::sync();
-      for (int i = 1 + lane; i <= 2 * n; i += G) ws.c[i] = ws.Z(i);
-      for (int i = 1 + lane; i <= nk1; i += G) {
-        ws.Gm(i, k2) = 0.;
-        for (int j = 1; j <= k1; j++) ws.Gm(i, j) = ws.A(i, j);
+      if constexpr (WS::BAND_GLOBAL) {
+        // the triangle and its right-hand sides come from the frame's scratch: every lane's loads in one batch (indices
+        // clamped), not one round trip per row
+        constexpr int NZ = (2 * NK + G - 1) / G, NRW = (NK - 4 + G - 1) / G;
+        double zv[NZ], av[NRW][4];
+#pragma unroll
+        for (int q = 0; q < NZ; q++) {
+          const int i = 1 + lane + q * G;
+          zv[q] = ws.Z(i <= 2 * n ? i : 2 * n);
+        }
+#pragma unroll
+        for (int q = 0; q < NRW; q++) {
+          const int i = 1 + lane + q * G, ic = i <= nk1 ? i : nk1;
+#pragma unroll
+          for (int j = 1; j <= 4; j++) av[q][j - 1] = ws.A(ic, j);
+        }
+#pragma unroll
+        for (int q = 0; q < NZ; q++) {
+          const int i = 1 + lane + q * G;
+          if (i <= 2 * n) ws.c[i] = zv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NRW; q++) {
+          const int i = 1 + lane + q * G;
+          if (i <= nk1) {
+            ws.Gm(i, k2) = 0.;
+#pragma unroll
+            for (int j = 1; j <= 4; j++) ws.Gm(i, j) = av[q][j - 1];
+          }
+        }
+      } else {
+        for (int i = 1 + lane; i <= 2 * n; i += G) ws.c[i] = ws.Z(i);
+        for (int i = 1 + lane; i <= nk1; i += G) {
+          ws.Gm(i, k2) = 0.;
+          for (int j = 1; j <= k1; j++) ws.Gm(i, j) = ws.A(i, j);
+        }
       }
       GR::sync();
+      PROFX_T1(5);
       if constexpr (G >= K + 4) {
         // Column-parallel rotations (fppara's smoothing rows b / p into the triangle g): lane q < k2 holds column q + 1 of
         // the incoming row and, at band row j, the element g(j, q + 1); lanes k2 and k2 + 1 hold the two right-hand
@@ -1368,10 +1410,12 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         fpback(gel, &ws.c[n], nk1, k2, &ws.c[n]);
       }
       GR::sync();
+      PROFX_T0(6);
       if constexpr (WS::RECOMPUTE) {
         (void)knot_reciprocals<G, WS::RD_A0>(ws.t, n, ws.rd);  // (checked when this knot set's observation pass built it)
         GR::sync();
       }
+      PROFX_T1(6);
       // f(p): terms per lane, accumulation in data order
       PROF(17);
       fp = 0.;

@@ -65,6 +65,10 @@ print(f"{N} frames, {len(out)} wavefronts; cycles per wavefront: min {tot.min()}
 names = {0: "whole kernel", 2: "centre points (select side, match loop)", 3: "eval#1 (dense path update)", 6: "overwrite_if_too_far", 30: "mpc_prepare", 1: "fit#1 (incl. parameter)", 4: "fit#2", 5: "eval#2 + cut", 7: "fit#3", 8: "eval#3", 9: "curvature windows",
          18: "filter + sample", 19: "build_parameter (all fits)", 10: "fit: basis prep (lanes)", 11: "fit: Givens pipeline", 12: "fit: fp serial sum",
          13: "fit: back substitution", 14: "fit: residual pass", 15: "fit: fpknot", 16: "fit: part-2 Givens+back", 17: "fit: f(p) pass", 28: "  f(p): terms (lanes)", 29: "  f(p): serial sum"}
+if which == "fit" and os.environ.get("FIT_DETAIL"):
+    names.update({1: "fit: pass prologue (zero band, reciprocals, first fetch)", 2: "fit: pass epilogue (flush, back subst., bookkeeping)",
+                  3: "fit: p start (sum of the diagonal)", 4: "fit: fpdisc", 5: "fit: smoothing iteration: band copy", 6: "fit: smoothing iteration: reciprocals"})
+    for k in (7, 8, 9, 18, 19, 30): names.pop(k, None)
 m = out.mean(axis=0)
 print(f"{'section':<42}{'mean cycles/wave ':>20}{'% of kernel':>14}")
 for k in sorted(names):
