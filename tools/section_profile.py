@@ -45,6 +45,8 @@ import os
 # fit_kernel: FSDP_FIT_G lanes per frame, prep / finish: 8)
 G = (int(os.environ.get("FSDP_FIT_G", "4")) if which == "fit" else 8) if N > 1024 else 64
 print(f"== {which} kernel ==")
+if os.environ.get("SECTION_DUMP"):
+    np.save(os.environ["SECTION_DUMP"], out)
 FPW = 64 // G
 out = out[: (N + FPW - 1) // FPW]
 tot = out[:, 0]
