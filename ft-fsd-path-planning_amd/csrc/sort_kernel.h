@@ -772,6 +772,13 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
   // near_mask[j]: any i in all with D[i][j] < 36 (diag 1e7) — the 'all' cones eight at a time (indices, then their
   // coordinates: two LDS round trips per eight instead of two per cone)
   constexpr int NW = SH::CAP / WAVE;
+  // The same sweep leaves, per 'all' cone a, the set of cones within 6 m of it (near6[a]: the lanes' hits as one ballot per
+  // word) in the bytes of the adjacency lists, which nothing reads after the search: the counting loop below then walks
+  // the handful of candidates near its cone instead of testing every candidate's distance again.
+  unsigned long long* const near6 = reinterpret_cast<unsigned long long*>(&S.nbr[0][0][0]);
+  constexpr int NEAR_CAP = (int)(sizeof(S.nbr) / (sizeof(unsigned long long) * NW));
+  static_assert(sizeof(S.x) % 8 == 0 && (2 * sizeof(S.x) + sizeof(S.type)) % 8 == 0, "near6 must be 8-byte aligned");
+  const bool tabled = n_all <= NEAR_CAP;
   unsigned long long near_w[NW], close_w[NW];
 #pragma unroll
   for (int w = 0; w < NW; w++) near_w[w] = 0ull;
@@ -791,8 +798,14 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
         ya[e] = S.y[ia[e]];
       }
 #pragma unroll
-      for (int e = 0; e < 8; e++)
-        if (a0 + e < n_all && ia[e] != j && cdist_sq(xa[e], ya[e], xj, yj) < 36.0) nr = true;
+      for (int e = 0; e < 8; e++) {
+        const bool hit = a0 + e < n_all && ia[e] != j && cdist_sq(xa[e], ya[e], xj, yj) < 36.0;
+        if (hit) nr = true;
+        if (tabled && a0 + e < n_all) {
+          const unsigned long long hm = __ballot(hit && j < n);
+          if (lane == 0) near6[(size_t)(a0 + e) * NW + w] = hm;
+        }
+      }
     }
     const unsigned long long mw = __ballot(nr && j < n);
 #pragma unroll
@@ -864,6 +877,13 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
         search_direction(S.x[a], S.y[a], S.x[b], S.y[b], cone_type, sdx, sdy);
         const int cj = e[j];
         const double xc = S.x[cj], yc = S.y[cj];
+        // row of cj in near6 = its position in all_list = the 'all' cones below it (cj is a cone of a kept configuration)
+        int rk = 0;
+        if (tabled)
+          for (int w = 0; w <= (cj >> 6); w++) {
+            const unsigned long long mw = S.all_mask[w];
+            rk += __popcll(w < (cj >> 6) ? mw : (mw & ((1ull << (cj & 63)) - 1ull)));
+          }
         int good = 0, bad = 0;
         for (int w = 0; w < n_words; w++) {
           unsigned long long cm = 0ull;
@@ -873,10 +893,11 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
           }
           unsigned long long om = S.close_mask[w] | (S.all_mask[w] & ~cm);
           if ((cj >> 6) == w) om &= ~(1ull << (cj & 63));
+          if (tabled) om &= near6[(size_t)rk * NW + w];  // (the same predicate on the same operands: cdist_sq(cone, other) < 36)
           while (om) {
             const int idx = w * WAVE + (__ffsll(om) - 1);
             om &= om - 1ull;
-            if (idx < n && cdist_sq(xc, yc, S.x[idx], S.y[idx]) < 36.0) {
+            if (idx < n && (tabled || cdist_sq(xc, yc, S.x[idx], S.y[idx]) < 36.0)) {
               double vx = S.x[idx] - xc, vy = S.y[idx] - yc;
               // the cosine towards -dir is the exact negative of the cosine towards +dir (IEEE negation commutes with
               // every operation of cos_between)
