@@ -986,6 +986,7 @@ void fsdp_destroy(fsdp_ctx* c) {
     if (w.stream) (void)hipStreamDestroy(w.stream);
   }
   for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
+  (void)hipFree(c->d_kclock);
   for (int i = 0; i < 8; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
