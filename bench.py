@@ -183,6 +183,63 @@ def streaming_leg(pkg, ctx, per_gpu: int, depth: int, n_batches: int, seed0: int
 
 
 
+def multi_planner_leg(pkg, devices, per_ctx: int, depth: int, n_batches: int, seed0: int, reference_rate=None):
+    """The user-facing multi-GPU class (multi.MultiPlanner: every GPU from one process and one thread) fed the way a caller feeds
+    it: `n_batches` DIFFERENT page-locked batches of `per_ctx` frames per context through plan_stream, host -> host.  Reports
+    the rate, the time the calling thread spent inside submit() per frame (what bounds the class when the GPUs are many), and
+    whether the batches went out zero-copy (slices of the caller's arrays) or through staging copies."""
+    n_ctx = len(devices)
+    try:
+        mp = pkg.MultiPlanner(devices, overlap=depth)
+        batches = []
+        for k in range(n_batches):
+            off, cones, poses = pkg.synth.make_replay_batch(per_ctx * n_ctx, CONES_PER_SIDE, 0.15, seed=seed0 + 2000 + k, color=True)
+            batches.append((pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64)))
+
+        def replay():
+            bad = 0
+            last = None
+            for res in mp.plan_stream(batches, depth=depth):
+                bad += int((res["status"] != 0).sum())
+                last = res
+            return bad, last
+
+        replay()  # warm-up (streams, buffers, the contexts' route predictions)
+        mp.reset_host_time()
+        zc0 = mp.zero_copy_batches
+        t0 = time.perf_counter()
+        bad, last = replay()
+        el = time.perf_counter() - t0
+        host_s, host_frames = mp.host_seconds, mp.host_frames
+        chk = mp.ctx[0].plan_batch(*batches[-1])
+        same = chk.tobytes() == last.tobytes()
+        # the same stream from pageable arrays (staged by one worker thread per context)
+        pageable = [tuple(np.array(a) for a in b) for b in batches[: max(2, n_batches // 4)]]
+        list(mp.plan_stream(pageable, depth=depth))
+        mp.reset_host_time()
+        t1 = time.perf_counter()
+        for _ in mp.plan_stream(pageable, depth=depth):
+            pass
+        el_pg = time.perf_counter() - t1
+        rate = per_ctx * n_ctx * n_batches / el
+        out = {"value": rate, "unit": "frames/s", "contexts": n_ctx, "devices": list(devices), "frames_per_batch": per_ctx * n_ctx,
+               "batches": n_batches, "depth_per_context": depth, "seconds": el,
+               "host_us_per_submitted_frame": host_s / max(host_frames, 1) * 1e6,
+               "host_thread_busy_fraction": host_s / el,
+               "zero_copy_batches": mp.zero_copy_batches - zc0, "result_copies": 0,
+               "pageable_input_frames_per_s": per_ctx * n_ctx * len(pageable) / el_pg,
+               "pageable_host_us_per_submitted_frame": mp.host_seconds / max(mp.host_frames, 1) * 1e6,
+               "last_batch_equals_one_context_plan_batch": bool(same), "frames_with_nonzero_status": bad,
+               "what": "multi.MultiPlanner.plan_stream, page-locked batches sharded as slices of the caller's arrays (fsdp_submit with "
+                       "cone_offsets[0] != 0), results returned as the page-locked blocks the GPUs wrote; host -> host, everything in the clock"}
+        if reference_rate:
+            out["vs_single_context_streaming"] = rate / reference_rate
+        mp.close()
+        return out
+    except Exception as e:  # noqa: BLE001  (an extra of the line, never its failure)
+        return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+
+
 class InProcess:
     """--single-process: every GPU of the node driven from THIS process (multi.py's form of the product: one context per
     device, no launcher, no socket, no RCCL).  Context 0 plays rank 0 (all the extras of the line are measured on it); the
@@ -432,13 +489,15 @@ def main():
         d.barrier()
         elapsed = d.max_over_ranks(mine)  # the job is done when the slowest rank is
     ev_total_ms, ev_main_ms = ctx.time_results()
-    # the refit kernel by its own clock (first wavefront's start to last wavefront's end of every launch of the timed region)
-    kclock_ms, kclock_n = ctx.time_kernel_clock() if hasattr(ctx, "time_kernel_clock") else (0.0, 0)
     names = ctx.stage_names()
     main_ms = [x / args.steps for x in ev_main_ms]  # non-zero for the bracketed kernel only
-    ctx.time_detail(True)
+    ctx.time_detail(True, kernel_clock=True)
     _, ev_stage_ms = ctx.time_runs(args.steps)      # untimed: every kernel bracketed, same passes in flight
     stage_ms = [x / args.steps for x in ev_stage_ms]
+    # the refit kernel by its own clock (first wavefront's start to last wavefront's end of every launch) — taken in this
+    # untimed repeat: the readings are two atomics per workgroup, and the timed region runs the production launches without them
+    kclock_ms, kclock_n = ctx.time_kernel_clock()
+    ctx.time_detail(True)
 
     # for reference: the same kernels one pass after the other (no overlap) — per-launch durations without chip sharing
     ctx.set_overlap(1)
@@ -528,6 +587,12 @@ def main():
         }
         if args.config == 2 and args.stream_batches > 0:
             out["streaming"] = streaming_leg(pkg, ctx, n_local, min(overlap, STREAM_DEPTH), args.stream_batches, d.shard_seed(args.seed))
+        if args.config == 2 and args.stream_batches > 0 and (world == 1 or single):
+            # multi.MultiPlanner from this one process: on every GPU of a --single-process run, else four contexts on the one GPU
+            devs = d.devices if single else [ctx.device or 0] * 4
+            nb = max(4, args.stream_batches // (1 if single else len(devs)))
+            out["multi_planner_stream"] = multi_planner_leg(pkg, devs, n_local, 3, nb, d.shard_seed(args.seed),
+                                                            (out.get("streaming") or {}).get("value"))
         if world == 1 and not args.no_latency:
             # sample-count flips against the reference, measured on the committed golden fuzz set
             out["flip_count"] = golden_flip_count(pkg, ctx)

@@ -132,6 +132,7 @@ def load() -> ctypes.CDLL:
     lib.fsdp_host_free.argtypes = [ctypes.c_void_p]
     lib.fsdp_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     lib.fsdp_host_unregister.argtypes = [ctypes.c_void_p]
+    lib.fsdp_host_is_pinned.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     lib.fsdp_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     lib.fsdp_collect.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
@@ -156,7 +157,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_comm_unique_id", "fsdp_comm_init", "fsdp_comm_size", "fsdp_comm_rank", "fsdp_comm_broadcast", "fsdp_comm_allreduce",
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path", "fsdp_skidpad_time_groups", "fsdp_skidpad_group_times", "fsdp_skidpad_submit_compact",
-    "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
+    "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_host_is_pinned", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
     "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena", "fsdp_selftest_absminmax", "fsdp_selftest_libm",
 ]
 
@@ -176,6 +177,59 @@ def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
     buf = (ctypes.c_byte * nbytes).from_address(ptr)
     weakref.finalize(buf, lib.fsdp_host_free, ptr)
     return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def is_pinned(a: np.ndarray) -> bool:
+    """Is the whole extent of this (contiguous) array page-locked as one mapping, i.e. will fsdp_submit let its kernels read /
+    write it in place?"""
+    return bool(a.flags.c_contiguous and (a.nbytes == 0 or load().fsdp_host_is_pinned(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))))
+
+
+class PinnedPool:
+    """Page-locked arrays that go back to a free list — not to hipHostFree — when the last reference to them is dropped.
+    hipHostMalloc costs about a millisecond for a 10 MB result block, a batch of 4096 frames takes 0.9 ms on the GPU: a stream of
+    batches must not allocate.  get() hands out an ordinary NumPy array (no copy is ever made of it); whoever holds it, or a view
+    of it, keeps the block."""
+
+    def __init__(self):
+        import threading
+
+        self._free = {}  # nbytes -> [address]
+        self._lock = threading.Lock()
+        self._lib = load()
+        self._closed = False
+
+    def _put(self, nbytes, ptr):
+        with self._lock:
+            if not self._closed:
+                self._free.setdefault(nbytes, []).append(ptr)
+                return
+        self._lib.fsdp_host_free(ptr)  # (an array that outlived its pool)
+
+    def get(self, n: int, dtype) -> np.ndarray:
+        import weakref
+
+        dtype = np.dtype(dtype)
+        want = max(1, int(n) * dtype.itemsize)
+        nbytes = 1 << (want - 1).bit_length()  # size classes: a stream of ragged batches reuses its blocks
+        with self._lock:
+            lst = self._free.get(nbytes)
+            ptr = lst.pop() if lst else None
+        if ptr is None:
+            ptr = self._lib.fsdp_host_alloc(nbytes)
+            if not ptr:
+                raise FsdpError(f"fsdp_host_alloc({nbytes}) failed")
+        buf = (ctypes.c_byte * nbytes).from_address(ptr)
+        weakref.finalize(buf, self._put, nbytes, ptr)
+        return np.frombuffer(buf, dtype=dtype, count=int(n))
+
+    def close(self):
+        with self._lock:
+            blocks, self._free = self._free, {}
+            self._closed = True
+        for lst in blocks.values():
+            for ptr in lst:
+                self._lib.fsdp_host_free(ptr)
 
 
 def pinned_copy(a, dtype=None) -> np.ndarray:
@@ -334,6 +388,17 @@ class Context:
                                           None if prev is None else prev.ctypes.data, out.ctypes.data, ctypes.byref(t)), "fsdp_submit")
         return Ticket(int(t.value), out, None, (offsets, cones, poses, prev))
 
+    def submit_slice(self, lo: int, hi: int, offsets, cones, poses, prev, out) -> Ticket:
+        """Frames [lo, hi) of a batch that is already in the ABI's layout (int32 offsets of the WHOLE batch, (N, 3) cones,
+        (F, 4) poses, optional (F, 40, 4) previous paths, RESULT_DTYPE out of the whole batch): the slice goes to fsdp_submit as
+        pointers into those arrays (include/fsdp.h: cone_offsets[0] need not be 0) — nothing is copied or rebased on the host."""
+        n = hi - lo
+        t = ctypes.c_longlong(-1)
+        self._check(self._lib.fsdp_submit(self._h, n, offsets.ctypes.data + 4 * lo, cones.ctypes.data if len(cones) else None,
+                                          poses.ctypes.data + 32 * lo, None if prev is None else prev.ctypes.data + prev.strides[0] * lo,
+                                          out.ctypes.data + out.strides[0] * lo, ctypes.byref(t)), "fsdp_submit")
+        return Ticket(int(t.value), out, None, (offsets, cones, poses, prev))
+
     def collect(self, ticket: Ticket) -> np.ndarray:
         """Wait for this ticket only; returns its result array."""
         self._check(self._lib.fsdp_collect(self._h, ctypes.c_longlong(ticket.id)), "fsdp_collect")
@@ -402,10 +467,11 @@ class Context:
         """Create the events of an `iters`-pass timed region ahead of time."""
         self._check(self._lib.fsdp_time_reserve(self._h, int(iters)), "fsdp_time_reserve")
 
-    def time_detail(self, every_kernel: bool):
+    def time_detail(self, every_kernel: bool, kernel_clock: bool = False):
         """Events around every kernel launch of the next time_runs (True, the default) or only around the path stage's
-        main kernel of every pass (False: the other kernels' times come back as 0)."""
-        self._check(self._lib.fsdp_time_detail(self._h, 1 if every_kernel else 0), "fsdp_time_detail")
+        main kernel of every pass (False: the other kernels' times come back as 0).  kernel_clock: the refit kernel's launches
+        also note their own start / end clock (time_kernel_clock) — two atomics per workgroup, so off unless asked for."""
+        self._check(self._lib.fsdp_time_detail(self._h, (1 if every_kernel else 0) | (2 if kernel_clock else 0)), "fsdp_time_detail")
 
     def time_results(self):
         """(ms of the whole region, summed ms per kernel) of the most recent time_runs."""

@@ -68,7 +68,21 @@ struct Inputs {
   const double* h_cones = nullptr;
   const double* h_poses = nullptr;
   const double* h_prev = nullptr;
+  int32_t h_base = 0;              // cone_offsets[0] of the caller's batch (the device copies are rebased to 0)
+  std::vector<int32_t> off_rebased;  // offsets - cone_offsets[0] for the copy paths (kept until the slot's next batch)
 };
+
+// A batch whose offsets do not start at 0 (a slice of a larger batch): the copy paths move offsets rebased to 0 and the
+// cones from the slice's first row.  Returns true when `off` now points at the slot's own (pageable) rebased copy.
+static bool rebase_batch(Inputs& in, int n_frames, const int32_t*& off, const double*& cones) {
+  if (n_frames <= 0 || off[0] == 0) return false;
+  const int32_t b = off[0];
+  in.off_rebased.resize((size_t)n_frames + 1);
+  for (int i = 0; i <= n_frames; i++) in.off_rebased[(size_t)i] = off[i] - b;
+  if (cones) cones += 3 * (size_t)b;
+  off = in.off_rebased.data();
+  return true;
+}
 
 // Tickets queue up behind each other on a slot's stream (stream order protects the slot's buffers), so a slot always has
 // its next batch waiting when the current one ends — the host's collect / submit round trip is off the GPU's critical path.
@@ -177,6 +191,7 @@ struct fsdp_ctx {
   std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
   int timed_iters = 0, timed_stages = 0;  // the most recent fsdp_time_runs (fsdp_time_results reads its events)
   bool time_main_only = false;            // fsdp_time_detail: events only around the path stage's main kernel
+  bool time_kernel_clock = false;         // fsdp_time_detail bit 1: the refit kernel's launches note their own start / end clock
   std::vector<unsigned> tev_recorded;     // per pass of the most recent fsdp_time_runs: which of its events were recorded
   unsigned long long* d_kclock = nullptr;  // [2 * kclock_cap]: first-wavefront-start | last-wavefront-end of the refit kernel, per timed pass
   int kclock_cap = 0;
@@ -428,6 +443,7 @@ static void launch_sort(fsdp_ctx* c, Work& q, const Inputs& in) {
   StageIn st;
   if (in.h_off) {
     st.src_off = in.h_off;
+    st.base = in.h_base;
     st.src_cones = in.h_cones;
     st.src_poses = in.h_poses;
     st.src_prev = in.h_prev;
@@ -757,10 +773,16 @@ static int check_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const doub
     c->err = "batch: NULL offsets / poses";
     return 1;
   }
-  *total = n_frames > 0 ? (size_t)off[n_frames] : 0;
+  // cone_offsets[0] = b >= 0: the batch's cones are the rows [b, cone_offsets[n_frames]) of cones_xyt — a slice of a larger
+  // batch is handed over by pointing at its offsets, without rebasing or copying anything (include/fsdp.h)
+  if (n_frames > 0 && off[0] < 0) {
+    c->err = "cone_offsets[0] must be >= 0";
+    return 1;
+  }
+  *total = n_frames > 0 ? (size_t)(off[n_frames] - off[0]) : 0;
   *max_cones = 0;
-  if (n_frames > 0 && off[0] != 0) {
-    c->err = "cone_offsets[0] must be 0";
+  if (n_frames > 0 && off[n_frames] < off[0]) {
+    c->err = "cone_offsets must be non-decreasing";
     return 1;
   }
   for (int i = 0; i < n_frames; i++) {
@@ -786,6 +808,7 @@ static int upload_inputs(fsdp_ctx* c, Inputs& in, hipStream_t stream, int n_fram
   in.max_cones = max_cones;
   in.use_prev = prev != nullptr;
   if (n_frames == 0) return 0;
+  (void)rebase_batch(in, n_frames, off, cones);
   HIP_TRY(c, hipMemcpyAsync(in.d_off, off, sizeof(int32_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, stream));
   if (total) HIP_TRY(c, hipMemcpyAsync(in.d_cones, cones, sizeof(double) * 3 * total, hipMemcpyHostToDevice, stream));
   HIP_TRY(c, hipMemcpyAsync(in.d_poses, poses, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, stream));
@@ -803,7 +826,10 @@ static int stage_inputs(fsdp_ctx* c, Inputs& in, hipStream_t stream, int n_frame
   if (n_frames == 0) return 0;
   CopySegs S;
   S.n = 0;
-  S.seg[S.n++] = CopySeg{device_view(off), in.d_off, sizeof(int32_t) * ((unsigned long long)n_frames + 1)};
+  if (rebase_batch(in, n_frames, off, cones))  // (the slot's rebased copy is pageable: its 4 bytes per frame go by the copy engine)
+    HIP_TRY(c, hipMemcpyAsync(in.d_off, off, sizeof(int32_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, stream));
+  else
+    S.seg[S.n++] = CopySeg{device_view(off), in.d_off, sizeof(int32_t) * ((unsigned long long)n_frames + 1)};
   if (total) S.seg[S.n++] = CopySeg{device_view(cones), in.d_cones, sizeof(double) * 3ull * total};
   S.seg[S.n++] = CopySeg{device_view(poses), in.d_poses, sizeof(double) * 4ull * (unsigned long long)n_frames};
   if (prev) S.seg[S.n++] = CopySeg{device_view(prev), in.d_prev, sizeof(double) * PATH_POINTS * 4ull * (unsigned long long)n_frames};
@@ -1023,6 +1049,8 @@ int fsdp_host_unregister(void* p) {
   return 0;
 }
 
+int fsdp_host_is_pinned(const void* p, size_t bytes) { return (p && is_pinned(p, bytes)) ? 1 : 0; }
+
 // ---- the resident batch ------------------------------------------------------------------------------------------------
 int fsdp_upload(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses) {
   if (!c) return 1;
@@ -1159,7 +1187,7 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
   if (n > q.cap_frames || n > q.in.cap_frames || t.total > q.in.cap_cones || (t.prev && n > q.in.cap_prev)) HIP_TRY(c, hipStreamSynchronize(q.stream));
   if (int rc = ensure_work(c, q, n > 0 ? n : 1)) return rc;
   const bool in_pinned = !force_sdma && n > 0 && is_pinned(t.off, sizeof(int32_t) * ((size_t)n + 1)) && is_pinned(t.poses, sizeof(double) * 4 * (size_t)n) &&
-                         (t.total == 0 || is_pinned(t.cones, sizeof(double) * 3 * t.total)) &&
+                         (t.total == 0 || is_pinned(t.cones + 3 * (size_t)t.off[0], sizeof(double) * 3 * t.total)) &&
                          (!t.prev || is_pinned(t.prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n));
   const bool out_pinned = n > 0 && is_pinned(t.user_results, sizeof(fsdp_frame_result) * (size_t)n);
   static const bool no_fuse = getenv("FSDP_STAGE_KERNEL") != nullptr;  // experiments: a separate stage_in_kernel in front of the pass
@@ -1173,7 +1201,9 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
       q.in.max_cones = t.max_cones;
       q.in.use_prev = t.prev != nullptr;
       q.in.h_off = (const int32_t*)device_view(t.off);
-      q.in.h_cones = t.total ? (const double*)device_view(t.cones) : (const double*)device_view(t.poses);  // (never read when total = 0)
+      q.in.h_base = t.off[0];
+      // (the view of the slice's first row, addressed by offsets relative to h_base; never read when total = 0)
+      q.in.h_cones = t.total ? (const double*)device_view(t.cones + 3 * (size_t)t.off[0]) : (const double*)device_view(t.poses);
       q.in.h_poses = (const double*)device_view(t.poses);
       q.in.h_prev = t.prev ? (const double*)device_view(t.prev) : nullptr;
     } else if (in_pinned) {
@@ -1551,8 +1581,10 @@ int fsdp_time_runs(fsdp_ctx* c, int iters, float* ms_total, float* ms_stage) {
     StageEvents t;
     t.ev = &c->tev[(size_t)EPP * (size_t)it];
     t.main_only = c->time_main_only;
-    t.clock_first = c->d_kclock + it;
-    t.clock_last = c->d_kclock + c->kclock_cap + it;
+    // (opt-in, fsdp_time_detail bit 1: the readings are two atomics per workgroup on one address — the launches of a region
+    // timed without them are the production launches)
+    t.clock_first = c->time_kernel_clock ? c->d_kclock + it : nullptr;
+    t.clock_last = c->time_kernel_clock ? c->d_kclock + c->kclock_cap + it : nullptr;
     if ((rc = launch_pass(c, q, c->res, &t))) return rc;
     n_stages = t.n - 1;
     c->tev_recorded[it] = t.recorded;
@@ -1599,7 +1631,8 @@ int fsdp_time_kernel_clock(fsdp_ctx* c, double* ms_sum, int* launches) {
 
 int fsdp_time_detail(fsdp_ctx* c, int every_kernel) {
   if (!c) return 1;
-  c->time_main_only = every_kernel == 0;
+  c->time_main_only = (every_kernel & 1) == 0;
+  c->time_kernel_clock = (every_kernel & 2) != 0;
   return 0;
 }
 
@@ -2008,7 +2041,9 @@ static int flush_skid(fsdp_ctx* c) {
     t.pending = false;
     // page-locked results: assemble_kernel writes them into the caller's buffer (over PCIe); the planners' information
     // records ride along into the ticket's pinned block
-    fsdp_frame_result* direct = t.user_results ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
+    // (only a buffer that is page-locked over its WHOLE extent — decided at submit time, `via_stage` otherwise: a view
+    // that merely starts inside a registered range must not be written from the device)
+    fsdp_frame_result* direct = (t.user_results && !t.via_stage) ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
     if (t.compact) {
       // compact results = the path stage's own records: one plain copy (and the information records) instead of the assembly of
       // 2.4 KB results whose sorting / matching fields a skidpad step leaves empty anyway

@@ -1183,6 +1183,7 @@ struct StageIn {
   double* dst_poses = nullptr;
   double* dst_prev = nullptr;
   int n_frames = 0;
+  int32_t base = 0;                   // src_off[0]: src_cones points at row `base` of the caller's array, the device copies start at 0
 };
 
 // The sorting stage of one frame on one wavefront; S = the frame state (LDS or global memory).
@@ -1193,8 +1194,8 @@ __device__ inline void sort_frame(SH& S, const Params& P, int frame, const int32
   const bool staging = stage.src_off != nullptr;
   const int32_t* offs = staging ? stage.src_off : cone_offsets;
   const double* pose_src = staging ? stage.src_poses : poses;
-  const int off = offs[frame];
-  int n = offs[frame + 1] - off;
+  const int off = offs[frame] - (staging ? stage.base : 0);  // (a slice of a larger batch keeps its offsets: fsdp.h fsdp_submit)
+  int n = offs[frame + 1] - offs[frame];
   const int n_all = n;
   const double px = pose_src[4 * frame + 0], py = pose_src[4 * frame + 1], dx = pose_src[4 * frame + 2], dy = pose_src[4 * frame + 3];
   if (staging) {

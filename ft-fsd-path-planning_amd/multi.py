@@ -39,7 +39,7 @@ def visible_devices() -> List[int]:
 class _Staging:
     """Page-locked input buffers of one shard: fsdp_submit reads page-locked memory from inside the slot's own kernels
     (no blocking copy), pageable memory is staged by the runtime and blocks the host thread — which would serialise the
-    GPUs behind one another."""
+    GPUs behind one another.  Only batches that are NOT already page-locked come through here (MultiPlanner.submit)."""
 
     def __init__(self):
         self.off = self.cones = self.poses = self.prev = None
@@ -66,15 +66,26 @@ class _Staging:
 
 
 class MultiTicket:
-    __slots__ = ("parts", "out")
+    __slots__ = ("parts", "out", "host_s")
 
-    def __init__(self, parts, out):
-        self.parts, self.out = parts, out
+    def __init__(self, parts, out, host_s=0.0):
+        self.parts, self.out, self.host_s = parts, out, host_s
 
 
 class MultiPlanner:
     """plan_batch over every visible GPU (or the given ``devices``; a device may appear more than once — two contexts
-    on one GPU is how the 1-GPU test box exercises this class)."""
+    on one GPU is how the 1-GPU test box exercises this class).
+
+    What the one calling thread does per batch (round 4 copied ~5.5 KB per frame through it — 26 GB/s of memcpy at ONE GPU's
+    streaming rate, so the class could not scale): a batch whose arrays are page-locked (``pinned_empty`` / ``pinned_copy`` /
+    ``fsdp_host_register``) is sharded ZERO-COPY — every context gets pointers into the caller's own arrays
+    (``Context.submit_slice``; include/fsdp.h: cone_offsets[0] need not be 0) and reads its slice over PCIe from inside its
+    sorting kernel; a pageable batch is staged into page-locked buffers by one worker thread per context, in parallel (NumPy's
+    copies release the GIL); results are written by the GPUs straight into one page-locked array of the whole batch, which is
+    what ``collect`` / ``plan_batch`` / ``plan_stream`` RETURN — no copy; the block goes back to a free list when the last
+    reference to it is dropped (``_capi.PinnedPool``)."""
+
+    STAGE_THREADS_MIN_FRAMES = 256  # below this a shard is staged inline (a thread hand-off costs ~50 us)
 
     def __init__(self, devices: Sequence[int] | None = None, params: dict | None = None, mission: int = 4, overlap: int = 2):
         devices = visible_devices() if devices is None else [int(d) for d in devices]
@@ -82,6 +93,12 @@ class MultiPlanner:
             raise _capi.FsdpError("MultiPlanner: no GPU visible (this package has no CPU fallback)")
         self.devices = devices
         self.ctx = [_capi.Context(device=d, mission=mission, params=params) for d in devices]
+        self._pool = _capi.PinnedPool()
+        self._workers = None
+        self.host_seconds = 0.0   # time the calling thread spent inside submit() since the last reset_host_time()
+        self.host_frames = 0
+        self.zero_copy_batches = 0
+        self.staged_batches = 0
         # staging sets per context: a batch's inputs must stay untouched until its ticket is collected, and `overlap`
         # batches per context may be in flight
         self._overlap = 0
@@ -104,52 +121,88 @@ class MultiPlanner:
         for c in self.ctx:
             c.set_global_path(xy)
 
+    def reset_host_time(self):
+        self.host_seconds, self.host_frames = 0.0, 0
+
     def close(self):
+        if self._workers is not None:
+            for w in self._workers:
+                w.shutdown(wait=True)
+            self._workers = None
         for c in self.ctx:
             c.close()
+        self._pool.close()
 
     # ---- one batch --------------------------------------------------------------------------------------------------
+    def _stage_and_submit(self, g, lo, hi, offsets, cones, poses, prev, out):
+        st = self._stage[g][self._turn[g] % len(self._stage[g])]
+        self._turn[g] += 1
+        o, c, p, q = st.load(offsets[lo : hi + 1], cones[offsets[lo] : offsets[hi]], poses[lo:hi], None if prev is None else prev[lo:hi])
+        return self.ctx[g].submit(o, c, p, q, out=out[lo:hi])
+
     def submit(self, offsets, cones, poses, prev_paths=None, out: np.ndarray | None = None) -> MultiTicket:
         """Cut the batch, enqueue every shard on its GPU, return at once.  ``out``: page-locked RESULT_DTYPE array of the
-        whole batch (``pinned_empty``); every GPU writes its range of it."""
+        whole batch (``pinned_empty``); every GPU writes its range of it.  Default: a block of the planner's pool."""
+        import time
+
+        t0 = time.perf_counter()
         offsets, cones, poses, n = _capi.Context._prep(offsets, cones, poses)
         prev = None if prev_paths is None else self.ctx[0].pad_paths(prev_paths)
         if prev is not None and len(prev) != n:
             raise ValueError("prev_paths: one (horizon, 4) path per frame")
         if out is None:
-            out = _capi.pinned_empty(n, _capi.RESULT_DTYPE)
+            out = self._pool.get(n, _capi.RESULT_DTYPE)
         assert out.dtype == _capi.RESULT_DTYPE and len(out) == n and out.flags.c_contiguous
+        ranges = [(g, lo, hi) for g, (lo, hi) in enumerate(shard_ranges(n, len(self.ctx))) if hi > lo]
+        zero_copy = n > 0 and _capi.is_pinned(offsets) and _capi.is_pinned(poses) and (len(cones) == 0 or _capi.is_pinned(cones)) and (
+            prev is None or _capi.is_pinned(prev))
         parts = []
-        for g, (lo, hi) in enumerate(shard_ranges(n, len(self.ctx))):
-            if hi == lo:
-                continue
-            st = self._stage[g][self._turn[g] % len(self._stage[g])]
-            self._turn[g] += 1
-            o, c, p, q = st.load(offsets[lo : hi + 1], cones[offsets[lo] : offsets[hi]], poses[lo:hi], None if prev is None else prev[lo:hi])
-            parts.append((g, self.ctx[g].submit(o, c, p, q, out=out[lo:hi])))
-        return MultiTicket(parts, out)
+        if zero_copy:
+            self.zero_copy_batches += 1
+            for g, lo, hi in ranges:
+                parts.append((g, self.ctx[g].submit_slice(lo, hi, offsets, cones, poses, prev, out)))
+        elif len(ranges) > 1 and n >= self.STAGE_THREADS_MIN_FRAMES * len(ranges):
+            # pageable input: every context's worker copies its shard into page-locked staging and submits it; the caller's
+            # arrays are his again when submit returns
+            self.staged_batches += 1
+            if self._workers is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                self._workers = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"fsdp-stage-{g}") for g in range(len(self.ctx))]
+            futs = [(g, self._workers[g].submit(self._stage_and_submit, g, lo, hi, offsets, cones, poses, prev, out)) for g, lo, hi in ranges]
+            parts = [(g, f.result()) for g, f in futs]
+        else:
+            self.staged_batches += 1
+            for g, lo, hi in ranges:
+                parts.append((g, self._stage_and_submit(g, lo, hi, offsets, cones, poses, prev, out)))
+        dt = time.perf_counter() - t0
+        self.host_seconds += dt
+        self.host_frames += n
+        return MultiTicket(parts, out, dt)
 
     def collect(self, ticket: MultiTicket) -> np.ndarray:
+        """Wait for the batch; returns the page-locked result array the GPUs wrote (not a copy)."""
         for g, t in ticket.parts:
             self.ctx[g].collect(t)
         return ticket.out
 
     def plan_batch(self, offsets, cones, poses, prev_paths=None) -> np.ndarray:
         """The bytes of ``Context.plan_batch`` / ``plan_batch_sequential`` over the whole batch, planned on all GPUs."""
-        return np.array(self.collect(self.submit(offsets, cones, poses, prev_paths)))
+        return self.collect(self.submit(offsets, cones, poses, prev_paths))
 
     # ---- a stream of batches ----------------------------------------------------------------------------------------
     def plan_stream(self, batches, depth: int | None = None):
         """Yield the results of an iterable of batches ``(offsets, cones, poses)`` in order, `depth` batches in flight on
-        every GPU (default: the overlap depth)."""
+        every GPU (default: the overlap depth).  Every yielded array is the page-locked block its GPUs wrote; drop it (and
+        its views) and the block serves a later batch."""
         depth = self._overlap if depth is None else max(1, min(int(depth), self._overlap))
         inflight = []
         for b in batches:
             if len(inflight) == depth:
-                yield np.array(self.collect(inflight.pop(0)))
+                yield self.collect(inflight.pop(0))
             inflight.append(self.submit(*b))
         for t in inflight:
-            yield np.array(self.collect(t))
+            yield self.collect(t)
 
 
 class MultiSkidpadBatch:
@@ -169,6 +222,7 @@ class MultiSkidpadBatch:
         self.tables = self.parts[0].tables
         self._depth = 1
         self._stage, self._turn = None, 0
+        self._pool = _capi.PinnedPool()
 
     @property
     def constants(self):
@@ -186,10 +240,15 @@ class MultiSkidpadBatch:
         self._turn = 0
 
     def submit(self, cone_offsets, cones_xyt, poses, out=None, info=None, compact: bool = False):
+        """One step of every planner as a ticket.  ``out``: page-locked array of the whole batch, RESULT_DTYPE or — compact —
+        PATH_RESULT_DTYPE (default: a block of this object's pool, returned to it when the last reference is dropped)."""
         off, cones, poses, n = _capi.Context._prep(cone_offsets, cones_xyt, poses)
         assert n == self.n
+        want = _capi.PATH_RESULT_DTYPE if compact else _capi.RESULT_DTYPE
         if out is None:
-            out = _capi.pinned_empty(n, _capi.PATH_RESULT_DTYPE if compact else _capi.RESULT_DTYPE)
+            out = self._pool.get(n, want)
+        if out.dtype != want:
+            raise ValueError(f"out.dtype is {out.dtype}, compact={compact} asks for {want}")
         if info is None:
             info = np.zeros(n, dtype=self._info_dtype)
         if self._stage is None:
@@ -199,7 +258,7 @@ class MultiSkidpadBatch:
         tickets = []
         for g, ((lo, hi), part) in enumerate(zip(self.ranges, self.parts)):
             o, c, p, _ = self._stage[g][k].load(off[lo : hi + 1], cones[off[lo] : off[hi]], poses[lo:hi], None)
-            tickets.append(part.submit(o, c, p, out=out[lo:hi], info=info[lo:hi]))
+            tickets.append(part.submit(o, c, p, out=out[lo:hi], info=info[lo:hi], compact=compact))
         return MultiTicket(tickets, (out, info))
 
     def collect(self, ticket: MultiTicket):
@@ -209,17 +268,19 @@ class MultiSkidpadBatch:
 
     def step(self, cone_offsets, cones_xyt, poses):
         out, info = self.collect(self.submit(cone_offsets, cones_xyt, poses))
-        return np.array(out), info
+        return out, info
 
     def replay(self, frames, depth: int = 32, compact: bool = False):
-        """SkidpadBatch.replay over all GPUs: `depth` steps submitted ahead on every context."""
+        """SkidpadBatch.replay over all GPUs: `depth` steps submitted ahead on every context.  The yielded result arrays are
+        the page-locked blocks the GPUs wrote (a pool: a block serves a later step once its array has been dropped)."""
         self.set_overlap(depth)
         inflight = []
         for f in frames:
             if len(inflight) == depth:
-                res, info = self.collect(inflight.pop(0))
-                yield np.array(res), info
+                yield self.collect(inflight.pop(0))
             inflight.append(self.submit(*f, compact=compact))
         for t in inflight:
-            res, info = self.collect(t)
-            yield np.array(res), info
+            yield self.collect(t)
+
+    def close(self):
+        self._pool.close()

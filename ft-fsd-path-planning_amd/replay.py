@@ -34,19 +34,59 @@ def select_mission_by_filename(filename: str) -> MissionTypes:
     return MissionTypes.trackdrive
 
 
+class Recording:
+    """A JSON recording in the layout the C ABI takes (include/fsdp.h): one (N, 3) [x, y, type] cone array for all frames
+    in the reference's flatten order (UNKNOWN, RIGHT, LEFT, ORANGE_SMALL, ORANGE_BIG — core_trace_sorter.py:37-54), CSR
+    offsets (F + 1,) and poses (F, 4) [px, py, dx, dy].  File schema (what demo/json_demo.py reads): a list of frames
+    {"car_position": [x, y], "car_direction": [dx, dy], "slam_cones": [5 lists of [x, y], one per ConeTypes value]}."""
+
+    N_TYPES = len(ConeTypes)
+
+    def __init__(self, offsets: np.ndarray, cones: np.ndarray, poses: np.ndarray):
+        self.offsets, self.cones, self.poses = offsets, cones, poses
+
+    @classmethod
+    def from_json(cls, data_path: Path) -> "Recording":
+        frames = json.loads(Path(data_path).read_text())
+        counts = np.array([[len(lst) for lst in f["slam_cones"]] for f in frames], dtype=np.int64).reshape(len(frames), cls.N_TYPES)
+        offsets = np.zeros(len(frames) + 1, dtype=np.int32)
+        np.cumsum(counts.sum(axis=1), out=offsets[1:])
+        cones = np.empty((int(offsets[-1]), 3))
+        poses = np.empty((len(frames), 4))
+        for k, f in enumerate(frames):
+            poses[k, :2] = f["car_position"]
+            poses[k, 2:] = f["car_direction"]
+            at = int(offsets[k])
+            for cone_type, lst in enumerate(f["slam_cones"]):
+                if lst:
+                    cones[at:at + len(lst), :2] = lst
+                    cones[at:at + len(lst), 2] = cone_type
+                    at += len(lst)
+        return cls(offsets, cones, poses)
+
+    def without_color(self) -> "Recording":
+        """Every cone UNKNOWN.  The cones of a frame are already stacked in type order, which is the order the reference's
+        colour stripping leaves them in (json_demo.py:266-273), so only the type column changes."""
+        cones = self.cones.copy()
+        cones[:, 2] = float(ConeTypes.UNKNOWN)
+        return Recording(self.offsets, cones, self.poses)
+
+    def __len__(self) -> int:
+        return len(self.poses)
+
+    def frame_cones_by_type(self, k: int) -> List[np.ndarray]:
+        """Frame k as the five per-type (n, 2) arrays `calculate_path_in_global_frame` takes."""
+        block = self.cones[self.offsets[k]:self.offsets[k + 1]]
+        return [block[block[:, 2] == t, :2] for t in range(self.N_TYPES)]
+
+
 def load_data_json(data_path: Path, remove_color_info: bool = False) -> Tuple[np.ndarray, np.ndarray, List[List[np.ndarray]]]:
-    data = json.loads(Path(data_path).read_text())
-    positions = np.array([d["car_position"] for d in data], dtype=float).reshape(-1, 2)
-    directions = np.array([d["car_direction"] for d in data], dtype=float).reshape(-1, 2)
-    observations = [[np.array(c, dtype=float).reshape(-1, 2) for c in d["slam_cones"]] for d in data]
+    """(positions (F, 2), directions (F, 2), per frame the five per-type cone arrays) — the tuple the reference's loader
+    returns, cut out of a `Recording`."""
+    rec = Recording.from_json(data_path)
     if remove_color_info:
-        stripped = []
-        for cones in observations:
-            new = [np.zeros((0, 2)) for _ in range(5)]
-            new[int(ConeTypes.UNKNOWN)] = np.concatenate([c.reshape(-1, 2) for c in cones], axis=0)  # stacked in type order
-            stripped.append(new)
-        observations = stripped
-    return positions, directions, observations
+        rec = rec.without_color()
+    return rec.poses[:, :2].copy(), rec.poses[:, 2:].copy(), [rec.frame_cones_by_type(k) for k in range(len(rec))]
 
 
 def replay_per_frame(mission, positions, directions, observations, device=None):

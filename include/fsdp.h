@@ -151,6 +151,10 @@ const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creat
 /* calculate_path_in_global_frame for a batch of independent frames (fresh-planner semantics).
  * cone_offsets: (n_frames+1) CSR offsets; cones_xyt: (total,3) rows [x,y,ConeTypes] — the reference's own
  * flattened layout (core_trace_sorter.py:37-54); poses: (n_frames,4) rows [px,py,dir_x,dir_y].
+ * Frame i owns the rows [cone_offsets[i], cone_offsets[i+1]) of cones_xyt.  cone_offsets[0] need not be 0 (every batch
+ * entry point): a SLICE [lo, hi) of a larger batch is handed over as (hi - lo, cone_offsets + lo, cones_xyt, poses + 4 lo,
+ * results + lo) — the larger batch's own offsets and cone array, nothing rebased or copied (how multi.py shards one
+ * page-locked batch over the GPUs of a node).  Sorted indices of a result stay frame-relative.
  * Host buffers; does H2D, the kernels of a pass and D2H on the context's stream, then synchronises. */
 int fsdp_plan_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
                     const double* poses, fsdp_frame_result* results);
@@ -194,6 +198,10 @@ void* fsdp_host_alloc(size_t bytes);            /* page-locked host memory (hipH
 void fsdp_host_free(void* p);
 int fsdp_host_register(void* p, size_t bytes);  /* pin memory the caller owns (hipHostRegister) */
 int fsdp_host_unregister(void* p);
+/* 1 if [p, p + bytes) is page-locked over its whole extent as ONE mapping (what fsdp_submit requires of a buffer before it
+ * lets kernels read / write it in place), else 0 — a caller that shards one batch over several contexts (multi.py) asks
+ * once and then hands out slices without copying them. */
+int fsdp_host_is_pinned(const void* p, size_t bytes);
 int fsdp_submit(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses,
                 const double* prev_paths, fsdp_frame_result* results, long long* ticket);
 int fsdp_collect(fsdp_ctx* ctx, long long ticket);
@@ -241,10 +249,12 @@ int fsdp_time_runs(fsdp_ctx* ctx, int iters, float* ms_total, float* ms_stage);
  * enqueues the passes and returns
  * when the last one has finished (no event is read), fsdp_time_results reads the times of that most recent region. */
 int fsdp_time_reserve(fsdp_ctx* ctx, int iters);
-/* Which launches the next fsdp_time_runs brackets with events: every kernel (1, the default), or only the main kernel of
- * the path stage — fit_kernel, or path_kernel<64> for small batches — of every pass (0): an event record is a packet in
- * the stream's queue, and seven of them per pass cost about 3 % of the throughput of overlapped passes.  ms_stage entries
- * of kernels that were not bracketed are 0.  (Reference: the Timer context managers of full_pipeline.py:113-176 time the
+/* Which launches the next fsdp_time_runs brackets with events: every kernel (bit 0 set; 1 is the default), or only the main
+ * kernel of the path stage — fit_kernel, or path_kernel<64> for small batches — of every pass (bit 0 clear): an event record is
+ * a packet in the stream's queue, and seven of them per pass cost about 3 % of the throughput of overlapped passes.  ms_stage
+ * entries of kernels that were not bracketed are 0.  Bit 1 (value 2) additionally lets every launch of the refit kernel note
+ * its own start / end clock for fsdp_time_kernel_clock (two atomics per workgroup: off by default, so that a region timed
+ * without it runs the production launches unchanged).  (Reference: the Timer context managers of full_pipeline.py:113-176 time the
  * stages on the host; they are switched off in the reference's own benchmark runs.) */
 int fsdp_time_detail(fsdp_ctx* ctx, int every_kernel);
 int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
@@ -252,7 +262,8 @@ int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
  * region notes when its first wavefront started and its last one ended (the device's constant-rate counter, s_memrealtime),
  * i.e. the duration a kernel trace reports — without the time the launch waited in its hardware queue, which an event bracket
  * on the stream includes when twenty streams share the command processor.  *ms_sum = summed duration, *launches = how many
- * launches it covers (0 when the region ran the one-kernel path stage).  No counterpart in the reference (measurement only). */
+ * launches it covers (0 when the region ran the one-kernel path stage, or was timed without bit 1 of fsdp_time_detail).
+ * No counterpart in the reference (measurement only). */
 int fsdp_time_kernel_clock(fsdp_ctx* ctx, double* ms_sum, int* launches);
 /* comma-separated kernel names behind ms_stage of the most recent pass, e.g.
  * "sort_kernel_128,match_kernel<32>,path_prep_kernel<8>,fit_kernel<4>,path_finish_kernel<8>,assemble_kernel" */
@@ -393,8 +404,8 @@ int fsdp_selftest_det3(fsdp_ctx* ctx, int n, const double* xy6, double* out);
 /* The device's libm where discrete decisions of the sorting stage take its values (the reference compares angles from
  * np.arctan2 / np.arccos: sorting_cones/trace_sorter/end_configurations.py:108-223, cost_function.py:40-120,
  * core_trace_sorter.py:344-377): out3n = [atan2(y, x) of the ROCm device library | det_atan2(y, x), the correctly rounded
- * value (csrc/det_math.h) | acos(cs)].  A test holds the first to within 1 ulp of the second on 10^6 arguments and the third to
- * within 2 ulp of the host's, so that a ROCm release that moves them cannot move a sorted index silently. */
+ * value (csrc/det_math.h) | acos(cs)].  A test holds the first to within 2 ulp of the second on 10^6 arguments (fewer than 1 % of
+ * them at 2 ulp) and the third to within 2 ulp of the host's, so that a ROCm release that moves them cannot move a sorted index silently. */
 int fsdp_selftest_libm(fsdp_ctx* ctx, int n, const double* y, const double* x, const double* cs, double* out3n);
 
 /* The constant initial previous path (core_calculate_path.py:103-107), (40,4), as computed on the device. */

@@ -78,6 +78,13 @@ def test_replay_loader_matches_reference_schema(pkg, golden_dir, tmp_path):
     for a, b in zip(obs, obs2):
         assert sum(len(x) for x in a) == len(b[0]) and all(len(x) == 0 for x in b[1:])
         assert np.array_equal(np.concatenate(a), b[0])  # stacked in type order
+    # the packed form the loader is built around equals the frames it was written from, and pack_frames of the per-type lists
+    rec = pkg.replay.Recording.from_json(f)
+    assert np.array_equal(rec.cones, g["cones"][g["offsets"][5] : g["offsets"][30]]) and np.array_equal(rec.poses, g["poses"][5:30])
+    assert np.array_equal(rec.offsets, g["offsets"][5:31] - g["offsets"][5])
+    off, cones, poses = pkg.planner.pack_frames(list(zip(obs, pos, dirs)))
+    assert np.array_equal(off, rec.offsets) and np.array_equal(cones, rec.cones) and np.array_equal(poses, rec.poses)
+    assert (rec.without_color().cones[:, 2] == 0).all() and np.array_equal(rec.without_color().cones[:, :2], rec.cones[:, :2])
     assert pkg.replay.select_mission_by_filename(f.name) == pkg.MissionTypes.skidpad
     assert pkg.replay.select_mission_by_filename("accel_run.json") == pkg.MissionTypes.acceleration
     assert pkg.replay.select_mission_by_filename("fsg_19_2_laps.json") == pkg.MissionTypes.trackdrive

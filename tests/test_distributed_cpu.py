@@ -111,17 +111,20 @@ def test_stranger_and_other_launch_on_the_port_span_are_skipped():
                 return
 
     threading.Thread(target=babble, daemon=True).start()
-    stars = {}
+    stars, errors = {}, {}
 
-    def rank0(key, name):
+    def rank0(key, name, timeout):
         os.environ["FSDP_LAUNCH_KEY"] = key  # (read at construction)
-        stars[name] = pkg.dist.Star(0, 2, "127.0.0.1", port, connect_timeout=30)
+        try:
+            stars[name] = pkg.dist.Star(0, 2, "127.0.0.1", port, connect_timeout=timeout)
+        except Exception as e:  # launch B's rank 0 never sees its rank 1: kept for the assertion below, not left to the thread
+            errors[name] = e
 
     os.environ["FSDP_LAUNCH_KEY"] = "launch-B"
-    tb = threading.Thread(target=rank0, args=("launch-B", "B"), daemon=True)
+    tb = threading.Thread(target=rank0, args=("launch-B", "B", 6.0), daemon=True)
     tb.start()
     time.sleep(0.5)  # B's rank 0 holds port + 2
-    ta = threading.Thread(target=rank0, args=("launch-A", "A"), daemon=True)
+    ta = threading.Thread(target=rank0, args=("launch-A", "A", 30.0), daemon=True)
     ta.start()
     time.sleep(0.5)  # A's rank 0 holds port + 3
     os.environ["FSDP_LAUNCH_KEY"] = "launch-A"
@@ -134,7 +137,10 @@ def test_stranger_and_other_launch_on_the_port_span_are_skipped():
     mine = client.allreduce(np.array([3.0, 2.0]), 1)
     th.join(timeout=10)
     assert mine.tolist() == [3.0, 5.0] and got[0].tolist() == [3.0, 5.0]
-    # launch B never gets its rank 1: a clear timeout, not a hang
+    # launch B never gets its rank 1: a clear timeout, not a hang — and the helper thread is joined, not abandoned
+    tb.join(timeout=20)
+    assert not tb.is_alive() and "B" not in stars
+    assert isinstance(errors.get("B"), TimeoutError) and "only ranks" in str(errors["B"])
     client.close()
     stars["A"].close()
     stranger.close()

@@ -121,3 +121,89 @@ def test_sharded_skidpad_instances_equal_one_batch(pkg, golden_dir):
             assert _same(res, ref[t][0]) and _same(info, ref[t][1]), (devs, t)
         for t, (res, info) in enumerate(mb.replay(frames[30:], 16), start=30):
             assert _same(res, ref[t][0]) and _same(info, ref[t][1]), (devs, t)
+
+
+def test_page_locked_batch_is_sharded_without_a_host_copy(pkg):
+    """A batch that already lives in page-locked memory goes to its GPUs as slices of the caller's own arrays (fsdp_submit with
+    cone_offsets[0] != 0, Context.submit_slice): same bytes as one context, no staging, and the result is the page-locked block
+    the GPUs wrote — handed back, not copied, and reused for a later batch once it has been dropped."""
+    capi = pkg._capi
+    off, cones, poses = pkg.synth.make_replay_batch(3001, 64, 0.15, seed=5, color=True)
+    one = pkg.Context(device=0)
+    ref = one.plan_batch(off, cones, poses)
+    prev = np.repeat(one.default_path()[None], len(poses), axis=0)
+    prev[:, :, 2] += np.linspace(-0.4, 0.4, len(poses))[:, None]
+    ref_prev = one.plan_batch_sequential(off, cones, poses, prev)
+    p_off, p_cones, p_poses, p_prev = capi.pinned_copy(off, np.int32), capi.pinned_copy(cones), capi.pinned_copy(poses), capi.pinned_copy(one.pad_paths(prev))
+    assert capi.is_pinned(p_cones) and not capi.is_pinned(cones) and not capi.is_pinned(p_cones[1:].reshape(-1)[:-1][::2])
+    for devs in _device_sets(pkg):
+        mp = pkg.MultiPlanner(devs)
+        got = mp.plan_batch(p_off, p_cones, p_poses)
+        assert mp.zero_copy_batches == 1 and mp.staged_batches == 0
+        assert _same(got, ref), devs
+        assert capi.is_pinned(got)
+        where = got.ctypes.data
+        del got
+        got = mp.plan_batch(p_off, p_cones, p_poses, prev_paths=p_prev)
+        assert got.ctypes.data == where  # the block of the dropped result
+        assert _same(got, ref_prev), devs
+        assert mp.zero_copy_batches == 2 and mp.host_frames == 2 * len(poses) and mp.host_seconds > 0
+        # the same batch from pageable arrays: staged by the contexts' worker threads, same bytes
+        got2 = mp.plan_batch(off, cones, poses)
+        assert mp.staged_batches == 1 and _same(got2, ref), devs
+        # a stream of page-locked batches, results kept: every one owns its block
+        outs = list(mp.plan_stream([(p_off, p_cones, p_poses)] * 5, depth=2))
+        assert len({o.ctypes.data for o in outs}) == 5 and all(_same(o, ref) for o in outs)
+        mp.close()
+
+
+def test_slices_of_a_batch_through_the_c_abi(pkg):
+    """include/fsdp.h: cone_offsets[0] need not be 0.  Slices [lo, hi) of one batch — pageable and page-locked, default and
+    UNKNOWN-filtering contexts (the three input routes: copy engine, the sorting kernel reading the host buffer, the staging
+    kernel) — equal the same frames planned as a batch of their own; sorted indices stay frame-relative."""
+    capi = pkg._capi
+    off, cones, poses = pkg.synth.make_replay_batch(900, 64, 0.15, seed=6, color=True)
+    rng = np.random.default_rng(0)
+    cones = cones.copy()
+    cones[rng.random(len(cones)) < 0.3, 2] = 0.0  # some UNKNOWN cones for the filtering context
+    for params in (None, {"use_unknown_cones": False}):
+        ctx = pkg.Context(device=0, params=params)
+        ref = ctx.plan_batch(off, cones, poses)
+        for pinned in (False, True):
+            o, c, p = (capi.pinned_copy(off, np.int32), capi.pinned_copy(cones), capi.pinned_copy(poses)) if pinned else (off, cones, poses)
+            out = capi.pinned_empty(len(poses), capi.RESULT_DTYPE)
+            out["status"] = -7
+            ctx.set_overlap(3)
+            tickets = [ctx.submit_slice(lo, hi, o, c, p, None, out) for lo, hi in ((0, 300), (300, 301), (301, 900))]
+            for t in tickets:
+                ctx.collect(t)
+            ctx.set_overlap(1)
+            assert _same(out, ref), (params, pinned)
+    # the blocking entry point takes a slice as well
+    import ctypes
+
+    ctx = pkg.Context(device=0)
+    ref = ctx.plan_batch(off, cones, poses)
+    lo, hi = 123, 457
+    out = np.zeros(hi - lo, dtype=capi.RESULT_DTYPE)
+    rc = ctx._lib.fsdp_plan_batch(ctx._h, hi - lo, capi._ip(off[lo:]), capi._dp(cones), capi._dp(poses[lo:]), ctypes.c_void_p(out.ctypes.data))
+    assert rc == 0 and _same(out, ref[lo:hi])
+
+
+def test_sharded_skidpad_compact_results(pkg, golden_dir):
+    """MultiSkidpadBatch forwards `compact` (round-4 advisor: it used to rely on the part re-deriving it from out.dtype) and
+    refuses an `out` of the other dtype; compact replays equal the one-context compact replay."""
+    n = 32
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, n)
+    frames = [sk.batch_for_step(g, t, tf) for t in range(40)]
+    one = pkg.SkidpadBatch(n, device=0)
+    ref = [(r.copy(), i.copy()) for r, i in one.replay(frames, 8, compact=True)]
+    mb = pkg.SkidpadBatch(n, devices=[0, 0])
+    got = list(mb.replay(frames, 8, compact=True))
+    assert got[0][0].dtype == pkg._capi.PATH_RESULT_DTYPE
+    for t, ((r, i), (rr, ri)) in enumerate(zip(got, ref)):
+        assert _same(r, rr) and _same(i, ri), t
+    mb.reset()
+    with pytest.raises(ValueError):
+        mb.submit(*frames[0], out=pkg._capi.pinned_empty(n, pkg._capi.RESULT_DTYPE), compact=True)

@@ -2,6 +2,9 @@
 (tests/golden/make_golden.py).  CPU-only."""
 import collections
 
+import os
+import warnings
+
 import numpy as np
 import pytest
 
@@ -117,7 +120,11 @@ def test_oracle_with_host_libm_is_the_reference_bit_for_bit(golden_dir, name):
     follows).  What separates the kernels (det mode) from this is therefore libm alone: correctly rounded sin / cos / atan2 and
     x * x where glibc is one bit off."""
     if not parity.host_libm_is_the_fixture_machines(golden_dir):
-        pytest.skip("this host's libm returns other last bits than the machine the goldens were captured on")
+        msg = "this host's libm returns other last bits than the machine the goldens were captured on"
+        if os.environ.get("FSDP_REQUIRE_FIXTURE_LIBM") == "1":
+            pytest.fail(msg + " (FSDP_REQUIRE_FIXTURE_LIBM=1)")
+        warnings.warn("host-libm bit-for-bit test skipped: " + msg)
+        pytest.skip(msg)
     g = np.load(golden_dir / f"{name}.npz")
     prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist())) if "param_names" in g else None
     with oracle_lib.math_mode(0):
