@@ -199,7 +199,7 @@ def multi_planner_leg(pkg, devices, per_ctx: int, depth: int, n_batches: int, se
         def replay():
             bad = 0
             last = None
-            for res in mp.plan_stream(batches, depth=depth):
+            for res in mp.plan_stream(batches):
                 bad += int((res["status"] != 0).sum())
                 last = res
             return bad, last
@@ -215,10 +215,10 @@ def multi_planner_leg(pkg, devices, per_ctx: int, depth: int, n_batches: int, se
         same = chk.tobytes() == last.tobytes()
         # the same stream from pageable arrays (staged by one worker thread per context)
         pageable = [tuple(np.array(a) for a in b) for b in batches[: max(2, n_batches // 4)]]
-        list(mp.plan_stream(pageable, depth=depth))
+        list(mp.plan_stream(pageable))
         mp.reset_host_time()
         t1 = time.perf_counter()
-        for _ in mp.plan_stream(pageable, depth=depth):
+        for _ in mp.plan_stream(pageable):
             pass
         el_pg = time.perf_counter() - t1
         rate = per_ctx * n_ctx * n_batches / el

@@ -99,6 +99,7 @@ struct Work {
   MatchOut* d_match = nullptr;
   PathOut* d_path = nullptr;
   double* d_arena = nullptr;  // per-frame working polyline + basis cache (ARENA_DOUBLES doubles), HBM/L2 scratch
+  double* d_tiles = nullptr;  // the refit's polylines as point-major tiles of 64 frames (fit_lanes_kernel), allocated when that kernel may run
   int* d_big = nullptr;       // [0] counter + frames beyond sort_kernel's LDS capacities (n + 1 ints)
   int* d_retry = nullptr;     // [0] counter + frames for the exact re-plan kernel (n + 1 ints)
   PathMid* d_mid = nullptr;   // hand-over records of the three-kernel path stage
@@ -168,6 +169,11 @@ struct fsdp_ctx {
   double* d_gpath = nullptr;         // PathPlanner.global_path (n_gpath,2), or NULL
   int n_gpath = 0;
   int force_path_mode = 0;    // 0 = by batch size; 1 = one kernel (64 lanes per frame); 2 = three kernels (FSDP_PATH_MODE=mono|split)
+  // frames per BATCH from which the refit runs one frame per LANE (fit_lanes_kernel: sixty-four frames per wavefront and 2.3 x
+  // fewer instructions per frame — but a launch then has n / 64 wavefronts, and the FP64 pipe of a SIMD wants two of them: the
+  // kernel pays from 131 072 frames per launch on (1024 SIMDs x 2 x 64), measured in profiles/r05_fit_lanes.txt; passes in flight
+  // do not help, their refit launches do not coincide); -1 = never (FSDP_FIT_LANES=0), FSDP_FIT_LANES=n sets the threshold
+  long long fit_lanes_min = 131072;
   int fit_g = 4;              // lanes per frame of fit_kernel when frames are packed: 4 = exactly the Givens quad, sixteen frames
                               // per wavefront (FSDP_FIT_G=4|8; +1.6 % frames/s over 8 since the basis records are 32 bytes:
                               // tools/ab_variants.py)
@@ -317,6 +323,7 @@ static int ensure_work(fsdp_ctx* c, Work& w, int n) {
   HIP_TRY(c, regrow(w.d_match, m));
   HIP_TRY(c, regrow(w.d_path, m));
   HIP_TRY(c, regrow(w.d_arena, (size_t)ARENA_DOUBLES * m));
+  if (c->fit_lanes_min >= 0 && (long long)m >= c->fit_lanes_min) HIP_TRY(c, regrow(w.d_tiles, TILE_DOUBLES * ((m + TILE_FRAMES - 1) / TILE_FRAMES)));
   HIP_TRY(c, regrow(w.d_big, m + 1));
   HIP_TRY(c, regrow(w.d_retry, m + 1));
   HIP_TRY(c, regrow(w.d_mid, m));
@@ -338,6 +345,7 @@ static void free_work(Work& w) {
   (void)hipFree(w.d_match);
   (void)hipFree(w.d_path);
   (void)hipFree(w.d_arena);
+  (void)hipFree(w.d_tiles);
   (void)hipFree(w.d_big);
   (void)hipFree(w.d_retry);
   (void)hipFree(w.d_mid);
@@ -480,10 +488,10 @@ static void launch_fit(fsdp_ctx* c, Work& q, int n, const StageEvents* t = nullp
                      q.d_arena, q.d_mid, q.d_retry, c->d_params, t ? t->clock_first : nullptr, t ? t->clock_last : nullptr);
 }
 template <int G>
-static void launch_prep(fsdp_ctx* c, Work& q, const Inputs& in, const double* prev) {
+static void launch_prep(fsdp_ctx* c, Work& q, const Inputs& in, const double* prev, double* tiles = nullptr) {
   const int n = in.n_frames;
   hipLaunchKernelGGL(path_prep_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, in.d_poses, q.d_match,
-                     c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry, c->d_params);
+                     c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry, c->d_params, tiles);
 }
 template <int G>
 static void launch_finish(fsdp_ctx* c, Work& q, int n) {
@@ -543,13 +551,18 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
   } else {
     mark(q, t);
     const bool packed = c->force_pack ? c->force_pack == 2 : (long long)n * c->overlap >= PACK_FRAMES;
-    const int gf = packed ? c->fit_g : 16;
+    // one frame per lane once a launch gives every SIMD two wavefronts at 64 frames each (fit_lanes.h)
+    const bool lanes = packed && q.d_tiles != nullptr && c->fit_lanes_min >= 0 && (long long)n >= c->fit_lanes_min;
+    const int gf = lanes ? 1 : (packed ? c->fit_g : 16);
     if (packed)
-      launch_prep<8>(c, q, in, prev);
+      launch_prep<8>(c, q, in, prev, lanes ? q.d_tiles : nullptr);
     else
       launch_prep<16>(c, q, in, prev);
     mark(q, t, MARK_MAIN);
-    if (gf == 4)
+    if (gf == 1)
+      hipLaunchKernelGGL(fit_lanes_kernel, dim3((n + TILE_FRAMES - 1) / TILE_FRAMES), dim3(WAVE), 0, q.stream, n, q.d_tiles, q.d_arena, q.d_mid, q.d_retry,
+                         c->d_params);
+    else if (gf == 4)
       launch_fit<4>(c, q, n, t);
     else if (gf == 8)
       launch_fit<8>(c, q, n, t);
@@ -561,7 +574,7 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
     else
       launch_finish<16>(c, q, n);
     const std::string g = packed ? "8" : "16";
-    names += "path_prep_kernel<" + g + ">,fit_kernel<" + std::to_string(gf) + ">,path_finish_kernel<" + g + ">,";
+    names += "path_prep_kernel<" + g + ">," + (gf == 1 ? std::string("fit_lanes_kernel") : "fit_kernel<" + std::to_string(gf) + ">") + ",path_finish_kernel<" + g + ">,";
   }
   return split;
 }
@@ -921,6 +934,7 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   for (int i = 0; i < FSDP_MAX_OVERLAP; i++) c->slot[i].index = i;
   if (const char* e = getenv("FSDP_PATH_MODE")) c->force_path_mode = !strcmp(e, "mono") ? 1 : (!strcmp(e, "split") ? 2 : 0);
   if (const char* e = getenv("FSDP_FIT_G")) c->fit_g = atoi(e) == 8 ? 8 : 4;
+  if (const char* e = getenv("FSDP_FIT_LANES")) c->fit_lanes_min = atoll(e) > 0 ? atoll(e) : (e[0] == '0' ? -1 : 1);  // frames in flight from which; 0 = never
   if (const char* e = getenv("FSDP_PACK")) c->force_pack = atoi(e) ? 2 : 1;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = create_slot_stream(&c->slot[0].stream, 0);

@@ -22,6 +22,7 @@
 #pragma once
 #include "fsdp_device.h"
 #include "spline_device.h"
+#include "fit_lanes.h"
 #include "det_math.h"
 
 namespace fsdp {
@@ -30,6 +31,11 @@ constexpr int PATH_CAP = 1408;  // points of the working polyline (dense fit-#1 
                                 // mission reaches ~1300 (outbound + return lane of its known path within 30 m)
 
 constexpr int FIT_KNOTS = 16;  // knots the kernels of the three-kernel path stage keep per fit in LDS (more: exact kernel, 64)
+
+// The refit's polyline of 64 consecutive frames as one point-major TILE for fit_lanes_kernel (one frame per lane):
+// tile[array][point][frame mod 64], array = u | x | y — "point i of my frame" is one coalesced access per array.
+constexpr int TILE_FRAMES = 64;
+constexpr size_t TILE_DOUBLES = (size_t)3 * PATH_CAP * TILE_FRAMES;
 
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
 constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
@@ -1163,7 +1169,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
                                                        const double* __restrict__ default_path, const double* __restrict__ prev_paths,
                                                        const double* __restrict__ gpath, int n_gpath, double* __restrict__ arena,
                                                        PathOut* __restrict__ out, PathMid* __restrict__ mid, int* __restrict__ retry,
-                                                       const Params* __restrict__ prm) {
+                                                       const Params* __restrict__ prm, double* __restrict__ tiles = nullptr) {
   using GR = Grp<G>;
   __shared__ PathShared<G, true> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
@@ -1186,6 +1192,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
     PROF_T1(30);
     plain = rc == 0 && n >= 4;  // degree 3 needs 4 points; everything else takes the exact route
     if (plain) build_parameter<G>(S, A, off, n);
+    if (plain && tiles != nullptr) {
+      // fit_lanes_kernel reads the polyline from the point-major tile of the frame's group of 64 (the eight frames of this
+      // wavefront are neighbours there: a store instruction covers eight points x 64 contiguous bytes)
+      double* T = tiles + (size_t)(frame / TILE_FRAMES) * TILE_DOUBLES + (frame % TILE_FRAMES);
+      for (int i = GR::lane(); i < n; i += G) {
+        T[(size_t)i * TILE_FRAMES] = A.u[off + i];
+        T[((size_t)PATH_CAP + i) * TILE_FRAMES] = A.x[off + i];
+        T[((size_t)2 * PATH_CAP + i) * TILE_FRAMES] = A.y[off + i];
+      }
+    }
   }
   const bool final_status = status != ST_OK && status != ST_RETRY && status != ST_OVERFLOW_KNOTS;
   if (final_status) write_path_status<G>(&out[frame], status, fallback, 0);  // sorting / matching / fit #1 decided the frame
@@ -1265,6 +1281,41 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES
 #ifndef FSDP_EMU
   if (clock_last && threadIdx.x == 0) atomicMax(clock_last, (unsigned long long)wall_clock64());
 #endif
+}
+
+// The refit with one frame per lane (fit_lanes.h): wavefront w plans frames 64 w .. 64 w + 63 from tile w.  Same hand-over as
+// fit_kernel: FitRec in the frame's arena, or the frame on the retry list.
+#ifndef FSDP_LANES_WAVES
+#define FSDP_LANES_WAVES 3
+#endif
+__global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(FSDP_LANES_WAVES) fit_lanes_kernel(int n_frames, const double* __restrict__ tiles, double* __restrict__ arena,
+                                                                                        PathMid* __restrict__ mid, int* __restrict__ retry,
+                                                                                        const Params* __restrict__ prm) {
+  const int lane = lane_id();
+  const int frame = blockIdx.x * TILE_FRAMES + lane;
+  int m = 0;
+  if (frame < n_frames && mid[frame].status == ST_OK) m = mid[frame].n;
+  if (m > 0) {
+    LaneWS<FIT_KNOTS> ws;
+    const double* T = tiles + (size_t)blockIdx.x * TILE_DOUBLES + lane;
+    const SplineFit f = spline_fit_lane<FIT_KNOTS, TILE_FRAMES>(ws, T, T + (size_t)PATH_CAP * TILE_FRAMES, T + (size_t)2 * PATH_CAP * TILE_FRAMES, m,
+                                                               prm->smoothing);
+    if (f.status != 0) {
+      mid[frame].status = ST_RETRY;
+      push_retry(retry, frame);
+    } else {
+      FitRec* fr = frame_arena(arena, frame, prm).fit;
+      for (int i = 0; i < f.n; i++) {
+        fr->t[i] = ws.t[1 + i];
+        fr->c[i] = ws.cx[1 + i];
+        fr->c[f.n + i] = ws.cy[1 + i];
+      }
+      fr->n = f.n;
+      fr->ier = f.ier;
+      fr->status = 0;
+      fr->fp = f.fp;
+    }
+  }
 }
 
 template <int G>

@@ -193,9 +193,10 @@ class MultiPlanner:
     # ---- a stream of batches ----------------------------------------------------------------------------------------
     def plan_stream(self, batches, depth: int | None = None):
         """Yield the results of an iterable of batches ``(offsets, cones, poses)`` in order, `depth` batches in flight on
-        every GPU (default: the overlap depth).  Every yielded array is the page-locked block its GPUs wrote; drop it (and
+        every GPU (default: two per pass slot — the contexts' ticket capacity: a slot's next batch is then already queued on
+        its stream when the current one ends).  Every yielded array is the page-locked block its GPUs wrote; drop it (and
         its views) and the block serves a later batch."""
-        depth = self._overlap if depth is None else max(1, min(int(depth), self._overlap))
+        depth = 2 * self._overlap if depth is None else max(1, min(int(depth), 2 * self._overlap))
         inflight = []
         for b in batches:
             if len(inflight) == depth:

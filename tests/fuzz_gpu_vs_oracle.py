@@ -18,11 +18,12 @@ import oracle_lib  # noqa: E402
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 MODES = {"mono64": {"FSDP_PATH_MODE": "mono"}, "split16": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "0"},
-         "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "8"},
-         "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4"}}
+         "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "8", "FSDP_FIT_LANES": "0"},
+         "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4", "FSDP_FIT_LANES": "0"},
+         "fit_lanes": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_LANES": "1"}}
 ctxs = {}
 for name, env in MODES.items():
-    for k in ("FSDP_PATH_MODE", "FSDP_PACK", "FSDP_FIT_G"):
+    for k in ("FSDP_PATH_MODE", "FSDP_PACK", "FSDP_FIT_G", "FSDP_FIT_LANES"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ctxs[name] = pkg.Context(device=0)  # the environment is read at context creation
@@ -45,7 +46,7 @@ for per_side, track_noise, frame_noise, colour in itertools.product((24, 64, 100
         err = np.where(np.isnan(err), 0.0, err).max(axis=1)
         bad |= ok & (err > 1e-9)
         bad_total += int(bad.sum())
-        print(f"cones/side {per_side:3d} track sigma {track_noise} frame sigma {frame_noise} colour {int(colour)} {name:8s}: "
+        print(f"cones/side {per_side:3d} track sigma {track_noise} frame sigma {frame_noise} colour {int(colour)} {name:12s}: "
               f"{int(bad.sum())} of {len(ok)} frames differ (status ok {int(ok.sum())}, arc {int(((ref['path_fallback'] & 16) != 0).sum())})"
               + (f"  first: {np.nonzero(bad)[0][:5].tolist()}" if bad.any() else ""), flush=True)
 print("TOTAL differing frames:", bad_total)

@@ -365,7 +365,7 @@ def test_twenty_passes_in_flight_equal_a_serial_pass(pkg):
     assert ctx.time_runs(20, collect=False) is None
     ctx.sync()
     names = ctx.stage_names()
-    assert any(n.startswith("fit_kernel") for n in names), names
+    assert "fit_kernel<4>" in names, names  # (the packed kernels: 81 920 frames in flight)
     for k in range(20):  # the last pass lands in a different slot every time: every slot's result block is checked
         got = ctx.download()
         for f in got.dtype.names:
@@ -448,15 +448,17 @@ def test_overlapped_passes_equal_serial_passes(pkg):
     assert ctx.plan_batch(off, cones, poses)["path"].tobytes() == ref["path"].tobytes()
 
 
-@pytest.mark.parametrize("mode", ["mono64", "split16", "packed8", "packed8_fit4"])
+@pytest.mark.parametrize("mode", ["mono64", "split16", "packed8", "packed8_fit4", "packed8_fit_lanes"])
 def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, mode):
     """The library picks the path-stage kernels from the batch size and the passes in flight (fsdp_lib.hip launch_path):
     one kernel with 64 lanes per frame, or prep / fit / finish with 16 lanes per frame, or the packed ones (8 lanes per
     frame; the fit kernel optionally 4) that bench.py's overlapped passes run.  The environment pins the choice; every
     instantiation must reproduce the oracle bit for bit."""
     env = {"mono64": {"FSDP_PATH_MODE": "mono"}, "split16": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "0"},
-           "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "8"},
-           "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4"}}[mode]
+           "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "8", "FSDP_FIT_LANES": "0"},
+           "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4", "FSDP_FIT_LANES": "0"},
+           # the refit with one frame per lane (fit_lanes_kernel), whatever the number of frames in flight
+           "packed8_fit_lanes": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_LANES": "1"}}[mode]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     ctx = pkg.Context(device=0)
@@ -468,7 +470,8 @@ def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, mode):
             ref = oracle_lib.plan_batch(o, c, p, n_threads=os.cpu_count() or 1)
         _assert_equal_to_oracle(res, ref)
     names = ctx.stage_names()
-    want = {"mono64": "path_kernel<64>", "split16": "fit_kernel<16>", "packed8": "fit_kernel<8>", "packed8_fit4": "fit_kernel<4>"}[mode]
+    want = {"mono64": "path_kernel<64>", "split16": "fit_kernel<16>", "packed8": "fit_kernel<8>", "packed8_fit4": "fit_kernel<4>",
+            "packed8_fit_lanes": "fit_lanes_kernel"}[mode]
     assert want in names, names
     assert ("path_prep_kernel<8>" in names) == mode.startswith("packed"), names
 

@@ -69,7 +69,7 @@ def test_emulated_kernels_with_non_default_parameters(golden_dir, name):
     assert flips == [f for f in arc.flips("det") if f in set(idx.tolist())], flips
 
 
-@pytest.mark.parametrize("group", [1004, 1008, 1016])
+@pytest.mark.parametrize("group", [1004, 1008, 1016, 1001])
 def test_knot_capacity_reached_in_the_middle_of_a_round(group):
     """A fit whose round of new knots crosses the workspace's capacity (16 knots in the three-kernel path stage) must be
     handed to the exact kernel: stopping at the capacity and going on would converge on a knot set the reference never
