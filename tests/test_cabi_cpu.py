@@ -117,3 +117,29 @@ def test_in_process_shards_are_the_ranks_shards():
             assert max(sizes) - min(sizes) <= 1
             if n % g == 0:
                 assert r == [pkg.dist.frame_range(k, g, n) for k in range(g)]
+
+
+def test_vectorised_fma_is_correctly_rounded_and_reproduces_numpy_dot():
+    """acceleration.fma (float64 operations only: Dekker product, TwoSum, inner sum rounded to odd) is the IEEE fused multiply-add —
+    against exact rational arithmetic on random, cancelling and double-rounding-prone operands — and with it the two orders in
+    which NumPy / OpenBLAS rotate points (one point: gemv, several: gemm) are reproduced bit for bit for many angles at once."""
+    import importlib
+    from fractions import Fraction
+
+    acc = importlib.import_module("ft-fsd-path-planning_amd.acceleration")
+    rng = np.random.default_rng(0)
+    n = 3000
+    a = rng.normal(0, 10 ** rng.uniform(-3, 3, n))
+    b = rng.normal(0, 10 ** rng.uniform(-3, 3, n))
+    for c in (rng.normal(0, 10 ** rng.uniform(-3, 3, n)), -(a * b) * (1 + rng.integers(-4, 5, n) * 2.0 ** -52), (a * b) * 2.0 ** rng.integers(-60, 60, n)):
+        got = acc.fma(a, b, c)
+        want = np.array([float(Fraction(float(x)) * Fraction(float(y)) + Fraction(float(z))) for x, y, z in zip(a, b, c)])
+        assert np.array_equal(got, want)
+    theta = rng.uniform(-3, 3, 200)
+    pts = rng.normal(0, 40, (200, 2))
+    x, y = acc.rotate_single_points(pts[:, 0], pts[:, 1], theta)
+    rows = rng.normal(0, 40, (200, 7, 2))
+    rx, ry = acc.rotate_point_rows(rows[:, :, 0], rows[:, :, 1], theta[:, None])
+    for i in range(200):
+        assert np.array_equal(acc._rotate(pts[i], theta[i]), [x[i], y[i]])           # np.dot(1-D, 2-D): gemv
+        assert np.array_equal(acc._rotate(rows[i], theta[i]), np.column_stack([rx[i], ry[i]]))  # np.dot(2-D, 2-D): gemm
