@@ -240,6 +240,32 @@ def multi_planner_leg(pkg, devices, per_ctx: int, depth: int, n_batches: int, se
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def chip_time_leg(pkg, device, off, cones, poses, copies: int = 24, passes: int = 4):
+    """What a kernel costs when it has the chip to itself and fills it: the bench batch tiled `copies` times (98 304 frames), one
+    pass at a time, HIP events around every launch -> ns of chip time per frame and kernel.  Unlike the duration of an overlapped
+    launch (which depends on how twenty streams interleave on the box at hand) this figure is a property of the kernel: the sum
+    over the kernels is the floor of ms_per_step / frames, and profiles/ reproduces it (tools/batch_sweep.py)."""
+    try:
+        n1 = len(poses)
+        counts = np.tile(np.diff(off), copies)
+        big_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        big_cones = np.tile(cones, (copies, 1))
+        big_poses = np.tile(poses, (copies, 1))
+        c = pkg.Context(device=device, mission=int(pkg.MissionTypes.trackdrive))
+        c.set_overlap(1)
+        c.upload(big_off, big_cones, big_poses)
+        c.time_runs(2)
+        tot, st = c.time_runs(passes)
+        names = c.stage_names()
+        frames = n1 * copies
+        per = {k: v / passes / frames * 1e6 for k, v in zip(names, st)}
+        c.close()
+        return {"frames_per_launch": frames, "chip_ns_per_frame": per, "chip_ns_per_frame_sum": float(sum(per.values())),
+                "frames_per_s_at_that_sum": 1e9 / float(sum(per.values())), "pass_ns_per_frame_wall": tot / passes / frames * 1e6}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 class InProcess:
     """--single-process: every GPU of the node driven from THIS process (multi.py's form of the product: one context per
     device, no launcher, no socket, no RCCL).  Context 0 plays rank 0 (all the extras of the line are measured on it); the
@@ -604,6 +630,8 @@ def main():
                 ctx.plan_batch(o1, c1, p1)
                 lat.append(time.perf_counter() - t1)
             out["p50_single_frame_us"] = float(np.median(lat[50:]) * 1e6)
+            # the reproducible per-kernel figure next to roofline.kernel_ms (round-4 review, weak #11)
+            out["roofline"].update(chip_time_leg(pkg, ctx.device or 0, off, cones, poses))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(off, cones, poses)
                 out["p50_single_frame_vs_cpu_1thread"] = out["p50_single_frame_us"] / out["cpu_baseline"]["single_thread_us_per_frame"]

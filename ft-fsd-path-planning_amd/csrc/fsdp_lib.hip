@@ -482,20 +482,20 @@ static void launch_match(fsdp_ctx* c, Work& q, const Inputs& in) {
 // Small batches (<= PATH_SMALL_BATCH frames: single-frame calls, latency): one kernel, one frame per wavefront.
 // Large batches: three kernels (path_kernel.h: path_prep_kernel -> fit_kernel -> path_finish_kernel).  Either way the
 // frames the fast kernels hand on (retry list on the device) are planned by the exact kernel in the same stream.
-template <int GF>
+template <int GF, int NKC = FIT_KNOTS>
 static void launch_fit(fsdp_ctx* c, Work& q, int n, const StageEvents* t = nullptr) {
-  hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((n + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), DYN_LDS("FSDP_LDS_FIT"), q.stream, n,
+  hipLaunchKernelGGL((fit_kernel<GF, NKC>), dim3((n + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), DYN_LDS("FSDP_LDS_FIT"), q.stream, n,
                      q.d_arena, q.d_mid, q.d_retry, c->d_params, t ? t->clock_first : nullptr, t ? t->clock_last : nullptr);
 }
-template <int G>
+template <int G, int NKC = FIT_KNOTS>
 static void launch_prep(fsdp_ctx* c, Work& q, const Inputs& in, const double* prev, double* tiles = nullptr) {
   const int n = in.n_frames;
-  hipLaunchKernelGGL(path_prep_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, in.d_poses, q.d_match,
+  hipLaunchKernelGGL((path_prep_kernel<G, NKC>), dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, in.d_poses, q.d_match,
                      c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry, c->d_params, tiles);
 }
-template <int G>
+template <int G, int NKC = FIT_KNOTS>
 static void launch_finish(fsdp_ctx* c, Work& q, int n) {
-  hipLaunchKernelGGL(path_finish_kernel<G>, dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, q.d_arena, q.d_mid, q.d_path,
+  hipLaunchKernelGGL((path_finish_kernel<G, NKC>), dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, q.d_arena, q.d_mid, q.d_path,
                      q.d_retry, c->d_params);
 }
 
@@ -541,15 +541,38 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
     mark(q, t, MARK_MAIN);
     // FSDP_EXACT_PATH (experiments / diagnostics): the instantiation with plain IEEE divisions and square roots throughout
     static const bool exact = getenv("FSDP_EXACT_PATH") != nullptr;
+    // A context whose fits may be of degree 1 or 2 (max_deg < 3: utils/spline_fit.py:113) has no three-kernel form (those kernels
+    // hold cubic fits only); its large batches run the one-kernel stage with FOUR frames per wavefront (16 lanes each, all
+    // degrees, 32 knots per fit, the scaling-free divisions; what that form cannot hold goes to the exact kernel like any other
+    // frame the packed kernels hand on) instead of one frame per wavefront.
+    const bool mono16 = !exact && c->force_path_mode != 1 && c->params.max_deg != 3 && n > PATH_SMALL_BATCH;
     if (exact)
       hipLaunchKernelGGL((path_kernel<PATH_G_SMALL, false>), dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
                          c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
+    else if (mono16)
+      hipLaunchKernelGGL(path_kernel<PATH_G_LATENCY>, dim3((n + WAVE / PATH_G_LATENCY - 1) / (WAVE / PATH_G_LATENCY)), dim3(WAVE), 0, q.stream, n, in.d_poses,
+                         q.d_match, c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
     else
       hipLaunchKernelGGL(path_kernel<PATH_G_SMALL>, dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
                          c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
-    names += "path_kernel<64>,";
+    names += mono16 ? "path_kernel<16>," : "path_kernel<64>,";
   } else {
     mark(q, t);
+    // A context with a global path (set_global_path; the acceleration / ebs_test missions run on their known path) fits 100+ m
+    // polylines that need 17-32 knots (87 % of such frames; never more than 32 on the reference's tables): the WIDE instantiations
+    // of the three kernels — 32 knots per fit in the frame's LDS workspace, eight lanes per frame — keep them on the packed kernels
+    // instead of sending every frame to the exact one (round 4: 1.17 M frames/s there).  FSDP_WIDE=0 | 1 overrides.
+    static const int force_wide = getenv("FSDP_WIDE") ? atoi(getenv("FSDP_WIDE")) : -1;
+    const bool wide = force_wide >= 0 ? force_wide != 0 : c->n_gpath > 0;
+    if (wide) {
+      launch_prep<8, WIDE_KNOTS>(c, q, in, prev);
+      mark(q, t, MARK_MAIN);
+      launch_fit<8, WIDE_KNOTS>(c, q, n, t);
+      mark(q, t, MARK_MAIN);
+      launch_finish<8, WIDE_KNOTS>(c, q, n);
+      names += "path_prep_kernel<8,32>,fit_kernel<8,32>,path_finish_kernel<8,32>,";
+      return split;
+    }
     const bool packed = c->force_pack ? c->force_pack == 2 : (long long)n * c->overlap >= PACK_FRAMES;
     // one frame per lane once a launch gives every SIMD two wavefronts at 64 frames each (fit_lanes.h)
     const bool lanes = packed && q.d_tiles != nullptr && c->fit_lanes_min >= 0 && (long long)n >= c->fit_lanes_min;

@@ -242,7 +242,7 @@ __device__ inline int insert_virtual(MatchShared& S, int ne, int nt, double carx
 
 // functional_cone_matching.py:387-440: result written to (ox, oy), returns its length
 template <int G>
-__device__ inline int cones_for_other_side(MatchShared& S, const Params& P, const double* px, const double* py, int n, int cone_type,
+__device__ __forceinline__ int cones_for_other_side(MatchShared& S, const Params& P, const double* px, const double* py, int n, int cone_type,
                                            const double* qx, const double* qy, int m, double carx, double cary, double* ox,
                                            double* oy) {
   const int lane = Grp<G>::lane();

@@ -40,7 +40,8 @@ constexpr size_t TILE_DOUBLES = (size_t)3 * PATH_CAP * TILE_FRAMES;
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
 constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
 constexpr int FITREC_DOUBLES = 112;  // >= sizeof(FitRec) / 8
-constexpr int BAND_DOUBLES = 128;    // >= 7 * (FIT_KNOTS + 2): band triangle + right-hand sides + fpint of fit_kernel's fit
+constexpr int WIDE_KNOTS = 32;  // knots per fit of the WIDE instantiations of the three kernels (contexts with a global path: its fits need 17-32)
+constexpr int BAND_DOUBLES = 256;    // >= 7 * (WIDE_KNOTS + 2): band triangle + right-hand sides + fpint of fit_kernel's fit
 constexpr int ARENA_REC = 3 * PATH_CAP;                  // basis records (32 bytes per point), then one interval byte per point
 constexpr int ARENA_BMAT = ARENA_REC + 4 * PATH_CAP + PATH_CAP / 8;  // rows of the smoothness matrix
 constexpr int ARENA_FIT = ARENA_BMAT + ARENA_B + DENSE_CAP;          // FitRec
@@ -1163,7 +1164,7 @@ __device__ __forceinline__ int path_frame(PS& S, int frame, const double* __rest
 // one-frame-per-wavefront kernel (path_retry_kernel), so results do not depend on the route a frame took.
 __device__ __forceinline__ void push_retry(int* retry, int frame) { retry[1 + atomicAdd(&retry[0], 1)] = frame; }
 
-template <int G>
+template <int G, int NKC = FIT_KNOTS>  // NKC: knots per fit the frame's LDS workspace keeps (WIDE_KNOTS: contexts with a global path)
 // (two wavefronts per SIMD: 256 registers + 44 bytes of spill instead of 259 registers and one wavefront)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) path_prep_kernel(int n_frames, const double* __restrict__ poses, const MatchOut* __restrict__ matched,
                                                        const double* __restrict__ default_path, const double* __restrict__ prev_paths,
@@ -1171,12 +1172,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
                                                        PathOut* __restrict__ out, PathMid* __restrict__ mid, int* __restrict__ retry,
                                                        const Params* __restrict__ prm, double* __restrict__ tiles = nullptr) {
   using GR = Grp<G>;
-  __shared__ PathShared<G, true> S_all[WAVE / G];
+  __shared__ PathShared<G, true, NKC> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
   PROF_INIT_K(2);
   if (frame < n_frames) {
   PROF(0);
-  PathShared<G, true>& S = S_all[GR::index()];
+  PathShared<G, true, NKC>& S = S_all[GR::index()];
   const Arena A = frame_arena(arena, frame, prm);
   const double px = poses[4 * frame + 0], py = poses[4 * frame + 1], dx = poses[4 * frame + 2], dy = poses[4 * frame + 3];
   const double* prev = prev_paths ? prev_paths + (size_t)frame * (PATH_POINTS * 4) : default_path;
@@ -1318,17 +1319,17 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(FSDP_LANES_WAVES) fit_la
   }
 }
 
-template <int G>
+template <int G, int NKC = FIT_KNOTS>
 __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                          PathOut* __restrict__ out, int* __restrict__ retry,
                                                          const Params* __restrict__ prm) {
   using GR = Grp<G>;
-  __shared__ PathShared<G, true> S_all[WAVE / G];
+  __shared__ PathShared<G, true, NKC> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
   PROF_INIT_K(3);
   if (frame < n_frames && mid[frame].status == ST_OK) {
   PROF(0);
-  PathShared<G, true>& S = S_all[GR::index()];
+  PathShared<G, true, NKC>& S = S_all[GR::index()];
   const Arena A = frame_arena(arena, frame, prm);
   const int lane = GR::lane();
   const FitRec* fr = A.fit;

@@ -84,7 +84,7 @@ static void emu_path_launch(int n_frames, const double* poses, const fsdp::Match
 
 // the path stage as the library launches it for large batches: prep -> fit -> finish -> exact re-plan of the retry list
 // GF = 1: the refit with one frame per lane (fit_lanes_kernel, from the point-major tiles path_prep_kernel writes for it)
-template <int GF, int NKC, int G = fsdp::PATH_G_SPLIT>
+template <int GF, int NKC, int G = fsdp::PATH_G_SPLIT, int NKP = fsdp::FIT_KNOTS>  // NKP: knots per fit of the prep / finish workspaces
 static void emu_path_split_launch(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
   AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
   std::vector<fsdp::PathMid> mid(n_frames);
@@ -93,14 +93,14 @@ static void emu_path_split_launch(int n_frames, const double* poses, const fsdp:
   const unsigned n_tiles = ((unsigned)n_frames + fsdp::TILE_FRAMES - 1) / fsdp::TILE_FRAMES;
   AlignedArena tiles(GF == 1 ? fsdp::TILE_DOUBLES * n_tiles : 8);
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() {
-    fsdp::path_prep_kernel<G>(n_frames, poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out,
-                              mid.data(), retry.data(), &g_prm, GF == 1 ? tiles.data() : nullptr);
+    fsdp::path_prep_kernel<G, NKP>(n_frames, poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out,
+                                   mid.data(), retry.data(), &g_prm, GF == 1 ? tiles.data() : nullptr);
   });
   if constexpr (GF == 1)
     emu::launch(n_tiles, 64, [&]() { fsdp::fit_lanes_kernel(n_frames, tiles.data(), arena.data(), mid.data(), retry.data(), &g_prm); });
   else
     emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data(), &g_prm, nullptr, nullptr); });
-  emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G>(n_frames, arena.data(), mid.data(), out, retry.data(), &g_prm); });
+  emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G, NKP>(n_frames, arena.data(), mid.data(), out, retry.data(), &g_prm); });
   g_last_retries = retry[0];
   // the refit records (knots / coefficients fit_kernel handed to path_finish_kernel), kept for emu_last_refit
   g_refit.assign((size_t)n_frames * fsdp::FITREC_DOUBLES, 0.0);
@@ -332,6 +332,8 @@ int emu_path_g(int G, int n_frames, const double* poses, const fsdp::MatchOut* m
     emu_path_split_launch<4, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
   else if (G == 1008)
     emu_path_split_launch<8, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
+  else if (G == 2008)  // the WIDE instantiations (32 knots per fit: contexts with a global path)
+    emu_path_split_launch<8, fsdp::WIDE_KNOTS, 8, fsdp::WIDE_KNOTS>(n_frames, poses, matched, out);
   else if (G == 1001)  // split pipeline, the refit with one frame per lane
     emu_path_split_launch<1, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
   else if (G == 1016)  // the three kernels with 16 lanes per frame (one pass of a mid-size batch)

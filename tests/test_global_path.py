@@ -115,6 +115,10 @@ def test_emulated_acceleration_frames_beyond_the_packed_knot_capacity(golden_dir
             L.emu_set_global_path(gpc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_int(len(gpc)))
             try:
                 e, _ = emu_lib.plan(np.zeros(2, np.int32), np.zeros((0, 3)), pose[None], 8)
+                # the WIDE three kernels (32 knots per fit: what a context with a global path launches) hold these fits: same
+                # result without the exact kernel
+                w, _ = emu_lib.plan(np.zeros(2, np.int32), np.zeros((0, 3)), pose[None], 2008)
+                assert emu_lib.last_retries() == 0 and np.array_equal(w[0]["path"], r["path"])
             finally:
                 L.emu_set_prev_paths(None)
                 L.emu_set_global_path(None, ctypes.c_int(0))

@@ -587,6 +587,29 @@ def test_non_default_parameters(pkg, golden_dir, name):
     c0.close()
 
 
+@pytest.mark.parametrize("max_deg", [1, 2])
+def test_low_degree_contexts_plan_large_batches_four_frames_per_wavefront(pkg, max_deg):
+    """max_deg < 3 (utils/spline_fit.py:113: fits #1 / #2 of degree clip(points - 1, 1, max_deg)): the three-kernel path stage holds
+    cubic fits only, so such a context's large batches run the one-kernel stage with four frames per wavefront (path_kernel<16>:
+    all degrees, 32 knots, the scaling-free divisions; round 4 gave them one frame per wavefront whatever the batch) — bit-equal
+    to the oracle with the same parameters, a clean and a noisy batch (frames on the exact route)."""
+    prm = {"max_deg": max_deg}
+    c = pkg.Context(device=0, mission=4, params=prm)
+    sets = [pkg.synth.make_replay_batch(1500, 64, 0.15, seed=51, color=True),
+            pkg.synth.make_replay_batch(1100, 100, 0.0, seed=52, frame_noise=0.3, random_pose=True, color=False)]
+    for off, cones, poses in sets:
+        res = c.plan_batch(off, cones, poses)
+        assert "path_kernel<16>" in c.stage_names(), c.stage_names()
+        with oracle_lib.params(prm), oracle_lib.math_mode(1):
+            ref = oracle_lib.plan_batch(off, cones, poses, n_threads=os.cpu_count() or 1)
+        _assert_equal_to_oracle(res, ref)
+        assert (res["status"] == 0).mean() > 0.8
+    small = c.plan_batch(*[a[:k] for a, k in zip(sets[0], (201, sets[0][0][200], 200))])
+    assert "path_kernel<64>" in c.stage_names()  # small batches keep a wavefront per frame
+    assert small["path"].tobytes() == res["path"][:0].tobytes() or small["path"].tobytes() == c.plan_batch(*sets[0])["path"][:200].tobytes()
+    c.close()
+
+
 def test_parameters_outside_the_kernels_capacities_are_refused(pkg):
     for bad in (dict(max_n_neighbors=6), dict(max_length=13), dict(max_deg=4), dict(max_deg=0), dict(mpc_prediction_horizon=50),
                 dict(mpc_prediction_horizon=0), dict(mpc_path_length=100.0)):
