@@ -102,6 +102,7 @@ struct Work {
   double* d_tiles = nullptr;  // the refit's polylines as point-major tiles of 64 frames (fit_lanes_kernel), allocated when that kernel may run
   int* d_big = nullptr;       // [0] counter + frames beyond sort_kernel's LDS capacities (n + 1 ints)
   int* d_retry = nullptr;     // [0] counter + frames for the exact re-plan kernel (n + 1 ints)
+  int* d_wide = nullptr;      // [0] counter + frames whose refit needs 17-32 knots, for the 32-knot refit / finish kernels (n + 1 ints)
   PathMid* d_mid = nullptr;   // hand-over records of the three-kernel path stage
   fsdp_frame_result* d_result = nullptr;  // the pass's results in the ABI's layout (assemble_kernel)
   SkidInfo* d_skid_info = nullptr;        // skidpad contexts
@@ -326,6 +327,7 @@ static int ensure_work(fsdp_ctx* c, Work& w, int n) {
   if (c->fit_lanes_min >= 0 && (long long)m >= c->fit_lanes_min) HIP_TRY(c, regrow(w.d_tiles, TILE_DOUBLES * ((m + TILE_FRAMES - 1) / TILE_FRAMES)));
   HIP_TRY(c, regrow(w.d_big, m + 1));
   HIP_TRY(c, regrow(w.d_retry, m + 1));
+  HIP_TRY(c, regrow(w.d_wide, m + 1));
   HIP_TRY(c, regrow(w.d_mid, m));
   HIP_TRY(c, regrow(w.d_result, m));
   if (c->mission == 2) {
@@ -348,6 +350,7 @@ static void free_work(Work& w) {
   (void)hipFree(w.d_tiles);
   (void)hipFree(w.d_big);
   (void)hipFree(w.d_retry);
+  (void)hipFree(w.d_wide);
   (void)hipFree(w.d_mid);
   (void)hipFree(w.d_result);
   (void)hipFree(w.d_skid_info);
@@ -483,9 +486,9 @@ static void launch_match(fsdp_ctx* c, Work& q, const Inputs& in) {
 // Large batches: three kernels (path_kernel.h: path_prep_kernel -> fit_kernel -> path_finish_kernel).  Either way the
 // frames the fast kernels hand on (retry list on the device) are planned by the exact kernel in the same stream.
 template <int GF, int NKC = FIT_KNOTS>
-static void launch_fit(fsdp_ctx* c, Work& q, int n, const StageEvents* t = nullptr) {
+static void launch_fit(fsdp_ctx* c, Work& q, int n, const StageEvents* t = nullptr, int* wide = nullptr, const int* list = nullptr) {
   hipLaunchKernelGGL((fit_kernel<GF, NKC>), dim3((n + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), DYN_LDS("FSDP_LDS_FIT"), q.stream, n,
-                     q.d_arena, q.d_mid, q.d_retry, c->d_params, t ? t->clock_first : nullptr, t ? t->clock_last : nullptr);
+                     q.d_arena, q.d_mid, q.d_retry, c->d_params, t ? t->clock_first : nullptr, t ? t->clock_last : nullptr, wide, list);
 }
 template <int G, int NKC = FIT_KNOTS>
 static void launch_prep(fsdp_ctx* c, Work& q, const Inputs& in, const double* prev, double* tiles = nullptr) {
@@ -494,9 +497,9 @@ static void launch_prep(fsdp_ctx* c, Work& q, const Inputs& in, const double* pr
                      c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry, c->d_params, tiles);
 }
 template <int G, int NKC = FIT_KNOTS>
-static void launch_finish(fsdp_ctx* c, Work& q, int n) {
+static void launch_finish(fsdp_ctx* c, Work& q, int n, const int* list = nullptr) {
   hipLaunchKernelGGL((path_finish_kernel<G, NKC>), dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, q.d_arena, q.d_mid, q.d_path,
-                     q.d_retry, c->d_params);
+                     q.d_retry, c->d_params, list);
 }
 
 // the same steps through the packed kernels (csrc/skidpad_kernel.h "steps in flight, many frames per wavefront")
@@ -518,10 +521,10 @@ static void launch_skid_packed_kernels(fsdp_ctx* c, int frames) {
                      c->d_default_path, c->d_g_arena, c->d_g_mid);
   skid_group_mark(c);
   hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid,
-                     c->d_g_retry, c->d_params, (unsigned long long*)nullptr, (unsigned long long*)nullptr);
+                     c->d_g_retry, c->d_params, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (const int*)nullptr);
   skid_group_mark(c);
   hipLaunchKernelGGL(path_finish_kernel<G>, dim3((frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid, c->d_g_out,
-                     c->d_g_retry, c->d_params);
+                     c->d_g_retry, c->d_params, (const int*)nullptr);
   skid_group_mark(c);
 }
 
@@ -532,7 +535,7 @@ static void launch_skid_packed_kernels(fsdp_ctx* c, int frames) {
 constexpr int PACK_FRAMES = 12288;
 
 // the path stage's fast kernels (no route, no assembly); returns whether it was the three-kernel form
-static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, std::string& names) {
+static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, std::string& names, bool with_routes = true) {
   const double* prev = in.use_prev ? in.d_prev : nullptr;
   const int n = in.n_frames;
   // (the packed kernels hold degree-3 fits only: a context with max_deg < 3 plans every batch with the one-kernel stage)
@@ -582,20 +585,32 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
     else
       launch_prep<16>(c, q, in, prev);
     mark(q, t, MARK_MAIN);
+    // A pass that carries the route kernels (the context has met frames the fast kernels hand on) also carries the 32-knot refit /
+    // finish kernels: a refit that needs 17-32 knots (2 % of the frames of a noisy batch: most of its retry list) goes to their
+    // list and stays on packed kernels — eight frames per wavefront, only the refit and what follows it done again — instead of
+    // having its whole path stage planned from scratch by a wavefront of the exact kernel.  Without them in the pass the fit
+    // kernel hands such a frame to the retry list as before: results do not depend on the prediction.
+    static const bool no_wide_list = getenv("FSDP_WIDE_LIST") && atoi(getenv("FSDP_WIDE_LIST")) == 0;
+    int* wlist = (with_routes && !lanes && !no_wide_list) ? q.d_wide : nullptr;
+    if (wlist) (void)hipMemsetAsync(wlist, 0, sizeof(int), q.stream);
     if (gf == 1)
       hipLaunchKernelGGL(fit_lanes_kernel, dim3((n + TILE_FRAMES - 1) / TILE_FRAMES), dim3(WAVE), 0, q.stream, n, q.d_tiles, q.d_arena, q.d_mid, q.d_retry,
                          c->d_params);
     else if (gf == 4)
-      launch_fit<4>(c, q, n, t);
+      launch_fit<4>(c, q, n, t, wlist);
     else if (gf == 8)
-      launch_fit<8>(c, q, n, t);
+      launch_fit<8>(c, q, n, t, wlist);
     else
-      launch_fit<16>(c, q, n, t);
+      launch_fit<16>(c, q, n, t, wlist);
     mark(q, t, MARK_MAIN);
     if (packed)
       launch_finish<8>(c, q, n);
     else
       launch_finish<16>(c, q, n);
+    if (wlist) {  // (inside the finish kernel's bracket of a timed pass: FSDP_MAX_STAGES has no room for two more names)
+      launch_fit<8, WIDE_KNOTS>(c, q, n, nullptr, nullptr, wlist);
+      launch_finish<8, WIDE_KNOTS>(c, q, n, wlist);
+    }
     const std::string g = packed ? "8" : "16";
     names += "path_prep_kernel<" + g + ">," + (gf == 1 ? std::string("fit_lanes_kernel") : "fit_kernel<" + std::to_string(gf) + ">") + ",path_finish_kernel<" + g + ">,";
   }
@@ -671,7 +686,7 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
   mark(q, t);
   launch_match(c, q, in);
   names += "match_kernel<" + std::to_string(MATCH_G) + ">,";
-  const bool split = launch_path(c, q, in, t, names);
+  const bool split = launch_path(c, q, in, t, names, with_retry);
   MarkKind after_path = split ? MARK_PLAIN : MARK_MAIN;  // (the one-kernel path stage is the main kernel: close its bracket)
   if (with_retry) {
     mark(q, t, after_path);
@@ -1890,7 +1905,7 @@ int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
   if (c->profile_sort)
     launch_sort(c, q, c->res);
   else
-    launch_path(c, q, c->res, nullptr, names);
+    launch_path(c, q, c->res, nullptr, names, false);
   HIP_TRY(c, hipMemsetAsync(q.d_big, 0, sizeof(int), q.stream));
   HIP_TRY(c, hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -1237,7 +1237,10 @@ template <int G, int NKC>
 // to change nothing, profiles/r04_ab_variants.txt 1)
 __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES : FSDP_FIT_WAVES) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                  int* __restrict__ retry, const Params* __restrict__ prm,
-                                                 unsigned long long* __restrict__ clock_first, unsigned long long* __restrict__ clock_last) {
+                                                 unsigned long long* __restrict__ clock_first, unsigned long long* __restrict__ clock_last,
+                                                 int* __restrict__ wide = nullptr, const int* __restrict__ list = nullptr) {
+  // wide (optional): where a fit that needs more knots than NKC is handed on when the pass carries the 32-knot kernels (else:
+  // the retry list, i.e. the exact kernel).  list (optional): this launch IS that 32-knot refit — group i plans frame list[1 + i].
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;
 #ifndef FSDP_EMU
@@ -1247,9 +1250,10 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES
 #endif
   static_assert(7 * (NKC + 2) <= BAND_DOUBLES, "band region of the arena");
   __shared__ WS ws_all[WAVE / G];
-  const int frame = blockIdx.x * (WAVE / G) + GR::index();
+  int frame = blockIdx.x * (WAVE / G) + GR::index();
+  if (list != nullptr) frame = frame < list[0] ? list[1 + frame] : n_frames;
   PROF_INIT_K(1);
-  if (frame < n_frames && mid[frame].status == ST_OK) {
+  if (frame < n_frames && mid[frame].status == (list != nullptr ? ST_WIDE : ST_OK)) {
     PROF(0);
     WS& ws = ws_all[GR::index()];
     const Arena A = frame_arena(arena, frame, prm);
@@ -1260,10 +1264,16 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES
     const int lane = GR::lane();
     if (f.status != 0) {
       if (lane == 0) {
-        mid[frame].status = ST_RETRY;
-        push_retry(retry, frame);
+        if (wide != nullptr && f.status == ST_OVERFLOW_KNOTS) {
+          mid[frame].status = ST_WIDE;
+          push_retry(wide, frame);
+        } else {
+          mid[frame].status = ST_RETRY;
+          push_retry(retry, frame);
+        }
       }
     } else {
+      if (list != nullptr && lane == 0) mid[frame].status = ST_WIDE_FIT;
       FitRec* fr = A.fit;
       for (int i = lane; i < f.n; i += G) {
         fr->t[i] = ws.t[1 + i];
@@ -1322,12 +1332,13 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(FSDP_LANES_WAVES) fit_la
 template <int G, int NKC = FIT_KNOTS>
 __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                          PathOut* __restrict__ out, int* __restrict__ retry,
-                                                         const Params* __restrict__ prm) {
+                                                         const Params* __restrict__ prm, const int* __restrict__ list = nullptr) {
   using GR = Grp<G>;
   __shared__ PathShared<G, true, NKC> S_all[WAVE / G];
-  const int frame = blockIdx.x * (WAVE / G) + GR::index();
+  int frame = blockIdx.x * (WAVE / G) + GR::index();
+  if (list != nullptr) frame = frame < list[0] ? list[1 + frame] : n_frames;  // (the frames the 32-knot refit kernel has refitted)
   PROF_INIT_K(3);
-  if (frame < n_frames && mid[frame].status == ST_OK) {
+  if (frame < n_frames && mid[frame].status == (list != nullptr ? ST_WIDE_FIT : ST_OK)) {
   PROF(0);
   PathShared<G, true, NKC>& S = S_all[GR::index()];
   const Arena A = frame_arena(arena, frame, prm);
@@ -1349,6 +1360,7 @@ __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* _
   const int rc = mpc_finish<G, true, true>(S, A, true, f, out[frame].path, &n_dense);
   if (rc == 0) {
     write_path_status<G>(&out[frame], ST_OK, mid[frame].fallback, n_dense);
+    if (list != nullptr && lane == 0) mid[frame].status = ST_OK;
   } else if (lane == 0) {
     mid[frame].status = ST_RETRY;
     push_retry(retry, frame);

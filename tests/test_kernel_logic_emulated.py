@@ -91,6 +91,25 @@ def test_knot_capacity_reached_in_the_middle_of_a_round(group):
     assert np.array_equal(res["path"][ok], ref["path"][ok])
 
 
+def test_refits_beyond_16_knots_stay_on_packed_kernels_when_the_pass_carries_the_32_knot_ones():
+    """A pass that carries the route kernels also carries the 32-knot refit / finish kernels (fsdp_lib.hip launch_path): a refit that
+    overflows the 16 knots of fit_kernel goes to THEIR list, not to the exact kernel — same bits either way (noisy colourless set:
+    8 frames on the exact route without them, 1 with them)."""
+    import importlib
+
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    off, cones, poses = pkg.synth.make_replay_batch(211, 100, 0.0, seed=22, frame_noise=0.3, random_pose=True, color=False)
+    res, _ = emu_lib.plan(off, cones, poses, 3004)
+    n_retry, n_wide = emu_lib.last_retries(), int(emu_lib.lib().emu_last_wide())
+    plain, _ = emu_lib.plan(off, cones, poses, 1004)
+    assert n_wide >= 3 and n_retry < emu_lib.last_retries() and n_retry + n_wide >= emu_lib.last_retries()
+    with oracle_lib.math_mode(1):
+        ref = oracle_lib.plan_batch(off, cones, poses)
+    assert np.array_equal(res["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert np.array_equal(res["path"][ok], ref["path"][ok]) and np.array_equal(plain["path"][ok], ref["path"][ok])
+
+
 def test_sorting_state_sizes_agree(golden_dir, monkeypatch):
     """The library sorts a batch whose frames hold at most 128 cones with the 128-cone frame state (sort_kernel_128, four
     wavefronts per SIMD) and any other batch with the 255-cone state: same code, same results (every output field)."""
