@@ -585,12 +585,13 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
     else
       launch_prep<16>(c, q, in, prev);
     mark(q, t, MARK_MAIN);
-    // A pass that carries the route kernels (the context has met frames the fast kernels hand on) also carries the 32-knot refit /
-    // finish kernels: a refit that needs 17-32 knots (2 % of the frames of a noisy batch: most of its retry list) goes to their
-    // list and stays on packed kernels — eight frames per wavefront, only the refit and what follows it done again — instead of
-    // having its whole path stage planned from scratch by a wavefront of the exact kernel.  Without them in the pass the fit
-    // kernel hands such a frame to the retry list as before: results do not depend on the prediction.
-    static const bool no_wide_list = getenv("FSDP_WIDE_LIST") && atoi(getenv("FSDP_WIDE_LIST")) == 0;
+    // Experiment, OFF by default (FSDP_WIDE_LIST=1 turns it on): a pass that carries the route kernels also carries the 32-knot
+    // refit / finish kernels, and a refit that needs 17-32 knots (2 % of the frames of a noisy batch: most of its retry list) goes
+    // to THEIR device list instead of the exact kernel's.  Bit-equal (emulator test, GPU hash) — and slower: such a fit is
+    // milliseconds of one serial chain whatever runs it, the pass waits for the slowest one, and 8 or 16 lanes per frame get
+    // through its data-parallel passes slower than the exact kernel's 64 (config 4r: 229 k -> 180 k / 195 k frames/s one pass at a
+    // time, 1.46 -> 1.26 / 1.29 M with ten in flight; profiles/r05_routes.txt).  Results never depend on it.
+    static const bool no_wide_list = !(getenv("FSDP_WIDE_LIST") && atoi(getenv("FSDP_WIDE_LIST")) == 1);
     int* wlist = (with_routes && !lanes && !no_wide_list) ? q.d_wide : nullptr;
     if (wlist) (void)hipMemsetAsync(wlist, 0, sizeof(int), q.stream);
     if (gf == 1)
