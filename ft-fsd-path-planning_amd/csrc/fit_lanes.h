@@ -572,7 +572,11 @@ __device__ __forceinline__ SplineFit spline_fit_lane(LaneWS<NK>& ws, const doubl
           const double piv = hh1;
           double cs, sn;
           double ww = ws.g[j][0];
-          fpgivs(piv, ww, cs, sn);
+          {
+            int b2 = 0;
+            fpgivs_guarded<true>(piv, ww, cs, sn, b2);
+            bad |= b2 != 0;
+          }
           ws.g[j][0] = ww;
           double c1 = ws.cx[j], c2 = ws.cy[j];
           fprota(cs, sn, xi1, c1);

@@ -359,6 +359,27 @@ __device__ __forceinline__ double sqrt_1_2(double x) {
 #endif
 }
 
+// fpgivs with the scaling-free divisions (the arithmetic of giv_step<true>: max / min instead of the branch, two refined reciprocals,
+// sqrt_1_2) for the rotations of the smoothing rows; operands outside the divisions' exponent band set `bad` (the frame is then
+// planned again with plain divisions).  FAST = false: fpgivs itself.
+template <bool FAST>
+__device__ __forceinline__ void fpgivs_guarded(double piv, double& ww, double& cs, double& sn, int& bad) {
+  if constexpr (FAST) {
+    const double w = ww;
+    const double den = max_abs_nn(piv, w), num = min_abs_nn(piv, w);
+    bad |= (int)!((den >= 0x1p-255) & (den <= 0x1p+255) & ((num == 0.0) | (num >= 0x1p-255)));
+    const double rq = rcp_refined(den);
+    const double q = div_rcp(num, den, rq);
+    const double dd = den * sqrt_1_2(1.0 + q * q);
+    const double rd = rcp_refined(dd);
+    cs = div_rcp(w, dd, rd);
+    sn = div_rcp(piv, dd, rd);
+    ww = dd;
+  } else {
+    fpgivs(piv, ww, cs, sn);
+  }
+}
+
 // fpbspl for degree 3 as straight-line code: the six knots around the interval are fetched together (one LDS round
 // trip instead of a dependent read per term), coincident knots are handled by selects (the quotient of the skipped
 // branch is computed and dropped), and with FAST the six divisions use the exact scaled-free sequence above (operands
@@ -1266,6 +1287,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
     }
     PROFX_T1(4);
     PROFX_T0(3);
+    int bad2 = 0;  // (FAST: an operand of the smoothing rows' rotations left the exponent band of the scaling-free divisions)
     double p1 = 0., f1 = fp0 - s, p3 = -one, f3 = fpms, p = 0.;
     for (int i = 1; i <= nk1; i++) p = p + ws.A(i, 1);
     PROFX_T1(3);
@@ -1336,7 +1358,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
             double ww = ws.Gm(j, 1);
             const double piv = GR::bcast(hq, 0);
             double cs, sn;
-            fpgivs(piv, ww, cs, sn);
+            fpgivs_guarded<FAST>(piv, ww, cs, sn, bad2);
             int i2 = k1;
             if (j > n8) i2 = nk1 - j;
             const bool col_on = lane >= 1 && lane < k2 && j != nk1 && lane <= i2;  // columns 2 .. i2 + 1
@@ -1380,7 +1402,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
             double piv = h[1];
             double cs, sn;
             double ww = ws.Gm(j, 1);
-            fpgivs(piv, ww, cs, sn);
+            fpgivs_guarded<FAST>(piv, ww, cs, sn, bad2);
             ws.Gm(j, 1) = ww;
             double c1 = ws.c[j], c2 = ws.c[j + n];
             fprota(cs, sn, xi1, c1);
@@ -1497,6 +1519,7 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         p = pn;
       }
     }
+    if (GR::ballot(bad2 != 0) != 0ull) R.status = ST_RETRY;
   }
   GR::sync();
   R.n = n;
