@@ -1,14 +1,14 @@
 #!/bin/bash
-# evidence pass of round 4: everything profiles/ holds for the round, taken with the library build of this snapshot.
+# evidence pass of round 5: everything profiles/ holds for the round, taken with the library build of this snapshot.
 # Every command runs under `timeout` (a hung process would cost the box's whole limit).
 set -u
-R=gpurun_out/r04
+R=gpurun_out/r05
 mkdir -p $R
 T="timeout 600"
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $R/gpu_tests.txt
 $T python __graft_entry__.py smoke >> $R/gpu_tests.txt 2>&1
-timeout 2400 bash tools/profile_gpu.sh r04 > $R/profile.log 2>&1
-cp gpurun_out/prof_r04/pmc_traffic.json profiles/pmc_traffic.json   # so that the bench lines below carry traffic / insts
+timeout 2400 bash tools/profile_gpu.sh r05 > $R/profile.log 2>&1
+cp gpurun_out/prof_r05/pmc_traffic.json profiles/pmc_traffic.json   # so that the bench lines below carry traffic / insts
 $T python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $R/bench_line.json
 $T python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-latency 2>/dev/null | tail -1 > $R/bench_line_100steps.json
 $T python bench.py --config 4 --frames 8192 --no-cpu-baseline --no-latency 2>/dev/null | tail -1 > $R/bench_cfg4_shard.json
@@ -21,8 +21,8 @@ $T python tools/stream_probe.py > $R/streaming.jsonl 2>&1
   for g in 1 2 4 8 12 16; do echo "1024 instances, groups of $g steps"; FSDP_SKID_GROUP=$g $T python tools/bench_skidpad.py 1024; done
   for g in 1 2 3 4; do echo "1024 instances, a wavefront per (instance, step), groups of $g steps"; FSDP_SKID_PACK_MIN=100000000 FSDP_SKID_GROUP=$g $T python tools/bench_skidpad.py 1024; done
   echo "4096 instances, a wavefront per (instance, step)"; FSDP_SKID_PACK_MIN=100000000 $T python tools/bench_skidpad.py 4096 ) > $R/skidpad_groups.txt 2>&1
-( export TMPDIR=/tmp; REPO=$(pwd); cd /tmp; FSDP_SKID_BENCH_LEGS=ahead timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r04/skid -o trace -- python $REPO/tools/bench_skidpad.py 1024 > $REPO/$R/skid_trace.log 2>&1 )
-python tools/kernel_stats.py gpurun_out/prof_r04/skid "python tools/bench_skidpad.py 1024, the replay submitted ahead only" > $R/skidpad_rocprofv3_summary.txt 2>&1
+( export TMPDIR=/tmp; REPO=$(pwd); cd /tmp; FSDP_SKID_BENCH_LEGS=ahead timeout 600 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r05/skid -o trace -- python $REPO/tools/bench_skidpad.py 1024 > $REPO/$R/skid_trace.log 2>&1 )
+python tools/kernel_stats.py gpurun_out/prof_r05/skid "python tools/bench_skidpad.py 1024, the replay submitted ahead only" > $R/skidpad_rocprofv3_summary.txt 2>&1
 $T python tools/bench_configs.py > $R/bench_configs.jsonl 2>&1
 # one process, two contexts on the one GPU (multi.py; the form the driver's 8-GPU node can run without a launcher)
 FSDP_SHARE_GPU=1 $T python bench.py --gpus 2 --single-process --steps 20 --warmup 3 --no-cpu-baseline --no-latency --stream-batches 0 2>$R/bench_single_process.err | grep '^{' | tail -1 > $R/bench_line_2contexts_one_process.json
