@@ -242,19 +242,22 @@ def multi_planner_leg(pkg, devices, per_ctx: int, depth: int, n_batches: int, se
 
 def chip_time_leg(pkg, device, off, cones, poses, copies: int = 24, passes: int = 4):
     """What a kernel costs when it has the chip to itself and fills it: the bench batch tiled `copies` times (98 304 frames), one
-    pass at a time, HIP events around every launch -> ns of chip time per frame and kernel.  Unlike the duration of an overlapped
+    pass at a time, HIP events around every launch -> ns of chip time per frame and kernel (24 different tracks of 4096 frames).  Unlike the duration of an overlapped
     launch (which depends on how twenty streams interleave on the box at hand) this figure is a property of the kernel: the sum
     over the kernels is the floor of ms_per_step / frames, and profiles/ reproduces it (tools/batch_sweep.py)."""
     try:
         n1 = len(poses)
-        counts = np.tile(np.diff(off), copies)
+        # `copies` different tracks (identical copies of one batch would run in lock-step and hit the memory system in bursts:
+        # measured 88 instead of 68 ns per frame for the refit kernel)
+        parts = [(off, cones, poses)] + [pkg.synth.make_replay_batch(n1, CONES_PER_SIDE, 0.15, seed=7000 + k, color=True) for k in range(1, copies)]
+        counts = np.concatenate([np.diff(o) for o, _, _ in parts])
         big_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        big_cones = np.tile(cones, (copies, 1))
-        big_poses = np.tile(poses, (copies, 1))
+        big_cones = np.concatenate([c_ for _, c_, _ in parts])
+        big_poses = np.concatenate([p_ for _, _, p_ in parts])
         c = pkg.Context(device=device, mission=int(pkg.MissionTypes.trackdrive))
         c.set_overlap(1)
         c.upload(big_off, big_cones, big_poses)
-        c.time_runs(2)
+        c.time_runs(3)
         tot, st = c.time_runs(passes)
         names = c.stage_names()
         frames = n1 * copies
@@ -615,6 +618,8 @@ def main():
             out["streaming"] = streaming_leg(pkg, ctx, n_local, min(overlap, STREAM_DEPTH), args.stream_batches, d.shard_seed(args.seed))
         if args.config == 2 and args.stream_batches > 0 and (world == 1 or single):
             # multi.MultiPlanner from this one process: on every GPU of a --single-process run, else four contexts on the one GPU
+            if not single:
+                ctx.set_overlap(1)  # (gives the twenty slots' streams back: hardware queues are shared by every context on the GPU)
             devs = d.devices if single else [ctx.device or 0] * 4
             nb = max(4, args.stream_batches // (1 if single else len(devs)))
             out["multi_planner_stream"] = multi_planner_leg(pkg, devs, n_local, 3, nb, d.shard_seed(args.seed),
