@@ -240,33 +240,24 @@ def multi_planner_leg(pkg, devices, per_ctx: int, depth: int, n_batches: int, se
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
-def chip_time_leg(pkg, device, off, cones, poses, copies: int = 24, passes: int = 4):
-    """What a kernel costs when it has the chip to itself and fills it: the bench batch tiled `copies` times (98 304 frames), one
-    pass at a time, HIP events around every launch -> ns of chip time per frame and kernel (24 different tracks of 4096 frames).  Unlike the duration of an overlapped
-    launch (which depends on how twenty streams interleave on the box at hand) this figure is a property of the kernel: the sum
-    over the kernels is the floor of ms_per_step / frames, and profiles/ reproduces it (tools/batch_sweep.py)."""
+def chip_time_leg(frames: int = 98304, timeout: float = 240.0):
+    """What a kernel costs when it has the chip to itself and fills it: one pass at a time over a resident batch of 98 304 frames
+    (24 x the bench batch, same generator), HIP events around every launch -> ns of chip time per frame and kernel.  Unlike the
+    duration of an overlapped launch (which depends on how twenty streams interleave on the box at hand) this figure is a property of
+    the kernel: the sum over the kernels is the floor of ms_per_step / frames, and profiles/ reproduces it — it IS
+    tools/batch_sweep.py, run as a child process with the packed kernels pinned (inside this process, after the bench's other
+    legs have allocated and freed tens of GB, the same launches measured 30 % slower for the scratch-heavy kernels)."""
+    import subprocess
+
     try:
-        n1 = len(poses)
-        # `copies` different tracks (identical copies of one batch would run in lock-step and hit the memory system in bursts:
-        # measured 88 instead of 68 ns per frame for the refit kernel)
-        parts = [(off, cones, poses)] + [pkg.synth.make_replay_batch(n1, CONES_PER_SIDE, 0.15, seed=7000 + k, color=True) for k in range(1, copies)]
-        counts = np.concatenate([np.diff(o) for o, _, _ in parts])
-        big_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        big_cones = np.concatenate([c_ for _, c_, _ in parts])
-        big_poses = np.concatenate([p_ for _, _, p_ in parts])
-        c = pkg.Context(device=device, mission=int(pkg.MissionTypes.trackdrive))
-        c.set_overlap(1)
-        c.upload(big_off, big_cones, big_poses)
-        c.time_runs(3)
-        tot, st = c.time_runs(passes)
-        names = c.stage_names()
-        frames = n1 * copies
-        per = {k: v / passes / frames * 1e6 for k, v in zip(names, st)}
-        c.close()
-        return {"frames_per_launch": frames, "chip_ns_per_frame": per, "chip_ns_per_frame_sum": float(sum(per.values())),
-                "frames_per_s_at_that_sum": 1e9 / float(sum(per.values())), "pass_ns_per_frame_wall": tot / passes / frames * 1e6}
+        env = dict(os.environ, FSDP_PACK="1")
+        r = subprocess.run([sys.executable, str(ROOT / "tools" / "batch_sweep.py"), str(frames)], capture_output=True, text=True, timeout=timeout, env=env)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        per = {k: v / j["frames"] * 1e6 for k, v in j["kernel_ms"].items()}
+        return {"frames_per_launch": j["frames"], "chip_ns_per_frame": per, "chip_ns_per_frame_sum": float(sum(per.values())),
+                "frames_per_s_at_that_sum": 1e9 / float(sum(per.values())), "chip_time_source": "tools/batch_sweep.py 98304 (FSDP_PACK=1), child process"}
     except Exception as e:  # noqa: BLE001
-        return {"error": f"{type(e).__name__}: {e}"[:300]}
+        return {"chip_time_error": f"{type(e).__name__}: {e}"[:300]}
 
 
 class InProcess:
@@ -636,7 +627,7 @@ def main():
                 lat.append(time.perf_counter() - t1)
             out["p50_single_frame_us"] = float(np.median(lat[50:]) * 1e6)
             # the reproducible per-kernel figure next to roofline.kernel_ms (round-4 review, weak #11)
-            out["roofline"].update(chip_time_leg(pkg, ctx.device or 0, off, cones, poses))
+            out["roofline"].update(chip_time_leg())
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(off, cones, poses)
                 out["p50_single_frame_vs_cpu_1thread"] = out["p50_single_frame_us"] / out["cpu_baseline"]["single_thread_us_per_frame"]
