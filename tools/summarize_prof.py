@@ -27,9 +27,11 @@ def db(sub):
 
 
 def short(name):
-    """'void fsdp::fit_kernel<8, 16>(int, ...)' -> 'fit_kernel<8>' (the names bench.py / fsdp_stage_names use)"""
+    """'void fsdp::fit_kernel<8, 16>(int, ...)' -> 'fit_kernel<8>', '...<8, 32>' -> 'fit_kernel<8,32>' (the names bench.py /
+    fsdp_stage_names use: the second parameter, knots per fit, is spelled out only for the wide instantiations)"""
     s = name.split("(")[0].replace("void ", "").split("::")[-1].strip()
-    return re.sub(r"<(\d+), \d+>", r"<\1>", s)
+    s = re.sub(r"<(\d+), 16>", r"<\1>", s)
+    return re.sub(r"<(\d+), (\d+)>", r"<\1,\2>", s)
 
 
 durations = {}
@@ -48,12 +50,14 @@ for sub, label in (("trace", "python bench.py --steps 20 --warmup 5 --no-cpu-bas
         print("-- per-kernel resources (code object metadata of lib/libfsdp_hip.so; launch geometry of the 4096-frame launches from the trace) --")
         try:
             import kernel_resources as kr
-            meta = {k["short"]: k for k in kr.kernels(kr.ROOT / "ft-fsd-path-planning_amd" / "lib" / "libfsdp_hip.so")}
+            meta = {short(k["short"]): k for k in kr.kernels(kr.ROOT / "ft-fsd-path-planning_amd" / "lib" / "libfsdp_hip.so")}
         except Exception as e:  # noqa: BLE001
             meta = {}
             print("(code object metadata unavailable:", e, ")")
 
         def lookup(nm):
+            if nm in meta:  # (same normalisation on both sides: <8, 16> -> <8>, <8, 32> -> <8,32>)
+                return meta[nm]
             base = nm.split("<")[0]
             for k, v in meta.items():
                 if k == nm or (k.split("<")[0] == base and nm.split("<")[-1].rstrip(">").split(",")[0] == k.split("<")[-1].rstrip(">").split(",")[0].strip()):
