@@ -654,6 +654,9 @@ __device__ __forceinline__ void giv_step(GivLane& st, bool feed, double h0, doub
   if constexpr (FAST) {
     // operands of the scaling-free divisions: den (and dd in [den, sqrt(2) den]) inside the safe band, num inside it or 0
     st.bad |= (int)(rot & !((den >= 0x1p-255) & (den <= 0x1p+255) & ((num == 0.0) | (num >= 0x1p-255))));
+    // (Tried in round 5 and not kept: den is the diagonal itself unless the pivot is larger, and the diagonal's refined reciprocal
+    // is the rd of the step that formed it — same bits, five instructions and a reciprocal's latency less.  The wave-uniform branch
+    // around the rare other case cost more than that: p50 894 -> 924 us, 7.00 -> 6.87 M frames/s; profiles/r05_givens_step.txt.)
     const double rq = rcp_refined(den);
     const double q = div_rcp(num, den, rq);
     dd = scale * sqrt_1_2(1.0 + q * q);
@@ -744,6 +747,179 @@ __device__ __forceinline__ void giv_feed(WS& ws, GivLane& st, int r0, int r1) {
   }
   if (r < r1) giv_step<FAST>(st, true, a.h0, a.h1, a.h2, a.h3, a.x, a.y);
 }
+
+// ---- the same pipeline on a 4 x 4 lane grid (groups of 16 lanes and more) ------------------------------------------------
+// Round 5.  In the quad form every lane carries a whole step — fpgivs AND five plane rotations — while the other lanes of a 16- or
+// 64-lane group idle.  Here the first sixteen lanes of the group form four quads: quad p owns the band rows j with j mod 4 = p (as
+// lane p did), and inside a quad lane e holds ONE column pair of that row: e = 0 (a2 | r0), e = 1 (a3 | r1), e = 2 (a4 | r2),
+// e = 3 both right-hand sides (z1 | x1), (z2 | x2).  Every lane of a quad keeps the diagonal a1 and receives the pivot, so every lane
+// forms cs / sn itself (fpgivs is the critical path anyway) and then rotates its own pair(s): two rotation slots instead of five,
+// ~88 instead of 109 instructions per step, same operations on the same operands in the same order per element.  A data row moves
+// quad -> quad by a row rotation (DPP row_ror:4); inside the target quad the pivot (element 0 of the row that leaves) goes to every
+// lane (quad_perm 0,0,0,0) and every other element one column to the left (quad_perm 1,2,2,3: r0 <- r1, r1 <- r2, r2 <- 0).
+struct GivGridLane {
+  double a1;      // the band row's diagonal (every lane of the quad)
+  double bA, bB;  // this lane's band element(s): e = 0..2: a2 / a3 / a4 (bB = 0); e = 3: z1, z2
+  int j;          // the band row the quad owns (0 = none yet)
+  double oA, oB;  // this lane's element(s) of the data row leaving the quad
+  double fp;      // as GivLane::fp, in the lane e = 3 of the stage-4 quad
+  int l, stage, t, fed, bad;
+};
+__device__ __forceinline__ void giv_init(GivGridLane& st) {
+  st.a1 = st.bA = st.bB = 0.0;
+  st.j = 0;
+  st.oA = st.oB = 0.0;
+  st.fp = 0.0;
+  st.l = 0;
+  st.stage = 1;
+  st.t = 0;
+  st.fed = 0;
+  st.bad = 0;
+}
+template <class WS>
+__device__ __forceinline__ void giv_flush(WS& ws, const GivGridLane& st, int lane, int n) {
+  if (lane < 16 && st.j > 0) {
+    const int e = lane & 3;
+    if (e == 0) {
+      ws.A(st.j, 1) = st.a1;
+      ws.A(st.j, 2) = st.bA;
+    } else if (e == 1) {
+      ws.A(st.j, 3) = st.bA;
+    } else if (e == 2) {
+      ws.A(st.j, 4) = st.bA;
+    } else {
+      ws.Z(st.j) = st.bA;
+      ws.Z(st.j + n) = st.bB;
+    }
+  }
+}
+// DPP moves of a double inside a row of 16 lanes.  CTRL: 0x124 = row_ror:4 (lane i <- lane i - 4 mod 16), 0x00 = quad_perm
+// [0,0,0,0], 0xE9 = quad_perm [1,2,2,3]
+template <int CTRL>
+__device__ __forceinline__ double dpp_row16(double d) {
+#ifdef FSDP_EMU
+  const int l = emu::B->cur, r = l & 15, base = l & ~15;
+  int src;
+  if (CTRL == 0x124)
+    src = base | ((r + 12) & 15);
+  else if (CTRL == 0x00)
+    src = l & ~3;
+  else
+    src = (l & ~3) | ((l & 3) == 0 ? 1 : ((l & 3) == 3 ? 3 : 2));
+  return emu::gexchange(d, src, 16);
+#else
+  int lo = __double2loint(d), hi = __double2hiint(d);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+#endif
+}
+// One pipeline step.  feed: the stage-1 quad takes the data row: h0 = its first element (pivot), fA / fB = this lane's element(s)
+// of it (e = 0..2: h1 / h2 / h3, 0; e = 3: x, y).
+template <bool FAST>
+__device__ __forceinline__ void giv_step(GivGridLane& st, int e, bool feed, double h0, double fA, double fB) {
+  const double tA = dpp_row16<0x124>(st.oA), tB = dpp_row16<0x124>(st.oB);
+  double piv = dpp_row16<0x00>(tA);
+  double eA = dpp_row16<0xE9>(tA);
+  eA = (e == 2) ? 0.0 : eA;  // (a row's fourth element is zero behind its first stage)
+  double eB = tB;
+  const bool take = (st.stage == 1) && feed;
+  piv = take ? h0 : piv;
+  eA = take ? fA : eA;
+  eB = take ? fB : eB;
+  const int idx = st.t - (st.stage - 1);
+  const bool valid = (unsigned)idx < (unsigned)st.fed;
+  const bool rot = valid && piv != 0.0;
+  const double ww = st.a1;
+  const double den = max_abs_nn(piv, ww), num = min_abs_nn(piv, ww);
+  double dd, cs, sn;
+  if constexpr (FAST) {
+    st.bad |= (int)(rot & !((den >= 0x1p-255) & (den <= 0x1p+255) & ((num == 0.0) | (num >= 0x1p-255))));
+    const double rq = rcp_refined(den);
+    const double q = div_rcp(num, den, rq);
+    dd = den * sqrt_1_2(1.0 + q * q);
+    const double rd = rcp_refined(dd);
+    cs = div_rcp(ww, dd, rd);
+    sn = div_rcp(piv, dd, rd);
+  } else {
+    const double q = num / den;
+    dd = den * sqrt(1.0 + q * q);
+    cs = ww / dd;
+    sn = piv / dd;
+  }
+  cs = rot ? cs : 1.0;
+  sn = rot ? sn : 0.0;
+  st.a1 = rot ? dd : st.a1;
+  const double nbA = cs * st.bA + sn * eA, nA = cs * eA - sn * st.bA;
+  const double nbB = cs * st.bB + sn * eB, nB = cs * eB - sn * st.bB;
+  st.bA = nbA;
+  st.bB = nbB;
+  {
+    double f = st.fp + nA * nA;
+    f = f + nB * nB;
+    st.fp = (valid && st.stage == 4 && e == 3) ? f : st.fp;
+  }
+  st.oA = nA;
+  st.oB = nB;
+  st.t++;
+}
+template <int G, bool FAST>
+__device__ __forceinline__ void giv_end_run(GivGridLane& st) {
+  if (st.l == 0) return;
+  const int e = Grp<G>::lane() & 3;
+  for (int q = 0; q < 3; q++) giv_step<FAST>(st, e, false, 0.0, 0.0, 0.0);
+  st.fp = Grp<G>::bcast(st.fp, 4 * (st.l & 3) + 3);  // lane e = 3 of the quad that owns band row l
+  st.l = 0;
+}
+template <class WS>
+__device__ __forceinline__ void giv_begin_run(WS& ws, GivGridLane& st, int l, int lane, int n) {
+  const int j0 = l - 3;
+  const int p = (lane >> 2) & 3;
+  st.stage = ((p - j0) & 3) + 1;
+  const int my_j = j0 + st.stage - 1;
+  if (st.j != my_j) {
+    giv_flush(ws, st, lane, n);
+    st.j = my_j;
+    st.a1 = st.bA = st.bB = 0.0;
+  }
+  st.l = l;
+  st.t = 0;
+  st.fed = 0;
+}
+template <bool FAST, class WS>
+__device__ __forceinline__ void giv_feed(WS& ws, GivGridLane& st, int r0, int r1) {
+  st.fed += r1 - r0;
+  const int e = Grp<WS::GRP>::lane() & 3;
+  // this lane's element of a chunk row: column 1 + e of the basis values, or x (e = 3); y for the second slot of e = 3
+  const double* const baseA = (e < 3) ? (&ws.hq[0][0] + 1 + e) : &ws.xq[0];
+  const int strideA = (e < 3) ? 4 : 1;
+  struct Row {
+    double h0, a, b;
+  };
+  auto load = [&](int r) {
+    const int q = r < r1 ? r : r1 - 1;
+    const double y = ws.yq[q];
+    return Row{ws.hq[q][0], baseA[q * strideA], (e == 3) ? y : 0.0};
+  };
+  Row a = load(r0), b = load(r0 + 1);
+  int r = r0;
+  for (; r + 1 < r1; r += 2) {
+    giv_step<FAST>(st, e, true, a.h0, a.a, a.b);
+    a = load(r + 2);
+    giv_step<FAST>(st, e, true, b.h0, b.a, b.b);
+    b = load(r + 3);
+  }
+  if (r < r1) giv_step<FAST>(st, e, true, a.h0, a.a, a.b);
+}
+
+template <bool GRID>
+struct GivState {
+  using type = GivLane;
+};
+template <>
+struct GivState<true> {
+  using type = GivGridLane;
+};
 
 // Residual terms sum_d (s_d(u_i) - x_d,i)^2 of one "super-chunk" of points [base, base + cnt) (cnt <= 4 * CH), one point
 // per lane and round, from the basis cache.  load() issues every scratch load of the super-chunk (registers), compute()
@@ -919,7 +1095,12 @@ __device__ __forceinline__ SplineFit spline_fit_k(WS& ws, const BasisCache& bc, 
         for (int j = 1; j <= k1; j++) ws.A(i, j) = 0.0;
       GR::sync();
       fp = 0.0;
+      // (groups of 16 lanes and more: the step on a 4 x 4 lane grid, two rotation slots per lane instead of five)
+#ifndef FSDP_NO_GIV_GRID
+      typename GivState<(G >= 16)>::type gst;
+#else
       GivLane gst;
+#endif
       giv_init(gst);
       if constexpr (WS::RECOMPUTE) {
         static_assert(!WS::RECOMPUTE || (FAST && K == 3), "the reciprocal table serves the scaling-free cubic fit only");
