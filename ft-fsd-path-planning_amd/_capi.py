@@ -23,39 +23,63 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "lib" / "libfsdp_hip.so"
 
-MAX_LEN, MAX_MATCH, PATH_POINTS, MAX_CONES = 12, 24, 40, 8192
+MAX_CONES = 8192
 MAX_STAGES = 8  # FSDP_MAX_STAGES
 
-# numpy mirror of fsdp_frame_result (include/fsdp.h)
-RESULT_DTYPE = np.dtype(
-    [
-        ("status", "<i4"),
-        ("n_left", "<i4"),
-        ("n_right", "<i4"),
-        ("left_idx", "<i4", (MAX_LEN,)),
-        ("right_idx", "<i4", (MAX_LEN,)),
-        ("n_left_v", "<i4"),
-        ("n_right_v", "<i4"),
-        ("left_v", "<f8", (MAX_MATCH, 2)),
-        ("right_v", "<f8", (MAX_MATCH, 2)),
-        ("l2r", "<i4", (MAX_MATCH,)),
-        ("r2l", "<i4", (MAX_MATCH,)),
-        ("path", "<f8", (PATH_POINTS, 4)),
-        ("n_configs_left", "<i4"),
-        ("n_configs_right", "<i4"),
-        ("first_k_left", "<i4", (2,)),
-        ("first_k_right", "<i4", (2,)),
-        ("best_cost_left", "<f8"),
-        ("best_cost_right", "<f8"),
-        ("path_fallback", "<i4"),
-        ("n_dense", "<i4"),
-    ],
-    align=True,
-)
+
+class Shapes:
+    """The array shapes of one build of the library (include/fsdp.h: FSDP_MAX_LEN, FSDP_MAX_NEIGHBORS, FSDP_MAX_MATCH,
+    FSDP_PATH_POINTS) with the NumPy mirrors of its records.  Two builds of the same sources exist: the standard one (the
+    reference's default structural parameters, config.py:34-37,58) and the wide one for contexts whose max_n_neighbors,
+    max_length or mpc_prediction_horizon exceed them."""
+
+    def __init__(self, name, lib_name, max_len, max_neighbors, max_match, path_points):
+        self.name, self.lib_path = name, PKG_DIR / "lib" / lib_name
+        self.max_len, self.max_neighbors, self.max_match, self.path_points = max_len, max_neighbors, max_match, path_points
+        # numpy mirror of fsdp_frame_result (include/fsdp.h)
+        self.result_dtype = np.dtype(
+            [
+                ("status", "<i4"),
+                ("n_left", "<i4"),
+                ("n_right", "<i4"),
+                ("left_idx", "<i4", (max_len,)),
+                ("right_idx", "<i4", (max_len,)),
+                ("n_left_v", "<i4"),
+                ("n_right_v", "<i4"),
+                ("left_v", "<f8", (max_match, 2)),
+                ("right_v", "<f8", (max_match, 2)),
+                ("l2r", "<i4", (max_match,)),
+                ("r2l", "<i4", (max_match,)),
+                ("path", "<f8", (path_points, 4)),
+                ("n_configs_left", "<i4"),
+                ("n_configs_right", "<i4"),
+                ("first_k_left", "<i4", (2,)),
+                ("first_k_right", "<i4", (2,)),
+                ("best_cost_left", "<f8"),
+                ("best_cost_right", "<f8"),
+                ("path_fallback", "<i4"),
+                ("n_dense", "<i4"),
+            ],
+            align=True,
+        )
+        # fsdp_path_result (include/fsdp.h): a skidpad step's compact result
+        self.path_result_dtype = np.dtype(
+            [("path", "<f8", (path_points, 4)), ("status", "<i4"), ("path_fallback", "<i4"), ("n_dense", "<i4"), ("pad", "<i4")], align=True)
+
+    def holds(self, params) -> bool:
+        """Do this build's shapes take these structural parameters (an fsdp_params)?"""
+        return (params.max_n_neighbors <= self.max_neighbors and params.max_length <= self.max_len
+                and params.mpc_prediction_horizon <= self.path_points)
 
 
-# fsdp_path_result (include/fsdp.h): a skidpad step's compact result
-PATH_RESULT_DTYPE = np.dtype([("path", "<f8", (PATH_POINTS, 4)), ("status", "<i4"), ("path_fallback", "<i4"), ("n_dense", "<i4"), ("pad", "<i4")], align=True)
+STANDARD = Shapes("standard", "libfsdp_hip.so", 12, 5, 24, 40)
+WIDE = Shapes("wide", "libfsdp_hip_wide.so", 16, 8, 32, 64)  # libfsdp_hip_wide.so = the same sources with -DFSDP_WIDE_SHAPES
+LIB_PATH = STANDARD.lib_path
+# the standard build's shapes under their historic names (what every context with the reference's default structural
+# parameters uses; a context knows its own: Context.shapes / Context.result_dtype)
+MAX_LEN, MAX_MATCH, PATH_POINTS = STANDARD.max_len, STANDARD.max_match, STANDARD.path_points
+RESULT_DTYPE = STANDARD.result_dtype
+PATH_RESULT_DTYPE = STANDARD.path_result_dtype
 
 
 class FsdpError(RuntimeError):
@@ -95,20 +119,20 @@ def make_params(overrides=None) -> Params:
     return p
 
 
-_lib = None
+_libs = {}
 
 
-def load() -> ctypes.CDLL:
-    """Load libfsdp_hip.so or raise FsdpError (no CPU fallback exists)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
+def load(shapes: Shapes = STANDARD) -> ctypes.CDLL:
+    """Load libfsdp_hip.so (or, for shapes = WIDE, libfsdp_hip_wide.so) or raise FsdpError (no CPU fallback exists)."""
+    if shapes.name in _libs:
+        return _libs[shapes.name]
+    path = shapes.lib_path
+    if not path.exists():
         raise FsdpError(
-            f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+            f"{path} not found: build it with `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950); this package has no CPU fallback"
         )
-    lib = ctypes.CDLL(str(LIB_PATH))
+    lib = ctypes.CDLL(str(path))
     lib.fsdp_version.restype = ctypes.c_char_p
     lib.fsdp_last_error.restype = ctypes.c_char_p
     lib.fsdp_last_error.argtypes = [ctypes.c_void_p]
@@ -143,14 +167,17 @@ def load() -> ctypes.CDLL:
     lib.fsdp_skidpad_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
     lib.fsdp_route_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong)]
-    if lib.fsdp_result_size() != RESULT_DTYPE.itemsize:
-        raise FsdpError(f"fsdp_frame_result layout mismatch: {lib.fsdp_result_size()} != {RESULT_DTYPE.itemsize}")
-    _lib = lib
+    got = (ctypes.c_int32 * 4)()
+    lib.fsdp_shapes(got)
+    want = [shapes.max_len, shapes.max_neighbors, shapes.max_match, shapes.path_points]
+    if list(got) != want or lib.fsdp_result_size() != shapes.result_dtype.itemsize:
+        raise FsdpError(f"{path.name}: shapes {list(got)} / result size {lib.fsdp_result_size()}, this binding expects {want} / {shapes.result_dtype.itemsize}")
+    _libs[shapes.name] = lib
     return lib
 
 
 EXPORTED_SYMBOLS = [
-    "fsdp_version", "fsdp_result_size", "fsdp_device_count", "fsdp_default_params", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
+    "fsdp_version", "fsdp_result_size", "fsdp_shapes", "fsdp_device_count", "fsdp_default_params", "fsdp_create", "fsdp_destroy", "fsdp_last_error",
     "fsdp_plan_batch", "fsdp_upload", "fsdp_run", "fsdp_sync", "fsdp_download", "fsdp_time_runs", "fsdp_time_reserve", "fsdp_time_results", "fsdp_time_kernel_clock", "fsdp_time_detail", "fsdp_stage_names", "fsdp_resident_frames",
     "fsdp_sort_batch", "fsdp_match_batch", "fsdp_path_batch", "fsdp_path_batch_centers", "fsdp_default_path",
     "fsdp_plan_batch_sequential", "fsdp_set_previous_paths", "fsdp_set_overlap", "fsdp_set_global_path",
@@ -260,30 +287,36 @@ def _ip(a):
 class Context:
     """One GPU context (= fsdp_ctx): device buffers + one HIP stream."""
 
-    def __init__(self, device: int | None = None, mission: int = 4, params: dict | None = None):
-        """params: overrides of the reference's configuration constants by their kwarg names (None = defaults)."""
-        lib = load()
+    def __init__(self, device: int | None = None, mission: int = 4, params: dict | None = None, shapes: Shapes | None = None):
+        """params: overrides of the reference's configuration constants by their kwarg names (None = defaults).
+        shapes: which build of the library carries the context (None = the standard build unless max_n_neighbors, max_length or
+        mpc_prediction_horizon exceed its shapes — then the wide build, whose records are larger: Context.result_dtype)."""
+        self.params = make_params(params)
+        if shapes is None:
+            shapes = STANDARD if STANDARD.holds(self.params) else WIDE
+        lib = load(shapes)
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) % max(lib.fsdp_device_count(), 1)
         h = ctypes.c_void_p()
-        self.params = make_params(params)
         rc = lib.fsdp_create(int(device), int(mission), ctypes.byref(self.params), ctypes.byref(h))
         if rc != 0:
             raise FsdpError(f"fsdp_create failed ({rc}): {lib.fsdp_last_error(None).decode()}")
         self._lib, self._h, self.device, self.n_frames = lib, h, device, 0
+        self.shapes, self.result_dtype, self.path_result_dtype = shapes, shapes.result_dtype, shapes.path_result_dtype
 
     @property
     def horizon(self) -> int:
-        """mpc_prediction_horizon of this context: rows of a path (the result struct holds 40, the rest NaN)."""
+        """mpc_prediction_horizon of this context: rows of a path (the result struct holds shapes.path_points, the rest NaN)."""
         return int(self.params.mpc_prediction_horizon)
 
     def pad_paths(self, paths) -> np.ndarray:
-        """(n, horizon, 4) previous paths as the reference keeps them -> the (n, 40, 4) block the C ABI reads."""
+        """(n, horizon, 4) previous paths as the reference keeps them -> the (n, shapes.path_points, 4) block the C ABI reads."""
+        rows = self.shapes.path_points
         p = np.asarray(paths, dtype=np.float64)
         p = p.reshape(-1, p.shape[-2], 4)
-        if p.shape[1] == PATH_POINTS:
+        if p.shape[1] == rows:
             return np.ascontiguousarray(p)
-        out = np.full((len(p), PATH_POINTS, 4), np.nan)
+        out = np.full((len(p), rows, 4), np.nan)
         out[:, : p.shape[1]] = p
         return out
 
@@ -316,7 +349,7 @@ class Context:
 
     def plan_batch(self, offsets, cones, poses) -> np.ndarray:
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
-        out = np.zeros(n, dtype=RESULT_DTYPE)
+        out = np.zeros(n, dtype=self.result_dtype)
         self._check(self._lib.fsdp_plan_batch(self._h, n, _ip(offsets), _dp(cones), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_plan_batch")
         self.n_frames = n
         return out
@@ -326,25 +359,25 @@ class Context:
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
         prev = self.pad_paths(prev_paths)
         assert len(prev) == n
-        out = np.zeros(n, dtype=RESULT_DTYPE)
+        out = np.zeros(n, dtype=self.result_dtype)
         self._check(self._lib.fsdp_plan_batch_sequential(self._h, n, _ip(offsets), _dp(cones), _dp(poses), _dp(prev), ctypes.c_void_p(out.ctypes.data)), "fsdp_plan_batch_sequential")
         self.n_frames = n
         return out
 
     def sort_batch(self, offsets, cones, poses) -> np.ndarray:
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
-        out = np.zeros(n, dtype=RESULT_DTYPE)
+        out = np.zeros(n, dtype=self.result_dtype)
         self._check(self._lib.fsdp_sort_batch(self._h, n, _ip(offsets), _dp(cones), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_sort_batch")
         return out
 
     def match_batch(self, sorted_left, n_left, sorted_right, n_right, poses) -> np.ndarray:
-        sorted_left = np.ascontiguousarray(sorted_left, np.float64).reshape(-1, MAX_LEN, 2)
-        sorted_right = np.ascontiguousarray(sorted_right, np.float64).reshape(-1, MAX_LEN, 2)
+        sorted_left = np.ascontiguousarray(sorted_left, np.float64).reshape(-1, self.shapes.max_len, 2)
+        sorted_right = np.ascontiguousarray(sorted_right, np.float64).reshape(-1, self.shapes.max_len, 2)
         n_left = np.ascontiguousarray(n_left, np.int32)
         n_right = np.ascontiguousarray(n_right, np.int32)
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 4)
         n = len(poses)
-        out = np.zeros(n, dtype=RESULT_DTYPE)
+        out = np.zeros(n, dtype=self.result_dtype)
         self._check(self._lib.fsdp_match_batch(self._h, n, _dp(sorted_left), _ip(n_left), _dp(sorted_right), _ip(n_right), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_match_batch")
         return out
 
@@ -352,7 +385,7 @@ class Context:
         """prev_paths (n,40,4): CalculatePath.previous_paths[-1] of every frame's planner (None = fresh planners)."""
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 4)
         results = np.ascontiguousarray(results)
-        assert results.dtype == RESULT_DTYPE and len(results) == len(poses)
+        assert results.dtype == self.result_dtype and len(results) == len(poses)
         prev = None if prev_paths is None else _dp(self.pad_paths(prev_paths))
         self._check(self._lib.fsdp_path_batch(self._h, len(poses), _dp(poses), prev, ctypes.c_void_p(results.ctypes.data)), "fsdp_path_batch")
         return results
@@ -362,7 +395,7 @@ class Context:
         (n_i, 2) arrays, the points every frame's first spline fit was given."""
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 4)
         results = np.ascontiguousarray(results)
-        assert results.dtype == RESULT_DTYPE and len(results) == len(poses)
+        assert results.dtype == self.result_dtype and len(results) == len(poses)
         prev = None if prev_paths is None else _dp(self.pad_paths(prev_paths))
         n = len(poses)
         centers = np.zeros((n, cap, 2))
@@ -377,12 +410,12 @@ class Context:
     def submit(self, offsets, cones, poses, prev_paths=None, out=None) -> Ticket:
         """Enqueue one batch (H2D, the kernels of a pass, D2H) on the next pass slot and return at once.  Arrays made by
         ``pinned_empty`` / ``pinned_copy`` are transferred asynchronously; others are accepted but staged.  ``out``: the
-        RESULT_DTYPE array the results go to (default: a new pinned array).  Raises when every slot holds a ticket."""
+        self.result_dtype array the results go to (default: a new pinned array).  Raises when every slot holds a ticket."""
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
         prev = None if prev_paths is None else self.pad_paths(prev_paths)
         if out is None:
-            out = pinned_empty(n, RESULT_DTYPE)
-        assert out.dtype == RESULT_DTYPE and len(out) == n and out.flags.c_contiguous
+            out = pinned_empty(n, self.result_dtype)
+        assert out.dtype == self.result_dtype and len(out) == n and out.flags.c_contiguous
         t = ctypes.c_longlong(-1)
         self._check(self._lib.fsdp_submit(self._h, n, offsets.ctypes.data, cones.ctypes.data if len(cones) else None, poses.ctypes.data,
                                           None if prev is None else prev.ctypes.data, out.ctypes.data, ctypes.byref(t)), "fsdp_submit")
@@ -390,7 +423,7 @@ class Context:
 
     def submit_slice(self, lo: int, hi: int, offsets, cones, poses, prev, out) -> Ticket:
         """Frames [lo, hi) of a batch that is already in the ABI's layout (int32 offsets of the WHOLE batch, (N, 3) cones,
-        (F, 4) poses, optional (F, 40, 4) previous paths, RESULT_DTYPE out of the whole batch): the slice goes to fsdp_submit as
+        (F, 4) poses, optional (F, 40, 4) previous paths, self.result_dtype out of the whole batch): the slice goes to fsdp_submit as
         pointers into those arrays (include/fsdp.h: cone_offsets[0] need not be 0) — nothing is copied or rebased on the host."""
         n = hi - lo
         t = ctypes.c_longlong(-1)
@@ -447,7 +480,7 @@ class Context:
 
     def download(self) -> np.ndarray:
         # sized from the library's own count: stage-level calls change the resident batch behind this object's back
-        out = np.zeros(int(self._lib.fsdp_resident_frames(self._h)), dtype=RESULT_DTYPE)
+        out = np.zeros(int(self._lib.fsdp_resident_frames(self._h)), dtype=self.result_dtype)
         self._check(self._lib.fsdp_download(self._h, ctypes.c_void_p(out.ctypes.data)), "fsdp_download")
         return out
 

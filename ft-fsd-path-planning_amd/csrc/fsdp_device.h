@@ -22,12 +22,24 @@ namespace fsdp {
 
 constexpr int WAVE = 64;
 constexpr int MAX_CONES = 256;   // cones per frame handled in LDS (status OVERFLOW beyond)
-constexpr int MAX_LEN = 12;      // reference config.py:36 max_length
-constexpr int KNN = 5;           // config.py:34 max_n_neighbors
+// Structural capacities.  Two builds of these sources exist (include/fsdp.h): the standard shapes are the reference's
+// defaults; -DFSDP_WIDE_SHAPES compiles the wide library for contexts whose parameters exceed them.
+#ifdef FSDP_WIDE_SHAPES
+constexpr int MAX_LEN = 16;      // reference config.py:36 max_length
+constexpr int KNN = 8;           // config.py:34 max_n_neighbors
+#else
+constexpr int MAX_LEN = 12;
+constexpr int KNN = 5;
+#endif
 constexpr int MAX_ENDS = 64;     // raw end configurations kept per side (OVERFLOW beyond)
-constexpr int MAX_STACK = 64;    // DFS stack bound: <= 5 pending siblings per depth * 12 depths
-constexpr int MAX_MATCH = 24;    // cones-with-virtual per side
-constexpr int PATH_POINTS = 40;  // config.py:58 mpc_prediction_horizon
+constexpr int MAX_STACK = (KNN * MAX_LEN + 63) / 64 * 64;  // DFS stack bound: <= KNN pending siblings per depth * MAX_LEN depths
+constexpr int MAX_MATCH = 2 * MAX_LEN;  // cones-with-virtual per side: a side's own (<= MAX_LEN) + inserted (<= MAX_LEN)
+#ifdef FSDP_WIDE_SHAPES
+constexpr int PATH_POINTS = 64;  // config.py:58 mpc_prediction_horizon (rows of every path array)
+#else
+constexpr int PATH_POINTS = 40;
+#endif
+constexpr int CHORD_POINTS = 40; // path_calculator_helpers.py:54-68: the almost-straight initial path has 40 points whatever the horizon
 
 constexpr int T_UNKNOWN = 0, T_RIGHT = 1, T_LEFT = 2;
 

@@ -29,7 +29,7 @@
 using namespace fsdp;
 
 static_assert(FSDP_MAX_LEN == MAX_LEN && FSDP_MAX_MATCH == MAX_MATCH && FSDP_PATH_POINTS == PATH_POINTS &&
-                  FSDP_MAX_CONES == BIG_CONES,
+                  FSDP_MAX_NEIGHBORS == KNN && FSDP_MAX_CONES == BIG_CONES,
               "header/device constant mismatch");
 
 static thread_local std::string g_create_error;
@@ -894,6 +894,12 @@ extern "C" {
 
 const char* fsdp_version(void) { return "fsdp-hip 0.3 (gfx950)"; }
 int fsdp_result_size(void) { return (int)sizeof(fsdp_frame_result); }
+void fsdp_shapes(int32_t* out4) {
+  out4[0] = FSDP_MAX_LEN;
+  out4[1] = FSDP_MAX_NEIGHBORS;
+  out4[2] = FSDP_MAX_MATCH;
+  out4[3] = FSDP_PATH_POINTS;
+}
 
 int fsdp_device_count(void) {
   int n = 0;
@@ -927,15 +933,19 @@ void fsdp_default_params(fsdp_params* p) {
 
 // what the kernels can take: structural parameters within the compiled capacities, the fixed ones at their values
 static const char* check_params(const fsdp_params& p) {
-  if (p.max_n_neighbors < 1 || p.max_n_neighbors > KNN) return "max_n_neighbors must be in 1..5";
-  if (p.max_length < 3 || p.max_length > MAX_LEN) return "max_length must be in 3..12";
+#define FSDP_STR2(x) #x
+#define FSDP_STR(x) FSDP_STR2(x)
+  if (p.max_n_neighbors < 1 || p.max_n_neighbors > KNN)
+    return "max_n_neighbors must be in 1.." FSDP_STR(FSDP_MAX_NEIGHBORS) " (this build's shapes; the wide build takes 8: include/fsdp.h)";
+  if (p.max_length < 3 || p.max_length > MAX_LEN)
+    return "max_length must be in 3.." FSDP_STR(FSDP_MAX_LEN) " (this build's shapes; the wide build takes 16: include/fsdp.h)";
   if (!(p.max_dist > 0) || !(p.max_dist_to_first > 0)) return "max_dist / max_dist_to_first must be positive";
   if (!(p.smoothing > 0) || !(p.predict_every > 0)) return "smoothing / predict_every must be positive";
   if (!(p.mpc_path_length > 0) || !(p.maximal_distance_for_valid_path >= 0)) return "mpc_path_length must be positive";
   if (!(p.min_track_width > 0) || !(p.max_search_range > 0)) return "min_track_width / max_search_range must be positive";
   if (p.max_deg < 1 || p.max_deg > 3) return "max_deg must be in 1..3";
   if (p.mpc_prediction_horizon < 1 || p.mpc_prediction_horizon > FSDP_PATH_POINTS)
-    return "mpc_prediction_horizon must be in 1..40 (a path of the result holds 40 rows)";
+    return "mpc_prediction_horizon must be in 1.." FSDP_STR(FSDP_PATH_POINTS) " (rows of a result path in this build; the wide build holds 64: include/fsdp.h)";
   // the dense path update (fit #1 evaluated every predict_every over <= ~80 m) must fit the working polyline
   if (p.predict_every < 0.05) return "predict_every below 0.05 exceeds the working polyline capacity";
   // the refit is evaluated every predict_every up to 1.5 * mpc_path_length (core_calculate_path.py:248-251) into the same
@@ -1012,7 +1022,7 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   // constant initial previous path: almost-straight chord (path_calculator_helpers.py:26-68) fitted and
   // parameterized on the device (core_calculate_path.py:103-121)
   {
-    double chord[PATH_POINTS][2];
+    double chord[CHORD_POINTS][2];
     default_chord_points(chord);
     double*& d_chord = c->d_chord;
     double* d_arena0 = nullptr;

@@ -310,7 +310,7 @@ __device__ __forceinline__ int cones_for_other_side(MatchShared& S, const Params
   return no;
 }
 
-constexpr int MATCH_G = 32;  // lanes per frame (>= MAX_MATCH + 1: the insertion work list is walked one cone per lane)
+constexpr int MATCH_G = (MAX_MATCH < 32) ? 32 : 64;  // lanes per frame (>= MAX_MATCH + 1: the insertion work list is walked one cone per lane; wide build: the whole wavefront)
 static_assert(MATCH_G > MAX_MATCH, "matching walks its lists one cone per lane");
 // (four wavefronts per SIMD, 126 registers: measured +2 % frames/s over the two the allocator takes unasked)
 template <int G>

@@ -865,7 +865,7 @@ __device__ __forceinline__ int finish_path(PS& S, const Arena& A, int n1, double
 
 // path_calculator_helpers.py:26-68 calculate_almost_straight_path (host side, libm = what NumPy uses)
 inline void default_chord_points(double (*chord)[2]) {
-  const int NP = PATH_POINTS;
+  const int NP = CHORD_POINTS;
   const double max_angle = FSDP_PI / 50;
   const double step = (fabs(max_angle) - 0.0) / (double)(NP - 1);
   const double c = cos(-(FSDP_PI / 2)), s = sin(-(FSDP_PI / 2));
@@ -911,7 +911,7 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
   __shared__ PathShared<G> S;
   const int lane = lane_id();
   const Arena A = frame_arena(arena, 0, prm);
-  if (lane < PATH_POINTS) {
+  if (lane < CHORD_POINTS) {
     A.x[lane] = chord[2 * lane];
     A.y[lane] = chord[2 * lane + 1];
   }
@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(64) default_path_kernel(const double* __restri
   SplineFit f;
   double max_u;
   constexpr bool FAST = false;  // one-off per context: plain divisions
-  int rc = fit_polyline<G, FAST>(S, A, 0, PATH_POINTS, A.prm->smoothing, f, max_u, A.prm->max_deg);
+  int rc = fit_polyline<G, FAST>(S, A, 0, CHORD_POINTS, A.prm->smoothing, f, max_u, A.prm->max_deg);
   int n1 = arange_len(max_u, A.prm->predict_every);
   if (rc == 0 && n1 <= PATH_CAP) {
     spline_eval(S.ws, f, A.prm->predict_every, n1, A.x, A.y, nullptr);

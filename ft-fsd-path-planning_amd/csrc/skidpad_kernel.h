@@ -519,7 +519,7 @@ __device__ __forceinline__ int skid_fill_update(const Arena& A, const SkidTables
     double yaw = detm::det_atan2(dy, dx);
     double sn, cs;
     detm::det_sincos(yaw, sn, cs);
-    n1 = PATH_POINTS - 1;
+    n1 = CHORD_POINTS - 1;
     for (int i = lane; i < n1; i += G) {
       double cxp = chord[2 * (i + 1)], cyp = chord[2 * (i + 1) + 1];
       A.x[1 + i] = blas_dot2(cxp, cs, cyp, -sn) + px;

@@ -250,7 +250,8 @@ __device__ inline bool candidate_can_be_added(const SH& S, const Params& P, int 
   return can;
 }
 
-// NumPy pairwise sum of the first n (<= 11) entries of a register array, static indexing only
+// NumPy pairwise sum of the first n (<= MAX_LEN - 1 <= 15: below the 16 of the unrolled loop's second block) entries of a
+// register array, static indexing only
 __device__ __forceinline__ double np_sum_reg(const double (&a)[MAX_LEN], int n) {
   if (n < 8) {
     double r = 0.0;
@@ -556,6 +557,15 @@ __device__ __forceinline__ void sort_side_prepare(SH& S, const Params& P, int n,
   __syncthreads();
 }
 
+template <bool WIDE>
+struct PairMask {
+  using type = unsigned;
+};
+template <>
+struct PairMask<true> {
+  using type = unsigned long long;
+};
+
 // Phase 2 (S8): DFS over the cost tree (end_configurations.py:320-431) of BOTH sides at once, one half-wavefront per
 // side.  A pop keeps at most 5 candidate lanes and 25 (candidate, neighbour) lanes busy, so the two independent searches
 // share every instruction; the loop runs until both stacks are empty.
@@ -615,14 +625,22 @@ __device__ inline void sort_dfs_both(SH& S, const Params& P, double px, double p
     }
     __syncthreads();
     const int n_nb = go ? S.nbr_cnt[adj][node] : 0;
-    // up to 5 x 5 (candidate, neighbour) pairs, one per lane; candidate c owns bits [c * n_nb, (c + 1) * n_nb)
-    bool btw = false;
-    if (sl < n_nb * n_nb) btw = neighbour_lies_between(S, node, S.nbr[adj][node][sl / n_nb], S.nbr[adj][node][sl % n_nb]);
-    const unsigned bm = (unsigned)(__ballot(btw) >> (32 * side));
+    // up to KNN x KNN (candidate, neighbour) pairs, one per lane (5 x 5: one round of the side's 32 lanes; the wide build's
+    // 8 x 8: two); candidate c owns bits [c * n_nb, (c + 1) * n_nb)
+    constexpr int PAIR_ROUNDS = (KNN * KNN + 31) / 32;
+    using pair_mask_t = typename PairMask<(PAIR_ROUNDS > 1)>::type;
+    pair_mask_t bm = 0;
+#pragma unroll
+    for (int r = 0; r < PAIR_ROUNDS; r++) {
+      const int pr = sl + 32 * r;
+      bool btw = false;
+      if (pr < n_nb * n_nb) btw = neighbour_lies_between(S, node, S.nbr[adj][node][pr / n_nb], S.nbr[adj][node][pr % n_nb]);
+      bm |= (pair_mask_t)(unsigned)(__ballot(btw) >> (32 * side)) << (32 * r);
+    }
     bool can = false;
     double cand_ang = 0.0;
     if (sl < n_nb) {
-      const bool between = ((bm >> (sl * n_nb)) & ((1u << n_nb) - 1u)) != 0u;
+      const bool between = ((bm >> (sl * n_nb)) & (((pair_mask_t)1 << n_nb) - 1u)) != 0u;
       const double ang_tl = (pos >= 2) ? S.attempt_ang[side][pos - 1] : 0.0;
       can = candidate_can_be_added(S, P, side, cone_type, pos, node, S.nbr[adj][node][sl], between, px, py, dx, dy, dnx, dny, a_car,
                                    node_ang, ang_tl, cand_ang);
@@ -921,29 +939,31 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
     }
 
   // ---------------- S11: cost per configuration (cost_function.py:213-304) ----------------
-  // Five kept configurations at a time, lane = (configuration k, position a): every lane evaluates the terms of its
-  // position (one turn angle, one segment length, one segment direction), then the twelve lanes of a configuration fetch
-  // each other's terms and add them up in the reference's order (all twelve redundantly; lane a = 0 stores the cost).
+  // WAVE / MAX_LEN (five) kept configurations at a time, lane = (configuration k, position a): every lane evaluates the terms of
+  // its position (one turn angle, one segment length, one segment direction), then the MAX_LEN (twelve) lanes of a configuration
+  // fetch each other's terms and add them up in the reference's order (all of them redundantly; lane a = 0 stores the cost).
   PROF_MARK(6);
   for (int c0 = 0; c0 < n_ends; c0 += WAVE) {
     unsigned long long km = __ballot(c0 + lane < n_ends && S.keep[(c0 + lane < n_ends) ? c0 + lane : 0]);
     while (km) {
-      const int k = lane / MAX_LEN, a = lane - k * MAX_LEN;  // k = 5: lanes 60..63 idle
+      constexpr int PER = WAVE / MAX_LEN;                    // configurations per round: 5 (4 in the wide build)
+      constexpr unsigned long long ROW = (1ull << MAX_LEN) - 1ull;  // the lanes of one configuration in a ballot
+      const int k = lane / MAX_LEN, a = lane - k * MAX_LEN;  // k = PER: lanes 60..63 idle (standard build)
       int cid = -1;
 #pragma unroll
-      for (int q = 0; q < 5; q++)
+      for (int q = 0; q < PER; q++)
         if (km) {
           if (q == k) cid = c0 + (__ffsll(km) - 1);
           km &= km - 1ull;
         }
       const bool act = cid >= 0;
-      const int base = (k < 5) ? k * MAX_LEN : 0;
+      const int base = (k < PER) ? k * MAX_LEN : 0;
       const int16_t* e = S.ends[side][act ? cid : 0];
       // this position's cone and the two after it (rows are -1 padded to MAX_LEN; -1 wraps to the last cone like NumPy)
       const int e0 = e[a], e1 = (a + 1 < MAX_LEN) ? e[a + 1] : -1, e2 = (a + 2 < MAX_LEN) ? e[a + 2] : -1;
       const int i0 = e0 < 0 ? n + e0 : e0, i1 = e1 < 0 ? n + e1 : e1, i2 = e2 < 0 ? n + e2 : e2;
       const double x0 = S.x[i0], y0 = S.y[i0], x1 = S.x[i1], y1 = S.y[i1], x2 = S.x[i2], y2 = S.y[i2];
-      const unsigned grp_in = (unsigned)((__ballot(act && a < L && e0 != -1) >> base) & 0xFFFull);
+      const unsigned grp_in = (unsigned)((__ballot(act && a < L && e0 != -1) >> base) & ROW);
       const int clen = __popc(grp_in);
       const int na = L - 2;
       // angle cost term :41-79
@@ -981,9 +1001,9 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
       }
       double init_cost = 0.0;
       if (act && a == 0) init_cost = angle_between(x1 - x0, y1 - y0, dx, dy);
-      const unsigned part_bits = (unsigned)((__ballot(is_part) >> base) & 0xFFFull);
-      const unsigned under_bits = (unsigned)((__ballot(under) >> base) & 0xFFFull);
-      const unsigned wrong_bits = (unsigned)((__ballot(wrong) >> base) & 0xFFFull);
+      const unsigned part_bits = (unsigned)((__ballot(is_part) >> base) & ROW);
+      const unsigned under_bits = (unsigned)((__ballot(under) >> base) & ROW);
+      const unsigned wrong_bits = (unsigned)((__ballot(wrong) >> base) & ROW);
       // the configuration's terms to every one of its lanes, then the sums in the reference's order
       double tmp[MAX_LEN];  // static indexing only (fully unrolled loops) so that it stays in registers
 #pragma unroll

@@ -27,7 +27,9 @@ constexpr int knot_capacity() {
 }
 constexpr int NK_MAX = 64;
 
-constexpr int DENSE_CAP = 128;  // dense samples of the final spline (120 or 121 in practice)
+// dense samples of the final spline: 3 x mpc_prediction_horizon, or one more (path_parameterization.py:163-193: 120 or 121
+// at the default horizon of 40; up to 193 in the wide build's 64 rows)
+constexpr int DENSE_CAP = (3 * PATH_POINTS + 1 <= 128) ? 128 : 200;
 
 // LDS workspace of one frame: 4.8 KB at G = 16/32, 4 KB at G = 8 (eight frames of a wavefront: five workgroups per CU).  Three
 // lifetimes share the bytes: what a running fit always needs (knots, coefficients, the band triangle and its

@@ -151,8 +151,8 @@ class MultiPlanner:
         if prev is not None and len(prev) != n:
             raise ValueError("prev_paths: one (horizon, 4) path per frame")
         if out is None:
-            out = self._pool.get(n, _capi.RESULT_DTYPE)
-        assert out.dtype == _capi.RESULT_DTYPE and len(out) == n and out.flags.c_contiguous
+            out = self._pool.get(n, self.ctx[0].result_dtype)
+        assert out.dtype == self.ctx[0].result_dtype and len(out) == n and out.flags.c_contiguous
         ranges = [(g, lo, hi) for g, (lo, hi) in enumerate(shard_ranges(n, len(self.ctx))) if hi > lo]
         zero_copy = n > 0 and _capi.is_pinned(offsets) and _capi.is_pinned(poses) and (len(cones) == 0 or _capi.is_pinned(cones)) and (
             prev is None or _capi.is_pinned(prev))
@@ -245,7 +245,7 @@ class MultiSkidpadBatch:
         PATH_RESULT_DTYPE (default: a block of this object's pool, returned to it when the last reference is dropped)."""
         off, cones, poses, n = _capi.Context._prep(cone_offsets, cones_xyt, poses)
         assert n == self.n
-        want = _capi.PATH_RESULT_DTYPE if compact else _capi.RESULT_DTYPE
+        want = self.parts[0]._ctx.path_result_dtype if compact else self.parts[0]._ctx.result_dtype
         if out is None:
             out = self._pool.get(n, want)
         if out.dtype != want:

@@ -132,7 +132,7 @@ def replay_batched(mission, positions, directions, observations, device=None, re
     for lo in range(0, len(frames), batch_frames):
         off, cones, poses = pack_frames(frames[lo:lo + batch_frames])
         chunks.append((_capi.pinned_copy(off, np.int32), _capi.pinned_copy(cones, np.float64), _capi.pinned_copy(poses, np.float64),
-                       _capi.pinned_empty(len(poses), _capi.RESULT_DTYPE)))
+                       _capi.pinned_empty(len(poses), ctx.result_dtype)))
     depth = max(1, min(depth, len(chunks)))
     ctx.set_overlap(depth)
 
@@ -150,7 +150,7 @@ def replay_batched(mission, positions, directions, observations, device=None, re
     for _ in range(repeats):
         one_replay()
     sec = (time.perf_counter() - t0) / repeats
-    res = np.concatenate([np.array(c[3]) for c in chunks]) if chunks else np.zeros(0, _capi.RESULT_DTYPE)
+    res = np.concatenate([np.array(c[3]) for c in chunks]) if chunks else np.zeros(0, ctx.result_dtype)
     ctx.set_overlap(1)
     return res, sec
 

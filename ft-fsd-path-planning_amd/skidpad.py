@@ -79,7 +79,7 @@ class SkidpadBatch:
     def step(self, cone_offsets, cones_xyt, poses):
         off, cones, poses, n = self._ctx._prep(cone_offsets, cones_xyt, poses)
         assert n == self.n
-        res = np.zeros(n, dtype=_capi.RESULT_DTYPE)
+        res = np.zeros(n, dtype=self._ctx.result_dtype)
         info = np.zeros(n, dtype=INFO_DTYPE)
         self._ctx._check(
             self._ctx._lib.fsdp_skidpad_step(self._ctx._h, ctypes.c_int(n), _capi._ip(off), _capi._dp(cones), _capi._dp(poses),
@@ -93,7 +93,7 @@ class SkidpadBatch:
         at once): consecutive steps share their launches (include/fsdp.h, fsdp_skidpad_submit).  Yields (results, info) per
         step, in order — the bits of ``step`` called once per frame."""
         self.set_overlap(depth)
-        ring = [_capi.pinned_empty(self.n, _capi.PATH_RESULT_DTYPE if compact else _capi.RESULT_DTYPE) for _ in range(depth + 1)]
+        ring = [_capi.pinned_empty(self.n, self._ctx.path_result_dtype if compact else self._ctx.result_dtype) for _ in range(depth + 1)]
         inflight = []
         for k, f in enumerate(frames):
             if len(inflight) == depth:
@@ -113,9 +113,9 @@ class SkidpadBatch:
         off, cones, poses, n = self._ctx._prep(cone_offsets, cones_xyt, poses)
         assert n == self.n
         if out is None:
-            out = _capi.pinned_empty(n, _capi.PATH_RESULT_DTYPE if compact else _capi.RESULT_DTYPE)
-        compact = out.dtype == _capi.PATH_RESULT_DTYPE
-        assert compact or out.dtype == _capi.RESULT_DTYPE
+            out = _capi.pinned_empty(n, self._ctx.path_result_dtype if compact else self._ctx.result_dtype)
+        compact = out.dtype == self._ctx.path_result_dtype
+        assert compact or out.dtype == self._ctx.result_dtype
         if info is None:
             info = np.zeros(n, dtype=INFO_DTYPE)
         t = ctypes.c_longlong(-1)

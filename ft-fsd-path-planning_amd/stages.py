@@ -24,13 +24,15 @@ from .planner import ConeTypes, flatten_cones_by_type_array, raise_for_status
 _shared_ctx = {}
 
 
-def _ctx(device=None, params=None):
-    """One context per (device, parameter set); the eight most recently used are kept (a parameter sweep through the stage
-    classes would otherwise pile up contexts, each with its device buffers)."""
-    key = (device, tuple(sorted((params or {}).items())))
+def _ctx(device=None, params=None, wide: bool = False):
+    """One context per (device, parameter set, library build); the eight most recently used are kept (a parameter sweep through
+    the stage classes would otherwise pile up contexts, each with its device buffers).  wide: the stage's INPUT needs the wide
+    build's shapes (more than 12 sorted cones per side, as a ConeSorting with max_length > 12 returns them); parameters beyond
+    the standard shapes select it by themselves (_capi.Context)."""
+    key = (device, tuple(sorted((params or {}).items())), bool(wide))
     ctx = _shared_ctx.pop(key, None)
     if ctx is None:
-        ctx = _capi.Context(device=device, mission=4, params=params)
+        ctx = _capi.Context(device=device, mission=4, params=params, shapes=_capi.WIDE if wide else None)
     _shared_ctx[key] = ctx  # (most recent last)
     while len(_shared_ctx) > 8:
         _shared_ctx.pop(next(iter(_shared_ctx))).close()
@@ -108,12 +110,15 @@ class ConeMatching:
     def run_cone_matching(self):
         left = np.asarray(self.input.sorted_cones[int(ConeTypes.LEFT)], float).reshape(-1, 2)
         right = np.asarray(self.input.sorted_cones[int(ConeTypes.RIGHT)], float).reshape(-1, 2)
-        if len(left) > 12 or len(right) > 12:
-            raise _capi.FsdpError("at most 12 sorted cones per side (config.py:36 max_length)")
-        sl, sr = np.zeros((1, 12, 2)), np.zeros((1, 12, 2))
+        longest = max(len(left), len(right))
+        if longest > _capi.WIDE.max_len:
+            raise _capi.FsdpError(f"at most {_capi.WIDE.max_len} sorted cones per side (config.py:36 max_length; include/fsdp.h shapes)")
+        ctx = _ctx(self._device, self._params, wide=longest > _capi.STANDARD.max_len)
+        cap = ctx.shapes.max_len
+        sl, sr = np.zeros((1, cap, 2)), np.zeros((1, cap, 2))
         sl[0, : len(left)], sr[0, : len(right)] = left, right
         pose = np.concatenate([np.asarray(self.input.slam_position, float).reshape(2), np.asarray(self.input.slam_direction, float).reshape(2)])
-        r = _ctx(self._device, self._params).match_batch(sl, [len(left)], sr, [len(right)], pose[None])[0]
+        r = ctx.match_batch(sl, [len(left)], sr, [len(right)], pose[None])[0]
         _check(r["status"])
         self.last_result = r
         ml, mr = int(r["n_left_v"]), int(r["n_right_v"])
@@ -150,16 +155,17 @@ class CalculatePath:
 
     def run_path_calculation(self):
         i = self.input
-        res = np.zeros(1, dtype=_capi.RESULT_DTYPE)
         lv, rv = np.asarray(i.left_cones, float).reshape(-1, 2), np.asarray(i.right_cones, float).reshape(-1, 2)
-        if len(lv) > 24 or len(rv) > 24:
-            raise _capi.FsdpError("at most 24 cones per side")
+        longest = max(len(lv), len(rv))
+        if longest > _capi.WIDE.max_match:
+            raise _capi.FsdpError(f"at most {_capi.WIDE.max_match} cones (with virtual ones) per side (include/fsdp.h shapes)")
+        ctx = _ctx(self._device, self._params, wide=longest > _capi.STANDARD.max_match)
+        res = np.zeros(1, dtype=ctx.result_dtype)
         res["n_left_v"], res["n_right_v"] = len(lv), len(rv)
         res["left_v"][0, : len(lv)], res["right_v"][0, : len(rv)] = lv, rv
         res["l2r"][0, : len(lv)] = np.asarray(i.left_to_right_matches, dtype=np.int32)
         res["r2l"][0, : len(rv)] = np.asarray(i.right_to_left_matches, dtype=np.int32)
         pose = np.concatenate([np.asarray(i.position_global, float).reshape(2), np.asarray(i.direction_global, float).reshape(2)])
-        ctx = _ctx(self._device, self._params)
         if i.global_path is not None:  # core_calculate_path.py:514-529: the path is drawn from the global path
             ctx.set_global_path(i.global_path)
         try:

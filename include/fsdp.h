@@ -29,9 +29,22 @@
 extern "C" {
 #endif
 
-#define FSDP_MAX_LEN 12      /* config.py:36 max_length                         */
-#define FSDP_MAX_MATCH 24    /* cones incl. virtual per side after matching     */
-#define FSDP_PATH_POINTS 40  /* config.py:58 mpc_prediction_horizon             */
+/* The shapes of a result record.  The library exists in two builds of the same sources: the STANDARD one (libfsdp_hip.so: the
+ * reference's default structural parameters, config.py:34-37,58) and the WIDE one (libfsdp_hip_wide.so, compiled — like a
+ * binding that talks to it — with -DFSDP_WIDE_SHAPES) for contexts whose max_n_neighbors, max_length or
+ * mpc_prediction_horizon exceed the standard shapes.  fsdp_shapes() reports which one a loaded library is; the Python host
+ * picks the build from a context's parameters (ft-fsd-path-planning_amd/_capi.py). */
+#ifdef FSDP_WIDE_SHAPES
+#define FSDP_MAX_LEN 16       /* config.py:36 max_length                         */
+#define FSDP_MAX_NEIGHBORS 8  /* config.py:34 max_n_neighbors                    */
+#define FSDP_MAX_MATCH 32     /* cones incl. virtual per side after matching (2 x FSDP_MAX_LEN) */
+#define FSDP_PATH_POINTS 64   /* config.py:58 mpc_prediction_horizon             */
+#else
+#define FSDP_MAX_LEN 12
+#define FSDP_MAX_NEIGHBORS 5
+#define FSDP_MAX_MATCH 24
+#define FSDP_PATH_POINTS 40
+#endif
 #define FSDP_MAX_CONES 8192  /* cones per frame (frames beyond 255 are sorted with their state in global memory) */
 
 /* ConeTypes — utils/cone_types.py:10-19 (values are part of the input format) */
@@ -65,7 +78,8 @@ enum {
  *
  * Capacities refused at fsdp_create (the reference takes any value; its buffers grow by doubling,
  * trace_sorter/end_configurations.py:74-105): max_n_neighbors > 5, max_length > 12 (register / result-struct shapes),
- * mpc_prediction_horizon > 40 (rows of a result path).  Refused per frame, with a status and never truncated:
+ * mpc_prediction_horizon > 40 (rows of a result path) in the standard build; > 8, > 16, > 64 in the wide build
+ * (FSDP_WIDE_SHAPES above).  Refused per frame, with a status and never truncated:
  * more than 8192 cones (201), more than 4096 raw end configurations on a side (202), a working polyline beyond 1408 points
  * (203), more than 64 knots in a spline (204), more than 64 skidpad centre clusters (205). */
 
@@ -105,7 +119,8 @@ typedef struct fsdp_ctx fsdp_ctx;
  * (cone_matching/core_cone_matching.py:50-71) and CalculatePath (calculate_path/core_calculate_path.py:69-110), whose defaults
  * are the factories of fsd_path_planning/config.py:28-163.  fsdp_default_params fills those defaults.  A context keeps its own
  * copy on the device.  Every value the reference accepts is accepted, within the compiled capacities of the structural
- * ones: max_n_neighbors <= 5, max_length <= 12, mpc_prediction_horizon <= 40 (a path of the result holds 40 rows: with a
+ * ones: max_n_neighbors <= 5, max_length <= 12, mpc_prediction_horizon <= 40 (8 / 16 / 64 in the wide build; a path of the
+ * result holds FSDP_PATH_POINTS rows: with a
  * horizon h < 40 rows [h, 40) are NaN, and previous paths handed in are read up to row h), max_deg in 1..3 (fits of degree
  * < 3 take the one-frame-per-wavefront path kernel).  use_unknown_cones = 0 drops the cones of type UNKNOWN before sorting
  * (core_cone_sorting.py:113-115); the sorted indices still refer to the caller's array.  matches_should_be_monotonic is the
@@ -138,6 +153,9 @@ void fsdp_default_params(fsdp_params* out);
 
 const char* fsdp_version(void);
 int fsdp_result_size(void);                 /* sizeof(fsdp_frame_result), for binding sanity checks */
+/* out4 = [FSDP_MAX_LEN, FSDP_MAX_NEIGHBORS, FSDP_MAX_MATCH, FSDP_PATH_POINTS] of this build: the largest max_length,
+ * max_n_neighbors and mpc_prediction_horizon its contexts accept (config.py:34-37,58) and the array shapes of its records. */
+void fsdp_shapes(int32_t* out4);
 int fsdp_device_count(void);                /* number of visible HIP devices (0 if none)            */
 
 /* PathPlanner(mission) — full_pipeline.py:54-69.  Creates the per-GPU context (device buffers,

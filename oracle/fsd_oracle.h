@@ -10,11 +10,22 @@
 extern "C" {
 #endif
 
+// Record shapes: the standard ones (the reference's default structural parameters) or, with -DFSDO_WIDE_SHAPES
+// (liboracle_wide.so), the shapes of the library's wide build (include/fsdp.h FSDP_WIDE_SHAPES).  The algorithm itself takes
+// any max_n_neighbors / max_length / horizon; only the result record is shaped.
+#ifdef FSDO_WIDE_SHAPES
+enum {
+  FSDO_MAX_LEN = 16,       // config.py:36 max_length
+  FSDO_MAX_MATCH = 32,     // cones-with-virtual per side: base (<=16) + inserted (<=16)
+  FSDO_PATH_POINTS = 64,   // config.py:58 mpc_prediction_horizon
+};
+#else
 enum {
   FSDO_MAX_LEN = 12,       // config.py:36 max_length
   FSDO_MAX_MATCH = 24,     // cones-with-virtual per side: base (<=12) + inserted (<=12)
   FSDO_PATH_POINTS = 40,   // config.py:58 mpc_prediction_horizon
 };
+#endif
 
 // Per-frame status.  0 = the reference returns normally and so does the oracle.
 // >= 100: the reference raises out of calculate_path_in_global_frame (or would corrupt

@@ -31,7 +31,7 @@ static int g_last_big = 0;
 static int g_last_wide = 0;
 static std::vector<double> g_refit;  // FitRec per frame of the last three-kernel path launch
 static void build_default() {
-  double chord[fsdp::PATH_POINTS][2];
+  double chord[fsdp::CHORD_POINTS][2];
   fsdp::default_chord_points(chord);
   AlignedArena arena(fsdp::ARENA_DOUBLES);
   emu::launch(1, 64, [&]() { fsdp::default_path_kernel(&chord[0][0], arena.data(), g_default_path, &g_prm); });
@@ -243,7 +243,7 @@ void emu_skidpad_steps(int n_inst, int n_steps, int step0, const int32_t* const*
   T.ref_left[1] = ref4[3];
   T.mean_distance = mean_distance;
   T.prm = &g_prm;
-  double chord[fsdp::PATH_POINTS][2];
+  double chord[fsdp::CHORD_POINTS][2];
   fsdp::default_chord_points(chord);
   AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_inst * n_steps);
   std::vector<int32_t> status((size_t)n_inst * n_steps, 0);
@@ -279,7 +279,7 @@ int emu_skidpad_steps_packed(int lanes, int n_inst, int n_steps, int step0, cons
   T.ref_left[1] = ref4[3];
   T.mean_distance = mean_distance;
   T.prm = &g_prm;
-  double chord[fsdp::PATH_POINTS][2];
+  double chord[fsdp::CHORD_POINTS][2];
   fsdp::default_chord_points(chord);
   const int frames = n_inst * n_steps;
   AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * frames);

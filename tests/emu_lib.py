@@ -11,9 +11,12 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 EMU_DIR = ROOT / "tests" / "emu"
-LIB = EMU_DIR / "libfsdp_emu.so"
+# tests/emu_lib_wide.py runs this file a second time as its own module with WIDE_SHAPES preset: the kernel sources compiled
+# with -DFSDP_WIDE_SHAPES (tests/emu/Makefile libfsdp_emu_wide.so), compared with oracle_lib_wide
+WIDE_SHAPES = bool(globals().get("WIDE_SHAPES", False))
+LIB = EMU_DIR / ("libfsdp_emu_wide.so" if WIDE_SHAPES else "libfsdp_emu.so")
 
-MAX_LEN, MAX_MATCH, PATH_POINTS = 12, 24, 40
+MAX_LEN, MAX_MATCH, PATH_POINTS = (16, 32, 64) if WIDE_SHAPES else (12, 24, 40)
 
 SORT_DTYPE = np.dtype(
     [
@@ -106,7 +109,10 @@ def default_path():
 def plan(offsets, cones, poses, group=8):
     """Full emulated pipeline; returns a structured array shaped like oracle_lib.RESULT_DTYPE.  group = lanes per frame
     of the path kernel (8: eight frames per wavefront, 16, or 64: one frame per wavefront)."""
-    import oracle_lib
+    if WIDE_SHAPES:
+        import oracle_lib_wide as oracle_lib
+    else:
+        import oracle_lib
 
     s = sort(offsets, cones, poses)
     m = match(offsets, cones, poses, s)

@@ -30,6 +30,10 @@ LIBM_LEVEL = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX2 
 SETS = ["scenarios", "cfg2_color", "cfg3_nocolor", "cfg4_200cones", "cfg4_noisy_nocolor", "fuzz", "big_frames", "lattice",
         "odd_inputs", "nonfinite_cones", "nonfinite_poses",
         "params_sort", "params_path", "params_monotonic", "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"]
+# parameter sets beyond the standard shapes (make_golden.py --params-r5): (F, 64, 4) paths, checked with the oracle's wide build.
+# `--wide` captures only these and MERGES them into the committed file (the other sets' captures stay as they are), after
+# checking that this machine's NumPy / libm return the probe values stored with them.
+SETS_WIDE = ["params_wide_sort", "params_wide_horizon", "params_wide_all"]
 
 
 def set_params(g):
@@ -54,7 +58,7 @@ def child(out_path):
         g = np.load(HERE / f"{name}.npz")
         prm = set_params(g)
         flattened = not (prm and prm.get("use_unknown_cones") is False)
-        paths = np.full((len(frames), 40, 4), np.nan)
+        paths = np.full((len(frames), g["path"].shape[1], 4), np.nan)
         for k, f in enumerate(frames):
             xyt = g["cones"][g["offsets"][f]: g["offsets"][f + 1]]
             with np.errstate(all="ignore"):
@@ -66,14 +70,17 @@ def child(out_path):
     np.savez(out_path, **out)
 
 
-def main():
+def main(wide=False):
     import numpy as np
 
     sys.path.insert(0, str(HERE.parent))
-    import oracle_lib
+    if wide:
+        import oracle_lib_wide as oracle_lib
+    else:
+        import oracle_lib
 
     todo = {}
-    for name in SETS:
+    for name in (SETS_WIDE if wide else SETS):
         g = np.load(HERE / f"{name}.npz")
         prm = set_params(g)
         with oracle_lib.math_mode(1):
@@ -99,6 +106,11 @@ def main():
         return np.where(np.isnan(e), 0.0, e).max(axis=1)
 
     store = {"level": np.array("NPY_DISABLE_CPU_FEATURES=" + LIBM_LEVEL), "probe_default": res["default"]["probe"], "probe_libm": res["libm"]["probe"]}
+    if wide:
+        old = dict(np.load(HERE / "arc_libm_level.npz"))
+        assert np.array_equal(old["probe_default"], store["probe_default"]) and np.array_equal(old["probe_libm"], store["probe_libm"]), \
+            "this machine's NumPy / libm differ from the one the committed captures were taken on"
+        store = old
     for name, frames in todo.items():
         g = np.load(HERE / f"{name}.npz")
         # the default-level run must BE the committed golden (same machine, same NumPy): otherwise the two captures are not comparable
@@ -133,4 +145,4 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
         child(sys.argv[2])
     else:
-        main()
+        main(wide="--wide" in sys.argv)

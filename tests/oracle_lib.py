@@ -14,9 +14,12 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 ORACLE_DIR = ROOT / "oracle"
-LIB_PATH = ORACLE_DIR / "liboracle.so"
+# tests/oracle_lib_wide.py runs this file a second time as its own module with WIDE_SHAPES preset: the same restatement built
+# with the record shapes of the library's wide build (oracle/Makefile liboracle_wide.so)
+WIDE_SHAPES = bool(globals().get("WIDE_SHAPES", False))
+LIB_PATH = ORACLE_DIR / ("liboracle_wide.so" if WIDE_SHAPES else "liboracle.so")
 
-MAX_LEN, MAX_MATCH, PATH_POINTS = 12, 24, 40
+MAX_LEN, MAX_MATCH, PATH_POINTS = (16, 32, 64) if WIDE_SHAPES else (12, 24, 40)
 
 
 class FrameResult(ctypes.Structure):

@@ -130,6 +130,8 @@ def compare_frame(res, g, k, require_exact_match=True, arc=None, math="det"):
 def is_sample_count_flip(p, q):
     """True when both paths start identically and their arc-length columns are the 40-index
     resamplings of 120 vs 121 (or L vs L+-1) dense samples of the same step."""
+    rows = ~np.isnan(p[:, 0])  # (a record's rows beyond the context's horizon are NaN: the wide build's 64 against a horizon of 40)
+    p, q = p[rows], q[rows]
     if abs(p[0, 1] - q[0, 1]) > 1e-5 or abs(p[0, 2] - q[0, 2]) > 1e-5:
         return False
     sp, sq = p[-1, 0], q[-1, 0]

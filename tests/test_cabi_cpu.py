@@ -24,11 +24,20 @@ def test_library_exports_every_declared_symbol(pkg):
     header = (ROOT / "include" / "fsdp.h").read_text()
     declared = set(re.findall(r"\b(fsdp_[a-z0-9_]+)\s*\(", header))
     declared -= {"fsdp_ctx"}
-    lib = ctypes.CDLL(str(pkg._capi.LIB_PATH))
-    for sym in sorted(declared):
-        assert hasattr(lib, sym), sym
     assert declared == set(pkg._capi.EXPORTED_SYMBOLS)
-    assert lib.fsdp_result_size() == pkg._capi.RESULT_DTYPE.itemsize
+    # both builds of the sources (include/fsdp.h: the standard shapes and -DFSDP_WIDE_SHAPES) export the whole ABI and report
+    # the shapes the binding mirrors
+    for shapes in (pkg._capi.STANDARD, pkg._capi.WIDE):
+        lib = ctypes.CDLL(str(shapes.lib_path))
+        for sym in sorted(declared):
+            assert hasattr(lib, sym), (shapes.name, sym)
+        assert lib.fsdp_result_size() == shapes.result_dtype.itemsize
+        got = (ctypes.c_int32 * 4)()
+        lib.fsdp_shapes(got)
+        assert list(got) == [shapes.max_len, shapes.max_neighbors, shapes.max_match, shapes.path_points]
+    assert list(got) == [16, 8, 32, 64] and pkg._capi.WIDE.result_dtype.itemsize == 3528
+    header_wide = re.search(r"#ifdef FSDP_WIDE_SHAPES(.*?)#else", header, re.S).group(1)
+    assert [int(v) for v in re.findall(r"#define FSDP_\w+ (\d+)", header_wide)] == [16, 8, 32, 64]
 
 
 def test_no_cpu_fallback(pkg):

@@ -269,8 +269,11 @@ def test_stage_classes_mirror_reference_protocol(pkg, golden_dir):
     pkg.ConeSorting(max_dist=7.0)
     with pytest.raises(TypeError):
         pkg.ConeSorting(no_such_kwarg=1)
+    cs = pkg.ConeSorting(max_n_neighbors=7)  # beyond the standard shapes: carried by the wide build (round 5)
+    cs.set_new_input(pkg.ConeSortingInput(xyt, pose[:2], pose[2:]))
+    assert len(cs.run_cone_sorting()) == 2
     with pytest.raises(pkg.FsdpError):
-        cs = pkg.ConeSorting(max_n_neighbors=7)
+        cs = pkg.ConeSorting(max_n_neighbors=9)
         cs.set_new_input(pkg.ConeSortingInput(xyt, pose[:2], pose[2:]))
         cs.run_cone_sorting()
 
@@ -611,12 +614,111 @@ def test_low_degree_contexts_plan_large_batches_four_frames_per_wavefront(pkg, m
 
 
 def test_parameters_outside_the_kernels_capacities_are_refused(pkg):
-    for bad in (dict(max_n_neighbors=6), dict(max_length=13), dict(max_deg=4), dict(max_deg=0), dict(mpc_prediction_horizon=50),
+    for bad in (dict(max_n_neighbors=9), dict(max_length=17), dict(max_deg=4), dict(max_deg=0), dict(mpc_prediction_horizon=65),
                 dict(mpc_prediction_horizon=0), dict(mpc_path_length=100.0)):
         with pytest.raises(pkg.FsdpError):
             pkg.Context(device=0, mission=4, params=bad)
+    # the standard build itself refuses what only the wide build's shapes hold (nothing is truncated silently)
+    for bad in (dict(max_n_neighbors=6), dict(max_length=13), dict(mpc_prediction_horizon=41)):
+        with pytest.raises(pkg.FsdpError):
+            pkg.Context(device=0, mission=4, params=bad, shapes=pkg._capi.STANDARD)
     with pytest.raises(TypeError):
         pkg.Context(device=0, mission=4, params=dict(no_such_parameter=1))
+
+
+WIDE_SETS = ["params_wide_sort", "params_wide_horizon", "params_wide_all"]
+
+
+def _wide_rows(res):
+    import oracle_lib_wide
+
+    out = np.zeros(len(res), oracle_lib_wide.RESULT_DTYPE)
+    for k in oracle_lib_wide.RESULT_DTYPE.names:
+        out[k] = res[k]
+    return out
+
+
+@pytest.mark.parametrize("name", WIDE_SETS)
+def test_parameters_beyond_the_standard_shapes_run_on_the_wide_build(pkg, golden_dir, name):
+    """max_n_neighbors up to 8, max_length up to 16, mpc_prediction_horizon up to 64 (the reference takes any value,
+    config.py:34-37,58; end_configurations.py:74-105): a context with such parameters is carried by libfsdp_hip_wide.so — the
+    same sources compiled with -DFSDP_WIDE_SHAPES — chosen by the Python host.  Goldens captured from the reference with those
+    kwargs (make_golden.py --params-r5): indices bit-equal, paths within 1e-5; bit-equal to the oracle's wide build."""
+    import oracle_lib_wide
+
+    g = np.load(golden_dir / f"{name}.npz")
+    prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist()))
+    c = pkg.Context(device=0, mission=4, params=prm)
+    assert c.shapes is pkg._capi.WIDE and c.result_dtype.itemsize > pkg.RESULT_DTYPE.itemsize
+    res = c.plan_batch(g["offsets"], g["cones"], g["poses"])
+    assert res["path"].shape[1:] == (64, 4) and res["left_idx"].shape[1] == 16
+    rows = _wide_rows(res)
+    cats = collections.Counter()
+    arc = parity.ArcLibm(golden_dir, name)
+    for k in range(len(rows)):
+        cat, detail = parity.compare_frame(rows[k], g, k, arc=arc)
+        cats[cat] += 1
+        assert cat in ("ok", "ref_undefined", "flip"), (k, cat, detail)
+    assert cats["flip"] == len(arc.flips("det")), (cats, arc.flips("det"))
+    with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+        ref = oracle_lib_wide.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=os.cpu_count() or 1)
+    _assert_equal_to_oracle(res, ref)
+    if name != "params_wide_horizon":
+        assert max(int(res["n_left"].max()), int(res["n_right"].max())) > 12
+    # a large batch with the same parameters (the packed kernels of the wide build), streamed and sequential forms included
+    off, cones, poses = pkg.synth.make_replay_batch(3000, 64, 0.15, seed=77, color=(name != "params_wide_all"))
+    big = c.plan_batch(off, cones, poses)
+    with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+        ref_big = oracle_lib_wide.plan_batch(off, cones, poses, n_threads=os.cpu_count() or 1)
+    _assert_equal_to_oracle(big, ref_big)
+    assert (big["status"] == 0).mean() > 0.9
+    c.set_overlap(3)
+    tickets = [c.submit(off, cones, poses) for _ in range(3)]
+    for t in tickets:
+        assert c.collect(t).tobytes() == big.tobytes()
+    c.set_overlap(1)
+    seq = c.plan_batch_sequential(off[:201], cones[: off[200]], poses[:200], big["path"][:200, : c.horizon])
+    assert np.array_equal(seq["left_idx"], big["left_idx"][:200]) and seq["path"].shape == (200, 64, 4)
+    # the standard build next to it is unaffected
+    d = np.load(golden_dir / "cfg2_color.npz")
+    c0 = pkg.Context(device=0, mission=4)
+    assert c0.shapes is pkg._capi.STANDARD
+    assert np.array_equal(c0.plan_batch(d["offsets"], d["cones"], d["poses"])["left_idx"], d["left_idx"])
+    c.close()
+    c0.close()
+
+
+def test_reference_shaped_planner_and_stage_classes_on_the_wide_build(pkg, golden_dir):
+    """PathPlanner / ConeSorting / ConeMatching / CalculatePath with max_length = 16, max_n_neighbors = 8: the stage objects hand
+    sides of up to 16 cones (32 with virtual ones) to each other like the reference's do (full_pipeline.py:142-176)."""
+    g = np.load(golden_dir / "params_wide_sort.npz")
+    cs = pkg.ConeSorting(device=0, max_n_neighbors=8, max_dist=6.5, max_dist_to_first=6.0, max_length=16,
+                         threshold_directional_angle=np.deg2rad(40), threshold_absolute_angle=np.deg2rad(65), use_unknown_cones=True,
+                         experimental_performance_improvements=False)
+    cm = pkg.ConeMatching(device=0)
+    cp = pkg.CalculatePath(device=0, stateful=False)
+    n_long = 0
+    for k in range(0, len(g["ok"]), 9):
+        if not g["ok"][k]:
+            continue
+        xyt = g["cones"][g["offsets"][k] : g["offsets"][k + 1]]
+        pos, direc = g["poses"][k][:2], g["poses"][k][2:]
+        cs.set_new_input(pkg.ConeSortingInput(xyt, pos, direc))
+        left, right = cs.run_cone_sorting()
+        nl, nr = int(g["n_left"][k]), int(g["n_right"][k])
+        assert np.array_equal(left, xyt[g["left_idx"][k][:nl], :2]) and np.array_equal(right, xyt[g["right_idx"][k][:nr], :2])
+        n_long += max(nl, nr) > 12
+        sorted_cones = [np.zeros((0, 2)) for _ in range(5)]
+        sorted_cones[int(pkg.ConeTypes.LEFT)], sorted_cones[int(pkg.ConeTypes.RIGHT)] = left, right
+        cm.set_new_input(pkg.ConeMatchingInput(sorted_cones, pos, direc))
+        lv, rv, l2r, r2l = cm.run_cone_matching()
+        ml, mr = int(g["n_left_v"][k]), int(g["n_right_v"][k])
+        assert np.array_equal(lv, g["left_v"][k][:ml]) and np.array_equal(rv, g["right_v"][k][:mr])
+        assert np.array_equal(l2r, g["l2r"][k][:ml]) and np.array_equal(r2l, g["r2l"][k][:mr])
+        cp.set_new_input(pkg.PathCalculationInput(lv, rv, l2r, r2l, pos, direc))
+        path, _centers = cp.run_path_calculation()
+        assert path.shape == (40, 4) and np.nanmax(np.abs(path - g["path"][k][:40])) < (1e-5 if not (k in (106, 131)) else 1.0)
+    assert n_long >= 3
 
 
 def test_stage_classes_take_the_reference_kwargs(pkg, golden_dir):

@@ -69,6 +69,67 @@ def test_emulated_kernels_with_non_default_parameters(golden_dir, name):
     assert flips == [f for f in arc.flips("det") if f in set(idx.tolist())], flips
 
 
+@pytest.mark.parametrize("name,group", [("params_wide_sort", 1008), ("params_wide_horizon", 1008), ("params_wide_all", 1004), ("params_wide_all", 64),
+                                        ("params_wide_sort", 16)])
+def test_emulated_wide_build_with_parameters_beyond_the_standard_shapes(golden_dir, name, group):
+    """The kernel sources compiled with -DFSDP_WIDE_SHAPES (libfsdp_hip_wide.so: max_n_neighbors <= 8 — two rounds of
+    (candidate, neighbour) pairs per pop —, max_length <= 16 — four configurations per cost round, matching on the whole
+    wavefront —, horizon <= 64 — up to 193 dense samples): kernels == the oracle's wide build bit for bit, and both == the
+    reference's goldens for those parameters (make_golden.py --params-r5)."""
+    import emu_lib_wide
+    import oracle_lib_wide
+
+    g = np.load(golden_dir / f"{name}.npz")
+    prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist()))
+    idx = np.arange(0, len(g["ok"]), 3 if group == 1008 else 5)
+    off = np.concatenate([[0], np.cumsum([g["offsets"][i + 1] - g["offsets"][i] for i in idx])]).astype(np.int32)
+    cones = np.concatenate([g["cones"][g["offsets"][i] : g["offsets"][i + 1]] for i in idx])
+    poses = g["poses"][idx]
+    with emu_lib_wide.params(prm):
+        res, _ = emu_lib_wide.plan(off, cones, poses, group)
+    with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+        ref = oracle_lib_wide.plan_batch(off, cones, poses)
+    assert np.array_equal(res["status"], ref["status"])
+    ok = ref["status"] == 0
+    for f in ("left_idx", "right_idx", "n_left_v", "n_right_v", "l2r", "r2l", "left_v", "right_v", "path_fallback"):
+        assert np.array_equal(res[f][ok], ref[f][ok]), f
+    parity.assert_intermediates_equal(res, ref, ok)
+    assert np.array_equal(res["path"][ok], ref["path"][ok], equal_nan=True)
+    if name != "params_wide_horizon":
+        assert max(int(ref["n_left"].max()), int(ref["n_right"].max())) > 12  # sides longer than the standard shapes hold
+    arc = parity.ArcLibm(golden_dir, name)
+    flips = []
+    for j, k in enumerate(idx):
+        cat, detail = parity.compare_frame(res[j], g, int(k), arc=arc)
+        assert cat in ("ok", "ref_undefined", "flip"), (k, cat, detail)
+        flips += [int(k)] if cat == "flip" else []
+    assert flips == [f for f in arc.flips("det") if f in set(idx.tolist())], flips
+
+
+@pytest.mark.parametrize("name,stride", [("scenarios", 1), ("cfg3_nocolor", 16), ("lattice", 6), ("odd_inputs", 1)])
+def test_emulated_wide_build_with_the_default_parameters(golden_dir, name, stride):
+    """The wide build under the reference's DEFAULT parameters (a stage object fed more than 12 sorted cones per side runs on it
+    whatever its parameters, stages.py): the same results as the standard build's oracle, in the wider records."""
+    import emu_lib_wide
+
+    g = np.load(golden_dir / f"{name}.npz")
+    idx = np.arange(0, len(g["ok"]), stride)
+    off = np.concatenate([[0], np.cumsum([g["offsets"][i + 1] - g["offsets"][i] for i in idx])]).astype(np.int32)
+    cones = np.concatenate([g["cones"][g["offsets"][i] : g["offsets"][i + 1]] for i in idx])
+    poses = g["poses"][idx]
+    res, _ = emu_lib_wide.plan(off, cones, poses, 8)
+    with oracle_lib.math_mode(1):
+        ref = oracle_lib.plan_batch(off, cones, poses)
+    assert np.array_equal(res["status"], ref["status"])
+    ok = ref["status"] == 0
+    for f, cap in (("left_idx", 12), ("right_idx", 12), ("l2r", 24), ("r2l", 24), ("left_v", 24), ("right_v", 24), ("path", 40)):
+        assert np.array_equal(res[f][ok][:, :cap], ref[f][ok], equal_nan=True), f
+    assert np.isnan(res["path"][ok][:, 40:]).all() and (res["left_idx"][ok][:, 12:] == -1).all()
+    for f in ("n_left", "n_right", "n_left_v", "n_right_v", "path_fallback"):
+        assert np.array_equal(res[f][ok], ref[f][ok]), f
+    parity.assert_intermediates_equal(res, ref, ok)
+
+
 @pytest.mark.parametrize("group", [1004, 1008, 1016, 1001])
 def test_knot_capacity_reached_in_the_middle_of_a_round(group):
     """A fit whose round of new knots crosses the workspace's capacity (16 knots in the three-kernel path stage) must be

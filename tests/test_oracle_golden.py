@@ -9,7 +9,17 @@ import numpy as np
 import pytest
 
 import oracle_lib
+import oracle_lib_wide
 import parity
+
+# parameter sets beyond the standard shapes (max_n_neighbors 8, max_length 16, mpc_prediction_horizon 64: make_golden.py
+# --params-r5): held against the oracle built with the wide record shapes (oracle/Makefile liboracle_wide.so)
+WIDE_SETS = ["params_wide_sort", "params_wide_horizon", "params_wide_all"]
+
+
+def _oracle(name):
+    return oracle_lib_wide if name in WIDE_SETS else oracle_lib
+
 
 # big_frames: 300 / 600 cones per frame; lattice: up to 190 end configurations per side (beyond the LDS capacities of
 # the product sorting kernel: planned by sort_big_kernel)
@@ -57,11 +67,12 @@ def test_empty_and_tiny_frames():
         assert np.isfinite(r["path"]).all()
 
 
-@pytest.mark.parametrize("name", ["params_sort", "params_path", "params_monotonic", "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"])
+@pytest.mark.parametrize("name", ["params_sort", "params_path", "params_monotonic", "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"] + WIDE_SETS)
 def test_oracle_with_non_default_parameters(golden_dir, name):
     """The reference's stage classes constructed with non-default kwargs (fixtures: make_golden.py params_golden): the
     oracle with the same constants (fsdo_set_params) reproduces indices, matches and paths."""
     g = np.load(golden_dir / f"{name}.npz")
+    oracle_lib = _oracle(name)
     prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist()))
     with oracle_lib.params(prm):
         res = oracle_lib.plan_batch(g["offsets"], g["cones"], g["poses"], n_threads=4)
@@ -78,16 +89,17 @@ def test_oracle_with_non_default_parameters(golden_dir, name):
     # and the defaults are back afterwards
     d = np.load(golden_dir / "cfg2_color.npz")
     r = oracle_lib.plan_batch(d["offsets"][:3], d["cones"][: d["offsets"][2]], d["poses"][:2])
-    assert np.array_equal(r["left_idx"], d["left_idx"][:2])
+    assert np.array_equal(r["left_idx"][:, :12], d["left_idx"][:2]) and (r["left_idx"][:, 12:] == -1).all()
 
 
-@pytest.mark.parametrize("name", SETS + ["params_sort", "params_path", "params_monotonic", "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"])
+@pytest.mark.parametrize("name", SETS + ["params_sort", "params_path", "params_monotonic", "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"] + WIDE_SETS)
 def test_oracle_splines_match_reference_per_frame(golden_dir, name):
     """Per-stage intermediates of the path stage: every smoothing spline a frame fits — fit #1 of the centre
     points, the refit, the parameterization fit, plus the fallback fits where they happen — captured from the reference's
     scipy.splprep calls inside calculate_path_in_global_frame; the oracle's FITPACK restatement gives the same degree,
     the same knots and the same coefficients, bit for bit, in the same call order."""
     g = np.load(golden_dir / f"{name}.npz")
+    oracle_lib = _oracle(name)
     prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist())) if "param_names" in g else None
     n_frames = n_fits = 0
     with oracle_lib.params(prm or {}):
@@ -111,7 +123,7 @@ def test_oracle_splines_match_reference_per_frame(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", SETS + ["nonfinite_poses", "nonfinite_cones", "odd_inputs", "params_sort", "params_path", "params_monotonic",
-                                         "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"])
+                                         "params_deg2", "params_deg1", "params_horizon", "params_no_unknown"] + WIDE_SETS)
 def test_oracle_with_host_libm_is_the_reference_bit_for_bit(golden_dir, name):
     """Every value of every path — arc length, x, y AND curvature, 40 x 4 doubles — of every frame the reference plans, in all
     eighteen golden sets (1 774 frames): the oracle in host-libm mode returns the reference's bits.  On arc-extension frames the
@@ -126,6 +138,7 @@ def test_oracle_with_host_libm_is_the_reference_bit_for_bit(golden_dir, name):
         warnings.warn("host-libm bit-for-bit test skipped: " + msg)
         pytest.skip(msg)
     g = np.load(golden_dir / f"{name}.npz")
+    oracle_lib = _oracle(name)
     prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist())) if "param_names" in g else None
     with oracle_lib.math_mode(0):
         if prm:
