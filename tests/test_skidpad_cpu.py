@@ -84,6 +84,32 @@ def test_emulated_kernels_equal_oracle_on_perturbed_instances(tables, golden_dir
     assert info["relocalized"].all()
 
 
+def test_emulated_wide_build_skidpad_with_a_long_horizon(tables, golden_dir):
+    """The skidpad mission on the wide build's shapes (mpc_prediction_horizon = 56 > the standard 40 rows, config.py:58): planner
+    states, previous paths and results hold 64 rows; two instances through the relocalization frame and beyond, kernel sources
+    (emulated, -DFSDP_WIDE_SHAPES) == the oracle's wide build bit for bit."""
+    import emu_lib_wide
+    import oracle_lib_wide
+
+    table, noise, ref, md = tables
+    g = sk.load_sequence(golden_dir)
+    tf = sk.perturbed_instances(g, 2)
+    prm = dict(mpc_prediction_horizon=56)
+    with emu_lib_wide.params(prm), oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+        em = emu_lib_wide.SkidpadEmu(2, table, noise, ref, md)
+        ops = [oracle_lib_wide.SkidpadPlanner(table, noise) for _ in tf]
+        for t in range(0, 36):
+            off, cones, poses = sk.batch_for_step(g, t, tf)
+            out, info = em.step(off, cones, poses)
+            for i, op in enumerate(ops):
+                r, oi = op.step(cones[off[i] : off[i + 1]], poses[i])
+                assert int(out[i]["status"]) == int(r["status"]) == 0
+                assert int(info[i]["relocalized"]) == int(oi[0]) and int(info[i]["index_along_path"]) == int(oi[4])
+                assert out[i]["path"].shape == (64, 4) and np.isfinite(out[i]["path"][:56]).all() and np.isnan(out[i]["path"][56:]).all()
+                assert np.array_equal(out[i]["path"], r["path"], equal_nan=True), (t, i)
+    assert info["relocalized"].all()
+
+
 def test_awkward_poses_equal_oracle(tables, golden_dir):
     """Steps that fall back to the previous path or fail: statuses, window indices and paths of the emulated kernels are the
     oracle's, and so is every later step (the states carry on identically)."""

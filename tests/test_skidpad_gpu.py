@@ -54,6 +54,39 @@ def test_perturbed_instances_equal_oracle(pkg, golden_dir):
     assert info["relocalized"].mean() > 0.9
 
 
+def test_skidpad_on_the_wide_build_with_a_long_horizon(pkg, golden_dir):
+    """mpc_prediction_horizon = 56 (config.py:58; beyond the standard build's 40 rows): the planners live in a context of the
+    wide build (64-row states, previous paths and results) — single steps and a replay submitted ahead (the packed path-stage
+    route included from 2048 pairs) against oracle planners of the wide oracle build, bit for bit."""
+    import oracle_lib_wide
+
+    g = sk.load_sequence(golden_dir)
+    n = 48
+    prm = dict(mpc_prediction_horizon=56)
+    tf = sk.perturbed_instances(g, n)
+    batch = pkg.SkidpadBatch(n, device=0, params=prm)
+    assert batch._ctx.shapes is pkg.WIDE
+    table, noise = batch.tables
+    frames = [sk.batch_for_step(g, t, tf) for t in range(60)]
+    with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+        ops = [oracle_lib_wide.SkidpadPlanner(table, noise) for _ in range(n)]
+        want = []
+        for off, cones, poses in frames:
+            want.append([op.step(cones[off[i] : off[i + 1]], poses[i]) for i, op in enumerate(ops)])
+    for t, (off, cones, poses) in enumerate(frames[:30]):
+        res, info = batch.step(off, cones, poses)
+        assert res["path"].shape == (n, 64, 4)
+        for i in range(n):
+            r, oi = want[t][i]
+            assert int(res[i]["status"]) == int(r["status"]) == 0 and int(info[i]["relocalized"]) == int(oi[0])
+            assert np.array_equal(res[i]["path"], r["path"], equal_nan=True), (t, i)
+    batch.reset()
+    for t, (res, info) in enumerate(batch.replay(frames, depth=16)):
+        for i in range(n):
+            r, oi = want[t][i]
+            assert int(info[i]["index_along_path"]) == int(oi[4]) and np.array_equal(res[i]["path"], r["path"], equal_nan=True), (t, i)
+
+
 def test_reset_gives_fresh_planners(pkg, golden_dir):
     g = sk.load_sequence(golden_dir)
     batch = pkg.SkidpadBatch(2, device=0)
