@@ -195,6 +195,12 @@ struct fsdp_ctx {
   bool always_route = getenv("FSDP_ALWAYS_ROUTE") != nullptr;  // experiments: launch both route kernels with every pass
   long long reruns = 0;  // passes re-run by verify_pass (diagnostics: fsdp_route_stats)
   bool no_sort128 = getenv("FSDP_NO_SORT128") != nullptr;  // experiments: always the 255-cone state
+  // Staggered passes (FSDP_STAGGER = k > 0): a pass's k-th kernel boundary is an event the NEXT pass's first kernel waits for, so
+  // passes enqueued together do not march through the stages in phase (twenty sorting kernels, then twenty matching kernels, ...)
+  // but settle into the mixed-stage schedule a long run reaches by itself.  0 = off.
+  int stagger = getenv("FSDP_STAGGER") ? atoi(getenv("FSDP_STAGGER")) : 0;
+  hipEvent_t stagger_ev[FSDP_MAX_OVERLAP] = {};
+  int stagger_last = -1;
   std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
   int timed_iters = 0, timed_stages = 0;  // the most recent fsdp_time_runs (fsdp_time_results reads its events)
   bool time_main_only = false;            // fsdp_time_detail: events only around the path stage's main kernel
@@ -534,6 +540,14 @@ static void launch_skid_packed_kernels(fsdp_ctx* c, int frames) {
 // each: exactly the Givens quad) and the kernels around it 8; below that, 4 frames per wavefront everywhere.
 constexpr int PACK_FRAMES = 12288;
 
+// FSDP_STAGGER = k: the k-th kernel boundary of a pass (1 after sorting, 2 after matching, 3 after the path stage's preparation, 4 after
+// the refit) is the event the next pass's first kernel waits for (launch_pass)
+static void stagger_point(fsdp_ctx* c, Work& q, int k) {
+  if (c->stagger != k || c->overlap <= 1 || !c->stagger_ev[q.index]) return;
+  (void)hipEventRecord(c->stagger_ev[q.index], q.stream);
+  c->stagger_last = q.index;
+}
+
 // the path stage's fast kernels (no route, no assembly); returns whether it was the three-kernel form
 static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, std::string& names, bool with_routes = true) {
   const double* prev = in.use_prev ? in.d_prev : nullptr;
@@ -584,6 +598,7 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
       launch_prep<8>(c, q, in, prev, lanes ? q.d_tiles : nullptr);
     else
       launch_prep<16>(c, q, in, prev);
+    stagger_point(c, q, 3);
     mark(q, t, MARK_MAIN);
     // Experiment, OFF by default (FSDP_WIDE_LIST=1 turns it on): a pass that carries the route kernels also carries the 32-knot
     // refit / finish kernels, and a refit that needs 17-32 knots (2 % of the frames of a noisy batch: most of its retry list) goes
@@ -603,6 +618,7 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
       launch_fit<8>(c, q, n, t, wlist);
     else
       launch_fit<16>(c, q, n, t, wlist);
+    stagger_point(c, q, 4);
     mark(q, t, MARK_MAIN);
     if (packed)
       launch_finish<8>(c, q, n);
@@ -677,8 +693,14 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
     if (int rc = launch_filter(c, q, in_, &fin)) return rc;
   const Inputs& in = filtered ? fin : in_;
   std::string names = std::string(sort128(c, in) ? "sort_kernel_128" : "sort_kernel") + ",";
+  const bool stagger = c->stagger > 0 && c->overlap > 1;
+  if (stagger) {
+    if (!c->stagger_ev[q.index]) HIP_TRY(c, hipEventCreateWithFlags(&c->stagger_ev[q.index], hipEventDisableTiming));
+    if (c->stagger_last >= 0 && c->stagger_last != q.index) HIP_TRY(c, hipStreamWaitEvent(q.stream, c->stagger_ev[c->stagger_last], 0));
+  }
   mark(q, t);
   launch_sort(c, q, in);
+  stagger_point(c, q, 1);
   if (with_big) {
     mark(q, t);
     if (int rc = launch_sort_big(c, q, in)) return rc;
@@ -686,6 +708,7 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
   }
   mark(q, t);
   launch_match(c, q, in);
+  stagger_point(c, q, 2);
   names += "match_kernel<" + std::to_string(MATCH_G) + ">,";
   const bool split = launch_path(c, q, in, t, names, with_retry);
   MarkKind after_path = split ? MARK_PLAIN : MARK_MAIN;  // (the one-kernel path stage is the main kernel: close its bracket)
@@ -1075,6 +1098,8 @@ void fsdp_destroy(fsdp_ctx* c) {
     if (w.stream) (void)hipStreamDestroy(w.stream);
   }
   for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->stagger_ev)
+    if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_kclock);
   for (int i = 0; i < 8; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
