@@ -126,7 +126,7 @@ def load(shapes: Shapes = STANDARD) -> ctypes.CDLL:
     """Load libfsdp_hip.so (or, for shapes = WIDE, libfsdp_hip_wide.so) or raise FsdpError (no CPU fallback exists)."""
     if shapes.name in _libs:
         return _libs[shapes.name]
-    path = shapes.lib_path
+    path = LIB_PATH if shapes is STANDARD else shapes.lib_path  # (LIB_PATH: what the A/B tools point at an experiment build)
     if not path.exists():
         raise FsdpError(
             f"{path} not found: build it with `python __graft_entry__.py build` "
@@ -185,7 +185,7 @@ EXPORTED_SYMBOLS = [
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path", "fsdp_skidpad_time_groups", "fsdp_skidpad_group_times", "fsdp_skidpad_submit_compact",
     "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_host_is_pinned", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
-    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena", "fsdp_selftest_absminmax", "fsdp_selftest_libm",
+    "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena", "fsdp_selftest_absminmax", "fsdp_selftest_libm", "fsdp_selftest_givens",
 ]
 
 
@@ -541,6 +541,13 @@ class Context:
         x, a, b = (np.ascontiguousarray(v, np.float64) for v in (x, a, b))
         out = np.zeros((5, len(x)))
         self._check(self._lib.fsdp_selftest_math(self._h, len(x), _dp(x), _dp(a), _dp(b), _dp(out)), "fsdp_selftest_math")
+        return out
+
+    def selftest_givens(self, piv, ww) -> np.ndarray:
+        """(7, n): cs, sn, dd of the kernels' fpgivs sequence | cs, sn, dd with the IEEE operations | operands inside the band."""
+        piv, ww = (np.ascontiguousarray(v, np.float64) for v in (piv, ww))
+        out = np.zeros((7, len(piv)))
+        self._check(self._lib.fsdp_selftest_givens(self._h, len(piv), _dp(piv), _dp(ww), _dp(out)), "fsdp_selftest_givens")
         return out
 
     def selftest_absminmax(self, a, b) -> np.ndarray:

@@ -124,10 +124,8 @@ __device__ __forceinline__ void givens_lane(double piv, double& ww, double& cs, 
   const double w = ww;
   const double den = max_abs_nn(piv, w), num = min_abs_nn(piv, w);
   bad |= rot & !((den >= 0x1p-255) & (den <= 0x1p+255) & ((num == 0.0) | (num >= 0x1p-255)));
-  const double rq = rcp_refined(den);
-  const double q = div_rcp(num, den, rq);
-  const double dd = den * sqrt_1_2(1.0 + q * q);
-  const double rd = rcp_refined(dd);
+  double dd, rd;
+  givens_dd_rd(den, num, dd, rd);
   const double c1 = div_rcp(w, dd, rd);
   const double s1 = div_rcp(piv, dd, rd);
   cs = rot ? c1 : 1.0;

@@ -2440,6 +2440,47 @@ extern "C" int fsdp_selftest_math(fsdp_ctx* c, int n, const double* x, const dou
   return 0;
 }
 
+// The Givens step's arithmetic (spline_device.h fpgivs_guarded<true>: max / min, the first quotient, sqrt on [1, 2], the reciprocal of dd
+// seeded from the square root's own iterate, the two quotients) next to FITPACK's fpgivs with the compiler's IEEE operations:
+// out = [cs | sn | dd] fast, [cs | sn | dd] IEEE, [guard: 1 = operands inside the fast sequence's band]
+__global__ void givens_selftest_kernel(int n, const double* __restrict__ piv, const double* __restrict__ ww, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double w = ww[i], cs, sn;
+  int bad = 0;
+  fpgivs_guarded<true>(piv[i], w, cs, sn, bad);
+  out[i] = cs;
+  out[(size_t)n + i] = sn;
+  out[2 * (size_t)n + i] = w;
+  double w2 = ww[i], cs2, sn2;
+  fpgivs(piv[i], w2, cs2, sn2);
+  out[3 * (size_t)n + i] = cs2;
+  out[4 * (size_t)n + i] = sn2;
+  out[5 * (size_t)n + i] = w2;
+  out[6 * (size_t)n + i] = bad ? 0.0 : 1.0;
+}
+extern "C" int fsdp_selftest_givens(fsdp_ctx* c, int n, const double* piv, const double* ww, double* out7n) {
+  if (!c || n <= 0 || !piv || !ww || !out7n) return 1;
+  HIP_TRY(c, hipSetDevice(c->device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  HIP_TRY(c, hipMalloc(&da, bytes));
+  HIP_TRY(c, hipMalloc(&db, bytes));
+  HIP_TRY(c, hipMalloc(&dout, 7 * bytes));
+  hipError_t e = hipMemcpyAsync(da, piv, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, ww, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(givens_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, da, db, dout);
+    e = hipMemcpyAsync(out7n, dout, 7 * bytes, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  HIP_TRY(c, e);
+  return 0;
+}
+
 // det3_lu (path_kernel.h: the sign of numpy.linalg.det of three homogeneous points) element-wise on the device
 __global__ void det3_selftest_kernel(int n, const double* __restrict__ xy6, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -361,6 +361,52 @@ __device__ __forceinline__ double sqrt_1_2(double x) {
 #endif
 }
 
+// The middle of fpgivs for operands in the divisions' safe band: den = max(|piv|, ww), num = min(|piv|, ww) ->
+//   dd = den * sqrt(1 + (num / den)^2)   and   rd = a refined reciprocal of dd for the two quotients cs = ww / dd, sn = piv / dd.
+// The reciprocal is the head of the second half of the step's dependent chain (rcp_refined(dd): v_rcp_f64 and two Newton steps, five
+// links after dd is known).  Its seed need not wait for dd: 1 / dd = (1 / den) * (1 / sqrt(x)), and both factors exist while the square
+// root is still being corrected — rq = rcp_refined(den) from the first quotient, and h, the half reciprocal square root the
+// Goldschmidt iteration refines next to g (relative error ~2^-45 after its coupled step, what v_rcp_f64 + ONE Newton step gives).
+// r0 = (2 rq) h is formed in the shadow of sqrt's last two corrections, and ONE Newton step against dd itself (error^2 ~ 2^-90, then
+// the rounding of the fma) makes it the reciprocal rcp_refined returns for all the quotients care: two links after dd instead of
+// five, three instructions less per step.  The quotients are div_rcp's (product, exact remainder, correction): correctly rounded
+// with either reciprocal (fsdp_selftest_givens holds cs / sn / dd against the IEEE operations on the device: tests/test_gpu_parity.py).
+// FSDP_GIVENS_RSQ_SEED=0 (A/B builds): the reciprocal from v_rcp_f64 again.
+#ifndef FSDP_GIVENS_RSQ_SEED
+#define FSDP_GIVENS_RSQ_SEED 1
+#endif
+__device__ __forceinline__ void givens_dd_rd(double den, double num, double& dd, double& rd) {
+#ifdef FSDP_EMU
+  const double q = num / den;
+  dd = den * sqrt(1.0 + q * q);
+  rd = dd;  // (the emulator's div_rcp divides directly)
+#else
+  const double rq = rcp_refined(den);
+  const double q = div_rcp(num, den, rq);
+#if FSDP_GIVENS_RSQ_SEED
+  const double x = 1.0 + q * q;
+  // sqrt_1_2(x), keeping h
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double r0 = (rq + rq) * h;  // ~ 1 / (den sqrt(x)), off the chain
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  dd = den * g;
+  const double e = fma(-dd, r0, 1.0);
+  rd = fma(r0, e, r0);
+#else
+  dd = den * sqrt_1_2(1.0 + q * q);
+  rd = rcp_refined(dd);
+#endif
+#endif
+}
+
 // fpgivs with the scaling-free divisions (the arithmetic of giv_step<true>: max / min instead of the branch, two refined reciprocals,
 // sqrt_1_2) for the rotations of the smoothing rows; operands outside the divisions' exponent band set `bad` (the frame is then
 // planned again with plain divisions).  FAST = false: fpgivs itself.
@@ -370,10 +416,8 @@ __device__ __forceinline__ void fpgivs_guarded(double piv, double& ww, double& c
     const double w = ww;
     const double den = max_abs_nn(piv, w), num = min_abs_nn(piv, w);
     bad |= (int)!((den >= 0x1p-255) & (den <= 0x1p+255) & ((num == 0.0) | (num >= 0x1p-255)));
-    const double rq = rcp_refined(den);
-    const double q = div_rcp(num, den, rq);
-    const double dd = den * sqrt_1_2(1.0 + q * q);
-    const double rd = rcp_refined(dd);
+    double dd, rd;
+    givens_dd_rd(den, num, dd, rd);
     cs = div_rcp(w, dd, rd);
     sn = div_rcp(piv, dd, rd);
     ww = dd;
@@ -659,10 +703,8 @@ __device__ __forceinline__ void giv_step(GivLane& st, bool feed, double h0, doub
     // (Tried in round 5 and not kept: den is the diagonal itself unless the pivot is larger, and the diagonal's refined reciprocal
     // is the rd of the step that formed it — same bits, five instructions and a reciprocal's latency less.  The wave-uniform branch
     // around the rare other case cost more than that: p50 894 -> 924 us, 7.00 -> 6.87 M frames/s; profiles/r05_givens_step.txt.)
-    const double rq = rcp_refined(den);
-    const double q = div_rcp(num, den, rq);
-    dd = scale * sqrt_1_2(1.0 + q * q);
-    const double rd = rcp_refined(dd);
+    double rd;
+    givens_dd_rd(scale, num, dd, rd);
     cs = div_rcp(ww, dd, rd);
     sn = div_rcp(piv, dd, rd);
   } else {
@@ -837,10 +879,8 @@ __device__ __forceinline__ void giv_step(GivGridLane& st, int e, bool feed, doub
   double dd, cs, sn;
   if constexpr (FAST) {
     st.bad |= (int)(rot & !((den >= 0x1p-255) & (den <= 0x1p+255) & ((num == 0.0) | (num >= 0x1p-255))));
-    const double rq = rcp_refined(den);
-    const double q = div_rcp(num, den, rq);
-    dd = den * sqrt_1_2(1.0 + q * q);
-    const double rd = rcp_refined(dd);
+    double rd;
+    givens_dd_rd(den, num, dd, rd);
     cs = div_rcp(ww, dd, rd);
     sn = div_rcp(piv, dd, rd);
   } else {

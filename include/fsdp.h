@@ -415,6 +415,14 @@ int fsdp_selftest_math(fsdp_ctx* ctx, int n, const double* x, const double* a, c
  * absolute-value source modifier: spline_device.h max_abs_nn / min_abs_nn): out2n = [max (n) | min (n)]. */
 int fsdp_selftest_absminmax(fsdp_ctx* ctx, int n, const double* a, const double* b, double* out2n);
 
+/* FITPACK's fpgivs (the plane rotation every data row of a spline fit goes through four times: utils/spline_fit.py:117 -> splprep ->
+ * fppara / fpgivs) as the spline kernels compute it — max / min instead of the branch, scaling-free quotients, the reciprocal of the
+ * new diagonal seeded from the square root's own iterate (spline_device.h givens_dd_rd) — next to the same routine with the
+ * compiler's IEEE division and square root: out7n = [cs | sn | dd] of the kernels' sequence, [cs | sn | dd] IEEE, [1 where the operands
+ * lie inside the sequence's exponent band (outside it the kernels re-plan the frame with the IEEE operations)].  piv: pivots, ww >= 0:
+ * diagonals. */
+int fsdp_selftest_givens(fsdp_ctx* ctx, int n, const double* piv, const double* ww, double* out7n);
+
 /* The device's restatement of numpy.linalg.det for three homogeneous points (calculate_path/path_parameterization.py:86-92
  * takes the curvature's sign from it): xy6 = (n,6) rows x0,y0,x1,y1,x2,y2 -> out (n) determinants whose SIGN is NumPy's. */
 int fsdp_selftest_det3(fsdp_ctx* ctx, int n, const double* xy6, double* out);

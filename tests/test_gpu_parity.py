@@ -763,6 +763,38 @@ def test_device_math_helpers(ctx):
     assert (o2[4] == 0.0).all()
 
 
+def test_device_givens_sequence_returns_the_ieee_bits(ctx):
+    """FITPACK's fpgivs as the spline kernels compute it (spline_device.h fpgivs_guarded<true> / giv_step<true>: max / min for the
+    branch, scaling-free quotients, and — round 5 — the reciprocal of the new diagonal seeded from the square root's own Goldschmidt
+    iterate instead of v_rcp_f64: three links off the step's dependent chain) against the same routine with the compiler's IEEE
+    division and square root, on the device: cs, sn and dd bit for bit on four million (pivot, diagonal) pairs — ordinary magnitudes,
+    pivots far below / above the diagonal, equal magnitudes, fresh band rows (diagonal 0), zero pivots."""
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    for rnd in range(4):
+        piv = rng.normal(0, 1, n) * 10.0 ** rng.uniform(-6, 4, n)
+        ww = np.abs(rng.normal(0, 1, n)) * 10.0 ** rng.uniform(-6, 4, n)
+        if rnd == 1:  # a data row against a well-filled band row: |piv| << ww, and the other way round
+            piv[: n // 2] *= 10.0 ** rng.uniform(-12, -3, n // 2)
+            ww[n // 2 :] *= 10.0 ** rng.uniform(-12, -3, n - n // 2)
+        if rnd == 2:  # spline basis values: pivots in [0, 1], diagonals that are norms of a few of them
+            piv = rng.uniform(0, 1, n) ** 3
+            ww = np.sqrt(rng.uniform(0, 1, n) ** 2 * rng.integers(1, 200, n))
+        ww[:2000] = 0.0                       # fresh band rows
+        piv[2000:4000] = 0.0                  # nothing to rotate
+        piv[4000:6000] = ww[4000:6000] * rng.choice([-1.0, 1.0], 2000)  # equal magnitudes
+        out = ctx.selftest_givens(piv, ww)
+        ok = out[6] == 1.0
+        assert ok.mean() > 0.99
+        for k, name in enumerate(("cs", "sn", "dd")):
+            a, b = out[k][ok], out[3 + k][ok]
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (rnd, name, int((a != b).sum()), a[a != b][:3], b[a != b][:3])
+        nz = ok & (piv != 0) & (ww != 0)
+        assert np.all(np.abs(out[0][nz] ** 2 + out[1][nz] ** 2 - 1.0) < 1e-15)
+    band = ctx.selftest_givens(np.array([1e-300, 1e300, 1.0]), np.array([1.0, 1.0, 1e300]))
+    assert (band[6] == 0.0).all()  # outside the band the guard says so (the frame is planned with the IEEE operations)
+
+
 def test_device_abs_min_max_on_special_operands(ctx):
     """max_abs_nn / min_abs_nn (inline v_max_f64 |a|, b / v_min_f64 |a|, b — the emulator replaces them by compares) on
     everything a pivot / diagonal pair can be: ordinary values, +-0, denormals, equal magnitudes, infinities.  With a NaN
