@@ -28,6 +28,8 @@ $T python tools/bench_configs.py > $R/bench_configs.jsonl 2>&1
 FSDP_SHARE_GPU=1 $T python bench.py --gpus 2 --single-process --steps 20 --warmup 3 --no-cpu-baseline --no-latency --stream-batches 0 2>$R/bench_single_process.err | grep '^{' | tail -1 > $R/bench_line_2contexts_one_process.json
 $T python tools/ab_routes.py > $R/routes.txt 2>&1
 python tools/kernel_resources.py > $R/kernel_resources.txt 2>&1
+python tools/kernel_resources.py ft-fsd-path-planning_amd/lib/libfsdp_hip_wide.so > $R/kernel_resources_wide.txt 2>&1
+$T python tools/wide_probe.py > $R/wide_build.jsonl 2>&1
 $T tools/ubench/mfma_f64_order > $R/mfma_f64_order.txt 2>&1
 $T python tools/batch_sweep.py 1024 2048 4096 8192 16384 32768 65536 98304 > $R/batch_sweep.jsonl 2>&1
 FSDP_PACK=1 $T python tools/batch_sweep.py 2048 4096 8192 16384 32768 98304 > $R/batch_sweep_packed_kernels.jsonl 2>&1
