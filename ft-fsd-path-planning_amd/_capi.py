@@ -572,6 +572,6 @@ class Context:
         return out
 
     def default_path(self) -> np.ndarray:
-        out = np.zeros((PATH_POINTS, 4))
+        out = np.zeros((self.shapes.path_points, 4))
         self._check(self._lib.fsdp_default_path(self._h, _dp(out)), "fsdp_default_path")
         return out

@@ -110,7 +110,7 @@ typedef struct {
   int32_t first_k_left[2], first_k_right[2];
   double best_cost_left, best_cost_right;
   int32_t path_fallback;
-  int32_t n_dense; /* number of dense spline samples the 40 outputs were drawn from */
+  int32_t n_dense; /* number of dense spline samples the outputs (one per row of the horizon) were drawn from */
 } fsdp_frame_result;
 
 typedef struct fsdp_ctx fsdp_ctx;
@@ -121,7 +121,7 @@ typedef struct fsdp_ctx fsdp_ctx;
  * copy on the device.  Every value the reference accepts is accepted, within the compiled capacities of the structural
  * ones: max_n_neighbors <= 5, max_length <= 12, mpc_prediction_horizon <= 40 (8 / 16 / 64 in the wide build; a path of the
  * result holds FSDP_PATH_POINTS rows: with a
- * horizon h < 40 rows [h, 40) are NaN, and previous paths handed in are read up to row h), max_deg in 1..3 (fits of degree
+ * horizon h below FSDP_PATH_POINTS the rows [h, FSDP_PATH_POINTS) are NaN, and previous paths handed in are read up to row h), max_deg in 1..3 (fits of degree
  * < 3 take the one-frame-per-wavefront path kernel).  use_unknown_cones = 0 drops the cones of type UNKNOWN before sorting
  * (core_cone_sorting.py:113-115); the sorted indices still refer to the caller's array.  matches_should_be_monotonic is the
  * branch of functional_cone_matching.py:164-171 (the pipeline passes False, full_pipeline.py:65; ConeMatching's own default
@@ -177,7 +177,7 @@ const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creat
 int fsdp_plan_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
                     const double* poses, fsdp_frame_result* results);
 
-/* Sequential-replay form: frame i additionally gets prev_paths[i] (40,4) = the path this planner returned for its previous
+/* Sequential-replay form: frame i additionally gets prev_paths[i] (FSDP_PATH_POINTS,4) = the path this planner returned for its previous
  * frame, i.e. CalculatePath.previous_paths[-1] (core_calculate_path.py:203,219-221,236,531-536,568-573).  prev_paths NULL =
  * fresh planners (identical to fsdp_plan_batch).  Typical use: n_frames = number of cars advanced in lock-step. */
 int fsdp_plan_batch_sequential(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
@@ -210,7 +210,7 @@ int fsdp_set_global_path(fsdp_ctx* ctx, const double* xy, int n);
  * be page-locked: allocate them with fsdp_host_alloc or pin existing memory with fsdp_host_register — the batch then
  * crosses PCIe inside kernels of the slot's own stream (one reads the inputs from host memory, the last one of the pass
  * writes the results into it; no copy-engine command at all); pageable buffers are accepted (inputs are then copied
- * before fsdp_submit returns, results pass through a pinned block and a memcpy in fsdp_collect).  prev_paths: (n_frames,40,4) as for fsdp_plan_batch_sequential, or NULL.
+ * before fsdp_submit returns, results pass through a pinned block and a memcpy in fsdp_collect).  prev_paths: (n_frames,FSDP_PATH_POINTS,4) as for fsdp_plan_batch_sequential, or NULL.
  * While tickets are outstanding the blocking / resident entry points of the context return an error. */
 void* fsdp_host_alloc(size_t bytes);            /* page-locked host memory (hipHostMalloc), NULL on failure */
 void fsdp_host_free(void* p);
@@ -291,12 +291,12 @@ int fsdp_stage_names(fsdp_ctx* ctx, char* out, int cap);
 /* ConeSorting.run_cone_sorting — fills status, n_left/right, left/right_idx and the sorting diagnostics. */
 int fsdp_sort_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
                     const double* poses, fsdp_frame_result* results);
-/* ConeMatching.run_cone_matching — sorted_left/right: (n_frames,12,2) padded, counts (n_frames,). */
+/* ConeMatching.run_cone_matching — sorted_left/right: (n_frames,FSDP_MAX_LEN,2) padded, counts (n_frames,). */
 int fsdp_match_batch(fsdp_ctx* ctx, int n_frames, const double* sorted_left, const int32_t* n_left,
                      const double* sorted_right, const int32_t* n_right, const double* poses,
                      fsdp_frame_result* results);
 /* CalculatePath.run_path_calculation — inputs: the matching fields of `results` (left_v, right_v, l2r, r2l,
- * counts) and poses; prev_paths (n_frames,40,4) = CalculatePath.previous_paths[-1] of every frame's planner, or NULL for
+ * counts) and poses; prev_paths (n_frames,FSDP_PATH_POINTS,4) = CalculatePath.previous_paths[-1] of every frame's planner, or NULL for
  * fresh planners; fills path, path_fallback, n_dense, status. */
 int fsdp_path_batch(fsdp_ctx* ctx, int n_frames, const double* poses, const double* prev_paths, fsdp_frame_result* results);
 /* The same call with the SECOND value run_path_calculation returns (calculate_path/core_calculate_path.py:575,
@@ -434,7 +434,7 @@ int fsdp_selftest_det3(fsdp_ctx* ctx, int n, const double* xy6, double* out);
  * them at 2 ulp) and the third to within 2 ulp of the host's, so that a ROCm release that moves them cannot move a sorted index silently. */
 int fsdp_selftest_libm(fsdp_ctx* ctx, int n, const double* y, const double* x, const double* cs, double* out3n);
 
-/* The constant initial previous path (core_calculate_path.py:103-107), (40,4), as computed on the device. */
+/* The constant initial previous path (core_calculate_path.py:103-107), (FSDP_PATH_POINTS,4) — rows beyond the horizon NaN —, as computed on the device. */
 int fsdp_default_path(fsdp_ctx* ctx, double* out40x4);
 
 #ifdef __cplusplus

@@ -650,6 +650,10 @@ def test_parameters_beyond_the_standard_shapes_run_on_the_wide_build(pkg, golden
     prm = dict(zip(g["param_names"].tolist(), g["param_values"].tolist()))
     c = pkg.Context(device=0, mission=4, params=prm)
     assert c.shapes is pkg._capi.WIDE and c.result_dtype.itemsize > pkg.RESULT_DTYPE.itemsize
+    with oracle_lib_wide.params(prm):
+        dp, dp_ref = c.default_path(), oracle_lib_wide.default_path()
+    assert dp.shape == (64, 4) and np.array_equal(np.isnan(dp), np.isnan(dp_ref)) and np.nanmax(np.abs(dp - dp_ref)) < 1e-12
+    assert np.isfinite(dp[: c.horizon]).all() and np.isnan(dp[c.horizon :]).all()
     res = c.plan_batch(g["offsets"], g["cones"], g["poses"])
     assert res["path"].shape[1:] == (64, 4) and res["left_idx"].shape[1] == 16
     rows = _wide_rows(res)
