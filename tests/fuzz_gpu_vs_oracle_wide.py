@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""The GPU fuzz of fuzz_gpu_vs_oracle.py for the WIDE build (libfsdp_hip_wide.so, -DFSDP_WIDE_SHAPES) against the oracle's wide build
+(det-math mode): random frame sets under three parameter sets only that build takes, two path-stage instantiations each — a manual
+sweep for the GPU box (not collected by pytest):  python tests/fuzz_gpu_vs_oracle_wide.py [frames_per_set]"""
+import importlib
+import itertools
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib_wide as oracle_lib  # noqa: E402
+
+pkg = importlib.import_module("ft-fsd-path-planning_amd")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+PARAMS = {"k8_l16": dict(max_n_neighbors=8, max_length=16),
+          "h64_30m": dict(mpc_prediction_horizon=64, mpc_path_length=30),
+          "k7_l15_d7_h55": dict(max_n_neighbors=7, max_length=15, max_dist=7.0, mpc_prediction_horizon=55)}
+MODES = {"mono64": {"FSDP_PATH_MODE": "mono"}, "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4", "FSDP_FIT_LANES": "0"}}
+bad_total = frames_total = 0
+seed = 500
+for pname, prm in PARAMS.items():
+    ctxs = {}
+    for name, env in MODES.items():
+        for k in ("FSDP_PATH_MODE", "FSDP_PACK", "FSDP_FIT_G", "FSDP_FIT_LANES"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ctxs[name] = pkg.Context(device=0, params=prm)  # the environment is read at context creation
+        assert ctxs[name].shapes is pkg.WIDE
+    for per_side, track_noise, frame_noise, colour in itertools.product((24, 64), (0.1, 0.3), (0.0, 0.3), (True, False)):
+        seed += 1
+        off, cones, poses = pkg.synth.make_replay_batch(N, per_side, track_noise, seed=seed, frame_noise=frame_noise,
+                                                        random_pose=frame_noise > 0, color=colour)
+        with oracle_lib.params(prm), oracle_lib.math_mode(1):
+            ref = oracle_lib.plan_batch(off, cones, poses, n_threads=os.cpu_count() or 1)
+        ok = ref["status"] == 0
+        for name, ctx in ctxs.items():
+            res = ctx.plan_batch(off, cones, poses)
+            bad = res["status"] != ref["status"]
+            for f in ("n_left", "n_right", "left_idx", "right_idx", "n_left_v", "n_right_v", "l2r", "r2l", "left_v", "right_v", "path_fallback"):
+                d = res[f] != ref[f]
+                bad |= ok & (d.reshape(len(d), -1).any(axis=1))
+            err = np.abs(res["path"] - ref["path"]).reshape(len(ok), -1)
+            err = np.where(np.isnan(err), 0.0, err).max(axis=1)
+            bad |= ok & (err > 1e-9)
+            bad |= ok & (np.isnan(res["path"]) != np.isnan(ref["path"])).reshape(len(ok), -1).any(axis=1)
+            bad_total += int(bad.sum())
+            frames_total += len(ok)
+            print(f"{pname:14s} cones/side {per_side:3d} track sigma {track_noise} frame sigma {frame_noise} colour {int(colour)} {name:12s}: "
+                  f"{int(bad.sum())} of {len(ok)} frames differ (status ok {int(ok.sum())}, longest side {int(max(ref['n_left'].max(), ref['n_right'].max()))})"
+                  + (f"  first: {np.nonzero(bad)[0][:5].tolist()}" if bad.any() else ""), flush=True)
+    for c in ctxs.values():
+        c.close()
+print(f"TOTAL differing frames: {bad_total} of {frames_total}")

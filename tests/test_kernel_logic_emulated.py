@@ -106,6 +106,36 @@ def test_emulated_wide_build_with_parameters_beyond_the_standard_shapes(golden_d
     assert flips == [f for f in arc.flips("det") if f in set(idx.tolist())], flips
 
 
+@pytest.mark.parametrize("name,stride", [("big_frames", 3), ("lattice", 5)])
+def test_emulated_wide_build_routes_beyond_the_lds_capacities(golden_dir, name, stride):
+    """The wide build's sort_big_kernel (frame state in global memory: 300 / 600 cones per frame, more than 64 raw end
+    configurations per side) under max_n_neighbors = 8, max_length = 16: equal to the oracle's wide build; where eight neighbours
+    on a lattice make a side grow beyond the 4096 raw end configurations the state holds (the oracle counts 37 000 and more) the
+    frame is refused with FSDP_OVERFLOW_ENDS, never truncated (include/fsdp.h)."""
+    import emu_lib_wide
+    import oracle_lib_wide
+
+    prm = dict(max_n_neighbors=8, max_length=16, mpc_prediction_horizon=64)
+    g = np.load(golden_dir / f"{name}.npz")
+    idx = np.arange(0, len(g["ok"]), stride)
+    off = np.concatenate([[0], np.cumsum([g["offsets"][i + 1] - g["offsets"][i] for i in idx])]).astype(np.int32)
+    cones = np.concatenate([g["cones"][g["offsets"][i] : g["offsets"][i + 1]] for i in idx])
+    poses = g["poses"][idx]
+    with emu_lib_wide.params(prm):
+        res, _ = emu_lib_wide.plan(off, cones, poses, 8)
+        assert emu_lib_wide.lib().emu_last_big() > 0
+    with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+        ref = oracle_lib_wide.plan_batch(off, cones, poses, n_threads=4)
+    refused = res["status"] == 202
+    assert (np.maximum(ref["n_configs_left"], ref["n_configs_right"])[refused] > 2048).all()  # (the oracle's counts AFTER the post-filters: the raw ones, which the state holds, are larger)
+    ok = (ref["status"] == 0) & ~refused
+    assert ok.sum() >= 2 and np.array_equal(res["status"][~refused], ref["status"][~refused])
+    for f in ("left_idx", "right_idx", "n_left_v", "n_right_v", "l2r", "r2l", "left_v", "right_v", "path_fallback"):
+        assert np.array_equal(res[f][ok], ref[f][ok]), f
+    parity.assert_intermediates_equal(res, ref, ok)
+    assert np.array_equal(res["path"][ok], ref["path"][ok], equal_nan=True)
+
+
 @pytest.mark.parametrize("name,stride", [("scenarios", 1), ("cfg3_nocolor", 16), ("lattice", 6), ("odd_inputs", 1)])
 def test_emulated_wide_build_with_the_default_parameters(golden_dir, name, stride):
     """The wide build under the reference's DEFAULT parameters (a stage object fed more than 12 sorted cones per side runs on it

@@ -37,4 +37,5 @@ $T python tools/latency_breakdown.py > $R/latency_breakdown.txt 2>&1
 $T python tools/overlap_depths.py default > $R/overlap_depths.txt 2>&1
 timeout 1500 python tests/fuzz_gpu_vs_oracle.py 2048 > $R/fuzz_gpu_vs_oracle.txt 2>&1
 timeout 900 python tests/fuzz_skidpad_gpu_vs_oracle.py 192 90 > $R/fuzz_skidpad_gpu_vs_oracle.txt 2>&1
+timeout 900 python tests/fuzz_gpu_vs_oracle_wide.py 1024 > $R/fuzz_gpu_vs_oracle_wide.txt 2>&1
 cat $R/gpu_tests.txt; cut -c1-300 $R/bench_line.json; tail -3 $R/fuzz_gpu_vs_oracle.txt
