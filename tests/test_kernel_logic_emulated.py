@@ -106,7 +106,7 @@ def test_emulated_wide_build_with_parameters_beyond_the_standard_shapes(golden_d
     assert flips == [f for f in arc.flips("det") if f in set(idx.tolist())], flips
 
 
-@pytest.mark.parametrize("name,stride", [("big_frames", 3), ("lattice", 5)])
+@pytest.mark.parametrize("name,stride", [("big_frames", 3), ("lattice", 7)])
 def test_emulated_wide_build_routes_beyond_the_lds_capacities(golden_dir, name, stride):
     """The wide build's sort_big_kernel (frame state in global memory: 300 / 600 cones per frame, more than 64 raw end
     configurations per side) under max_n_neighbors = 8, max_length = 16: equal to the oracle's wide build; where eight neighbours
@@ -115,7 +115,8 @@ def test_emulated_wide_build_routes_beyond_the_lds_capacities(golden_dir, name, 
     import emu_lib_wide
     import oracle_lib_wide
 
-    prm = dict(max_n_neighbors=8, max_length=16, mpc_prediction_horizon=64)
+    # (on the lattice eight neighbours make most sides explode; six with length 14 leave frames on either side of the capacity)
+    prm = dict(max_n_neighbors=8, max_length=16, mpc_prediction_horizon=64) if name == "big_frames" else dict(max_n_neighbors=6, max_length=14)
     g = np.load(golden_dir / f"{name}.npz")
     idx = np.arange(0, len(g["ok"]), stride)
     off = np.concatenate([[0], np.cumsum([g["offsets"][i + 1] - g["offsets"][i] for i in idx])]).astype(np.int32)
@@ -127,7 +128,7 @@ def test_emulated_wide_build_routes_beyond_the_lds_capacities(golden_dir, name, 
     with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
         ref = oracle_lib_wide.plan_batch(off, cones, poses, n_threads=4)
     refused = res["status"] == 202
-    assert (np.maximum(ref["n_configs_left"], ref["n_configs_right"])[refused] > 2048).all()  # (the oracle's counts AFTER the post-filters: the raw ones, which the state holds, are larger)
+    assert (np.maximum(ref["n_configs_left"], ref["n_configs_right"])[refused] > 1024).all()  # (the oracle's counts AFTER the post-filters: the raw ones, which the state holds, are larger)
     ok = (ref["status"] == 0) & ~refused
     assert ok.sum() >= 2 and np.array_equal(res["status"][~refused], ref["status"][~refused])
     for f in ("left_idx", "right_idx", "n_left_v", "n_right_v", "l2r", "r2l", "left_v", "right_v", "path_fallback"):
