@@ -22,7 +22,9 @@ timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -
 echo "write rc=$?"
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1
 echo "sq rc=$?"
-# counter calibration: kernels that move exactly 1 GiB each with 4 / 8 / 16 bytes per lane
+# counter calibration: kernels that move exactly 1 GiB each with 4 / 8 / 16 bytes per lane (a build output, not in the history:
+# compiled here when the snapshot came without it)
+[ -x $REPO/tools/ubench/fetch_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off $REPO/tools/ubench/fetch_calib.hip -o $REPO/tools/ubench/fetch_calib > $OUT/calib_build.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/calib_fetch -o pmc -- $REPO/tools/ubench/fetch_calib > $OUT/calib_fetch.log 2>&1
 echo "calib fetch rc=$?"
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/calib_write -o pmc -- $REPO/tools/ubench/fetch_calib > $OUT/calib_write.log 2>&1

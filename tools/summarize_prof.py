@@ -139,6 +139,12 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         pmc.setdefault(kn, {})[c] = v
 
 if json_out and pmc:
+    # no calibration run, no byte counts: FETCH_SIZE under-reports by 2 x on this stack, and a silent factor of 1 would halve every
+    # traffic figure (the calibration binary is a build output: tools/profile_gpu.sh compiles it on the box when it is missing)
+    have_calib = bool(calib.get("read_b64") and (calib.get("read_rec64") or calib.get("read_b128")) and calib.get("write_b64"))
+    if not have_calib:
+        print("!! counter calibration missing (tools/ubench/fetch_calib did not run): FETCH_SIZE / WRITE_SIZE are listed raw, "
+              "hbm_bytes_per_launch is NOT written")
     f8 = calib.get("read_b64") or 1.0
     f16 = calib.get("read_rec64") or calib.get("read_b128") or 1.0
     fw = calib.get("write_b64") or 1.0
@@ -155,8 +161,9 @@ if json_out and pmc:
         if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
             e["FETCH_SIZE_KB"] = round(d.get("FETCH_SIZE", 0.0), 1)
             e["WRITE_SIZE_KB"] = round(d.get("WRITE_SIZE", 0.0), 1)
-            e["fetch_factor"] = ff
-            e["hbm_bytes_per_launch"] = int(1024 * (ff * d.get("FETCH_SIZE", 0.0) + fw * d.get("WRITE_SIZE", 0.0)))
+            if have_calib:
+                e["fetch_factor"] = ff
+                e["hbm_bytes_per_launch"] = int(1024 * (ff * d.get("FETCH_SIZE", 0.0) + fw * d.get("WRITE_SIZE", 0.0)))
         if "SQ_INSTS_VALU" in d:
             e["valu_insts_per_frame"] = round(d["SQ_INSTS_VALU"] / FRAMES, 1)
             dur = durations.get("trace_serial", {}).get(kn)
