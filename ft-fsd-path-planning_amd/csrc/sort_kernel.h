@@ -15,6 +15,8 @@
 // LDS per frame (one wavefront): cone x/y 4 KB, type 256 B, per-cone start-cone scalars 2.3 KB, neighbour lists
 // 1.5 KB, end configurations 1.5 KB, misc < 1 KB  => ~11 KB, 14 frames resident per CU.
 #pragma once
+#include <stddef.h>
+
 #include "fsdp_device.h"
 
 namespace fsdp {
@@ -738,18 +740,33 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
     const int c = c0 + lane;
     bool keep = c < n_ends && S.keep[c] != 0;
     if (keep) {
-      int16_t cfg[MAX_LEN];
+      // rows as 64-bit words (four positions each; a row starts on an 8-byte boundary): "same" = no word differs, "this row is a
+      // prefix of the other" = they differ nowhere this row holds a cone (its -1 positions masked out) — the per-position
+      // predicates (a == b for all l; a == b or b == -1 for all l) three or four words at a time
+      constexpr int CW = MAX_LEN / 4;
+      static_assert(MAX_LEN % 4 == 0 && sizeof(S.ends[0][0]) == 8 * CW && offsetof(SH, ends) % 8 == 0, "a configuration row is CW aligned 64-bit words");
+      const unsigned long long* mine_row = reinterpret_cast<const unsigned long long*>(&S.ends[side][c][0]);
+      unsigned long long mine[CW], holds[CW];
 #pragma unroll
-      for (int l = 0; l < MAX_LEN; l++) cfg[l] = S.ends[side][c][l];
+      for (int w = 0; w < CW; w++) {
+        mine[w] = mine_row[w];
+        // 0xFFFF at the positions whose entry is not -1 (0xFFFF): per 16-bit lane "~entry != 0", smeared over the lane
+        const unsigned long long t = ~mine[w];
+        const unsigned long long h = (((t & 0x7FFF7FFF7FFF7FFFull) + 0x7FFF7FFF7FFF7FFFull) | t) & 0x8000800080008000ull;
+        holds[w] = (h - (h >> 15)) | h;
+      }
       bool drop = false;
       for (int o = 0; o < n_ends && !drop; o++) {
         if (o == c || !S.keep[o]) continue;
-        bool same = true, prefix = true;
-        for (int l = 0; l < MAX_LEN; l++) {
-          int a = S.ends[side][o][l], b = cfg[l];
-          if (a != b) same = false;
-          if (!(a == b || b == -1)) prefix = false;
+        const unsigned long long* other = reinterpret_cast<const unsigned long long*>(&S.ends[side][o][0]);
+        unsigned long long diff = 0ull, pdiff = 0ull;
+#pragma unroll
+        for (int w = 0; w < CW; w++) {
+          const unsigned long long x = other[w] ^ mine[w];
+          diff |= x;
+          pdiff |= x & holds[w];
         }
+        const bool same = diff == 0ull, prefix = pdiff == 0ull;
         if (same && o < c) drop = true;       // duplicate of an earlier row
         if (!same && prefix) drop = true;     // strict prefix of another row
       }
@@ -832,7 +849,40 @@ __device__ __forceinline__ int sort_side_finish(SH& S, int n, int cone_type, int
   }
   // sorted_set_diff(near_all, all) with the searchsorted quirk (:88-94) on register-resident words (every lane computes
   // the same): for every b of `all` in ascending order, drop the first element of near_all that is >= b
-  {
+  if constexpr (NW <= 4) {
+    // LDS kernels (two or four words): one element b of `all` per lane.  Every b looks for its element in the UNCHANGED near set
+    // (near_w is not modified below), so the b are independent: each lane finds its position and clears that bit of the close set
+    // (an atomic AND in LDS; two b may clear the same bit) — a handful of instructions instead of a wave-uniform loop over `all`.
+    if (lane == 0) {
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        S.near_mask[w] = near_w[w];
+        S.close_mask[w] = near_w[w];
+      }
+    }
+    __syncthreads();
+    bool undefined = false;
+    for (int a0 = 0; a0 < n_all; a0 += WAVE) {
+      const int a = a0 + lane;
+      if (a < n_all) {
+        const int b = S.all_list[a];
+        const int bw = b >> 6;
+        int pos = -1;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          unsigned long long mw = near_w[w];
+          if (w == bw) mw &= ~((1ull << (b & 63)) - 1ull);
+          if (w >= bw && pos < 0 && mw) pos = w * WAVE + (__ffsll(mw) - 1);
+        }
+        if (pos < 0)
+          undefined = true;
+        else
+          atomicAnd(&S.close_mask[pos >> 6], ~(1ull << (pos & 63)));
+      }
+    }
+    if (__ballot(undefined) != 0ull) return ST_REF_UNDEFINED_SET_DIFF;
+    __syncthreads();
+  } else {
 #pragma unroll
     for (int w = 0; w < NW; w++) close_w[w] = near_w[w];
     bool undefined = false;

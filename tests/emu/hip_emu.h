@@ -7,7 +7,7 @@
 //
 // Supported subset (what the kernels use): __global__/__device__/__shared__, threadIdx /
 // blockIdx / blockDim / gridDim (.x), __syncthreads, __ballot, __shfl/__shfl_xor/__shfl_down/
-// __shfl_up (int, unsigned, long long, double), __popcll, __ffsll, __clzll, atomicOr/atomicAdd, __hip_atomic_load/store, __threadfence
+// __shfl_up (int, unsigned, long long, double), __popcll, __ffsll, __clzll, atomicOr/atomicAnd/atomicAdd, __hip_atomic_load/store, __threadfence
 // on shared ints.  Cross-lane operations are rendezvous of an aligned G-lane group (G = 64
 // by default; the path stage runs several frames per wavefront with G = 16): all lanes of a group must reach them
 // (group-uniform control flow) — the same discipline the kernels follow on hardware; groups may diverge.
@@ -289,6 +289,12 @@ template <class T>
 inline T atomicOr(T* p, T v) {
   T o = *p;
   *p = o | v;
+  return o;
+}
+template <class T>
+inline T atomicAnd(T* p, T v) {
+  T o = *p;
+  *p = o & v;
   return o;
 }
 template <class T>
