@@ -692,6 +692,57 @@ def test_parameters_beyond_the_standard_shapes_run_on_the_wide_build(pkg, golden
     c0.close()
 
 
+def test_host_classes_on_the_wide_build(pkg, golden_dir):
+    """The host classes with parameters beyond the standard shapes: a stateful PathPlanner (the reference's call, previous path
+    chained), MultiPlanner (contexts on the one GPU; page-locked and pageable batches, a stream of them) and AccelerationBatch
+    with a 56-row horizon against planner objects — every one carried by the wide build without the caller naming it."""
+    import oracle_lib_wide
+
+    prm = dict(max_n_neighbors=8, max_length=16, mpc_prediction_horizon=56)
+    off, cones, poses = pkg.synth.make_replay_batch(2400, 64, 0.15, seed=31, color=True)
+    with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+        ref = oracle_lib_wide.plan_batch(off, cones, poses, n_threads=os.cpu_count() or 1)
+    # one process, three contexts on the GPU: the same bytes as one context
+    one = pkg.Context(device=0, params=prm)
+    want = one.plan_batch(off, cones, poses)
+    _assert_equal_to_oracle(want, ref)
+    mp = pkg.MultiPlanner([0, 0, 0], params=prm)
+    assert mp.ctx[0].shapes is pkg.WIDE
+    got = mp.plan_batch(off, cones, poses)
+    assert got.dtype == pkg.WIDE.result_dtype and got.tobytes() == want.tobytes()
+    pinned = (pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64))
+    outs = list(mp.plan_stream([pinned, (off, cones, poses), pinned]))
+    assert all(o.tobytes() == want.tobytes() for o in outs)
+    mp.close()
+    one.close()
+    # the reference's call, frame after frame (the previous path chained: core_calculate_path.py:572-573)
+    planner = pkg.PathPlanner(pkg.MissionTypes.trackdrive, device=0, params=prm)
+    prev = None
+    for k in range(0, 60, 3):
+        xyt = cones[off[k] : off[k + 1]]
+        path = planner.calculate_path_in_global_frame(xyt, poses[k][:2], poses[k][2:])
+        with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+            r = oracle_lib_wide.plan_frame_prev(xyt, poses[k], prev)
+        assert path.shape == (56, 4) and np.array_equal(path, r["path"][:56])
+        prev = r["path"]
+    # acceleration mission, planners in lock-step, 56 rows
+    acc = pkg.acceleration
+    g = np.load(golden_dir / "global_path.npz")
+    n = 3
+    seeds = [int(g["acc_seed"]), 7, 8]
+    planners = [pkg.PathPlanner(pkg.MissionTypes.acceleration, device=0, relocalization_seed=sd, params=dict(mpc_prediction_horizon=56)) for sd in seeds]
+    batch = acc.AccelerationBatch(n, pkg.MissionTypes.acceleration, seeds=seeds, device=0, params=dict(mpc_prediction_horizon=56))
+    o, c, p = g["acc_offsets"], g["acc_cones"], g["acc_poses"]
+    for t in range(min(20, len(p))):
+        xyt = c[o[t] : o[t + 1]]
+        offs = np.arange(n + 1, dtype=np.int32) * len(xyt)
+        paths, status = batch.step(offs, np.concatenate([xyt] * n), np.repeat(p[t][None], n, axis=0))
+        for i in range(n):
+            w = planners[i].calculate_path_in_global_frame(xyt, p[t][:2], p[t][2:])
+            assert status[i] == 0 and paths[i].shape == (56, 4) and np.array_equal(paths[i], w), (t, i)
+    assert batch.relocalized.all()
+
+
 def test_reference_shaped_planner_and_stage_classes_on_the_wide_build(pkg, golden_dir):
     """PathPlanner / ConeSorting / ConeMatching / CalculatePath with max_length = 16, max_n_neighbors = 8: the stage objects hand
     sides of up to 16 cones (32 with virtual ones) to each other like the reference's do (full_pipeline.py:142-176)."""
