@@ -132,50 +132,82 @@ def streaming_leg(pkg, ctx, per_gpu: int, depth: int, n_batches: int, seed0: int
     """Host -> host: `n_batches` DIFFERENT batches (a different synthetic track each) through `depth` pass slots with
     fsdp_submit / fsdp_collect — every batch is copied to the GPU, planned and its results copied back inside the
     timed region, all buffers page-locked (fsdp_host_alloc).  This is the rate a caller of the public API gets for a
-    stream of batches (the reference's harness feeds frames one after the other, demo/json_demo.py:103-131)."""
+    stream of batches (the reference's harness feeds frames one after the other, demo/json_demo.py:103-131).  `value` is the
+    stream with COMPACT result records (fsdp_submit_compact: path + sorted indices + status, the 1384 bytes SURVEY 8d counts as a
+    frame's output); `full_records_frames_per_s` the same stream with the 2408-byte records that also carry the matching
+    intermediates.  One batch at a time = blocking fsdp_plan_batch calls on the same buffers (a batch is pipelined in chunks
+    inside the call)."""
     batches = []
     for k in range(n_batches):
         off, cones, poses = pkg.synth.make_replay_batch(per_gpu, CONES_PER_SIDE, 0.15, seed=seed0 + 1000 + k, color=True)
         batches.append((pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64)))
     outs = [pkg.pinned_empty(per_gpu, pkg.RESULT_DTYPE) for _ in range(n_batches)]
+    outs_c = [pkg.pinned_empty(per_gpu, pkg.COMPACT_DTYPE) for _ in range(n_batches)]
     ctx.set_overlap(depth)
-    def replay():
+
+    def replay(compact):
         inflight = []
         for k in range(n_batches):
             if len(inflight) == ctx.ticket_capacity:
                 ctx.collect(inflight.pop(0))
-            inflight.append(ctx.submit(*batches[k], out=outs[k]))
+            inflight.append(ctx.submit(*batches[k], out=(outs_c if compact else outs)[k], compact=compact))
         for t in inflight:
             ctx.collect(t)
 
     # warm-up: one untimed replay of the whole stream — every slot's stream and buffers exist, and the context has seen
     # which route kernels this stream's batches need (a pass that lacks one is repeated: that belongs to a stream's first
     # seconds, not to its rate)
-    replay()
-    for o in outs:
+    replay(False)
+    replay(True)
+    for o in outs + outs_c:
         o["status"] = -1
     reruns0 = ctx.route_stats()[2]
     t0 = time.perf_counter()
-    replay()
+    replay(False)
+    el_full = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    replay(True)
     el = time.perf_counter() - t0
-    # one pass at a time through the same entry points, for comparison (what plan_batch-style calls deliver)
+    # one batch at a time: blocking calls, page-locked buffers in place
     n_ser = min(8, n_batches)
+    ctx.plan_batch(*batches[0], out=outs[0])
     t1 = time.perf_counter()
     for k in range(n_ser):
-        ctx.collect(ctx.submit(*batches[k], out=outs[k]))
+        ctx.plan_batch(*batches[k], out=outs[k])
     el_ser = time.perf_counter() - t1
-    # the streamed results are the serial results
-    chk = ctx.plan_batch(*batches[n_batches - 1])
-    same = chk.tobytes() == outs[n_batches - 1].tobytes()
-    bad = int(sum(int((o["status"] != 0).sum()) for o in outs))
+    ctx.plan_batch(*batches[0], out=outs_c[0], compact=True)
+    t1 = time.perf_counter()
+    for k in range(n_ser):
+        ctx.plan_batch(*batches[k], out=outs_c[k], compact=True)
+    el_ser_c = time.perf_counter() - t1
+    pageable = [tuple(np.array(a) for a in b) for b in batches[:n_ser]]
+    ctx.plan_batch(*pageable[0])
+    t1 = time.perf_counter()
+    for b in pageable:
+        ctx.plan_batch(*b)
+    el_ser_pg = time.perf_counter() - t1
+    # the streamed results are the serial results; the compact records are the full records' fields
+    ctx.set_option("plan_chunks", 1)
+    chk = ctx.plan_batch(*pageable[n_ser - 1])
+    ctx.set_option("plan_chunks", 0)
+    same = chk.tobytes() == outs[n_ser - 1].tobytes()
+    same_c = all(np.array_equal(outs_c[n_ser - 1][f], chk[f], equal_nan=True) for f in ("path", "left_idx", "right_idx", "status"))
+    bad = int(sum(int((o["status"] != 0).sum()) for o in outs_c))
     h2d = sum(a.nbytes for a in batches[0])
-    d2h = outs[0].nbytes
+    ceiling = ctx.pcie_probe(h2d, 30)
     return {
         "value": per_gpu * n_batches / el, "unit": "frames/s", "batches": n_batches, "frames_per_batch": per_gpu, "depth": depth,
-        "seconds": el, "one_batch_at_a_time_frames_per_s": per_gpu * n_ser / el_ser,
-        "pcie_bytes_per_batch": {"h2d": int(h2d), "d2h": int(d2h)},
-        "pcie_GBps": {"h2d": h2d * n_batches / el / 1e9, "d2h": d2h * n_batches / el / 1e9},
-        "last_batch_equals_serial_plan_batch": bool(same), "frames_with_nonzero_status": bad,
+        "seconds": el, "result_records": "compact (fsdp_compact_result, 1384 B)",
+        "full_records_frames_per_s": per_gpu * n_batches / el_full,
+        "one_batch_at_a_time_frames_per_s": per_gpu * n_ser / el_ser_c,
+        "one_batch_at_a_time_full_records_frames_per_s": per_gpu * n_ser / el_ser,
+        "one_batch_at_a_time_pageable_frames_per_s": per_gpu * n_ser / el_ser_pg,
+        "pcie_bytes_per_batch": {"h2d": int(h2d), "d2h": int(outs_c[0].nbytes), "d2h_full_records": int(outs[0].nbytes)},
+        "pcie_GBps": {"h2d": h2d * n_batches / el / 1e9, "d2h": outs_c[0].nbytes * n_batches / el / 1e9},
+        # what the box's link carries for page-locked copies of a batch's size (fsdp_pcie_probe: hipMemcpyAsync, 30 x 12.7 MB)
+        "pcie_ceiling_GBps": ceiling,
+        "last_batch_equals_serial_plan_batch": bool(same), "compact_records_equal_full_records_fields": bool(same_c),
+        "frames_with_nonzero_status": bad,
         "passes_rerun_for_routes": ctx.route_stats()[2] - reruns0,
         "what": "different batches host -> host (page-locked buffers), H2D + kernels + D2H of every batch inside the timed region; "
                 "warm-up = one untimed replay of the same stream",
@@ -400,6 +432,9 @@ def main():
                     help="N > 1 without a launcher, sockets or RCCL: one context per GPU, all driven from this process (multi.py); "
                          "also what --gpus N falls back to when its own launch of N ranks fails")
     ap.add_argument("--stream-batches", type=int, default=100, help="different batches of the host -> host streaming leg (0: skip)")
+    ap.add_argument("--allow-tcp-fallback", action="store_true",
+                    help="N > 1 ranks: accept a run whose start-up collectives went over the TCP star because RCCL did not come up on "
+                         "every rank (the line then says communicator: tcp-fallback); without it such a run exits with status 3")
     args = ap.parse_args()
     if os.environ.get("FSDP_HANG_DUMP"):  # diagnostics: Python stacks of all threads after N seconds, then exit
         import faulthandler
@@ -419,7 +454,7 @@ def main():
         lines = [l for l in text.splitlines() if l.startswith("{") and '"metric"' in l]
         if lines:
             print(lines[-1], flush=True)
-            sys.exit(0)
+            sys.exit(3 if rc == 3 else 0)  # (3: the ranks ran, but not over RCCL — see --allow-tcp-fallback)
         print(f"bench.py: the {args.gpus} ranks produced no line (exit status {rc}); planning on the {args.gpus} GPUs from this process instead", file=sys.stderr)
         single = True
     rank = int(os.environ.get("RANK", "0"))
@@ -560,6 +595,9 @@ def main():
                                + d.describe(),
                 "processes": 1 if single else world,
                 "communicator": d.transport,
+                # what ncclCommCount returned while the RCCL communicator carried the start-up broadcast (it is released before the
+                # timed region); 0 = RCCL never ran: for N > 1 ranks this must equal n_gpus, or the process exits with status 3
+                "rccl_ranks": int(getattr(d, "rccl_ranks", 0)),
                 "pass_overlap": overlap,
             },
             "roofline": {
@@ -570,6 +608,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pk.get("hbm_bytes_per_launch", 0) / 1e9 if pk.get("hbm_bytes_per_launch") else None,
+                "basis": "average duration of the dominant kernel's launches inside the timed region (twenty passes in flight share the chip)",
                 "kernel_ms_timed_region": main_ms[dom] if main_ms[dom] > 0 else None,
                 "kernel_bracketed_in_timed_region": names[int(np.argmax(main_ms))],
                 # the same launches by the kernel's own clock readings (s_memrealtime: first wavefront's start to last
@@ -628,6 +667,18 @@ def main():
             out["p50_single_frame_us"] = float(np.median(lat[50:]) * 1e6)
             # the reproducible per-kernel figure next to roofline.kernel_ms (round-4 review, weak #11)
             out["roofline"].update(chip_time_leg())
+            chip = (out["roofline"].get("chip_ns_per_frame") or {}).get(names[dom])
+            if chip:
+                # The line's achieved / frac: the dominant kernel ALONE on a chip it fills (one launch of 98 304 frames, HIP events
+                # around it on its stream, measured by a child of this run) — a property of the kernel, reproducible from profiles/
+                # (r06_batch_sweep_packed_kernels.jsonl, r06_chip_time_rocprofv3_summary.txt).  The duration of one of twenty
+                # overlapped launches (..._timed_region below) is a property of how twenty streams interleave on the box at hand.
+                rf = out["roofline"]
+                rf["achieved_timed_region"], rf["frac_timed_region"] = rf["achieved"], rf["frac"]
+                rf["achieved"] = algo_bytes / chip  # bytes per ns = GB/s
+                rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
+                rf["basis"] = (f"{algo_bytes} algorithmic bytes per frame / {chip:.1f} ns of chip time per frame of {names[dom]} "
+                               "(chip_ns_per_frame: the kernel alone, 98 304 frames per launch)")
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(off, cones, poses)
                 out["p50_single_frame_vs_cpu_1thread"] = out["p50_single_frame_us"] / out["cpu_baseline"]["single_thread_us_per_frame"]
@@ -645,12 +696,16 @@ def main():
     import signal
     import threading
 
+    exit_status = pkg.dist.multi_rank_exit_status(world, single, d.transport, int(getattr(d, "rccl_ranks", 0)), args.allow_tcp_fallback)
+    if exit_status and rank == 0:
+        print(f"bench.py: {world} ranks, but communicator = {d.transport!r} with {getattr(d, 'rccl_ranks', 0)} RCCL rank(s) "
+              f"({getattr(d, 'fallback_reason', None)}): exit status {exit_status} (--allow-tcp-fallback accepts such a run)", file=sys.stderr)
     sys.stdout.flush()
     sys.stderr.flush()
     # (ranks other than 0 reach this point while rank 0 still measures its single-GPU extras — streaming, latency, CPU
     # baseline, ~20 s — and then wait for it in the barrier: their fuse is longer)
     fuse = 30.0 if rank == 0 else 240.0
-    killer = threading.Timer(fuse, lambda: os._exit(0))
+    killer = threading.Timer(fuse, lambda: os._exit(exit_status))
     killer.daemon = True
     killer.start()
     signal.signal(signal.SIGALRM, signal.SIG_DFL)
@@ -658,6 +713,7 @@ def main():
     d.barrier()
     d.close()
     ctx.close()
+    sys.exit(exit_status)
 
 
 if __name__ == "__main__":

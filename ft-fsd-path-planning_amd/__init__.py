@@ -11,4 +11,4 @@ from .stages import CalculatePath, ConeMatching, ConeSorting, ConeMatchingInput,
 from .skidpad import SkidpadBatch  # noqa: F401
 from .acceleration import AccelerationBatch  # noqa: F401
 from .multi import MultiPlanner, MultiSkidpadBatch  # noqa: F401
-from ._capi import STANDARD, WIDE, Context, FsdpError, PATH_RESULT_DTYPE, RESULT_DTYPE, pinned_copy, pinned_empty  # noqa: F401
+from ._capi import COMPACT_DTYPE, STANDARD, WIDE, Context, FsdpError, PATH_RESULT_DTYPE, RESULT_DTYPE, pinned_copy, pinned_empty  # noqa: F401

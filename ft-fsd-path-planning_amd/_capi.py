@@ -65,6 +65,10 @@ class Shapes:
         # fsdp_path_result (include/fsdp.h): a skidpad step's compact result
         self.path_result_dtype = np.dtype(
             [("path", "<f8", (path_points, 4)), ("status", "<i4"), ("path_fallback", "<i4"), ("n_dense", "<i4"), ("pad", "<i4")], align=True)
+        # fsdp_compact_result (include/fsdp.h): path + sorted indices + status of a trackdrive frame (1384 bytes in the standard build)
+        self.compact_dtype = np.dtype(
+            [("path", "<f8", (path_points, 4)), ("left_idx", "<i4", (max_len,)), ("right_idx", "<i4", (max_len,)), ("status", "<i4"),
+             ("n_left", "u1"), ("n_right", "u1"), ("path_fallback", "u1"), ("n_dense", "u1")], align=True)
 
     def holds(self, params) -> bool:
         """Do this build's shapes take these structural parameters (an fsdp_params)?"""
@@ -80,6 +84,33 @@ LIB_PATH = STANDARD.lib_path
 MAX_LEN, MAX_MATCH, PATH_POINTS = STANDARD.max_len, STANDARD.max_match, STANDARD.path_points
 RESULT_DTYPE = STANDARD.result_dtype
 PATH_RESULT_DTYPE = STANDARD.path_result_dtype
+COMPACT_DTYPE = STANDARD.compact_dtype
+
+# Options every new Context applies on top of the library's defaults (fsdp_set_option, include/fsdp.h): the hook tests and
+# measurement tools use to pin a route or a packing (monkeypatch.setitem(_capi.DEFAULT_OPTIONS, "pack", 2)).  Results never
+# depend on them.  The library itself reads no environment variable for this; tools that are driven from a shell translate
+# theirs with options_from_env().
+DEFAULT_OPTIONS: dict = {}
+OPTION_NAMES = ("path_mode", "pack", "fit_g", "always_route", "no_sort128", "retry_pack_min", "plan_chunks", "skid_group", "skid_pack_min")
+
+
+def options_from_env(env=None) -> dict:
+    """Measurement tools only (tools/*.py, tests/fuzz_*.py): FSDP_PATH_MODE=mono|split, FSDP_PACK=0|1, FSDP_FIT_G=4|8,
+    FSDP_ALWAYS_ROUTE, FSDP_NO_SORT128, FSDP_RETRY_PACK_MIN, FSDP_PLAN_CHUNKS, FSDP_SKID_GROUP, FSDP_SKID_PACK_MIN -> the options of
+    fsdp_set_option.  The product never calls this."""
+    env = os.environ if env is None else env
+    out = {}
+    if env.get("FSDP_PATH_MODE") in ("mono", "split"):
+        out["path_mode"] = 1 if env["FSDP_PATH_MODE"] == "mono" else 2
+    if "FSDP_PACK" in env:
+        out["pack"] = 2 if int(env["FSDP_PACK"]) else 1
+    for name in ("fit_g", "retry_pack_min", "plan_chunks", "skid_group", "skid_pack_min"):
+        if f"FSDP_{name.upper()}" in env:
+            out[name] = int(env[f"FSDP_{name.upper()}"])
+    for name in ("always_route", "no_sort128"):
+        if f"FSDP_{name.upper()}" in env:
+            out[name] = 1
+    return out
 
 
 class FsdpError(RuntimeError):
@@ -159,6 +190,13 @@ def load(shapes: Shapes = STANDARD) -> ctypes.CDLL:
     lib.fsdp_host_is_pinned.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     lib.fsdp_submit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
+    lib.fsdp_submit_compact.argtypes = lib.fsdp_submit.argtypes
+    lib.fsdp_plan_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fsdp_plan_batch_sequential.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.fsdp_plan_batch_compact.argtypes = lib.fsdp_plan_batch_sequential.argtypes
+    lib.fsdp_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong]
+    lib.fsdp_pcie_probe.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double)]
     lib.fsdp_collect.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
     lib.fsdp_ticket_done.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
     lib.fsdp_ticket_capacity.argtypes = [ctypes.c_void_p]
@@ -170,6 +208,7 @@ def load(shapes: Shapes = STANDARD) -> ctypes.CDLL:
     got = (ctypes.c_int32 * 4)()
     lib.fsdp_shapes(got)
     want = [shapes.max_len, shapes.max_neighbors, shapes.max_match, shapes.path_points]
+    assert shapes.compact_dtype.itemsize == 32 * shapes.path_points + 8 * shapes.max_len + 8
     if list(got) != want or lib.fsdp_result_size() != shapes.result_dtype.itemsize:
         raise FsdpError(f"{path.name}: shapes {list(got)} / result size {lib.fsdp_result_size()}, this binding expects {want} / {shapes.result_dtype.itemsize}")
     _libs[shapes.name] = lib
@@ -185,8 +224,18 @@ EXPORTED_SYMBOLS = [
     "fsdp_comm_barrier", "fsdp_comm_destroy", "fsdp_selftest_math", "fsdp_debug_refit",
     "fsdp_skidpad_set_tables", "fsdp_skidpad_constants", "fsdp_skidpad_reset", "fsdp_skidpad_step", "fsdp_skidpad_time_path", "fsdp_skidpad_time_groups", "fsdp_skidpad_group_times", "fsdp_skidpad_submit_compact",
     "fsdp_host_alloc", "fsdp_host_free", "fsdp_host_register", "fsdp_host_unregister", "fsdp_host_is_pinned", "fsdp_submit", "fsdp_collect", "fsdp_ticket_done",
+    "fsdp_submit_compact", "fsdp_plan_batch_compact", "fsdp_set_option", "fsdp_pcie_probe",
     "fsdp_skidpad_submit", "fsdp_route_stats", "fsdp_ticket_capacity", "fsdp_selftest_det3", "fsdp_debug_arena", "fsdp_selftest_absminmax", "fsdp_selftest_libm", "fsdp_selftest_givens",
 ]
+
+
+def host_lib() -> ctypes.CDLL:
+    """The library the host-memory helpers go through: any build that is already loaded (a process whose contexts all run on
+    the wide build never needs libfsdp_hip.so for them), else the standard one.  Page-locked memory is a property of the HIP
+    runtime, which the builds share."""
+    for lib in _libs.values():
+        return lib
+    return load()
 
 
 def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
@@ -194,7 +243,7 @@ def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
     Freed when the array (and every view of it) is gone."""
     import weakref
 
-    lib = load()
+    lib = host_lib()
     dtype = np.dtype(dtype)
     n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
     nbytes = max(1, n * dtype.itemsize)
@@ -209,7 +258,7 @@ def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
 def is_pinned(a: np.ndarray) -> bool:
     """Is the whole extent of this (contiguous) array page-locked as one mapping, i.e. will fsdp_submit let its kernels read /
     write it in place?"""
-    return bool(a.flags.c_contiguous and (a.nbytes == 0 or load().fsdp_host_is_pinned(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))))
+    return bool(a.flags.c_contiguous and (a.nbytes == 0 or host_lib().fsdp_host_is_pinned(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))))
 
 
 class PinnedPool:
@@ -223,7 +272,7 @@ class PinnedPool:
 
         self._free = {}  # nbytes -> [address]
         self._lock = threading.Lock()
-        self._lib = load()
+        self._lib = host_lib()
         self._closed = False
 
     def _put(self, nbytes, ptr):
@@ -287,8 +336,10 @@ def _ip(a):
 class Context:
     """One GPU context (= fsdp_ctx): device buffers + one HIP stream."""
 
-    def __init__(self, device: int | None = None, mission: int = 4, params: dict | None = None, shapes: Shapes | None = None):
+    def __init__(self, device: int | None = None, mission: int = 4, params: dict | None = None, shapes: Shapes | None = None,
+                 options: dict | None = None):
         """params: overrides of the reference's configuration constants by their kwarg names (None = defaults).
+        options: fsdp_set_option knobs for tests / measurements (on top of _capi.DEFAULT_OPTIONS); results never depend on them.
         shapes: which build of the library carries the context (None = the standard build unless max_n_neighbors, max_length or
         mpc_prediction_horizon exceed its shapes — then the wide build, whose records are larger: Context.result_dtype)."""
         self.params = make_params(params)
@@ -303,6 +354,13 @@ class Context:
             raise FsdpError(f"fsdp_create failed ({rc}): {lib.fsdp_last_error(None).decode()}")
         self._lib, self._h, self.device, self.n_frames = lib, h, device, 0
         self.shapes, self.result_dtype, self.path_result_dtype = shapes, shapes.result_dtype, shapes.path_result_dtype
+        self.compact_dtype = shapes.compact_dtype
+        for k, v in {**DEFAULT_OPTIONS, **(options or {})}.items():
+            self.set_option(k, v)
+
+    def set_option(self, name: str, value: int):
+        """fsdp_set_option (include/fsdp.h): pin a route / packing for a test or a measurement; 0 = the library's choice."""
+        self._check(self._lib.fsdp_set_option(self._h, name.encode(), int(value)), f"fsdp_set_option({name})")
 
     @property
     def horizon(self) -> int:
@@ -347,22 +405,32 @@ class Context:
             raise ValueError("cone_offsets must be non-decreasing")
         return offsets, cones, poses, n
 
-    def plan_batch(self, offsets, cones, poses) -> np.ndarray:
+    def plan_batch(self, offsets, cones, poses, prev_paths=None, out=None, compact: bool = False) -> np.ndarray:
+        """One blocking call: the batch in, its results out (a batch of 2048 frames or more is pipelined in chunks inside the
+        library).  prev_paths: per-frame previous paths (plan_batch_sequential).  out: the array the results go to — a page-locked
+        one (pinned_empty) is written in place by the GPU.  compact: fsdp_compact_result records (path, sorted indices, status:
+        self.compact_dtype) instead of the full ones."""
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
-        out = np.zeros(n, dtype=self.result_dtype)
-        self._check(self._lib.fsdp_plan_batch(self._h, n, _ip(offsets), _dp(cones), _dp(poses), ctypes.c_void_p(out.ctypes.data)), "fsdp_plan_batch")
+        prev = None if prev_paths is None else self.pad_paths(prev_paths)
+        assert prev is None or len(prev) == n
+        dt = self.compact_dtype if compact else self.result_dtype
+        if out is None:
+            out = np.zeros(n, dtype=dt)
+        assert out.dtype == dt and len(out) == n and out.flags.c_contiguous
+        pp = None if prev is None else prev.ctypes.data
+        cp = cones.ctypes.data if len(cones) else None
+        if compact:
+            self._check(self._lib.fsdp_plan_batch_compact(self._h, n, offsets.ctypes.data, cp, poses.ctypes.data, pp, out.ctypes.data), "fsdp_plan_batch_compact")
+        elif prev is not None:
+            self._check(self._lib.fsdp_plan_batch_sequential(self._h, n, offsets.ctypes.data, cp, poses.ctypes.data, pp, out.ctypes.data), "fsdp_plan_batch_sequential")
+        else:
+            self._check(self._lib.fsdp_plan_batch(self._h, n, offsets.ctypes.data, cp, poses.ctypes.data, out.ctypes.data), "fsdp_plan_batch")
         self.n_frames = n
         return out
 
     def plan_batch_sequential(self, offsets, cones, poses, prev_paths) -> np.ndarray:
         """plan_batch with a per-frame previous path (n_frames,40,4): the stateful fallbacks of the reference."""
-        offsets, cones, poses, n = self._prep(offsets, cones, poses)
-        prev = self.pad_paths(prev_paths)
-        assert len(prev) == n
-        out = np.zeros(n, dtype=self.result_dtype)
-        self._check(self._lib.fsdp_plan_batch_sequential(self._h, n, _ip(offsets), _dp(cones), _dp(poses), _dp(prev), ctypes.c_void_p(out.ctypes.data)), "fsdp_plan_batch_sequential")
-        self.n_frames = n
-        return out
+        return self.plan_batch(offsets, cones, poses, prev_paths=prev_paths)
 
     def sort_batch(self, offsets, cones, poses) -> np.ndarray:
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
@@ -407,18 +475,21 @@ class Context:
         return results, [centers[i, : counts[i]].copy() for i in range(n)]
 
     # streams of batches: several different batches in flight (fsdp_submit / fsdp_collect)
-    def submit(self, offsets, cones, poses, prev_paths=None, out=None) -> Ticket:
+    def submit(self, offsets, cones, poses, prev_paths=None, out=None, compact: bool = False) -> Ticket:
         """Enqueue one batch (H2D, the kernels of a pass, D2H) on the next pass slot and return at once.  Arrays made by
         ``pinned_empty`` / ``pinned_copy`` are transferred asynchronously; others are accepted but staged.  ``out``: the
-        self.result_dtype array the results go to (default: a new pinned array).  Raises when every slot holds a ticket."""
+        self.result_dtype (compact: self.compact_dtype) array the results go to (default: a new pinned array).  Raises when
+        every slot holds a ticket.  The arrays must stay untouched until collect()."""
         offsets, cones, poses, n = self._prep(offsets, cones, poses)
         prev = None if prev_paths is None else self.pad_paths(prev_paths)
+        dt = self.compact_dtype if compact else self.result_dtype
         if out is None:
-            out = pinned_empty(n, self.result_dtype)
-        assert out.dtype == self.result_dtype and len(out) == n and out.flags.c_contiguous
+            out = pinned_empty(n, dt)
+        assert out.dtype == dt and len(out) == n and out.flags.c_contiguous
         t = ctypes.c_longlong(-1)
-        self._check(self._lib.fsdp_submit(self._h, n, offsets.ctypes.data, cones.ctypes.data if len(cones) else None, poses.ctypes.data,
-                                          None if prev is None else prev.ctypes.data, out.ctypes.data, ctypes.byref(t)), "fsdp_submit")
+        fn = self._lib.fsdp_submit_compact if compact else self._lib.fsdp_submit
+        self._check(fn(self._h, n, offsets.ctypes.data, cones.ctypes.data if len(cones) else None, poses.ctypes.data,
+                       None if prev is None else prev.ctypes.data, out.ctypes.data, ctypes.byref(t)), "fsdp_submit")
         return Ticket(int(t.value), out, None, (offsets, cones, poses, prev))
 
     def submit_slice(self, lo: int, hi: int, offsets, cones, poses, prev, out) -> Ticket:
@@ -570,6 +641,12 @@ class Context:
         out = np.zeros(len(xy6))
         self._check(self._lib.fsdp_selftest_det3(self._h, len(xy6), _dp(xy6), _dp(out)), "fsdp_selftest_det3")
         return out
+
+    def pcie_probe(self, nbytes: int, iters: int = 30) -> dict:
+        """GB/s of page-locked hipMemcpyAsync over this GPU's host link: {'h2d', 'd2h', 'both_each'} (fsdp_pcie_probe)."""
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.fsdp_pcie_probe(self._h, ctypes.c_size_t(int(nbytes)), int(iters), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "fsdp_pcie_probe")
+        return {"h2d": a.value, "d2h": b.value, "both_each": c.value}
 
     def default_path(self) -> np.ndarray:
         out = np.zeros((self.shapes.path_points, 4))

@@ -105,6 +105,59 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
   }
 }
 
+// The same trip with COMPACT records (include/fsdp.h fsdp_compact_result: path | sorted indices | status | counts — what a
+// caller that only drives the car reads): 1384 instead of 2408 bytes per frame over PCIe.  One wavefront per frame; the
+// path is one contiguous run of the path record, the indices one run of the sorting record.
+constexpr int COMPACT_WORDS = (int)(sizeof(fsdp_compact_result) / 4);
+static_assert(sizeof(fsdp_compact_result) % 8 == 0 && offsetof(fsdp_compact_result, left_idx) == sizeof(double) * 4 * PATH_POINTS &&
+                  offsetof(fsdp_compact_result, right_idx) == offsetof(fsdp_compact_result, left_idx) + 4 * MAX_LEN &&
+                  offsetof(fsdp_compact_result, status) == offsetof(fsdp_compact_result, right_idx) + 4 * MAX_LEN &&
+                  sizeof(fsdp_compact_result) == offsetof(fsdp_compact_result, status) + 8,
+              "compact record layout");
+__global__ void __launch_bounds__(256) assemble_compact_kernel(int n_frames, const SortOut* __restrict__ sorted, const MatchOut* __restrict__ matched,
+                                                                const PathOut* __restrict__ paths, fsdp_compact_result* __restrict__ results,
+                                                                int* __restrict__ big, int* __restrict__ retry, PassTrailer* __restrict__ trailer, int seq,
+                                                                const int32_t* __restrict__ remap, const int32_t* __restrict__ remap_off) {
+  const int32_t* s32 = (const int32_t*)sorted;
+  const int32_t* m32 = (const int32_t*)matched;
+  const int32_t* p32 = (const int32_t*)paths;
+  int32_t* r32 = (int32_t*)results;
+  constexpr int SW = (int)(sizeof(SortOut) / 4), MW = (int)(sizeof(MatchOut) / 4), PW = (int)(sizeof(PathOut) / 4);
+  constexpr int IDX0 = (int)(offsetof(fsdp_compact_result, left_idx) / 4), ST0 = (int)(offsetof(fsdp_compact_result, status) / 4);
+  const int lane = (int)(threadIdx.x & 63);
+  const int waves_per_block = (int)(blockDim.x >> 6);
+  const long long wave0 = (long long)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+  const long long n_waves = (long long)gridDim.x * waves_per_block;
+  for (long long f = wave0; f < n_frames; f += n_waves) {
+    const int32_t* s = s32 + (size_t)f * SW;
+    const int32_t* m = m32 + (size_t)f * MW;
+    const int32_t* p = p32 + (size_t)f * PW;
+    int32_t* r = r32 + (size_t)f * COMPACT_WORDS;
+    for (int w = lane; w < IDX0; w += 64) r[w] = p[FSDP_PW(path) + w];
+    if (lane < 2 * MAX_LEN) {  // left_idx | right_idx are one run of the sorting record
+      int32_t v = s[FSDP_SW(left_idx) + lane];
+      if (remap && v >= 0) v = remap[remap_off[f] + v];
+      r[IDX0 + lane] = v;
+    }
+    if (lane == 0) {
+      int st = s[FSDP_SW(status)];
+      if (m[FSDP_MW(status)] != 0) st = m[FSDP_MW(status)];
+      if (p[FSDP_PW(status)] != 0) st = p[FSDP_PW(status)];
+      r[ST0] = st;
+      // n_left | n_right | path_fallback | n_dense, one byte each (little endian: the struct's field order)
+      r[ST0 + 1] = (s[FSDP_SW(n_left)] & 255) | ((s[FSDP_SW(n_right)] & 255) << 8) | ((p[FSDP_PW(fallback)] & 255) << 16) | ((p[FSDP_PW(n_dense)] & 255) << 24);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && trailer != nullptr) {
+    const int nb = big ? big[0] : 0, nr = retry ? retry[0] : 0;
+    if (big) big[0] = 0;
+    if (retry) retry[0] = 0;
+    __hip_atomic_store(&trailer->n_big, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&trailer->n_retry, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&trailer->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Host -> device of a batch whose buffers are page-locked, as a kernel: the batch comes over PCIe by plain loads from host
 // memory (the GPU maps page-locked host memory into its address space) into the slot's device buffers — up to four
 // segments (offsets, cones, poses, previous paths) in one launch.  Used by the skidpad steps and by contexts that filter
@@ -122,6 +175,7 @@ struct CopySeg {
 struct CopySegs {
   CopySeg seg[4];
   int n;
+  int32_t rebase;  // subtracted from every 4-byte word of seg[0] (the CSR offsets of a slice of a larger batch: the device copy starts at 0)
 };
 __global__ void __launch_bounds__(256) stage_in_kernel(CopySegs S) {
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,7 +184,9 @@ __global__ void __launch_bounds__(256) stage_in_kernel(CopySegs S) {
     const char* src = (const char*)S.seg[k].src;
     char* dst = (char*)S.seg[k].dst;
     const unsigned long long bytes = S.seg[k].bytes;
-    if ((((unsigned long long)src | (unsigned long long)dst) & 15ull) == 0) {
+    if (k == 0 && S.rebase != 0) {
+      for (unsigned long long w = tid; w < bytes / 4; w += nth) ((int32_t*)dst)[w] = ((const int32_t*)src)[w] - S.rebase;
+    } else if ((((unsigned long long)src | (unsigned long long)dst) & 15ull) == 0) {
       const unsigned long long n16 = bytes / 16;
       typedef unsigned int u4 __attribute__((ext_vector_type(4)));
       const u4* s4 = (const u4*)src;

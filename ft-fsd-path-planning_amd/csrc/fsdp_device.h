@@ -54,8 +54,6 @@ constexpr int ST_OVERFLOW_ENDS = 202;
 constexpr int ST_OVERFLOW_PATH = 203;
 constexpr int ST_OVERFLOW_KNOTS = 204;
 constexpr int ST_RETRY = 299;  // internal: the fast kernels hand the frame to the exact one-frame-per-wavefront kernel (never leaves the library)
-constexpr int ST_WIDE = 298;      // internal (PathMid only): the refit needs more than 16 knots — on the list of the 32-knot refit / finish kernels
-constexpr int ST_WIDE_FIT = 297;  // internal (PathMid only): refitted by the 32-knot kernel, waiting for the 32-knot finish kernel
 
 // The reference's configuration constants (fsd_path_planning/config.py:33-41,48,55-59,124-129), one device copy per
 // context (fsdp_create): the kernels read them with scalar loads.  Structural ones are bounded by the compiled capacities

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -33,20 +34,6 @@ static_assert(FSDP_MAX_LEN == MAX_LEN && FSDP_MAX_MATCH == MAX_MATCH && FSDP_PAT
               "header/device constant mismatch");
 
 static thread_local std::string g_create_error;
-
-// FSDP_TRACE=1: host-side duration of the steps of fsdp_submit that take longer than 0.5 ms, to stderr (diagnostics)
-#include <chrono>
-static const bool g_trace = getenv("FSDP_TRACE") != nullptr;
-struct TraceStep {
-  const char* what;
-  std::chrono::steady_clock::time_point t0;
-  explicit TraceStep(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
-  ~TraceStep() {
-    if (!g_trace) return;
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (ms > 0.5) fprintf(stderr, "[fsdp trace] %s: %.3f ms\n", what, ms);
-  }
-};
 
 constexpr int SORT_BIG_BLOCKS = 32;
 
@@ -99,10 +86,8 @@ struct Work {
   MatchOut* d_match = nullptr;
   PathOut* d_path = nullptr;
   double* d_arena = nullptr;  // per-frame working polyline + basis cache (ARENA_DOUBLES doubles), HBM/L2 scratch
-  double* d_tiles = nullptr;  // the refit's polylines as point-major tiles of 64 frames (fit_lanes_kernel), allocated when that kernel may run
   int* d_big = nullptr;       // [0] counter + frames beyond sort_kernel's LDS capacities (n + 1 ints)
   int* d_retry = nullptr;     // [0] counter + frames for the exact re-plan kernel (n + 1 ints)
-  int* d_wide = nullptr;      // [0] counter + frames whose refit needs 17-32 knots, for the 32-knot refit / finish kernels (n + 1 ints)
   PathMid* d_mid = nullptr;   // hand-over records of the three-kernel path stage
   fsdp_frame_result* d_result = nullptr;  // the pass's results in the ABI's layout (assemble_kernel)
   SkidInfo* d_skid_info = nullptr;        // skidpad contexts
@@ -126,6 +111,7 @@ struct Work {
   bool ran_big = false, ran_retry = false, unverified = false, pass_skid = false;
   fsdp_frame_result* result_dst = nullptr;  // where assemble_kernel writes the next pass's results: NULL = d_result; a ticket with a
                                             // page-locked result buffer: that buffer, straight over PCIe (no copy command at all)
+  bool result_compact = false;              // ... as fsdp_compact_result records (fsdp_submit_compact)
   // tickets of fsdp_submit / fsdp_skidpad_submit queued on this slot's stream (id -1: free entry)
   struct Ticket {
     long long id = -1;
@@ -144,7 +130,9 @@ struct Work {
     fsdp_frame_result* user_results = nullptr;
     fsdp_skidpad_info* user_info = nullptr;
     bool via_stage = false;                // results go through h_stage (the caller's buffer is pageable)
-    bool compact = false;                  // skidpad step: user_results holds fsdp_path_result records (path + status only)
+    bool compact = false;                  // user_results holds compact records: fsdp_path_result (skidpad step) or
+                                           // fsdp_compact_result (fsdp_submit_compact)
+    size_t rec_bytes() const { return !compact ? sizeof(fsdp_frame_result) : (skid ? sizeof(PathOut) : sizeof(fsdp_compact_result)); }
     fsdp_frame_result* h_stage = nullptr;  // pinned
     SkidInfo* h_info = nullptr;            // pinned
     int cap_stage = 0, cap_info = 0;
@@ -169,16 +157,11 @@ struct fsdp_ctx {
   double* d_chord = nullptr;         // (40,2) almost-straight chord (trivial path of the skidpad mission)
   double* d_gpath = nullptr;         // PathPlanner.global_path (n_gpath,2), or NULL
   int n_gpath = 0;
-  int force_path_mode = 0;    // 0 = by batch size; 1 = one kernel (64 lanes per frame); 2 = three kernels (FSDP_PATH_MODE=mono|split)
-  // frames per BATCH from which the refit runs one frame per LANE (fit_lanes_kernel: sixty-four frames per wavefront and 2.3 x
-  // fewer instructions per frame — but a launch then has n / 64 wavefronts, and the FP64 pipe of a SIMD wants two of them: the
-  // kernel pays from 131 072 frames per launch on (1024 SIMDs x 2 x 64), measured in profiles/r05_fit_lanes.txt; passes in flight
-  // do not help, their refit launches do not coincide); -1 = never (FSDP_FIT_LANES=0), FSDP_FIT_LANES=n sets the threshold
-  long long fit_lanes_min = 131072;
-  int fit_g = 4;              // lanes per frame of fit_kernel when frames are packed: 4 = exactly the Givens quad, sixteen frames
-                              // per wavefront (FSDP_FIT_G=4|8; +1.6 % frames/s over 8 since the basis records are 32 bytes:
-                              // tools/ab_variants.py)
-  int force_pack = 0;         // 0 = by frames in flight; 1 = 4 frames per wavefront; 2 = packed (FSDP_PACK=0|1)
+  // fsdp_set_option (include/fsdp.h): what a test or a measurement may pin; 0 = the library's own choice
+  int force_path_mode = 0;    // "path_mode": 0 = by batch size; 1 = one kernel (64 lanes per frame); 2 = three kernels
+  int fit_g = 4;              // "fit_g": lanes per frame of fit_kernel when frames are packed: 4 = exactly the Givens quad, sixteen
+                              // frames per wavefront (+1.6 % frames/s over 8 since the basis records are 32 bytes)
+  int force_pack = 0;         // "pack": 0 = by frames in flight; 1 = 4 frames per wavefront; 2 = packed
   std::string stage_names;    // kernels of the most recent pass, comma-separated
   bool profile_sort = false;  // profiling build: which kernel fsdp_profile_path runs
   int overlap = 1;
@@ -192,15 +175,10 @@ struct fsdp_ctx {
   // from then on the kernel is part of every pass until ROUTE_DECAY (4096) passes in a row came back with an empty list.
   bool expect_big = false, expect_retry = false;
   int clean_big = 0, clean_retry = 0;
-  bool always_route = getenv("FSDP_ALWAYS_ROUTE") != nullptr;  // experiments: launch both route kernels with every pass
+  int plan_chunks = 0;        // "plan_chunks": most chunks a blocking fsdp_plan_batch call is pipelined in (0: up to 4; 1: never cut)
+  bool always_route = false;  // "always_route": both route kernels with every pass (tests: results never depend on the prediction)
   long long reruns = 0;  // passes re-run by verify_pass (diagnostics: fsdp_route_stats)
-  bool no_sort128 = getenv("FSDP_NO_SORT128") != nullptr;  // experiments: always the 255-cone state
-  // Staggered passes (FSDP_STAGGER = k > 0): a pass's k-th kernel boundary is an event the NEXT pass's first kernel waits for, so
-  // passes enqueued together do not march through the stages in phase (twenty sorting kernels, then twenty matching kernels, ...)
-  // but settle into the mixed-stage schedule a long run reaches by itself.  0 = off.
-  int stagger = getenv("FSDP_STAGGER") ? atoi(getenv("FSDP_STAGGER")) : 0;
-  hipEvent_t stagger_ev[FSDP_MAX_OVERLAP] = {};
-  int stagger_last = -1;
+  bool no_sort128 = false;  // "no_sort128": always the 255-cone state of the sorting kernel (tests)
   std::vector<hipEvent_t> tev;  // per-launch timing events of fsdp_time_runs
   int timed_iters = 0, timed_stages = 0;  // the most recent fsdp_time_runs (fsdp_time_results reads its events)
   bool time_main_only = false;            // fsdp_time_detail: events only around the path stage's main kernel
@@ -222,7 +200,7 @@ struct fsdp_ctx {
   uint32_t skid_ticket_base = 0;
   int skid_step_no = 0;              // steps submitted since fsdp_skidpad_reset
   bool skid_all_reloc = false;       // a collected step reported every planner relocalized: cones have no reader any more
-  int skid_group_env = 0;            // FSDP_SKID_GROUP: steps per launch when the caller submits ahead (0: chosen from the instance count)
+  int skid_group_env = 0;            // "skid_group": steps per launch when the caller submits ahead (0: chosen from the instance count)
   // fsdp_skidpad_time_groups: HIP events around the packed kernels of every group of steps (select | prep | fit | finish | commit)
   bool skid_time_groups = false;
   std::vector<hipEvent_t> skid_group_ev;  // six per group
@@ -301,23 +279,9 @@ static void free_inputs(Inputs& in) {
   in = Inputs();
 }
 
-// A slot's stream.  Experiments only (FSDP_SLOT_PRIO = K): slots K, K + 1, ... get the device's highest stream priority
-// (K < 0: the slots below |K|) — how the hardware queues' arbitration shapes the fill and drain of a burst of passes
-// (profiles/r04_ab_variants.txt 10).
-static hipError_t create_slot_stream(hipStream_t* s, int index) {
-  static const int k = getenv("FSDP_SLOT_PRIO") ? atoi(getenv("FSDP_SLOT_PRIO")) : 0;
-  static const bool on = getenv("FSDP_SLOT_PRIO") != nullptr;
-  if (on && ((k >= 0 && index >= k) || (k < 0 && index < -k))) {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
-  }
-  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-}
-
 // stream, trailer and intermediates of slot w for passes of up to n frames
 static int ensure_work(fsdp_ctx* c, Work& w, int n) {
-  if (!w.stream) HIP_TRY(c, create_slot_stream(&w.stream, w.index));
+  if (!w.stream) HIP_TRY(c, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
   if (!w.h_trailer) {
     HIP_TRY(c, hipHostMalloc((void**)&w.h_trailer, sizeof(PassTrailer) * N_TRAILERS, hipHostMallocMapped | hipHostMallocCoherent));
     memset(w.h_trailer, 0, sizeof(PassTrailer) * N_TRAILERS);
@@ -330,10 +294,8 @@ static int ensure_work(fsdp_ctx* c, Work& w, int n) {
   HIP_TRY(c, regrow(w.d_match, m));
   HIP_TRY(c, regrow(w.d_path, m));
   HIP_TRY(c, regrow(w.d_arena, (size_t)ARENA_DOUBLES * m));
-  if (c->fit_lanes_min >= 0 && (long long)m >= c->fit_lanes_min) HIP_TRY(c, regrow(w.d_tiles, TILE_DOUBLES * ((m + TILE_FRAMES - 1) / TILE_FRAMES)));
   HIP_TRY(c, regrow(w.d_big, m + 1));
   HIP_TRY(c, regrow(w.d_retry, m + 1));
-  HIP_TRY(c, regrow(w.d_wide, m + 1));
   HIP_TRY(c, regrow(w.d_mid, m));
   HIP_TRY(c, regrow(w.d_result, m));
   if (c->mission == 2) {
@@ -353,10 +315,8 @@ static void free_work(Work& w) {
   (void)hipFree(w.d_match);
   (void)hipFree(w.d_path);
   (void)hipFree(w.d_arena);
-  (void)hipFree(w.d_tiles);
   (void)hipFree(w.d_big);
   (void)hipFree(w.d_retry);
-  (void)hipFree(w.d_wide);
   (void)hipFree(w.d_mid);
   (void)hipFree(w.d_result);
   (void)hipFree(w.d_skid_info);
@@ -416,17 +376,6 @@ static bool is_pinned(const void* p, size_t bytes) {
   return de != nullptr && de - dv == (ptrdiff_t)(bytes - 1);
 }
 
-#ifdef FSDP_LDS_KNOBS
-// experiment builds only: extra dynamic LDS per workgroup (bytes) from the environment, to probe occupancy sensitivity
-static int lds_knob(const char* name) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : 0;
-}
-#define DYN_LDS(name) lds_knob(name)
-#else
-#define DYN_LDS(name) 0
-#endif
-
 // ---- the kernels of one pass ----------------------------------------------------------------------------------------------
 // sort_kernel -> [sort_big_kernel] -> match_kernel -> path stage -> [path_retry_kernel] -> assemble_kernel, all on the
 // slot's stream.  The bracketed ones are the *routes* for what the fast kernels hand on (device lists): frames beyond the
@@ -471,10 +420,10 @@ static void launch_sort(fsdp_ctx* c, Work& q, const Inputs& in) {
     st.n_frames = in.n_frames;
   }
   if (sort128(c, in))
-    hipLaunchKernelGGL(sort_kernel_128, dim3(in.n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_SORT"), q.stream, in.n_frames, in.d_off, in.d_cones,
+    hipLaunchKernelGGL(sort_kernel_128, dim3(in.n_frames), dim3(WAVE), 0, q.stream, in.n_frames, in.d_off, in.d_cones,
                        in.d_poses, q.d_sort, q.d_big, c->d_params, st);
   else
-    hipLaunchKernelGGL(sort_kernel, dim3(in.n_frames), dim3(WAVE), DYN_LDS("FSDP_LDS_SORT"), q.stream, in.n_frames, in.d_off, in.d_cones, in.d_poses,
+    hipLaunchKernelGGL(sort_kernel, dim3(in.n_frames), dim3(WAVE), 0, q.stream, in.n_frames, in.d_off, in.d_cones, in.d_poses,
                        q.d_sort, q.d_big, c->d_params, st);
 }
 static int launch_sort_big(fsdp_ctx* c, Work& q, const Inputs& in) {
@@ -484,7 +433,7 @@ static int launch_sort_big(fsdp_ctx* c, Work& q, const Inputs& in) {
   return 0;
 }
 static void launch_match(fsdp_ctx* c, Work& q, const Inputs& in) {
-  hipLaunchKernelGGL(match_kernel<MATCH_G>, dim3((in.n_frames + WAVE / MATCH_G - 1) / (WAVE / MATCH_G)), dim3(WAVE), DYN_LDS("FSDP_LDS_MATCH"), q.stream,
+  hipLaunchKernelGGL(match_kernel<MATCH_G>, dim3((in.n_frames + WAVE / MATCH_G - 1) / (WAVE / MATCH_G)), dim3(WAVE), 0, q.stream,
                      in.n_frames, in.d_off, in.d_cones, in.d_poses, q.d_sort, q.d_match, c->d_params);
 }
 // ---- the path stage of one pass ------------------------------------------------------------------------------------------
@@ -492,20 +441,20 @@ static void launch_match(fsdp_ctx* c, Work& q, const Inputs& in) {
 // Large batches: three kernels (path_kernel.h: path_prep_kernel -> fit_kernel -> path_finish_kernel).  Either way the
 // frames the fast kernels hand on (retry list on the device) are planned by the exact kernel in the same stream.
 template <int GF, int NKC = FIT_KNOTS>
-static void launch_fit(fsdp_ctx* c, Work& q, int n, const StageEvents* t = nullptr, int* wide = nullptr, const int* list = nullptr) {
-  hipLaunchKernelGGL((fit_kernel<GF, NKC>), dim3((n + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), DYN_LDS("FSDP_LDS_FIT"), q.stream, n,
-                     q.d_arena, q.d_mid, q.d_retry, c->d_params, t ? t->clock_first : nullptr, t ? t->clock_last : nullptr, wide, list);
+static void launch_fit(fsdp_ctx* c, Work& q, int n, const StageEvents* t = nullptr) {
+  hipLaunchKernelGGL((fit_kernel<GF, NKC>), dim3((n + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, q.stream, n,
+                     q.d_arena, q.d_mid, q.d_retry, c->d_params, t ? t->clock_first : nullptr, t ? t->clock_last : nullptr);
 }
 template <int G, int NKC = FIT_KNOTS>
-static void launch_prep(fsdp_ctx* c, Work& q, const Inputs& in, const double* prev, double* tiles = nullptr) {
+static void launch_prep(fsdp_ctx* c, Work& q, const Inputs& in, const double* prev) {
   const int n = in.n_frames;
-  hipLaunchKernelGGL((path_prep_kernel<G, NKC>), dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, in.d_poses, q.d_match,
-                     c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry, c->d_params, tiles);
+  hipLaunchKernelGGL((path_prep_kernel<G, NKC>), dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match,
+                     c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_mid, q.d_retry, c->d_params);
 }
 template <int G, int NKC = FIT_KNOTS>
-static void launch_finish(fsdp_ctx* c, Work& q, int n, const int* list = nullptr) {
-  hipLaunchKernelGGL((path_finish_kernel<G, NKC>), dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), DYN_LDS("FSDP_LDS_PREP"), q.stream, n, q.d_arena, q.d_mid, q.d_path,
-                     q.d_retry, c->d_params, list);
+static void launch_finish(fsdp_ctx* c, Work& q, int n) {
+  hipLaunchKernelGGL((path_finish_kernel<G, NKC>), dim3((n + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, q.stream, n, q.d_arena, q.d_mid, q.d_path,
+                     q.d_retry, c->d_params);
 }
 
 // the same steps through the packed kernels (csrc/skidpad_kernel.h "steps in flight, many frames per wavefront")
@@ -527,10 +476,10 @@ static void launch_skid_packed_kernels(fsdp_ctx* c, int frames) {
                      c->d_default_path, c->d_g_arena, c->d_g_mid);
   skid_group_mark(c);
   hipLaunchKernelGGL((fit_kernel<GF, FIT_KNOTS>), dim3((frames + WAVE / GF - 1) / (WAVE / GF)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid,
-                     c->d_g_retry, c->d_params, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (const int*)nullptr);
+                     c->d_g_retry, c->d_params, (unsigned long long*)nullptr, (unsigned long long*)nullptr);
   skid_group_mark(c);
   hipLaunchKernelGGL(path_finish_kernel<G>, dim3((frames + WAVE / G - 1) / (WAVE / G)), dim3(WAVE), 0, xs, frames, c->d_g_arena, c->d_g_mid, c->d_g_out,
-                     c->d_g_retry, c->d_params, (const int*)nullptr);
+                     c->d_g_retry, c->d_params);
   skid_group_mark(c);
 }
 
@@ -540,97 +489,74 @@ static void launch_skid_packed_kernels(fsdp_ctx* c, int frames) {
 // each: exactly the Givens quad) and the kernels around it 8; below that, 4 frames per wavefront everywhere.
 constexpr int PACK_FRAMES = 12288;
 
-// FSDP_STAGGER = k: the k-th kernel boundary of a pass (1 after sorting, 2 after matching, 3 after the path stage's preparation, 4 after
-// the refit) is the event the next pass's first kernel waits for (launch_pass)
-static void stagger_point(fsdp_ctx* c, Work& q, int k) {
-  if (c->stagger != k || c->overlap <= 1 || !c->stagger_ev[q.index]) return;
-  (void)hipEventRecord(c->stagger_ev[q.index], q.stream);
-  c->stagger_last = q.index;
+// How many frames are in flight on the GPU decides the packing.  A resident batch replayed through `overlap` slots keeps
+// overlap x n frames in flight; a ticket of fsdp_submit counts what is really queued (the frames of the uncollected tickets
+// plus its own): a lone batch submitted to a context of depth 10 is a lone batch, and gets the lanes of one.
+static long long frames_in_flight(const fsdp_ctx* c, int n, bool ticket) {
+  if (!ticket) return (long long)n * c->overlap;
+  long long sum = n;
+  for (int i = 0; i < FSDP_MAX_OVERLAP; i++)
+    for (const Work::Ticket& t : c->slot[i].tk)
+      if (t.id >= 0 && !t.skid) sum += t.n;
+  return sum;
 }
 
 // the path stage's fast kernels (no route, no assembly); returns whether it was the three-kernel form
-static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, std::string& names, bool with_routes = true) {
+static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, std::string& names, long long in_flight) {
   const double* prev = in.use_prev ? in.d_prev : nullptr;
   const int n = in.n_frames;
   // (the packed kernels hold degree-3 fits only: a context with max_deg < 3 plans every batch with the one-kernel stage)
   const bool split = c->params.max_deg != 3 ? false : (c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH);
   if (!split) {
     mark(q, t, MARK_MAIN);
-    // FSDP_EXACT_PATH (experiments / diagnostics): the instantiation with plain IEEE divisions and square roots throughout
-    static const bool exact = getenv("FSDP_EXACT_PATH") != nullptr;
     // A context whose fits may be of degree 1 or 2 (max_deg < 3: utils/spline_fit.py:113) has no three-kernel form (those kernels
     // hold cubic fits only); its large batches run the one-kernel stage with FOUR frames per wavefront (16 lanes each, all
     // degrees, 32 knots per fit, the scaling-free divisions; what that form cannot hold goes to the exact kernel like any other
     // frame the packed kernels hand on) instead of one frame per wavefront.
-    const bool mono16 = !exact && c->force_path_mode != 1 && c->params.max_deg != 3 && n > PATH_SMALL_BATCH;
-    if (exact)
-      hipLaunchKernelGGL((path_kernel<PATH_G_SMALL, false>), dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
-                         c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
-    else if (mono16)
+    const bool mono16 = c->force_path_mode != 1 && c->params.max_deg != 3 && n > PATH_SMALL_BATCH;
+    if (mono16)
       hipLaunchKernelGGL(path_kernel<PATH_G_LATENCY>, dim3((n + WAVE / PATH_G_LATENCY - 1) / (WAVE / PATH_G_LATENCY)), dim3(WAVE), 0, q.stream, n, in.d_poses,
                          q.d_match, c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
     else
       hipLaunchKernelGGL(path_kernel<PATH_G_SMALL>, dim3(n), dim3(WAVE), 0, q.stream, n, in.d_poses, q.d_match, c->d_default_path, prev,
                          c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
     names += mono16 ? "path_kernel<16>," : "path_kernel<64>,";
-  } else {
-    mark(q, t);
-    // A context with a global path (set_global_path; the acceleration / ebs_test missions run on their known path) fits 100+ m
-    // polylines that need 17-32 knots (87 % of such frames; never more than 32 on the reference's tables): the WIDE instantiations
-    // of the three kernels — 32 knots per fit in the frame's LDS workspace, eight lanes per frame — keep them on the packed kernels
-    // instead of sending every frame to the exact one (round 4: 1.17 M frames/s there).  FSDP_WIDE=0 | 1 overrides.
-    static const int force_wide = getenv("FSDP_WIDE") ? atoi(getenv("FSDP_WIDE")) : -1;
-    const bool wide = force_wide >= 0 ? force_wide != 0 : c->n_gpath > 0;
-    if (wide) {
-      launch_prep<8, WIDE_KNOTS>(c, q, in, prev);
-      mark(q, t, MARK_MAIN);
-      launch_fit<8, WIDE_KNOTS>(c, q, n, t);
-      mark(q, t, MARK_MAIN);
-      launch_finish<8, WIDE_KNOTS>(c, q, n);
-      names += "path_prep_kernel<8,32>,fit_kernel<8,32>,path_finish_kernel<8,32>,";
-      return split;
-    }
-    const bool packed = c->force_pack ? c->force_pack == 2 : (long long)n * c->overlap >= PACK_FRAMES;
-    // one frame per lane once a launch gives every SIMD two wavefronts at 64 frames each (fit_lanes.h)
-    const bool lanes = packed && q.d_tiles != nullptr && c->fit_lanes_min >= 0 && (long long)n >= c->fit_lanes_min;
-    const int gf = lanes ? 1 : (packed ? c->fit_g : 16);
-    if (packed)
-      launch_prep<8>(c, q, in, prev, lanes ? q.d_tiles : nullptr);
-    else
-      launch_prep<16>(c, q, in, prev);
-    stagger_point(c, q, 3);
-    mark(q, t, MARK_MAIN);
-    // Experiment, OFF by default (FSDP_WIDE_LIST=1 turns it on): a pass that carries the route kernels also carries the 32-knot
-    // refit / finish kernels, and a refit that needs 17-32 knots (2 % of the frames of a noisy batch: most of its retry list) goes
-    // to THEIR device list instead of the exact kernel's.  Bit-equal (emulator test, GPU hash) — and slower: such a fit is
-    // milliseconds of one serial chain whatever runs it, the pass waits for the slowest one, and 8 or 16 lanes per frame get
-    // through its data-parallel passes slower than the exact kernel's 64 (config 4r: 229 k -> 180 k / 195 k frames/s one pass at a
-    // time, 1.46 -> 1.26 / 1.29 M with ten in flight; profiles/r05_routes.txt).  Results never depend on it.
-    static const bool no_wide_list = !(getenv("FSDP_WIDE_LIST") && atoi(getenv("FSDP_WIDE_LIST")) == 1);
-    int* wlist = (with_routes && !lanes && !no_wide_list) ? q.d_wide : nullptr;
-    if (wlist) (void)hipMemsetAsync(wlist, 0, sizeof(int), q.stream);
-    if (gf == 1)
-      hipLaunchKernelGGL(fit_lanes_kernel, dim3((n + TILE_FRAMES - 1) / TILE_FRAMES), dim3(WAVE), 0, q.stream, n, q.d_tiles, q.d_arena, q.d_mid, q.d_retry,
-                         c->d_params);
-    else if (gf == 4)
-      launch_fit<4>(c, q, n, t, wlist);
-    else if (gf == 8)
-      launch_fit<8>(c, q, n, t, wlist);
-    else
-      launch_fit<16>(c, q, n, t, wlist);
-    stagger_point(c, q, 4);
-    mark(q, t, MARK_MAIN);
-    if (packed)
-      launch_finish<8>(c, q, n);
-    else
-      launch_finish<16>(c, q, n);
-    if (wlist) {  // (inside the finish kernel's bracket of a timed pass: FSDP_MAX_STAGES has no room for two more names)
-      launch_fit<8, WIDE_KNOTS>(c, q, n, nullptr, nullptr, wlist);
-      launch_finish<8, WIDE_KNOTS>(c, q, n, wlist);
-    }
-    const std::string g = packed ? "8" : "16";
-    names += "path_prep_kernel<" + g + ">," + (gf == 1 ? std::string("fit_lanes_kernel") : "fit_kernel<" + std::to_string(gf) + ">") + ",path_finish_kernel<" + g + ">,";
+    return split;
   }
+  mark(q, t);
+  // A context with a global path (set_global_path; the acceleration / ebs_test missions run on their known path) fits 100+ m
+  // polylines that need 17-32 knots (87 % of such frames; never more than 32 on the reference's tables): the WIDE instantiations
+  // of the three kernels — 32 knots per fit in the frame's LDS workspace, eight lanes per frame — keep them on the packed kernels
+  // instead of sending every frame to the exact one.
+  if (c->n_gpath > 0) {
+    launch_prep<8, WIDE_KNOTS>(c, q, in, prev);
+    mark(q, t, MARK_MAIN);
+    launch_fit<8, WIDE_KNOTS>(c, q, n, t);
+    mark(q, t, MARK_MAIN);
+    launch_finish<8, WIDE_KNOTS>(c, q, n);
+    names += "path_prep_kernel<8,32>,fit_kernel<8,32>,path_finish_kernel<8,32>,";
+    return split;
+  }
+  const bool packed = c->force_pack ? c->force_pack == 2 : in_flight >= PACK_FRAMES;
+  const int gf = packed ? c->fit_g : 16;
+  if (packed)
+    launch_prep<8>(c, q, in, prev);
+  else
+    launch_prep<16>(c, q, in, prev);
+  mark(q, t, MARK_MAIN);
+  if (gf == 4)
+    launch_fit<4>(c, q, n, t);
+  else if (gf == 8)
+    launch_fit<8>(c, q, n, t);
+  else
+    launch_fit<16>(c, q, n, t);
+  mark(q, t, MARK_MAIN);
+  if (packed)
+    launch_finish<8>(c, q, n);
+  else
+    launch_finish<16>(c, q, n);
+  const std::string g = packed ? "8" : "16";
+  names += "path_prep_kernel<" + g + ">,fit_kernel<" + std::to_string(gf) + ">,path_finish_kernel<" + g + ">,";
   return split;
 }
 static void launch_path_retry(fsdp_ctx* c, Work& q, const Inputs& in) {
@@ -641,17 +567,20 @@ static void launch_path_retry(fsdp_ctx* c, Work& q, const Inputs& in) {
 }
 static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid, fsdp_frame_result* dst = nullptr, hipStream_t stream = nullptr,
                             const SkidInfo* info_src = nullptr, SkidInfo* info_dst = nullptr, const int32_t* remap = nullptr,
-                            const int32_t* remap_off = nullptr) {
+                            const int32_t* remap_off = nullptr, bool compact = false) {
   (void)c;
   long long blocks = ((long long)n + 3) / 4;  // one wavefront per frame, four per workgroup (grid-stride beyond the cap)
   // results that go straight to host memory leave at the link's pace: a few hundred wavefronts keep it busy, more would
   // only sit on the SIMDs' wavefront slots with their stores pending while the other slots' kernels wait for a place
-  static const int host_blocks = getenv("FSDP_ASM_BLOCKS") ? atoi(getenv("FSDP_ASM_BLOCKS")) : 128;
-  static const int dev_blocks = getenv("FSDP_ASM_DEV_BLOCKS") ? atoi(getenv("FSDP_ASM_DEV_BLOCKS")) : 16384;
-  const long long cap = dst ? host_blocks : dev_blocks;
+  const long long cap = dst ? 128 : 16384;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   q.seq++;
+  if (compact) {  // fsdp_compact_result records (into the slot's result block or the caller's page-locked buffer)
+    hipLaunchKernelGGL(assemble_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, stream ? stream : q.stream, n, q.d_sort, q.d_match, q.d_path,
+                       (fsdp_compact_result*)(dst ? dst : q.d_result), q.d_big, q.d_retry, q.d_trailer + q.trailer_idx, q.seq, remap, remap_off);
+    return;
+  }
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, stream ? stream : q.stream, n, skid ? (const SortOut*)nullptr : q.d_sort,
                      skid ? (const MatchOut*)nullptr : q.d_match, q.d_path, dst ? dst : q.d_result, q.d_big, q.d_retry, q.d_trailer + q.trailer_idx, q.seq,
                      (const int32_t*)info_src, (int32_t*)info_dst, info_dst ? (int)(sizeof(SkidInfo) / 4) * n : 0, remap, remap_off);
@@ -683,7 +612,9 @@ static int launch_filter(fsdp_ctx* c, Work& q, const Inputs& in, Inputs* view) {
 }
 
 // sorting -> matching -> path stage -> result assembly of batch `in` on slot q
-static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t = nullptr, bool force_routes = false) {
+// in_flight: frames on the GPU while this pass runs, its own included (launch_path); < 0: a resident batch replayed through
+// every slot of the overlap depth
+static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t = nullptr, bool force_routes = false, long long in_flight = -1) {
   c->primed[q.index] = true;
   const bool with_big = force_routes || c->always_route || c->expect_big;
   const bool with_retry = force_routes || c->always_route || c->expect_retry;
@@ -693,14 +624,8 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
     if (int rc = launch_filter(c, q, in_, &fin)) return rc;
   const Inputs& in = filtered ? fin : in_;
   std::string names = std::string(sort128(c, in) ? "sort_kernel_128" : "sort_kernel") + ",";
-  const bool stagger = c->stagger > 0 && c->overlap > 1;
-  if (stagger) {
-    if (!c->stagger_ev[q.index]) HIP_TRY(c, hipEventCreateWithFlags(&c->stagger_ev[q.index], hipEventDisableTiming));
-    if (c->stagger_last >= 0 && c->stagger_last != q.index) HIP_TRY(c, hipStreamWaitEvent(q.stream, c->stagger_ev[c->stagger_last], 0));
-  }
   mark(q, t);
   launch_sort(c, q, in);
-  stagger_point(c, q, 1);
   if (with_big) {
     mark(q, t);
     if (int rc = launch_sort_big(c, q, in)) return rc;
@@ -708,9 +633,8 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
   }
   mark(q, t);
   launch_match(c, q, in);
-  stagger_point(c, q, 2);
   names += "match_kernel<" + std::to_string(MATCH_G) + ">,";
-  const bool split = launch_path(c, q, in, t, names, with_retry);
+  const bool split = launch_path(c, q, in, t, names, in_flight >= 0 ? in_flight : frames_in_flight(c, in.n_frames, false));
   MarkKind after_path = split ? MARK_PLAIN : MARK_MAIN;  // (the one-kernel path stage is the main kernel: close its bracket)
   if (with_retry) {
     mark(q, t, after_path);
@@ -719,7 +643,8 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
     names += "path_retry_kernel,";
   }
   mark(q, t, after_path);
-  launch_assemble(c, q, in.n_frames, false, q.result_dst, nullptr, nullptr, nullptr, filtered ? q.f_map : nullptr, filtered ? q.f_off : nullptr);
+  launch_assemble(c, q, in.n_frames, false, q.result_dst, nullptr, nullptr, nullptr, filtered ? q.f_map : nullptr, filtered ? q.f_off : nullptr,
+                  q.result_compact);
   names += "assemble_kernel";
   mark(q, t, MARK_LAST);
   c->stage_names = names;
@@ -901,15 +826,15 @@ static int stage_inputs(fsdp_ctx* c, Inputs& in, hipStream_t stream, int n_frame
   if (n_frames == 0) return 0;
   CopySegs S;
   S.n = 0;
-  if (rebase_batch(in, n_frames, off, cones))  // (the slot's rebased copy is pageable: its 4 bytes per frame go by the copy engine)
-    HIP_TRY(c, hipMemcpyAsync(in.d_off, off, sizeof(int32_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, stream));
-  else
-    S.seg[S.n++] = CopySeg{device_view(off), in.d_off, sizeof(int32_t) * ((unsigned long long)n_frames + 1)};
-  if (total) S.seg[S.n++] = CopySeg{device_view(cones), in.d_cones, sizeof(double) * 3ull * total};
+  // a slice of a larger batch (cone_offsets[0] = b > 0): the kernel subtracts b from the offsets on their way in and the cones
+  // are read from row b — nothing is rebased or copied on the host, nothing pageable is handed to the runtime (round-5 advisor:
+  // a pageable copy made the host wait for the stream's earlier work)
+  S.rebase = off[0];
+  S.seg[S.n++] = CopySeg{device_view(off), in.d_off, sizeof(int32_t) * ((unsigned long long)n_frames + 1)};
+  if (total) S.seg[S.n++] = CopySeg{device_view(cones + 3 * (size_t)off[0]), in.d_cones, sizeof(double) * 3ull * total};
   S.seg[S.n++] = CopySeg{device_view(poses), in.d_poses, sizeof(double) * 4ull * (unsigned long long)n_frames};
   if (prev) S.seg[S.n++] = CopySeg{device_view(prev), in.d_prev, sizeof(double) * PATH_POINTS * 4ull * (unsigned long long)n_frames};
-  static const int stage_blocks = getenv("FSDP_STAGE_BLOCKS") ? atoi(getenv("FSDP_STAGE_BLOCKS")) : 256;
-  hipLaunchKernelGGL(stage_in_kernel, dim3(stage_blocks), dim3(256), 0, stream, S);
+  hipLaunchKernelGGL(stage_in_kernel, dim3(256), dim3(256), 0, stream, S);
   return 0;
 }
 
@@ -1004,12 +929,8 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   c->device = device;
   c->mission = mission;
   for (int i = 0; i < FSDP_MAX_OVERLAP; i++) c->slot[i].index = i;
-  if (const char* e = getenv("FSDP_PATH_MODE")) c->force_path_mode = !strcmp(e, "mono") ? 1 : (!strcmp(e, "split") ? 2 : 0);
-  if (const char* e = getenv("FSDP_FIT_G")) c->fit_g = atoi(e) == 8 ? 8 : 4;
-  if (const char* e = getenv("FSDP_FIT_LANES")) c->fit_lanes_min = atoll(e) > 0 ? atoll(e) : (e[0] == '0' ? -1 : 1);  // frames in flight from which; 0 = never
-  if (const char* e = getenv("FSDP_PACK")) c->force_pack = atoi(e) ? 2 : 1;
   hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = create_slot_stream(&c->slot[0].stream, 0);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->slot[0].stream, hipStreamNonBlocking);
   c->stream = c->slot[0].stream;
   for (int i = 0; i < 8 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
   c->params.max_n_neighbors = pp.max_n_neighbors;
@@ -1030,7 +951,6 @@ int fsdp_create(int device, int mission, const fsdp_params* params, fsdp_ctx** o
   c->params.matches_should_be_monotonic = pp.matches_should_be_monotonic ? 1 : 0;
   c->params.use_unknown_cones = pp.use_unknown_cones ? 1 : 0;
   c->params.retry_pack_min = 512;
-  if (const char* e = getenv("FSDP_RETRY_PACK_MIN")) c->params.retry_pack_min = atoi(e);
   c->params.centers_cap = 0;
   c->params.centers = nullptr;
   c->params.n_centers = nullptr;
@@ -1098,8 +1018,6 @@ void fsdp_destroy(fsdp_ctx* c) {
     if (w.stream) (void)hipStreamDestroy(w.stream);
   }
   for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : c->stagger_ev)
-    if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_kclock);
   for (int i = 0; i < 8; i++)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1281,21 +1199,19 @@ static Work::Ticket* find_ticket(fsdp_ctx* c, long long ticket, Work** slot) {
 }
 
 // enqueue ticket t's batch on slot q: inputs, the pass, the results' way back, the ticket's event
-static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_routes) {
-  static const bool force_sdma = getenv("FSDP_STREAM_SDMA") != nullptr;  // experiments: copy engines also for page-locked buffers
+// in_flight: frames on the GPU next to this batch, its own included (< 0: counted from the outstanding tickets)
+static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_routes, long long in_flight = -1) {
   const int n = t.n;
   // a bigger batch than the slot has seen: its buffers are replaced — not under the feet of the passes queued on the stream
   if (n > q.cap_frames || n > q.in.cap_frames || t.total > q.in.cap_cones || (t.prev && n > q.in.cap_prev)) HIP_TRY(c, hipStreamSynchronize(q.stream));
   if (int rc = ensure_work(c, q, n > 0 ? n : 1)) return rc;
-  const bool in_pinned = !force_sdma && n > 0 && is_pinned(t.off, sizeof(int32_t) * ((size_t)n + 1)) && is_pinned(t.poses, sizeof(double) * 4 * (size_t)n) &&
+  const bool in_pinned = n > 0 && is_pinned(t.off, sizeof(int32_t) * ((size_t)n + 1)) && is_pinned(t.poses, sizeof(double) * 4 * (size_t)n) &&
                          (t.total == 0 || is_pinned(t.cones + 3 * (size_t)t.off[0], sizeof(double) * 3 * t.total)) &&
                          (!t.prev || is_pinned(t.prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n));
-  const bool out_pinned = n > 0 && is_pinned(t.user_results, sizeof(fsdp_frame_result) * (size_t)n);
-  static const bool no_fuse = getenv("FSDP_STAGE_KERNEL") != nullptr;  // experiments: a separate stage_in_kernel in front of the pass
+  const bool out_pinned = n > 0 && is_pinned(t.user_results, t.rec_bytes() * (size_t)n);
   q.in.h_off = nullptr;
   {
-    TraceStep ts("submit: host -> device");
-    if (in_pinned && !no_fuse && c->params.use_unknown_cones) {
+    if (in_pinned && c->params.use_unknown_cones) {
       // the pass's sorting kernel reads the batch from the caller's buffers and leaves the device copies (StageIn)
       if (int rc = ensure_inputs(c, q.in, n, t.total, t.prev != nullptr)) return rc;
       q.in.n_frames = n;
@@ -1315,15 +1231,13 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
   }
   t.via_stage = false;
   if (n > 0) {
-    q.result_dst = (out_pinned && !force_sdma) ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
+    q.result_dst = out_pinned ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
+    q.result_compact = t.compact;
     q.trailer_idx = (int)(&t - q.tk);  // the ticket's own trailer
-    int rc;
-    {
-      TraceStep ts("submit: kernel launches");
-      rc = launch_pass(c, q, q.in, nullptr, force_routes);
-    }
+    const int rc = launch_pass(c, q, q.in, nullptr, force_routes, in_flight >= 0 ? in_flight : frames_in_flight(c, n, true));
     const bool direct = q.result_dst != nullptr;
     q.result_dst = nullptr;
+    q.result_compact = false;
     q.trailer_idx = SLOT_QUEUE;
     q.in.h_off = nullptr;  // (the views served that one sorting launch)
     q.unverified = false;  // settled by fsdp_collect through the ticket
@@ -1332,7 +1246,6 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
     t.ran_big = q.ran_big;
     t.ran_retry = q.ran_retry;
     if (!direct) {
-      TraceStep ts("submit: device -> host copy");
       fsdp_frame_result* dst = t.user_results;
       if (!out_pinned) {
         if (n > t.cap_stage) {
@@ -1345,7 +1258,7 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
         dst = t.h_stage;
         t.via_stage = true;
       }
-      HIP_TRY(c, hipMemcpyAsync(dst, q.d_result, sizeof(fsdp_frame_result) * (size_t)n, hipMemcpyDeviceToHost, q.stream));
+      HIP_TRY(c, hipMemcpyAsync(dst, q.d_result, t.rec_bytes() * (size_t)n, hipMemcpyDeviceToHost, q.stream));
     }
     HIP_TRY(c, hipGetLastError());
   }
@@ -1354,8 +1267,8 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
   return 0;
 }
 
-int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses, const double* prev_paths,
-                fsdp_frame_result* results, long long* ticket) {
+static int submit_impl(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses, const double* prev_paths,
+                       fsdp_frame_result* results, long long* ticket, bool compact) {
   if (!c || !ticket) return 1;
   *ticket = -1;
   if (c->mission == 2) {
@@ -1413,6 +1326,7 @@ int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
   t->max_cones = max_cones;
   t->user_results = results;
   t->user_info = nullptr;
+  t->compact = compact;
   if (int rc = enqueue_ticket(c, q, *t, false)) {
     // Part of the batch may already be queued on the slot's stream — kernels that read the caller's buffers or write his
     // page-locked results — and no ticket goes out that he could wait on: wait here, so that an error return means the
@@ -1420,6 +1334,7 @@ int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
     (void)hipStreamSynchronize(q.stream);
     (void)hipGetLastError();
     t->user_results = nullptr;
+    t->compact = false;
     return rc;
   }
   t->id = c->next_ticket++;
@@ -1427,6 +1342,14 @@ int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* con
   c->last_slot = si;
   *ticket = t->id;
   return 0;
+}
+int fsdp_submit(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses, const double* prev_paths,
+                fsdp_frame_result* results, long long* ticket) {
+  return submit_impl(c, n_frames, off, cones, poses, prev_paths, results, ticket, false);
+}
+int fsdp_submit_compact(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses, const double* prev_paths,
+                        fsdp_compact_result* results, long long* ticket) {
+  return submit_impl(c, n_frames, off, cones, poses, prev_paths, (fsdp_frame_result*)results, ticket, true);
 }
 
 // 1: fsdp_collect will not block (unless the pass has to be repeated with a route kernel); 0: still running; < 0: unknown ticket
@@ -1494,7 +1417,7 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
     }
   }
   if (rc == 0 && n > 0) {
-    if (t.via_stage) memcpy(t.user_results, t.h_stage, (t.compact ? sizeof(PathOut) : sizeof(fsdp_frame_result)) * (size_t)n);
+    if (t.via_stage) memcpy(t.user_results, t.h_stage, t.rec_bytes() * (size_t)n);
     if (t.user_info && t.h_info) {
       if (!c->skid_all_reloc) {
         bool all = true;
@@ -1529,42 +1452,184 @@ int fsdp_route_stats(fsdp_ctx* c, int* expect_big, int* expect_retry, long long*
 }
 
 // ---- blocking calls on host buffers -------------------------------------------------------------------------------------
+// A batch of PLAN_CHUNK_MIN x 2 frames or more is cut into up to PLAN_CHUNKS contiguous chunks, each a ticket on a slot of its
+// own: one chunk's transfers (in place for page-locked buffers, staged by the runtime for pageable ones — then the host
+// copies chunk k + 1 while the kernels of chunk k run) go under the other chunks' kernels, and the first chunk's results
+// are on their way back while the last one is still being planned.  The chunks know they share the GPU (in_flight = the
+// whole batch): they run the kernels the whole batch would.  Results do not depend on the chunking.
+constexpr int PLAN_CHUNKS = 4, PLAN_CHUNK_MIN = 1024;
+
 static int plan_blocking(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses, const double* prev,
-                         fsdp_frame_result* results) {
+                         fsdp_frame_result* results, bool compact) {
   if (!c) return 1;
   if (c->outstanding) return busy_error(c, "fsdp_plan_batch");
   if (n_frames > 0 && !results) return 1;
+  if (c->mission == 2) {
+    c->err = "fsdp_plan_batch: a skidpad context plans through fsdp_skidpad_step";
+    return 1;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
   size_t total;
   int max_cones;
   if (int rc = check_batch(c, n_frames, off, cones, poses, &total, &max_cones)) return rc;
   if (int rc = sync_all(c)) return rc;
-  Work& q = c->slot[0];
-  if (int rc = ensure_work(c, q, n_frames > 0 ? n_frames : 1)) return rc;
-  if (int rc = upload_inputs(c, q.in, q.stream, n_frames, off, cones, poses, prev, total, max_cones)) return rc;
   c->last_slot = 0;
   c->last_n = n_frames;
   if (n_frames == 0) return 0;
-  if (int rc = launch_pass(c, q, q.in)) return rc;
-  HIP_TRY(c, hipGetLastError());
-  for (int attempt = 0; attempt < 2; attempt++) {
-    HIP_TRY(c, hipMemcpyAsync(results, q.d_result, sizeof(fsdp_frame_result) * (size_t)n_frames, hipMemcpyDeviceToHost, q.stream));
-    HIP_TRY(c, hipStreamSynchronize(q.stream));
-    bool rerun = false;
-    if (int rc = verify_pass(c, q, &rerun)) return rc;
-    if (!rerun) break;
+  const int chunks = std::max(1, std::min(c->plan_chunks > 0 ? c->plan_chunks : PLAN_CHUNKS, n_frames / PLAN_CHUNK_MIN));
+  const size_t rec = compact ? sizeof(fsdp_compact_result) : sizeof(fsdp_frame_result);
+  long long ids[PLAN_CHUNKS];
+  int issued = 0, rc = 0;
+  for (int k = 0; k < chunks && rc == 0; k++) {
+    const int lo = (int)((long long)n_frames * k / chunks), hi = (int)((long long)n_frames * (k + 1) / chunks);
+    Work& q = c->slot[k];  // (slots beyond the overlap depth get their stream here: a chunk is a pass in flight)
+    Work::Ticket& t = q.tk[0];
+    if ((rc = ensure_work(c, q, hi - lo))) break;
+    t.n = hi - lo;
+    t.skid = false;
+    t.off = off + lo;
+    t.cones = cones;
+    t.poses = poses + 4 * (size_t)lo;
+    t.prev = prev ? prev + (size_t)PATH_POINTS * 4 * (size_t)lo : nullptr;
+    t.total = (size_t)(off[hi] - off[lo]);
+    t.max_cones = max_cones;
+    t.user_results = (fsdp_frame_result*)((char*)results + rec * (size_t)lo);
+    t.user_info = nullptr;
+    t.compact = compact;
+    if ((rc = enqueue_ticket(c, q, t, false, n_frames))) {
+      (void)hipStreamSynchronize(q.stream);
+      (void)hipGetLastError();
+      t.user_results = nullptr;
+      t.compact = false;
+      break;
+    }
+    t.id = ids[issued++] = c->next_ticket++;
+    c->outstanding++;
+    c->last_slot = k;
+    c->last_n = hi - lo;
   }
-  return 0;
+  for (int k = 0; k < issued; k++) {
+    const int rck = fsdp_collect(c, ids[k]);  // (every issued chunk is waited for, also after an error: the buffers are the caller's again)
+    if (rc == 0) rc = rck;
+  }
+  c->next_ticket -= issued;  // (the chunks' numbers were internal: the caller's tickets keep counting up from where they were)
+  return rc;
 }
 
 int fsdp_plan_batch_sequential(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses,
                                const double* prev_paths, fsdp_frame_result* results) {
-  return plan_blocking(c, n_frames, off, cones, poses, prev_paths, results);
+  return plan_blocking(c, n_frames, off, cones, poses, prev_paths, results, false);
 }
 
 int fsdp_plan_batch(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses,
                     fsdp_frame_result* results) {
-  return plan_blocking(c, n_frames, off, cones, poses, nullptr, results);
+  return plan_blocking(c, n_frames, off, cones, poses, nullptr, results, false);
+}
+
+int fsdp_plan_batch_compact(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses, const double* prev_paths,
+                            fsdp_compact_result* results) {
+  return plan_blocking(c, n_frames, off, cones, poses, prev_paths, (fsdp_frame_result*)results, true);
+}
+
+// Options (include/fsdp.h fsdp_set_option): what tests and measurements pin.  Results never depend on them.
+int fsdp_set_option(fsdp_ctx* c, const char* name, long long v) {
+  if (!c || !name) return 1;
+  if (c->outstanding) return busy_error(c, "fsdp_set_option");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = sync_all(c)) return rc;
+  const std::string k(name);
+  auto bad = [&]() {
+    c->err = "fsdp_set_option: unknown option or value out of range: " + k + " = " + std::to_string(v);
+    return 1;
+  };
+  if (k == "path_mode") {
+    if (v < 0 || v > 2) return bad();
+    c->force_path_mode = (int)v;
+  } else if (k == "pack") {
+    if (v < 0 || v > 2) return bad();
+    c->force_pack = (int)v;
+  } else if (k == "fit_g") {
+    if (v != 0 && v != 4 && v != 8) return bad();
+    c->fit_g = v == 8 ? 8 : 4;
+  } else if (k == "always_route") {
+    c->always_route = v != 0;
+  } else if (k == "no_sort128") {
+    c->no_sort128 = v != 0;
+  } else if (k == "retry_pack_min") {
+    if (v < 0 || v > 0x7fffffff) return bad();
+    c->params.retry_pack_min = v == 0 ? 512 : (int)v;
+    HIP_TRY(c, copy_sync(c, c->d_params, &c->params, sizeof(Params), hipMemcpyHostToDevice));
+  } else if (k == "plan_chunks") {
+    if (v < 0 || v > PLAN_CHUNKS) return bad();
+    c->plan_chunks = (int)v;
+  } else if (k == "skid_group") {
+    if (v < 0 || v > SKID_GROUP_MAX) return bad();
+    c->skid_group_env = (int)v;
+  } else if (k == "skid_pack_min") {
+    if (v < 0 || v > 0x7fffffff) return bad();
+    c->skid_pack_min = v == 0 ? 2048 : (int)v;
+  } else {
+    return bad();
+  }
+  for (bool& p : c->primed) p = false;  // (the kernels of a pass may have changed: fsdp_time_reserve warms the slots again)
+  c->res_checked = false;
+  return 0;
+}
+
+// What the link between this GPU and the host carries for page-locked buffers of `bytes` bytes: hipMemcpyAsync host -> device alone,
+// device -> host alone, and both directions at once on two streams (GB/s each; measurement only — the ceiling a stream of batches
+// is held against, bench.py "streaming.pcie_ceiling_GBps").
+int fsdp_pcie_probe(fsdp_ctx* c, size_t bytes, int iters, double* h2d_GBps, double* d2h_GBps, double* both_each_GBps) {
+  if (!c || bytes == 0 || iters <= 0) return 1;
+  if (c->outstanding) return busy_error(c, "fsdp_pcie_probe");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = sync_all(c)) return rc;
+  void *h_up = nullptr, *h_dn = nullptr, *d_up = nullptr, *d_dn = nullptr;
+  hipStream_t s2 = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  auto cleanup = [&]() {
+    if (h_up) (void)hipHostFree(h_up);
+    if (h_dn) (void)hipHostFree(h_dn);
+    (void)hipFree(d_up);
+    (void)hipFree(d_dn);
+    if (s2) (void)hipStreamDestroy(s2);
+    for (hipEvent_t e : {e0, e1, e2})
+      if (e) (void)hipEventDestroy(e);
+  };
+  hipError_t e = hipHostMalloc(&h_up, bytes, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(&h_dn, bytes, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(&d_up, bytes);
+  if (e == hipSuccess) e = hipMalloc(&d_dn, bytes);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipEventCreate(&e2);
+  if (e == hipSuccess) {
+    memset(h_up, 1, bytes);
+    e = hipMemsetAsync(d_dn, 2, bytes, c->stream);
+  }
+  auto run = [&](bool up, bool dn, double* each) -> hipError_t {
+    hipError_t r = hipStreamSynchronize(c->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(s2);
+    if (r != hipSuccess) return r;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters && r == hipSuccess; i++) {
+      if (up) r = hipMemcpyAsync(d_up, h_up, bytes, hipMemcpyHostToDevice, c->stream);
+      if (dn && r == hipSuccess) r = hipMemcpyAsync(h_dn, d_dn, bytes, hipMemcpyDeviceToHost, s2);
+    }
+    if (r == hipSuccess) r = hipStreamSynchronize(c->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(s2);
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (each) *each = (double)bytes * iters / sec / 1e9;
+    return r;
+  };
+  if (e == hipSuccess) e = run(true, true, nullptr);  // warm
+  if (e == hipSuccess) e = run(true, false, h2d_GBps);
+  if (e == hipSuccess) e = run(false, true, d2h_GBps);
+  if (e == hipSuccess) e = run(true, true, both_each_GBps);
+  cleanup();
+  HIP_TRY(c, e);
+  return 0;
 }
 
 // ---- timing of the resident batch ---------------------------------------------------------------------------------------
@@ -1903,7 +1968,7 @@ static int path_batch_impl(fsdp_ctx* c, int n_frames, const double* poses, const
   if (prev_paths)
     HIP_TRY(c, hipMemcpyAsync(q.in.d_prev, prev_paths, sizeof(double) * PATH_POINTS * 4 * (size_t)n_frames, hipMemcpyHostToDevice, q.stream));
   std::string names;
-  launch_path(c, q, q.in, nullptr, names);
+  launch_path(c, q, q.in, nullptr, names, n_frames);
   launch_path_retry(c, q, q.in);
   HIP_TRY(c, hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream));  // (no assemble_kernel follows to reset the list)
   c->stage_names = names + "path_retry_kernel";
@@ -1954,7 +2019,7 @@ int fsdp_profile_path(fsdp_ctx* c, long long* out32_per_frame) {
   if (c->profile_sort)
     launch_sort(c, q, c->res);
   else
-    launch_path(c, q, c->res, nullptr, names, false);
+    launch_path(c, q, c->res, nullptr, names, frames_in_flight(c, c->res.n_frames, false));
   HIP_TRY(c, hipMemsetAsync(q.d_big, 0, sizeof(int), q.stream));
   HIP_TRY(c, hipMemsetAsync(q.d_retry, 0, sizeof(int), q.stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2044,8 +2109,6 @@ int fsdp_skidpad_reset(fsdp_ctx* c, int n_instances) {
   c->skid_ticket_base = 0;
   c->skid_step_no = 0;
   c->skid_all_reloc = false;
-  c->skid_group_env = getenv("FSDP_SKID_GROUP") ? atoi(getenv("FSDP_SKID_GROUP")) : 0;
-  if (const char* e = getenv("FSDP_SKID_PACK_MIN")) c->skid_pack_min = atoi(e);
   return 0;
 }
 
@@ -2150,6 +2213,7 @@ static int flush_skid(fsdp_ctx* c) {
       // 2.4 KB results whose sorting / matching fields a skidpad step leaves empty anyway
       CopySegs segs;
       segs.n = 0;
+      segs.rebase = 0;
       if (direct) segs.seg[segs.n++] = CopySeg{q.d_path, direct, sizeof(PathOut) * (unsigned long long)n};
       if (t.user_info) segs.seg[segs.n++] = CopySeg{q.d_skid_info, device_view(t.h_info), sizeof(SkidInfo) * (unsigned long long)n};
       if (segs.n) hipLaunchKernelGGL(stage_in_kernel, dim3(128), dim3(256), 0, xs, segs);

@@ -22,7 +22,6 @@
 #pragma once
 #include "fsdp_device.h"
 #include "spline_device.h"
-#include "fit_lanes.h"
 #include "det_math.h"
 
 namespace fsdp {
@@ -32,13 +31,8 @@ constexpr int PATH_CAP = 1408;  // points of the working polyline (dense fit-#1 
 
 constexpr int FIT_KNOTS = 16;  // knots the kernels of the three-kernel path stage keep per fit in LDS (more: exact kernel, 64)
 
-// The refit's polyline of 64 consecutive frames as one point-major TILE for fit_lanes_kernel (one frame per lane):
-// tile[array][point][frame mod 64], array = u | x | y — "point i of my frame" is one coalesced access per array.
-constexpr int TILE_FRAMES = 64;
-constexpr size_t TILE_DOUBLES = (size_t)3 * PATH_CAP * TILE_FRAMES;
-
 // per-frame scratch in HBM/L2: working polyline x | y | parameter u, then the basis cache of the running fit
-constexpr int ARENA_B = 384;  // >= (NK_MAX + 2) * 5 rows of the smoothness matrix
+constexpr int ARENA_B = 1296;  // >= (NK_BIG + 2) * 5 rows of the smoothness matrix
 constexpr int FITREC_DOUBLES = 112;  // >= sizeof(FitRec) / 8
 constexpr int WIDE_KNOTS = 32;  // knots per fit of the WIDE instantiations of the three kernels (contexts with a global path: its fits need 17-32)
 constexpr int BAND_DOUBLES = 256;    // >= 7 * (WIDE_KNOTS + 2): band triangle + right-hand sides + fpint of fit_kernel's fit
@@ -1170,7 +1164,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
                                                        const double* __restrict__ default_path, const double* __restrict__ prev_paths,
                                                        const double* __restrict__ gpath, int n_gpath, double* __restrict__ arena,
                                                        PathOut* __restrict__ out, PathMid* __restrict__ mid, int* __restrict__ retry,
-                                                       const Params* __restrict__ prm, double* __restrict__ tiles = nullptr) {
+                                                       const Params* __restrict__ prm) {
   using GR = Grp<G>;
   __shared__ PathShared<G, true, NKC> S_all[WAVE / G];
   const int frame = blockIdx.x * (WAVE / G) + GR::index();
@@ -1193,16 +1187,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) pa
     PROF_T1(30);
     plain = rc == 0 && n >= 4;  // degree 3 needs 4 points; everything else takes the exact route
     if (plain) build_parameter<G>(S, A, off, n);
-    if (plain && tiles != nullptr) {
-      // fit_lanes_kernel reads the polyline from the point-major tile of the frame's group of 64 (the eight frames of this
-      // wavefront are neighbours there: a store instruction covers eight points x 64 contiguous bytes)
-      double* T = tiles + (size_t)(frame / TILE_FRAMES) * TILE_DOUBLES + (frame % TILE_FRAMES);
-      for (int i = GR::lane(); i < n; i += G) {
-        T[(size_t)i * TILE_FRAMES] = A.u[off + i];
-        T[((size_t)PATH_CAP + i) * TILE_FRAMES] = A.x[off + i];
-        T[((size_t)2 * PATH_CAP + i) * TILE_FRAMES] = A.y[off + i];
-      }
-    }
   }
   const bool final_status = status != ST_OK && status != ST_RETRY && status != ST_OVERFLOW_KNOTS;
   if (final_status) write_path_status<G>(&out[frame], status, fallback, 0);  // sorting / matching / fit #1 decided the frame
@@ -1237,10 +1221,7 @@ template <int G, int NKC>
 // to change nothing, profiles/r04_ab_variants.txt 1)
 __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES : FSDP_FIT_WAVES) fit_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                  int* __restrict__ retry, const Params* __restrict__ prm,
-                                                 unsigned long long* __restrict__ clock_first, unsigned long long* __restrict__ clock_last,
-                                                 int* __restrict__ wide = nullptr, const int* __restrict__ list = nullptr) {
-  // wide (optional): where a fit that needs more knots than NKC is handed on when the pass carries the 32-knot kernels (else:
-  // the retry list, i.e. the exact kernel).  list (optional): this launch IS that 32-knot refit — group i plans frame list[1 + i].
+                                                 unsigned long long* __restrict__ clock_first, unsigned long long* __restrict__ clock_last) {
   using GR = Grp<G>;
   using WS = FitWS<G, NKC>;
 #ifndef FSDP_EMU
@@ -1250,10 +1231,9 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES
 #endif
   static_assert(7 * (NKC + 2) <= BAND_DOUBLES, "band region of the arena");
   __shared__ WS ws_all[WAVE / G];
-  int frame = blockIdx.x * (WAVE / G) + GR::index();
-  if (list != nullptr) frame = frame < list[0] ? list[1 + frame] : n_frames;
+  const int frame = blockIdx.x * (WAVE / G) + GR::index();
   PROF_INIT_K(1);
-  if (frame < n_frames && mid[frame].status == (list != nullptr ? ST_WIDE : ST_OK)) {
+  if (frame < n_frames && mid[frame].status == ST_OK) {
     PROF(0);
     WS& ws = ws_all[GR::index()];
     const Arena A = frame_arena(arena, frame, prm);
@@ -1264,16 +1244,10 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES
     const int lane = GR::lane();
     if (f.status != 0) {
       if (lane == 0) {
-        if (wide != nullptr && f.status == ST_OVERFLOW_KNOTS) {
-          mid[frame].status = ST_WIDE;
-          push_retry(wide, frame);
-        } else {
-          mid[frame].status = ST_RETRY;
-          push_retry(retry, frame);
-        }
+        mid[frame].status = ST_RETRY;
+        push_retry(retry, frame);
       }
     } else {
-      if (list != nullptr && lane == 0) mid[frame].status = ST_WIDE_FIT;
       FitRec* fr = A.fit;
       for (int i = lane; i < f.n; i += G) {
         fr->t[i] = ws.t[1 + i];
@@ -1294,51 +1268,15 @@ __global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(G == 4 ? FSDP_FIT4_WAVES
 #endif
 }
 
-// The refit with one frame per lane (fit_lanes.h): wavefront w plans frames 64 w .. 64 w + 63 from tile w.  Same hand-over as
-// fit_kernel: FitRec in the frame's arena, or the frame on the retry list.
-#ifndef FSDP_LANES_WAVES
-#define FSDP_LANES_WAVES 3
-#endif
-__global__ void __launch_bounds__(64) FSDP_WAVES_PER_EU(FSDP_LANES_WAVES) fit_lanes_kernel(int n_frames, const double* __restrict__ tiles, double* __restrict__ arena,
-                                                                                        PathMid* __restrict__ mid, int* __restrict__ retry,
-                                                                                        const Params* __restrict__ prm) {
-  const int lane = lane_id();
-  const int frame = blockIdx.x * TILE_FRAMES + lane;
-  int m = 0;
-  if (frame < n_frames && mid[frame].status == ST_OK) m = mid[frame].n;
-  if (m > 0) {
-    LaneWS<FIT_KNOTS> ws;
-    const double* T = tiles + (size_t)blockIdx.x * TILE_DOUBLES + lane;
-    const SplineFit f = spline_fit_lane<FIT_KNOTS, TILE_FRAMES>(ws, T, T + (size_t)PATH_CAP * TILE_FRAMES, T + (size_t)2 * PATH_CAP * TILE_FRAMES, m,
-                                                               prm->smoothing);
-    if (f.status != 0) {
-      mid[frame].status = ST_RETRY;
-      push_retry(retry, frame);
-    } else {
-      FitRec* fr = frame_arena(arena, frame, prm).fit;
-      for (int i = 0; i < f.n; i++) {
-        fr->t[i] = ws.t[1 + i];
-        fr->c[i] = ws.cx[1 + i];
-        fr->c[f.n + i] = ws.cy[1 + i];
-      }
-      fr->n = f.n;
-      fr->ier = f.ier;
-      fr->status = 0;
-      fr->fp = f.fp;
-    }
-  }
-}
-
 template <int G, int NKC = FIT_KNOTS>
 __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* __restrict__ arena, PathMid* __restrict__ mid,
                                                          PathOut* __restrict__ out, int* __restrict__ retry,
-                                                         const Params* __restrict__ prm, const int* __restrict__ list = nullptr) {
+                                                         const Params* __restrict__ prm) {
   using GR = Grp<G>;
   __shared__ PathShared<G, true, NKC> S_all[WAVE / G];
-  int frame = blockIdx.x * (WAVE / G) + GR::index();
-  if (list != nullptr) frame = frame < list[0] ? list[1 + frame] : n_frames;  // (the frames the 32-knot refit kernel has refitted)
+  const int frame = blockIdx.x * (WAVE / G) + GR::index();
   PROF_INIT_K(3);
-  if (frame < n_frames && mid[frame].status == (list != nullptr ? ST_WIDE_FIT : ST_OK)) {
+  if (frame < n_frames && mid[frame].status == ST_OK) {
   PROF(0);
   PathShared<G, true, NKC>& S = S_all[GR::index()];
   const Arena A = frame_arena(arena, frame, prm);
@@ -1360,7 +1298,6 @@ __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* _
   const int rc = mpc_finish<G, true, true>(S, A, true, f, out[frame].path, &n_dense);
   if (rc == 0) {
     write_path_status<G>(&out[frame], ST_OK, mid[frame].fallback, n_dense);
-    if (list != nullptr && lane == 0) mid[frame].status = ST_OK;
   } else if (lane == 0) {
     mid[frame].status = ST_RETRY;
     push_retry(retry, frame);
@@ -1371,7 +1308,7 @@ __global__ void __launch_bounds__(64) path_finish_kernel(int n_frames, double* _
 
 // grid = ceil(n_frames / (64 / G)) workgroups of one wavefront; group g of block b plans frame b * (64 / G) + g.
 // retry (optional): [0] = counter, [1..] = frames that ended with ST_OVERFLOW_KNOTS (the packed kernels keep 32 knots per
-// fit); path_retry_kernel plans those again with the one-frame-per-wavefront instantiation (64 knots).
+// fit); path_retry_kernel plans those again with the one-frame-per-wavefront instantiation (256 knots).
 #ifndef FSDP_PATH_WAVES
 #define FSDP_PATH_WAVES 1
 #endif
@@ -1383,7 +1320,7 @@ __global__ void __launch_bounds__(64, FSDP_PATH_WAVES) path_kernel(int n_frames,
                                                      const double* __restrict__ gpath, int n_gpath,
                                                      double* __restrict__ arena, PathOut* __restrict__ out,
                                                      int* __restrict__ retry, const Params* __restrict__ prm) {
-  __shared__ PathShared<G> S_all[WAVE / G];
+  __shared__ PathShared<G, false, G == WAVE ? NK_BIG : 0> S_all[WAVE / G];  // (a frame with the wavefront to itself: 256 knots)
   const int frame = blockIdx.x * (WAVE / G) + Grp<G>::index();
   PROF_INIT();
   if (frame < n_frames) {
@@ -1413,7 +1350,7 @@ __global__ void __launch_bounds__(64, FSDP_RETRY_WAVES) path_retry_kernel(const 
   constexpr int G1 = 16, PER = WAVE / G1;
   union Shared {
     PathShared<G1, false, NK_MAX> quad[PER];
-    PathShared<WAVE> whole;
+    PathShared<WAVE, false, NK_BIG> whole;
     __device__ Shared() {}
   };
   __shared__ Shared S;

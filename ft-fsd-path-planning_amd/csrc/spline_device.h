@@ -26,6 +26,12 @@ constexpr int knot_capacity() {
   return G == 64 ? 64 : 32;
 }
 constexpr int NK_MAX = 64;
+// The exact kernels' last level — one frame, the whole wavefront, plain IEEE divisions (path_kernel<64>, the second level of
+// path_retry_kernel) — keeps 256 knots: the most a knot interval stored in one byte per data point allows (BasisCache::l holds
+// l <= n - 4 = 252), 29 KB of LDS for a kernel that runs one wavefront per SIMD anyway.  FITPACK itself allows nest = m + 2k knots
+// (utils/spline_fit.py:117); the noisiest frames of the fuzz sets end with 68 ... 171 (profiles/r05_fuzz_gpu_vs_oracle_wide.txt), which
+// 64 knots refused with FSDP_OVERFLOW_KNOTS.
+constexpr int NK_BIG = 256;
 
 // dense samples of the final spline: 3 x mpc_prediction_horizon, or one more (path_parameterization.py:163-193: 120 or 121
 // at the default horizon of 40; up to 193 in the wide build's 64 rows)
@@ -66,8 +72,10 @@ struct SplineWS {
       };
     };
     struct {  // ---- no fit running (path stage) ----
-      double curv[LEAN_ ? 3 * (NK + 2) : DCAP];  // raw curvature; overlays t | c: written only after the last spline
-                                                 // evaluation (LEAN: never written, the bytes of t | c)
+      // raw curvature; overlays t | c: written only after the last spline evaluation (LEAN: never written, the bytes of t | c).
+      // At least as long as t | c, so that the dense samples behind it — written WHILE the final spline is evaluated — never
+      // lie on the knots and coefficients being read (NK = 256: t | c are 774 doubles, the curvature 128 / 200)
+      double curv[(LEAN_ || 3 * (NK + 2) > DCAP) ? 3 * (NK + 2) : DCAP];
       double dxyu[DENSE_ARRAYS * DCAP];  // dense samples x | y of the final spline (third array: more room for the segment
                                          // lengths before fit #3); in the extension the tail points of the polyline
     };
@@ -158,7 +166,7 @@ struct alignas(32) BRec {
 static_assert(sizeof(BRec) == 32, "basis record");
 struct BasisCache {
   BRec* rec;
-  uint8_t* l;  // knot interval per data point (<= NK_MAX)
+  uint8_t* l;  // knot interval per data point (<= NK_BIG - 4)
   double* b;   // (NK + 2) x 5 rows of the smoothness matrix (fpdisc) of the running fit, row-major, element (i, j) at 5 i + j - 1
 };
 

@@ -218,6 +218,16 @@ class Star:
         self.peers, self.sock = {}, None
 
 
+def multi_rank_exit_status(world: int, single_process: bool, transport: str, rccl_ranks: int, allow_tcp_fallback: bool) -> int:
+    """Exit status of a benchmark process (bench.py) whose line claims a multi-rank run: 0 when the ranks' start-up collectives
+    really went over RCCL with all `world` ranks in the communicator (or the run is one rank / one process by design, or the
+    caller accepted the TCP star with --allow-tcp-fallback); 3 otherwise — a curve over 1, 2, 4, 8 GPUs must not quietly be a
+    curve of ranks that never met over xGMI (round-5 review, item 8)."""
+    if world <= 1 or single_process or allow_tcp_fallback:
+        return 0
+    return 0 if (transport == "rccl" and rccl_ranks == world) else 3
+
+
 def frame_range(rank: int, world: int, n_total: int):
     """Contiguous shard [lo, hi) of a global batch (strong-scaling form, SURVEY.md 8e: [g*B/G, (g+1)*B/G))."""
     per = (n_total + world - 1) // world
@@ -260,6 +270,7 @@ class Dist:
         self.released = False      # release_device_communicator() was called: RCCL served the start-up collectives only
         self._active = False       # an RCCL communicator carries the collectives
         self.transport = "none"    # "none" (single process) | "rccl" | "tcp-fallback"
+        self.rccl_ranks = 0        # what ncclCommCount returned while the RCCL communicator was up (0: RCCL never carried a collective)
         self.fallback_reason = None
         self._star = None
         if self.world > 1:
@@ -332,6 +343,7 @@ class Dist:
             self.transport = "rccl"
             self.fallback_reason = None
             assert self.comm_size == self.world and int(self._comm._lib.fsdp_comm_rank(self._comm._h)) == self.rank
+            self.rccl_ranks = self.comm_size  # (kept after release_device_communicator: what a benchmark line reports)
             return
         if why is None:
             # mine works, another rank's does not: tear it down — under a deadline, its peers may never answer — and leave the

@@ -142,7 +142,11 @@ class MultiPlanner:
 
     def submit(self, offsets, cones, poses, prev_paths=None, out: np.ndarray | None = None) -> MultiTicket:
         """Cut the batch, enqueue every shard on its GPU, return at once.  ``out``: page-locked RESULT_DTYPE array of the
-        whole batch (``pinned_empty``); every GPU writes its range of it.  Default: a block of the planner's pool."""
+        whole batch (``pinned_empty``); every GPU writes its range of it.  Default: a block of the planner's pool.
+
+        Contract: page-locked input arrays are NOT copied (the GPUs read their slices in place) — they, and ``out``, must stay
+        untouched until ``collect``.  If a shard cannot be submitted, the shards already on their GPUs are waited for before the
+        exception leaves this method, so that neither the caller's arrays nor the result block are written behind his back."""
         import time
 
         t0 = time.perf_counter()
@@ -156,34 +160,61 @@ class MultiPlanner:
         ranges = [(g, lo, hi) for g, (lo, hi) in enumerate(shard_ranges(n, len(self.ctx))) if hi > lo]
         zero_copy = n > 0 and _capi.is_pinned(offsets) and _capi.is_pinned(poses) and (len(cones) == 0 or _capi.is_pinned(cones)) and (
             prev is None or _capi.is_pinned(prev))
-        parts = []
-        if zero_copy:
-            self.zero_copy_batches += 1
-            for g, lo, hi in ranges:
-                parts.append((g, self.ctx[g].submit_slice(lo, hi, offsets, cones, poses, prev, out)))
-        elif len(ranges) > 1 and n >= self.STAGE_THREADS_MIN_FRAMES * len(ranges):
-            # pageable input: every context's worker copies its shard into page-locked staging and submits it; the caller's
-            # arrays are his again when submit returns
-            self.staged_batches += 1
-            if self._workers is None:
-                from concurrent.futures import ThreadPoolExecutor
+        parts, futs = [], []
+        try:
+            if zero_copy:
+                self.zero_copy_batches += 1
+                for g, lo, hi in ranges:
+                    parts.append((g, self.ctx[g].submit_slice(lo, hi, offsets, cones, poses, prev, out)))
+            elif len(ranges) > 1 and n >= self.STAGE_THREADS_MIN_FRAMES * len(ranges):
+                # pageable input: every context's worker copies its shard into page-locked staging and submits it; the caller's
+                # arrays are his again when submit returns
+                self.staged_batches += 1
+                if self._workers is None:
+                    from concurrent.futures import ThreadPoolExecutor
 
-                self._workers = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"fsdp-stage-{g}") for g in range(len(self.ctx))]
-            futs = [(g, self._workers[g].submit(self._stage_and_submit, g, lo, hi, offsets, cones, poses, prev, out)) for g, lo, hi in ranges]
-            parts = [(g, f.result()) for g, f in futs]
-        else:
-            self.staged_batches += 1
-            for g, lo, hi in ranges:
-                parts.append((g, self._stage_and_submit(g, lo, hi, offsets, cones, poses, prev, out)))
+                    self._workers = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"fsdp-stage-{g}") for g in range(len(self.ctx))]
+                futs = [(g, self._workers[g].submit(self._stage_and_submit, g, lo, hi, offsets, cones, poses, prev, out)) for g, lo, hi in ranges]
+                for g, f in futs:
+                    parts.append((g, f.result()))
+            else:
+                self.staged_batches += 1
+                for g, lo, hi in ranges:
+                    parts.append((g, self._stage_and_submit(g, lo, hi, offsets, cones, poses, prev, out)))
+        except BaseException:
+            # (round-5 advisor) shards already submitted write into `out` / read the caller's arrays: wait for them — and for the
+            # workers still staging — before the block can go back to the pool and the exception to the caller
+            for g, f in futs:
+                try:
+                    t = f.result()
+                    if all(t is not pt for _, pt in parts):
+                        parts.append((g, t))
+                except BaseException:
+                    pass
+            self._drain(parts)
+            raise
         dt = time.perf_counter() - t0
         self.host_seconds += dt
         self.host_frames += n
         return MultiTicket(parts, out, dt)
 
+    def _drain(self, parts):
+        """Wait for shards whose results nobody will read (error paths): errors of the wait itself are swallowed."""
+        for g, t in parts:
+            try:
+                self.ctx[g].collect(t)
+            except Exception:
+                pass
+
     def collect(self, ticket: MultiTicket) -> np.ndarray:
         """Wait for the batch; returns the page-locked result array the GPUs wrote (not a copy)."""
-        for g, t in ticket.parts:
-            self.ctx[g].collect(t)
+        parts, ticket.parts = ticket.parts, []
+        for k, (g, t) in enumerate(parts):
+            try:
+                self.ctx[g].collect(t)
+            except BaseException:
+                self._drain(parts[k + 1 :])  # (the other GPUs still write their ranges of the block)
+                raise
         return ticket.out
 
     def plan_batch(self, offsets, cones, poses, prev_paths=None) -> np.ndarray:
@@ -198,12 +229,19 @@ class MultiPlanner:
         its views) and the block serves a later batch."""
         depth = 2 * self._overlap if depth is None else max(1, min(int(depth), 2 * self._overlap))
         inflight = []
-        for b in batches:
-            if len(inflight) == depth:
+        try:
+            for b in batches:
+                if len(inflight) == depth:
+                    yield self.collect(inflight.pop(0))
+                inflight.append(self.submit(*b))
+            while inflight:
                 yield self.collect(inflight.pop(0))
-            inflight.append(self.submit(*b))
-        for t in inflight:
-            yield self.collect(t)
+        finally:
+            # a generator closed early (or an exception part-way): the batches still in flight write into pool blocks that
+            # would otherwise be handed to a later batch while the GPUs are not done with them (round-5 advisor)
+            for t in inflight:
+                self._drain(t.parts)
+                t.parts = []
 
 
 class MultiSkidpadBatch:
@@ -284,4 +322,18 @@ class MultiSkidpadBatch:
             yield self.collect(t)
 
     def close(self):
+        for p in self.parts:
+            p.close()
         self._pool.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self._pool.close()
+        except Exception:
+            pass

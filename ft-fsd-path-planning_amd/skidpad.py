@@ -132,6 +132,10 @@ class SkidpadBatch:
     def set_overlap(self, depth: int):
         self._ctx.set_overlap(depth)
 
+    def close(self):
+        """Destroy the context (its device buffers, streams and page-locked blocks) now instead of when the object is collected."""
+        self._ctx.close()
+
     def time_groups(self, enable: bool = True):
         """HIP events around the packed kernels of every group of steps of the replays that follow (fsdp_skidpad_time_groups)."""
         self._ctx._check(self._ctx._lib.fsdp_skidpad_time_groups(self._ctx._h, ctypes.c_int(1 if enable else 0)), "fsdp_skidpad_time_groups")

@@ -62,7 +62,8 @@ enum {
   FSDP_OVERFLOW_CONES = 201, /* more than 8192 cones in a frame */
   FSDP_OVERFLOW_ENDS = 202,  /* more than 4096 raw end configurations on one side */
   FSDP_OVERFLOW_PATH = 203,
-  FSDP_OVERFLOW_KNOTS = 204, /* more than 64 knots (fits beyond the packed kernels' capacity are re-planned by the one-frame-per-wavefront kernel) */
+  FSDP_OVERFLOW_KNOTS = 204, /* more than 256 knots in a spline (fits beyond the packed kernels' 16 / 32 / 64 are re-planned by the
+                                one-frame-per-wavefront kernel, which keeps 256; a skidpad step: 64) */
   FSDP_OVERFLOW_CLUSTERS = 205, /* skidpad relocalization: more than 64 centre clusters */
   FSDP_SYNC_LOST = 206 /* skidpad steps sharing a launch: a step never saw its predecessor's state (internal error) */
 };
@@ -81,7 +82,8 @@ enum {
  * mpc_prediction_horizon > 40 (rows of a result path) in the standard build; > 8, > 16, > 64 in the wide build
  * (FSDP_WIDE_SHAPES above).  Refused per frame, with a status and never truncated:
  * more than 8192 cones (201), more than 4096 raw end configurations on a side (202), a working polyline beyond 1408 points
- * (203), more than 64 knots in a spline (204), more than 64 skidpad centre clusters (205). */
+ * (203), more than 256 knots in a spline (204; FITPACK's own bound is nest = m + 2k, utils/spline_fit.py:117 — the noisiest
+ * frames of the fuzz sets end with 171), more than 64 skidpad centre clusters (205). */
 
 /* path_fallback bits */
 enum {
@@ -112,6 +114,21 @@ typedef struct {
   int32_t path_fallback;
   int32_t n_dense; /* number of dense spline samples the outputs (one per row of the horizon) were drawn from */
 } fsdp_frame_result;
+
+/* The COMPACT result: what a caller that only drives the car reads of calculate_path_in_global_frame — the path
+ * (full_pipeline.py:207, the non-intermediate return value), the sorted cone indices and the status: 1384 bytes per frame
+ * instead of 2408 (SURVEY.md 8d counts exactly these bytes as a frame's output).  A result block is what a batch moves back
+ * over PCIe; fsdp_submit_compact / fsdp_plan_batch_compact return these records, bit-equal to the same fields of the
+ * full record (tests/test_streaming_gpu.py). */
+typedef struct {
+  double path[FSDP_PATH_POINTS][4];  /* [spline parameter, x, y, curvature], rows beyond the horizon NaN */
+  int32_t left_idx[FSDP_MAX_LEN];    /* -1 padded, as in fsdp_frame_result */
+  int32_t right_idx[FSDP_MAX_LEN];
+  int32_t status;
+  uint8_t n_left, n_right;
+  uint8_t path_fallback; /* FSDP_FB_* bits */
+  uint8_t n_dense;
+} fsdp_compact_result;
 
 typedef struct fsdp_ctx fsdp_ctx;
 
@@ -176,6 +193,12 @@ const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creat
  * Host buffers; does H2D, the kernels of a pass and D2H on the context's stream, then synchronises. */
 int fsdp_plan_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
                     const double* poses, fsdp_frame_result* results);
+/* A batch of 2048 frames or more is pipelined inside the call: it is cut into up to four contiguous chunks of at least 1024
+ * frames, each on a pass slot (HIP stream) of its own, so that one chunk's transfers run under the other chunks' kernels;
+ * with page-locked buffers (fsdp_host_alloc / fsdp_host_register) the chunks are read and written in place.  Results do not
+ * depend on the chunking (frames are independent).  The same call with compact records: */
+int fsdp_plan_batch_compact(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
+                            const double* poses, const double* prev_paths /* or NULL */, fsdp_compact_result* results);
 
 /* Sequential-replay form: frame i additionally gets prev_paths[i] (FSDP_PATH_POINTS,4) = the path this planner returned for its previous
  * frame, i.e. CalculatePath.previous_paths[-1] (core_calculate_path.py:203,219-221,236,531-536,568-573).  prev_paths NULL =
@@ -222,6 +245,9 @@ int fsdp_host_unregister(void* p);
 int fsdp_host_is_pinned(const void* p, size_t bytes);
 int fsdp_submit(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses,
                 const double* prev_paths, fsdp_frame_result* results, long long* ticket);
+/* fsdp_submit with compact records (same tickets, same fsdp_collect) */
+int fsdp_submit_compact(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt, const double* poses,
+                        const double* prev_paths, fsdp_compact_result* results, long long* ticket);
 int fsdp_collect(fsdp_ctx* ctx, long long ticket);
 int fsdp_ticket_done(fsdp_ctx* ctx, long long ticket); /* 1: fsdp_collect will not block; 0: still running; -1: unknown ticket */
 int fsdp_ticket_capacity(const fsdp_ctx* ctx);         /* tickets that may be outstanding at the current depth */
@@ -254,6 +280,22 @@ int fsdp_set_overlap(fsdp_ctx* ctx, int depth);
  * every pass until 4096 passes in a row did not need it).  Results never depend on this.  Diagnostics: */
 int fsdp_route_stats(fsdp_ctx* ctx, int* expect_big, int* expect_retry, long long* reruns);
 
+/* Options of a context: what a test or a measurement may pin instead of leaving it to the library.  Results NEVER depend on
+ * them (every route and packing returns the same bits: tests/test_gpu_parity.py
+ * test_every_path_kernel_instantiation_equals_oracle).  0 restores the library's own choice.  The library reads no
+ * environment variable for any of this (the one it reads: FSDP_RCCL_LIB, the path of librccl.so, csrc/fsdp_comm.h).
+ *   "path_mode"       1: the one-kernel path stage (one frame per wavefront) whatever the batch; 2: the three-kernel form
+ *   "pack"            1: four frames per wavefront in the three-kernel form; 2: the packed kernels (8 / 16 frames per wavefront)
+ *   "fit_g"           4 | 8: lanes per frame of the packed refit kernel (default 4)
+ *   "always_route"    1: sort_big_kernel and path_retry_kernel with every pass (default: only when expected, see below)
+ *   "no_sort128"      1: the sorting kernel's 255-cone state also for frames of up to 128 cones
+ *   "retry_pack_min"  retry lists longer than this run four frames per wavefront in path_retry_kernel (default 512)
+ *   "plan_chunks"     most chunks a blocking fsdp_plan_batch call is pipelined in (default 4; 1: the batch is one pass)
+ *   "skid_group"      steps per launch of a skidpad replay that submits ahead (default: from the instance count)
+ *   "skid_pack_min"   (instance, step) pairs from which a group of skidpad steps takes the packed kernels (default 2048)
+ * Returns 1 on an unknown name or a value outside its range, or while tickets are outstanding. */
+int fsdp_set_option(fsdp_ctx* ctx, const char* name, long long value);
+
 /* Enqueue `iters` back-to-back passes over the resident batch (rotating through the slots when passes overlap; no host
  * synchronisation in between) and time them with HIP events recorded on the streams the kernels run on.
  * ms_total: whole region; ms_stage[FSDP_MAX_STAGES]: summed durations of every kernel of a pass, in launch order (events
@@ -283,6 +325,10 @@ int fsdp_time_results(fsdp_ctx* ctx, float* ms_total, float* ms_stage);
  * launches it covers (0 when the region ran the one-kernel path stage, or was timed without bit 1 of fsdp_time_detail).
  * No counterpart in the reference (measurement only). */
 int fsdp_time_kernel_clock(fsdp_ctx* ctx, double* ms_sum, int* launches);
+/* What the link between this GPU and the host carries for page-locked buffers of `bytes` bytes, hipMemcpyAsync x iters: host ->
+ * device alone, device -> host alone, and each direction with both running at once (GB/s).  Measurement only: the ceiling the
+ * rate of a stream of batches (fsdp_submit / fsdp_collect) is held against.  No counterpart in the reference. */
+int fsdp_pcie_probe(fsdp_ctx* ctx, size_t bytes, int iters, double* h2d_GBps, double* d2h_GBps, double* both_each_GBps);
 /* comma-separated kernel names behind ms_stage of the most recent pass, e.g.
  * "sort_kernel_128,match_kernel<32>,path_prep_kernel<8>,fit_kernel<4>,path_finish_kernel<8>,assemble_kernel" */
 int fsdp_stage_names(fsdp_ctx* ctx, char* out, int cap);
@@ -339,7 +385,7 @@ int fsdp_skidpad_step(fsdp_ctx* ctx, int n_instances, const int32_t* cone_offset
  * steps of a planner then share their launches.  A step's inputs and its relocalization attempt are enqueued at once, its
  * path stage when enough steps have been submitted (half the slots at most) or somebody asks for it (fsdp_collect,
  * fsdp_ticket_done, any blocking call):
- *   - from 2048 (instance, step) pairs (FSDP_SKID_PACK_MIN) the pairs are frames of the packed kernels of the autocross
+ *   - from 2048 (instance, step) pairs (option "skid_pack_min") the pairs are frames of the packed kernels of the autocross
  *     path stage — a planner's window index depends on the poses alone (skidpad_calculate_path.py:60-67), so every step's
  *     window is known up front — and one wavefront per planner then takes its steps in order, keeps the packed result or,
  *     where the step needs the planner's previous path (too far from the car, the ValueError retry) or left the packed

@@ -28,7 +28,7 @@ static int g_n_gpath = 0;
 static std::once_flag g_once;
 static int g_last_retries = 0;
 static int g_last_big = 0;
-static int g_last_wide = 0;
+static bool g_no_sort128 = false;  // emu_set_no_sort128: the 255-cone state also for small frames (the library's option "no_sort128")
 static std::vector<double> g_refit;  // FitRec per frame of the last three-kernel path launch
 static void build_default() {
   double chord[fsdp::CHORD_POINTS][2];
@@ -84,36 +84,18 @@ static void emu_path_launch(int n_frames, const double* poses, const fsdp::Match
 }
 
 // the path stage as the library launches it for large batches: prep -> fit -> finish -> exact re-plan of the retry list
-// GF = 1: the refit with one frame per lane (fit_lanes_kernel, from the point-major tiles path_prep_kernel writes for it)
-// WLIST: the pass carries the 32-knot refit / finish kernels for the frames whose refit overflows NKC knots (fsdp_lib.hip launch_path)
-template <int GF, int NKC, int G = fsdp::PATH_G_SPLIT, int NKP = fsdp::FIT_KNOTS, bool WLIST = false>  // NKP: knots per fit of the prep / finish workspaces
+template <int GF, int NKC, int G = fsdp::PATH_G_SPLIT, int NKP = fsdp::FIT_KNOTS>  // NKP: knots per fit of the prep / finish workspaces
 static void emu_path_split_launch(int n_frames, const double* poses, const fsdp::MatchOut* matched, fsdp::PathOut* out) {
   AlignedArena arena((size_t)fsdp::ARENA_DOUBLES * n_frames);
   std::vector<fsdp::PathMid> mid(n_frames);
-  std::vector<int> retry((size_t)n_frames + 1, 0), wide((size_t)n_frames + 1, 0);
-  const unsigned per = 64 / G, perf = GF == 1 ? 1 : 64 / GF;
-  const unsigned n_tiles = ((unsigned)n_frames + fsdp::TILE_FRAMES - 1) / fsdp::TILE_FRAMES;
-  AlignedArena tiles(GF == 1 ? fsdp::TILE_DOUBLES * n_tiles : 8);
+  std::vector<int> retry((size_t)n_frames + 1, 0);
+  const unsigned per = 64 / G, perf = 64 / GF;
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() {
     fsdp::path_prep_kernel<G, NKP>(n_frames, poses, matched, g_default_path, g_prev_paths, g_gpath, g_n_gpath, arena.data(), out,
-                                   mid.data(), retry.data(), &g_prm, GF == 1 ? tiles.data() : nullptr);
+                                   mid.data(), retry.data(), &g_prm);
   });
-  if constexpr (GF == 1)
-    emu::launch(n_tiles, 64, [&]() { fsdp::fit_lanes_kernel(n_frames, tiles.data(), arena.data(), mid.data(), retry.data(), &g_prm); });
-  else
-    emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() {
-      fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data(), &g_prm, nullptr, nullptr, WLIST ? wide.data() : nullptr, nullptr);
-    });
+  emu::launch(((unsigned)n_frames + perf - 1) / perf, 64, [&]() { fsdp::fit_kernel<GF, NKC>(n_frames, arena.data(), mid.data(), retry.data(), &g_prm, nullptr, nullptr); });
   emu::launch(((unsigned)n_frames + per - 1) / per, 64, [&]() { fsdp::path_finish_kernel<G, NKP>(n_frames, arena.data(), mid.data(), out, retry.data(), &g_prm); });
-  if constexpr (WLIST) {
-    g_last_wide = wide[0];
-    emu::launch(((unsigned)n_frames + 7) / 8, 64, [&]() {
-      fsdp::fit_kernel<8, fsdp::WIDE_KNOTS>(n_frames, arena.data(), mid.data(), retry.data(), &g_prm, nullptr, nullptr, nullptr, wide.data());
-    });
-    emu::launch(((unsigned)n_frames + 7) / 8, 64, [&]() {
-      fsdp::path_finish_kernel<8, fsdp::WIDE_KNOTS>(n_frames, arena.data(), mid.data(), out, retry.data(), &g_prm, wide.data());
-    });
-  }
   g_last_retries = retry[0];
   // the refit records (knots / coefficients fit_kernel handed to path_finish_kernel), kept for emu_last_refit
   g_refit.assign((size_t)n_frames * fsdp::FITREC_DOUBLES, 0.0);
@@ -148,7 +130,7 @@ int emu_last_refit(int f, double* knots34, double* coeffs68) {
   return r->n;
 }
 int emu_last_big() { return g_last_big; }
-int emu_last_wide() { return g_last_wide; }  // frames the last pass with the 32-knot list kernels handed to them
+void emu_set_no_sort128(int on) { g_no_sort128 = on != 0; }
 void emu_fit(const double* xy, int m, double smoothing, double* t_out, double* c_out, int* info, double* fp_out) {
   AlignedArena arena(fsdp::ARENA_DOUBLES);
   emu::launch(1, 64, [&]() { fsdp::fit_test_kernel(xy, m, smoothing, arena.data(), t_out, c_out, info, fp_out); });
@@ -162,7 +144,7 @@ static void emu_sort_plain(int n_frames, const int32_t* offsets, const double* c
   // the host library's choice (fsdp_lib.hip launch_sort): the 128-cone state when no frame of the batch holds more
   int max_cones = 0;
   for (int f = 0; f < n_frames; f++) max_cones = std::max(max_cones, (int)(offsets[f + 1] - offsets[f]));
-  if (max_cones <= fsdp::SortShared128::MAX_N && !getenv("FSDP_NO_SORT128"))
+  if (max_cones <= fsdp::SortShared128::MAX_N && !g_no_sort128)
     emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel_128(n_frames, offsets, cones, poses, out, big.data(), &g_prm); });
   else
     emu::launch((unsigned)n_frames, 64, [&]() { fsdp::sort_kernel(n_frames, offsets, cones, poses, out, big.data(), &g_prm); });
@@ -346,12 +328,8 @@ int emu_path_g(int G, int n_frames, const double* poses, const fsdp::MatchOut* m
     emu_path_split_launch<4, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
   else if (G == 1008)
     emu_path_split_launch<8, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
-  else if (G == 3004)  // split pipeline (4-lane fit) + the 32-knot refit / finish kernels for the refits that overflow 16 knots
-    emu_path_split_launch<4, fsdp::FIT_KNOTS, fsdp::PATH_G_SPLIT, fsdp::FIT_KNOTS, true>(n_frames, poses, matched, out);
   else if (G == 2008)  // the WIDE instantiations (32 knots per fit: contexts with a global path)
     emu_path_split_launch<8, fsdp::WIDE_KNOTS, 8, fsdp::WIDE_KNOTS>(n_frames, poses, matched, out);
-  else if (G == 1001)  // split pipeline, the refit with one frame per lane
-    emu_path_split_launch<1, fsdp::FIT_KNOTS>(n_frames, poses, matched, out);
   else if (G == 1016)  // the three kernels with 16 lanes per frame (one pass of a mid-size batch)
     emu_path_split_launch<16, fsdp::FIT_KNOTS, 16>(n_frames, poses, matched, out);
   else

@@ -81,7 +81,7 @@ def match(offsets, cones, poses, sorted_out):
 
 # lanes per frame of the one-kernel path stage (8 / 16 / 64), and the three-kernel path stage the library launches for
 # large batches with 4 or 8 lanes per frame in its fit kernel (1004 / 1008)
-PATH_GROUP_SIZES = (8, 16, 64, 1004, 1008, 1016, 1001, 2008, 3004)  # 1001: the refit with one frame per lane (fit_lanes_kernel); 2008: the wide (32-knot) three kernels; 3004: 1004 + the 32-knot list kernels behind it
+PATH_GROUP_SIZES = (8, 16, 64, 1004, 1008, 1016, 2008)  # 2008: the wide (32-knot) three kernels
 
 
 def last_retries():

@@ -17,16 +17,11 @@ import oracle_lib  # noqa: E402
 
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-MODES = {"mono64": {"FSDP_PATH_MODE": "mono"}, "split16": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "0"},
-         "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "8", "FSDP_FIT_LANES": "0"},
-         "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4", "FSDP_FIT_LANES": "0"},
-         "fit_lanes": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_LANES": "1"}}
-ctxs = {}
-for name, env in MODES.items():
-    for k in ("FSDP_PATH_MODE", "FSDP_PACK", "FSDP_FIT_G", "FSDP_FIT_LANES"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    ctxs[name] = pkg.Context(device=0)  # the environment is read at context creation
+# fsdp_set_option pins the path-stage instantiation; "default" = the library's own choice (a blocking call of 2048 frames or
+# more is pipelined in chunks, include/fsdp.h)
+MODES = {"mono64": {"path_mode": 1}, "split16": {"path_mode": 2, "pack": 1}, "packed8": {"path_mode": 2, "pack": 2, "fit_g": 8},
+         "packed8_fit4": {"path_mode": 2, "pack": 2, "fit_g": 4}, "default": {}}
+ctxs = {name: pkg.Context(device=0, options=opt) for name, opt in MODES.items()}
 bad_total = 0
 seed = 100
 for per_side, track_noise, frame_noise, colour in itertools.product((24, 64, 100), (0.1, 0.3), (0.0, 0.15, 0.3, 0.5), (True, False)):

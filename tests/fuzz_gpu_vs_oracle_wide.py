@@ -20,16 +20,13 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 PARAMS = {"k8_l16": dict(max_n_neighbors=8, max_length=16),
           "h64_30m": dict(mpc_prediction_horizon=64, mpc_path_length=30),
           "k7_l15_d7_h55": dict(max_n_neighbors=7, max_length=15, max_dist=7.0, mpc_prediction_horizon=55)}
-MODES = {"mono64": {"FSDP_PATH_MODE": "mono"}, "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4", "FSDP_FIT_LANES": "0"}}
+MODES = {"mono64": {"path_mode": 1}, "packed8_fit4": {"path_mode": 2, "pack": 2, "fit_g": 4}}
 bad_total = frames_total = refused_total = 0
 seed = 500
 for pname, prm in PARAMS.items():
     ctxs = {}
-    for name, env in MODES.items():
-        for k in ("FSDP_PATH_MODE", "FSDP_PACK", "FSDP_FIT_G", "FSDP_FIT_LANES"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        ctxs[name] = pkg.Context(device=0, params=prm)  # the environment is read at context creation
+    for name, opt in MODES.items():
+        ctxs[name] = pkg.Context(device=0, params=prm, options=opt)
         assert ctxs[name].shapes is pkg.WIDE
     for per_side, track_noise, frame_noise, colour in itertools.product((24, 64), (0.1, 0.3), (0.0, 0.3), (True, False)):
         seed += 1
@@ -40,7 +37,7 @@ for pname, prm in PARAMS.items():
         ok = ref["status"] == 0
         for name, ctx in ctxs.items():
             res = ctx.plan_batch(off, cones, poses)
-            # a refit beyond the 64 knots a frame's workspace holds is refused with FSDP_OVERFLOW_KNOTS (include/fsdp.h: never
+            # a refit beyond the 256 knots the exact kernel keeps would be refused with FSDP_OVERFLOW_KNOTS (include/fsdp.h: never
             # truncated); the oracle's vectors grow.  Sides of 16 cones on noisy frames get there now and then: counted apart
             refused = (res["status"] == 204) & (ref["status"] == 0)
             refused_total += int(refused.sum())
@@ -55,10 +52,10 @@ for pname, prm in PARAMS.items():
             bad |= ok & (np.isnan(res["path"]) != np.isnan(ref["path"])).reshape(len(ok), -1).any(axis=1)
             bad_total += int(bad.sum())
             frames_total += len(ok)
-            note = f", {int(refused.sum())} refused (more than 64 knots)" if refused.any() else ""
+            note = f", {int(refused.sum())} refused (more than 256 knots)" if refused.any() else ""
             print(f"{pname:14s} cones/side {per_side:3d} track sigma {track_noise} frame sigma {frame_noise} colour {int(colour)} {name:12s}: "
                   f"{int(bad.sum())} of {len(ok)} frames differ (status ok {int(ok.sum())}, longest side {int(max(ref['n_left'].max(), ref['n_right'].max()))}{note})"
                   + (f"  first: {np.nonzero(bad)[0][:5].tolist()}" if bad.any() else ""), flush=True)
     for c in ctxs.values():
         c.close()
-print(f"TOTAL differing frames: {bad_total} of {frames_total}; refused with FSDP_OVERFLOW_KNOTS (the oracle's refit holds 68 ... 171 knots there): {refused_total}")
+print(f"TOTAL differing frames: {bad_total} of {frames_total}; refused with FSDP_OVERFLOW_KNOTS (round 5, 64 knots: 4; the oracle holds 68 ... 171 there): {refused_total}")

@@ -188,3 +188,44 @@ def test_config4_union_does_not_depend_on_rank_count():
     parts = [pkg.synth.make_config4_shard(*pkg.dist.frame_range(r, 3, 12), 100, 0.1, seed=7) for r in range(3)]
     assert np.array_equal(np.concatenate([p[1] for p in parts]), whole[1])
     assert np.array_equal(np.concatenate([p[2] for p in parts]), whole[2])
+
+
+def test_a_multi_rank_line_without_rccl_is_an_error_unless_accepted():
+    """bench.py's exit status for N > 1 (dist.multi_rank_exit_status; round-5 review item 8): a scaling curve must not quietly be
+    made of ranks that met over the TCP star — status 3 unless RCCL carried the start-up collectives with every rank in the
+    communicator (`rccl_ranks` of the line = ncclCommCount before the release) or the caller passed --allow-tcp-fallback."""
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    st = pkg.dist.multi_rank_exit_status
+    assert st(1, False, "none", 0, False) == 0                 # one rank: nothing to claim
+    assert st(8, False, "rccl", 8, False) == 0                 # the real thing
+    assert st(8, False, "tcp-fallback", 0, False) == 3         # RCCL did not come up
+    assert st(8, False, "rccl", 4, False) == 3                 # a communicator that does not hold every rank
+    assert st(8, False, "tcp-fallback", 0, True) == 0          # accepted explicitly
+    assert st(8, True, "in-process", 0, False) == 0            # --single-process: one process by design, no collective at all
+    src = (ROOT / "bench.py").read_text()
+    assert "--allow-tcp-fallback" in src and "multi_rank_exit_status" in src and '"rccl_ranks"' in src
+
+
+def _fallback_worker(rank, world, port, key, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      FSDP_LAUNCH_KEY=key)
+    pkg = importlib.import_module("ft-fsd-path-planning_amd")
+    d = pkg.dist.Dist()  # no GPU here: the TCP star is the only transport, exactly the state of a rank whose RCCL bootstrap failed
+    q.put((rank, d.transport, d.rccl_ranks, pkg.dist.multi_rank_exit_status(d.world, False, d.transport, d.rccl_ranks, False),
+           pkg.dist.multi_rank_exit_status(d.world, False, d.transport, d.rccl_ranks, True)))
+    d.barrier()
+    d.close()
+
+
+def test_ranks_on_the_tcp_star_report_zero_rccl_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, f"test-{port}", q)) for r in range(2)]
+    for p in procs[::-1]:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, "tcp-fallback", 0, 3, 0), (1, "tcp-fallback", 0, 3, 0)]

@@ -94,8 +94,7 @@ def test_full_size_batches_against_oracle(pkg, ctx, cfg, monkeypatch):
     every frame against the oracle (all host cores).  cfg2_packed: the 8-lane kernels bench.py's overlapped passes run
     (a single pass would get the 16-lane ones)."""
     if cfg == "cfg2_packed":
-        monkeypatch.setenv("FSDP_PACK", "1")
-        ctx = pkg.Context(device=0)
+        ctx = pkg.Context(device=0, options={"pack": 2})
         cfg = "cfg2"
     if cfg == "cfg2":
         off, cones, poses = pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
@@ -451,20 +450,15 @@ def test_overlapped_passes_equal_serial_passes(pkg):
     assert ctx.plan_batch(off, cones, poses)["path"].tobytes() == ref["path"].tobytes()
 
 
-@pytest.mark.parametrize("mode", ["mono64", "split16", "packed8", "packed8_fit4", "packed8_fit_lanes"])
-def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, mode):
+@pytest.mark.parametrize("mode", ["mono64", "split16", "packed8", "packed8_fit4"])
+def test_every_path_kernel_instantiation_equals_oracle(pkg, mode):
     """The library picks the path-stage kernels from the batch size and the passes in flight (fsdp_lib.hip launch_path):
     one kernel with 64 lanes per frame, or prep / fit / finish with 16 lanes per frame, or the packed ones (8 lanes per
-    frame; the fit kernel optionally 4) that bench.py's overlapped passes run.  The environment pins the choice; every
+    frame; the fit kernel optionally 4) that bench.py's overlapped passes run.  fsdp_set_option pins the choice; every
     instantiation must reproduce the oracle bit for bit."""
-    env = {"mono64": {"FSDP_PATH_MODE": "mono"}, "split16": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "0"},
-           "packed8": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "8", "FSDP_FIT_LANES": "0"},
-           "packed8_fit4": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_G": "4", "FSDP_FIT_LANES": "0"},
-           # the refit with one frame per lane (fit_lanes_kernel), whatever the number of frames in flight
-           "packed8_fit_lanes": {"FSDP_PATH_MODE": "split", "FSDP_PACK": "1", "FSDP_FIT_LANES": "1"}}[mode]
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    ctx = pkg.Context(device=0)
+    options = {"mono64": {"path_mode": 1}, "split16": {"path_mode": 2, "pack": 1},
+               "packed8": {"path_mode": 2, "pack": 2, "fit_g": 8}, "packed8_fit4": {"path_mode": 2, "pack": 2, "fit_g": 4}}[mode]
+    ctx = pkg.Context(device=0, options=options)
     off, cones, poses = pkg.synth.make_replay_batch(300, 64, 0.15, seed=21, color=True)
     off2, cones2, poses2 = pkg.synth.make_replay_batch(211, 100, 0.0, seed=22, frame_noise=0.3, random_pose=True, color=False)
     for o, c, p in ((off, cones, poses), (off2, cones2, poses2)):
@@ -473,13 +467,12 @@ def test_every_path_kernel_instantiation_equals_oracle(pkg, monkeypatch, mode):
             ref = oracle_lib.plan_batch(o, c, p, n_threads=os.cpu_count() or 1)
         _assert_equal_to_oracle(res, ref)
     names = ctx.stage_names()
-    want = {"mono64": "path_kernel<64>", "split16": "fit_kernel<16>", "packed8": "fit_kernel<8>", "packed8_fit4": "fit_kernel<4>",
-            "packed8_fit_lanes": "fit_lanes_kernel"}[mode]
+    want = {"mono64": "path_kernel<64>", "split16": "fit_kernel<16>", "packed8": "fit_kernel<8>", "packed8_fit4": "fit_kernel<4>"}[mode]
     assert want in names, names
     assert ("path_prep_kernel<8>" in names) == mode.startswith("packed"), names
 
 
-def test_both_sorting_state_sizes_equal_oracle(pkg, monkeypatch):
+def test_both_sorting_state_sizes_equal_oracle(pkg):
     """A batch whose frames hold at most 128 cones is sorted by sort_kernel_128 (half-size frame state, four wavefronts per
     SIMD), any other batch by sort_kernel (255 cones): same results from both, equal to the oracle."""
     off, cones, poses = pkg.synth.make_replay_batch(512, 64, 0.15, seed=31, color=True)
@@ -489,8 +482,7 @@ def test_both_sorting_state_sizes_equal_oracle(pkg, monkeypatch):
     ctx = pkg.Context(device=0)
     small = [ctx.plan_batch(o, c, p) for o, c, p in ((off, cones, poses), (off2, cones2, poses2))]
     assert "sort_kernel_128" in ctx.stage_names()
-    monkeypatch.setenv("FSDP_NO_SORT128", "1")
-    ctx2 = pkg.Context(device=0)
+    ctx2 = pkg.Context(device=0, options={"no_sort128": 1})
     large = [ctx2.plan_batch(o, c, p) for o, c, p in ((off, cones, poses), (off2, cones2, poses2))]
     assert "sort_kernel_128" not in ctx2.stage_names()
     for a, b, ref in zip(small, large, refs):
@@ -499,7 +491,6 @@ def test_both_sorting_state_sizes_equal_oracle(pkg, monkeypatch):
             assert a[f].tobytes() == b[f].tobytes(), f
     # 129 cones in one frame of the batch: the library takes the 255-cone kernel by itself
     off3, cones3, poses3 = pkg.synth.make_replay_batch(8, 65, 0.15, seed=33, color=True)
-    monkeypatch.delenv("FSDP_NO_SORT128")
     ctx3 = pkg.Context(device=0)
     res3 = ctx3.plan_batch(off3, cones3, poses3)
     assert "sort_kernel_128" not in ctx3.stage_names()
@@ -909,8 +900,12 @@ def test_refit_spline_equals_oracle(pkg, ctx):
     about) of every sampled frame of a 2048-frame batch equal the oracle's second spline of that frame bit for bit —
     and the oracle's splines equal the reference's (tests/test_oracle_golden.py::test_oracle_splines_match_reference_per_frame)."""
     off, cones, poses = pkg.synth.make_replay_batch(2048, 64, 0.15, seed=1, color=True)
-    res = ctx.plan_batch(off, cones, poses)
-    nk, t, c = ctx.debug_refit()
+    ctx.set_option("plan_chunks", 1)  # (fsdp_debug_refit reads the most recent PASS: the batch is one)
+    try:
+        res = ctx.plan_batch(off, cones, poses)
+        nk, t, c = ctx.debug_refit()
+    finally:
+        ctx.set_option("plan_chunks", 0)
     assert (nk > 0).mean() > 0.95  # the fast route
     checked = 0
     with oracle_lib.math_mode(1):
@@ -1011,9 +1006,8 @@ def test_both_forms_of_the_exact_route_return_the_same_bytes(pkg, monkeypatch):
     gp = np.array([centre_fn(s)[0] for s in np.linspace(0, 1, 600, endpoint=False)])
     smooth = pkg.synth.make_replay_batch(1300, 40, 0.15, seed=33, color=True)
     got = {}
-    for form, env in (("whole", "1000000"), ("shared", "0")):
-        monkeypatch.setenv("FSDP_RETRY_PACK_MIN", env)
-        c = pkg.Context(device=0)
+    for form, pack_min in (("whole", 1000000), ("shared", 1)):
+        c = pkg.Context(device=0, options={"retry_pack_min": pack_min})
         r1 = c.plan_batch(*noisy)
         assert c.route_stats()[1]  # the exact route was needed
         c.set_global_path(gp)
@@ -1023,3 +1017,27 @@ def test_both_forms_of_the_exact_route_return_the_same_bytes(pkg, monkeypatch):
     for a, b in zip(got["whole"], got["shared"]):
         assert a.tobytes() == b.tobytes()
     assert (got["whole"][1]["status"] == 0).mean() > 0.99
+
+
+@pytest.mark.parametrize("seed,frame,knots", [(511, 901, 68), (516, 1001, 171)])
+def test_refits_beyond_64_knots_are_planned_on_the_gpu(pkg, seed, frame, knots):
+    """FITPACK's nest is m + 2k (utils/spline_fit.py:117): the noisiest frames of round 5's wide fuzz end their refit with 68 and 171 knots and
+    were refused with FSDP_OVERFLOW_KNOTS while the exact kernel kept 64; it keeps 256 now (csrc/spline_device.h NK_BIG).  Whole sets of 1024
+    frames through the library's own choice of kernels (three-kernel path stage -> retry list -> path_retry_kernel's two levels) and
+    through the one-kernel stage: no frame refused, every frame equal to the oracle's wide build."""
+    import oracle_lib_wide
+
+    per_side, track, noise, colour = {511: (64, 0.1, 0.3, True), 516: (64, 0.3, 0.3, False)}[seed]
+    off, cones, poses = pkg.synth.make_replay_batch(1024, per_side, track, seed=seed, frame_noise=noise, random_pose=True, color=colour)
+    prm = dict(max_n_neighbors=8, max_length=16)
+    with oracle_lib_wide.params(prm), oracle_lib_wide.math_mode(1):
+        ref = oracle_lib_wide.plan_batch(off, cones, poses, n_threads=os.cpu_count() or 1)
+        _, nf, fits = oracle_lib_wide.plan_frame_capture(cones[off[frame] : off[frame + 1]], poses[frame])
+    assert max(f[1] for f in fits[:nf]) == knots and ref["status"][frame] == 0
+    for options in ({}, {"path_mode": 1}, {"path_mode": 2, "pack": 2}):
+        ctx = pkg.Context(device=0, params=prm, options=options)
+        assert ctx.shapes is pkg.WIDE
+        res = ctx.plan_batch(off, cones, poses)
+        assert not (res["status"] == 204).any()
+        _assert_equal_to_oracle(res, ref)
+        ctx.close()

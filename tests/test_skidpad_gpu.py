@@ -156,19 +156,19 @@ def _same_fields(a, b):
     return a.dtype == b.dtype and all(np.ascontiguousarray(a[k]).tobytes() == np.ascontiguousarray(b[k]).tobytes() for k in a.dtype.names)
 
 
-@pytest.mark.parametrize("n,group,pack_min", [(3, None, None), (64, "3", None), (700, None, None), (1100, "5", None), (40, "16", "1"), (1600, None, None), (24, "7", "100")])
+@pytest.mark.parametrize("n,group,pack_min", [(3, None, None), (64, 3, None), (700, None, None), (1100, 5, None), (40, 16, 1), (1600, None, None), (24, 7, 100)])
 def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, n, group, pack_min):
     """Steps in flight (csrc/skidpad_kernel.h): a replay that submits ahead has up to 16 consecutive steps planned by one
     group of launches — a wavefront per (instance, step), each working from the window index its predecessors' poses lead
     to and waiting for its predecessor's published state before it keeps or repeats its result; or, from 2048 (instance,
-    step) pairs (FSDP_SKID_PACK_MIN), the packed kernels of the autocross path stage with the planners' own wavefronts
+    step) pairs (option "skid_pack_min"), the packed kernels of the autocross path stage with the planners' own wavefronts
     committing the steps in order.  Results, planner information and the states' further course must be those of one
     launch per step — bit for bit, through the relocalization, through steps that read the previous path (a car 60 m off
     the track), steps that fail (positions that are not finite) and jumps of the window index."""
     if group:
-        monkeypatch.setenv("FSDP_SKID_GROUP", group)
+        monkeypatch.setitem(pkg._capi.DEFAULT_OPTIONS, "skid_group", group)
     if pack_min:
-        monkeypatch.setenv("FSDP_SKID_PACK_MIN", pack_min)
+        monkeypatch.setitem(pkg._capi.DEFAULT_OPTIONS, "skid_pack_min", pack_min)
     g = sk.load_sequence(golden_dir)
     tf = sk.perturbed_instances(g, n)
     frames = sk.awkward_frames(g, tf, 64)
@@ -194,9 +194,9 @@ def test_steps_submitted_ahead_equal_single_steps(pkg, golden_dir, monkeypatch, 
 def test_random_skidpad_traffic(pkg, golden_dir, monkeypatch):
     """Stress of the deferred launches: 50 planners over 150 frames (the awkward ones first), steps submitted in bursts of
     random length, collected in random order and at random times (a collect launches whatever group is pending, so groups
-    of every size 1 ... 16 occur and both routes — FSDP_SKID_PACK_MIN lowered to 300 pairs — alternate), single blocking
+    of every size 1 ... 16 occur and both routes — option "skid_pack_min" lowered to 300 pairs — alternate), single blocking
     steps in between.  Every result must be the one-launch-per-step result, bit for bit."""
-    monkeypatch.setenv("FSDP_SKID_PACK_MIN", "300")
+    monkeypatch.setitem(pkg._capi.DEFAULT_OPTIONS, "skid_pack_min", 300)
     n = 50
     g = sk.load_sequence(golden_dir)
     tf = sk.perturbed_instances(g, n)
@@ -239,8 +239,8 @@ def test_timing_launches_leave_no_trace(pkg, golden_dir, monkeypatch):
     counters the wavefronts of grouped launches wait on (round-3 advisor: with stale counters the second step of the next
     group did not wait for the first one's state).  Steps, timing launches, then a replay submitted ahead through the
     wavefront-per-(instance, step) kernel: every result must equal the one-launch-per-step planners that were never timed."""
-    monkeypatch.setenv("FSDP_SKID_GROUP", "5")
-    monkeypatch.setenv("FSDP_SKID_PACK_MIN", "1000000")  # keep the groups on skid_path_kernel (the kernel that waits)
+    monkeypatch.setitem(pkg._capi.DEFAULT_OPTIONS, "skid_group", 5)
+    monkeypatch.setitem(pkg._capi.DEFAULT_OPTIONS, "skid_pack_min", 1000000)  # keep the groups on skid_path_kernel (the kernel that waits)
     n = 48
     g = sk.load_sequence(golden_dir)
     tf = sk.perturbed_instances(g, n)

@@ -69,13 +69,12 @@ def test_different_batches_in_flight_equal_serial_calls(pkg, golden_dir, depth, 
     ctx.close()
 
 
-def test_route_prediction_never_changes_results(pkg, golden_dir, monkeypatch):
-    """The same stream with both route kernels forced into every pass (FSDP_ALWAYS_ROUTE): no pass is repeated, same bytes."""
+def test_route_prediction_never_changes_results(pkg, golden_dir):
+    """The same stream with both route kernels forced into every pass (option "always_route"): no pass is repeated, same bytes."""
     batches = _batches(pkg, golden_dir)
     a = pkg.Context(device=0)
     a.set_overlap(3)
-    monkeypatch.setenv("FSDP_ALWAYS_ROUTE", "1")
-    b = pkg.Context(device=0)
+    b = pkg.Context(device=0, options={"always_route": 1})
     b.set_overlap(3)
     for batch in batches:
         ra = a.collect(a.submit(*batch))
@@ -179,3 +178,88 @@ def test_random_ticket_traffic(pkg, golden_dir):
         # blocking calls work again once nothing is outstanding
         assert _same(ctx.plan_batch(*pool[0]), ref[0])
         ctx.close()
+
+
+def _compact_of(pkg, full):
+    """The fields of fsdp_compact_result cut out of full result records."""
+    out = np.zeros(len(full), pkg.COMPACT_DTYPE)
+    for f in ("path", "left_idx", "right_idx", "status"):
+        out[f] = full[f]
+    for f in ("n_left", "n_right", "path_fallback", "n_dense"):
+        assert full[f].min(initial=0) >= 0 and full[f].max(initial=0) < 256, f
+        out[f] = full[f]
+    return out
+
+
+def _same_fields(a, b):
+    return a.dtype == b.dtype and len(a) == len(b) and all(np.ascontiguousarray(a[f]).tobytes() == np.ascontiguousarray(b[f]).tobytes() for f in a.dtype.names)
+
+
+@pytest.mark.parametrize("unknown", [True, False])
+def test_compact_results_are_the_full_results_fields(pkg, golden_dir, unknown):
+    """fsdp_submit_compact / fsdp_plan_batch_compact (include/fsdp.h: path, sorted indices, status — 1384 instead of 2408 bytes per frame
+    over PCIe): every record equals the same fields of the full record, page-locked (written in place by the assembly kernel) and
+    pageable (copied), as tickets and as the blocking call, also with use_unknown_cones = False (the indices go through the filter's
+    map back into the caller's index space) and for the frames of the route kernels."""
+    assert pkg.COMPACT_DTYPE.itemsize == 1384
+    params = None if unknown else dict(use_unknown_cones=False)
+    ctx = pkg.Context(device=0, params=params)
+    ctx.set_overlap(3)
+    for k, b in enumerate(_batches(pkg, golden_dir)):
+        full = ctx.plan_batch(*b)
+        want = _compact_of(pkg, full)
+        assert _same_fields(ctx.plan_batch(*b, compact=True), want), k
+        assert _same_fields(ctx.collect(ctx.submit(*b, compact=True, out=np.zeros(len(full), pkg.COMPACT_DTYPE))), want), k
+        pin = (pkg.pinned_copy(b[0], np.int32), pkg.pinned_copy(b[1], np.float64), pkg.pinned_copy(b[2], np.float64))
+        assert _same_fields(ctx.collect(ctx.submit(*pin, compact=True)), want), k
+        assert _same_fields(ctx.plan_batch(*pin, compact=True, out=pkg.pinned_empty(len(full), pkg.COMPACT_DTYPE)), want), k
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [2048, 2049, 4096, 5000])
+def test_a_blocking_call_pipelined_in_chunks_equals_one_pass(pkg, n):
+    """fsdp_plan_batch cuts a batch of 2048 frames or more into up to four chunks on pass slots of their own (include/fsdp.h): same
+    bytes as the batch in one pass (option "plan_chunks" = 1), pageable and page-locked, full and compact records, with previous
+    paths, and with frames that need the route kernels in some chunks only."""
+    off, cones, poses = pkg.synth.make_replay_batch(n, 100, 0.0, seed=70 + n % 7, color=False, frame_noise=0.3, random_pose=True)
+    prev = np.random.default_rng(3).normal(size=(n, 40, 4))
+    prev[:, :, 0] = np.abs(prev[:, :, 0]).cumsum(axis=1)
+    one = pkg.Context(device=0, options={"plan_chunks": 1})
+    ref = one.plan_batch(off, cones, poses)
+    ref_prev = one.plan_batch(off, cones, poses, prev_paths=prev)
+    assert one.route_stats()[1]  # the noisy set leaves the packed kernels
+    one.close()
+    ctx = pkg.Context(device=0)
+    assert _same(ctx.plan_batch(off, cones, poses), ref)
+    assert _same(ctx.plan_batch(off, cones, poses, prev_paths=prev), ref_prev)
+    pin = (pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64))
+    out = pkg.pinned_empty(n, pkg.RESULT_DTYPE)
+    assert _same(ctx.plan_batch(*pin, out=out), ref)
+    assert _same_fields(ctx.plan_batch(*pin, compact=True), _compact_of(pkg, ref))
+    # the context is as usable as before: tickets, the resident form
+    ctx.set_overlap(2)
+    assert _same(ctx.collect(ctx.submit(*pin)), ref)
+    ctx.upload(off, cones, poses)
+    ctx.run()
+    assert _same(ctx.download(), ref)
+    ctx.close()
+
+
+def test_options_are_checked_and_a_lone_ticket_is_planned_as_a_lone_batch(pkg):
+    """fsdp_set_option refuses what it does not know; and the packing follows the frames really in flight: one ticket of 4096 frames
+    on a context of depth 10 gets the lone batch's kernels (16 lanes per frame), ten of them in flight the packed ones."""
+    ctx = pkg.Context(device=0)
+    with pytest.raises(pkg.FsdpError, match="unknown option"):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(pkg.FsdpError, match="out of range"):
+        ctx.set_option("fit_g", 5)
+    off, cones, poses = pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
+    pin = (pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64))
+    ctx.set_overlap(10)
+    ref = ctx.collect(ctx.submit(*pin)).copy()
+    assert "fit_kernel<16>" in ctx.stage_names(), ctx.stage_names()
+    tickets = [ctx.submit(*pin) for _ in range(6)]
+    assert "fit_kernel<4>" in ctx.stage_names(), ctx.stage_names()
+    for t in tickets:
+        assert _same(ctx.collect(t), ref)
+    ctx.close()

@@ -9,6 +9,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 import os
 if os.environ.get("AB_LIB"):  # an experiment build (tools/build_variant.sh)
     pkg._capi.LIB_PATH = Path(os.environ["AB_LIB"])

@@ -9,6 +9,7 @@ import sys, importlib, time, json, numpy as np
 from pathlib import Path
 sys.path.insert(0, %r)
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 pkg._capi.LIB_PATH = Path(sys.argv[1])
 ctx = pkg.Context(device=0)
 off, cones, poses = pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)

@@ -14,6 +14,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 ctx = pkg.Context(device=0)
 off, cones, poses = pkg.synth.make_replay_batch(4096, 64, 0.15, seed=1, color=True)
 out = {}

@@ -27,6 +27,7 @@ import os
 
 os.environ.setdefault("FSDP_PACK", "1")  # the packed kernels the overlapped bench runs (a single pass alone would get 16 lanes per frame)
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 pkg._capi.LIB_PATH = so
 ctx = pkg.Context(device=0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -17,6 +17,7 @@ so.parent.mkdir(exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-sink-insts-to-avoid-spills=1", "-fPIC", "-shared",
                 "-DFSDP_PROFILE", str(PKG / "csrc" / "fsdp_lib.hip"), "-o", str(so), "-ldl"], check=True, capture_output=True)
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 pkg._capi.LIB_PATH = so
 ctx = pkg.Context(device=0)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]

@@ -8,6 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import skidpad_support as sk
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 n, depth = int(sys.argv[1]), int(sys.argv[2])
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 g = sk.load_sequence(ROOT / "tests" / "golden")

@@ -4,6 +4,7 @@ import numpy as np
 ROOT = Path("/root/repo"); sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import skidpad_support as sk
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 n = int(sys.argv[1]); DEPTH = 32
 g = sk.load_sequence(ROOT / "tests" / "golden")
 tf = sk.perturbed_instances(g, n)

@@ -11,6 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import oracle_lib
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 NAMES = ["start-cone bearing (sign, pi/10, 4pi/5)", "second cone on the vehicle's side (sign, 5 deg)", "|turn| vs absolute threshold (65 deg)",
          "turn vs directional threshold (40 deg)", "sign flip of consecutive turns (signs, 1.3 rad)", "acos thresholds, in the cosine (150/90/30 deg)",
          "wrong-direction cost terms (sign, 40 deg)", "cost arg-min: relative gap to the runner-up", "combination of the sides (turn signs)"]

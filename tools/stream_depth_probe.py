@@ -5,6 +5,7 @@ import importlib, sys, json, os
 sys.path.insert(0, os.getcwd())
 import bench
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 ctx = pkg.Context(device=0)
 for depth in (10, 14, 16, 20):
     r = bench.streaming_leg(pkg, ctx, 4096, depth, 100, 1)

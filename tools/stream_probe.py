@@ -8,6 +8,7 @@ sys.path.insert(0, str(ROOT))
 import numpy as np
 import bench
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 ctx = pkg.Context(device=0)
 for per_gpu, nb in ((4096, 40), (8192, 20), (2048, 80)):
     for depth in (1, 2, 4, 6, 10, 16):

@@ -7,6 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import numpy as np
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
