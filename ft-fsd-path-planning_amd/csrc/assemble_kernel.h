@@ -59,6 +59,10 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
     const int32_t* m = m32 ? m32 + (size_t)f * MW : nullptr;
     const int32_t* p = p32 + (size_t)f * PW;
     int32_t* r = r32 + (size_t)f * RESULT_WORDS;
+    // use_unknown_cones = False: indices of the compacted frame -> the caller's.  Only indices that ARE indices of that frame: a frame
+    // the sorting kernel handed to sort_big_kernel in a pass that does not carry it (the pass is then repeated) leaves its record's
+    // index fields unwritten, and mapping such a word read past the map (a GPU memory fault, found by round 6's compact-record tests)
+    const int32_t n_map = remap ? remap_off[f + 1] - remap_off[f] : 0;
     // status: the latest stage that reported something decides (fsdp_lib.hip assemble())
     if (lane == 0) {
       int st = s ? s[FSDP_SW(status)] : 0;
@@ -75,7 +79,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
     for (int w = FSDP_RW(n_left) + lane; w < FSDP_RW(n_left_v); w += 64) {
       int32_t v = s ? s[FSDP_SW(n_left) + (w - FSDP_RW(n_left))] : ((w >= FSDP_RW(left_idx)) ? -1 : 0);
       // (use_unknown_cones = False, filter_kernel.h: the sorter saw a compacted frame; indices go out in the caller's index space)
-      if (remap && w >= FSDP_RW(left_idx) && v >= 0) v = remap[remap_off[f] + v];
+      if (remap && w >= FSDP_RW(left_idx) && v >= 0 && v < n_map) v = remap[remap_off[f] + v];
       r[w] = v;
     }
     // left_v | right_v | l2r | r2l
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(int n_frames, const SortO
     for (int w = FSDP_RW(n_configs_left) + lane; w < FSDP_RW(path_fallback); w += 64) {
       int32_t v = 0;
       if (s) v = (w < FSDP_RW(best_cost_left)) ? s[FSDP_SW(n_configs_left) + (w - FSDP_RW(n_configs_left))] : s[FSDP_SW(best_cost_left) + (w - FSDP_RW(best_cost_left))];
-      if (remap && w >= FSDP_RW(first_k_left) && w < FSDP_RW(best_cost_left) && v >= 0) v = remap[remap_off[f] + v];
+      if (remap && w >= FSDP_RW(first_k_left) && w < FSDP_RW(best_cost_left) && v >= 0 && v < n_map) v = remap[remap_off[f] + v];
       r[w] = v;
     }
   }
@@ -136,7 +140,7 @@ __global__ void __launch_bounds__(256) assemble_compact_kernel(int n_frames, con
     for (int w = lane; w < IDX0; w += 64) r[w] = p[FSDP_PW(path) + w];
     if (lane < 2 * MAX_LEN) {  // left_idx | right_idx are one run of the sorting record
       int32_t v = s[FSDP_SW(left_idx) + lane];
-      if (remap && v >= 0) v = remap[remap_off[f] + v];
+      if (remap && v >= 0 && v < remap_off[f + 1] - remap_off[f]) v = remap[remap_off[f] + v];  // (see assemble_kernel)
       r[IDX0 + lane] = v;
     }
     if (lane == 0) {

@@ -133,7 +133,9 @@ struct Work {
     bool compact = false;                  // user_results holds compact records: fsdp_path_result (skidpad step) or
                                            // fsdp_compact_result (fsdp_submit_compact)
     size_t rec_bytes() const { return !compact ? sizeof(fsdp_frame_result) : (skid ? sizeof(PathOut) : sizeof(fsdp_compact_result)); }
-    fsdp_frame_result* h_stage = nullptr;  // pinned
+    fsdp_frame_result* h_stage = nullptr;  // pinned + mapped: the assembly kernel writes a pageable caller's results here
+    char* h_in = nullptr;                  // pinned + mapped: a small pageable batch is packed here and read by the sorting kernel itself
+    size_t cap_in = 0;
     SkidInfo* h_info = nullptr;            // pinned
     int cap_stage = 0, cap_info = 0;
     hipEvent_t done = nullptr;             // recorded behind the ticket's last command
@@ -329,6 +331,7 @@ static void free_work(Work& w) {
   if (w.h_trailer) (void)hipHostFree(w.h_trailer);
   for (Work::Ticket& t : w.tk) {
     if (t.h_stage) (void)hipHostFree(t.h_stage);
+    if (t.h_in) (void)hipHostFree(t.h_in);
     if (t.h_info) (void)hipHostFree(t.h_info);
     if (t.done) (void)hipEventDestroy(t.done);
   }
@@ -506,14 +509,15 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
   const double* prev = in.use_prev ? in.d_prev : nullptr;
   const int n = in.n_frames;
   // (the packed kernels hold degree-3 fits only: a context with max_deg < 3 plans every batch with the one-kernel stage)
-  const bool split = c->params.max_deg != 3 ? false : (c->force_path_mode ? c->force_path_mode == 2 : n > PATH_SMALL_BATCH);
+  // (by the frames in flight, like the packing: a 1024-frame chunk of a 4096-frame call is not a small batch)
+  const bool split = c->params.max_deg != 3 ? false : (c->force_path_mode ? c->force_path_mode == 2 : in_flight > PATH_SMALL_BATCH);
   if (!split) {
     mark(q, t, MARK_MAIN);
     // A context whose fits may be of degree 1 or 2 (max_deg < 3: utils/spline_fit.py:113) has no three-kernel form (those kernels
     // hold cubic fits only); its large batches run the one-kernel stage with FOUR frames per wavefront (16 lanes each, all
     // degrees, 32 knots per fit, the scaling-free divisions; what that form cannot hold goes to the exact kernel like any other
     // frame the packed kernels hand on) instead of one frame per wavefront.
-    const bool mono16 = c->force_path_mode != 1 && c->params.max_deg != 3 && n > PATH_SMALL_BATCH;
+    const bool mono16 = c->force_path_mode != 1 && c->params.max_deg != 3 && in_flight > PATH_SMALL_BATCH;
     if (mono16)
       hipLaunchKernelGGL(path_kernel<PATH_G_LATENCY>, dim3((n + WAVE / PATH_G_LATENCY - 1) / (WAVE / PATH_G_LATENCY)), dim3(WAVE), 0, q.stream, n, in.d_poses,
                          q.d_match, c->d_default_path, prev, c->d_gpath, c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
@@ -1198,44 +1202,97 @@ static Work::Ticket* find_ticket(fsdp_ctx* c, long long ticket, Work** slot) {
   return nullptr;
 }
 
-// enqueue ticket t's batch on slot q: inputs, the pass, the results' way back, the ticket's event
+// enqueue ticket t's batch on slot q: inputs, the pass with its results' way back, the ticket's event
 // in_flight: frames on the GPU next to this batch, its own included (< 0: counted from the outstanding tickets)
+// A pageable batch of up to SMALL_BATCH_BYTES is packed into the ticket's own page-locked block by the host (a memcpy of a few KB)
+// and then treated like any page-locked batch: the sorting kernel reads it over PCIe, no copy command is issued at all — three or
+// four hipMemcpyAsync calls from pageable memory cost a single-frame call ~30 us of its ~860.
+constexpr size_t SMALL_BATCH_BYTES = 256 * 1024;
+
 static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_routes, long long in_flight = -1) {
   const int n = t.n;
   // a bigger batch than the slot has seen: its buffers are replaced — not under the feet of the passes queued on the stream
   if (n > q.cap_frames || n > q.in.cap_frames || t.total > q.in.cap_cones || (t.prev && n > q.in.cap_prev)) HIP_TRY(c, hipStreamSynchronize(q.stream));
   if (int rc = ensure_work(c, q, n > 0 ? n : 1)) return rc;
-  const bool in_pinned = n > 0 && is_pinned(t.off, sizeof(int32_t) * ((size_t)n + 1)) && is_pinned(t.poses, sizeof(double) * 4 * (size_t)n) &&
-                         (t.total == 0 || is_pinned(t.cones + 3 * (size_t)t.off[0], sizeof(double) * 3 * t.total)) &&
-                         (!t.prev || is_pinned(t.prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n));
+  const int32_t* off = t.off;
+  const double* cones = t.cones;
+  const double* poses = t.poses;
+  const double* prev = t.prev;
+  bool in_pinned = n > 0 && is_pinned(off, sizeof(int32_t) * ((size_t)n + 1)) && is_pinned(poses, sizeof(double) * 4 * (size_t)n) &&
+                   (t.total == 0 || is_pinned(cones + 3 * (size_t)off[0], sizeof(double) * 3 * t.total)) &&
+                   (!prev || is_pinned(prev, sizeof(double) * PATH_POINTS * 4 * (size_t)n));
+  const size_t off_bytes = (sizeof(int32_t) * ((size_t)n + 1) + 15) & ~(size_t)15, cone_bytes = sizeof(double) * 3 * t.total,
+               pose_bytes = sizeof(double) * 4 * (size_t)n, prev_bytes = prev ? sizeof(double) * PATH_POINTS * 4 * (size_t)n : 0;
+  const size_t in_bytes = off_bytes + cone_bytes + pose_bytes + prev_bytes;
+  if (!in_pinned && n > 0 && in_bytes <= SMALL_BATCH_BYTES) {
+    if (in_bytes > t.cap_in) {
+      // (the block's previous user — this ticket entry's previous batch — was collected before the entry was handed out again)
+      if (t.h_in) (void)hipHostFree(t.h_in);
+      t.h_in = nullptr;
+      t.cap_in = 0;
+      const size_t want = std::max(in_bytes, (size_t)16384);
+      HIP_TRY(c, hipHostMalloc((void**)&t.h_in, want, hipHostMallocMapped));
+      t.cap_in = want;
+    }
+    int32_t* so = (int32_t*)t.h_in;
+    double* sc = (double*)(t.h_in + off_bytes);
+    double* sp = (double*)(t.h_in + off_bytes + cone_bytes);
+    double* sv = (double*)(t.h_in + off_bytes + cone_bytes + pose_bytes);
+    const int32_t b = off[0];
+    for (int i = 0; i <= n; i++) so[i] = off[i] - b;
+    if (cone_bytes) memcpy(sc, cones + 3 * (size_t)b, cone_bytes);
+    memcpy(sp, poses, pose_bytes);
+    if (prev) memcpy(sv, prev, prev_bytes);
+    off = so;
+    cones = sc;
+    poses = sp;
+    prev = prev ? sv : nullptr;
+    in_pinned = true;
+  }
   const bool out_pinned = n > 0 && is_pinned(t.user_results, t.rec_bytes() * (size_t)n);
   q.in.h_off = nullptr;
-  {
-    if (in_pinned && c->params.use_unknown_cones) {
-      // the pass's sorting kernel reads the batch from the caller's buffers and leaves the device copies (StageIn)
-      if (int rc = ensure_inputs(c, q.in, n, t.total, t.prev != nullptr)) return rc;
-      q.in.n_frames = n;
-      q.in.max_cones = t.max_cones;
-      q.in.use_prev = t.prev != nullptr;
-      q.in.h_off = (const int32_t*)device_view(t.off);
-      q.in.h_base = t.off[0];
-      // (the view of the slice's first row, addressed by offsets relative to h_base; never read when total = 0)
-      q.in.h_cones = t.total ? (const double*)device_view(t.cones + 3 * (size_t)t.off[0]) : (const double*)device_view(t.poses);
-      q.in.h_poses = (const double*)device_view(t.poses);
-      q.in.h_prev = t.prev ? (const double*)device_view(t.prev) : nullptr;
-    } else if (in_pinned) {
-      if (int rc = stage_inputs(c, q.in, q.stream, n, t.off, t.cones, t.poses, t.prev, t.total, t.max_cones)) return rc;
-    } else if (int rc = upload_inputs(c, q.in, q.stream, n, t.off, t.cones, t.poses, t.prev, t.total, t.max_cones)) {
-      return rc;
-    }
+  if (in_pinned && c->params.use_unknown_cones) {
+    // the pass's sorting kernel reads the batch from the page-locked buffers and leaves the device copies (StageIn)
+    if (int rc = ensure_inputs(c, q.in, n, t.total, prev != nullptr)) return rc;
+    q.in.n_frames = n;
+    q.in.max_cones = t.max_cones;
+    q.in.use_prev = prev != nullptr;
+    q.in.h_off = (const int32_t*)device_view(off);
+    q.in.h_base = off[0];
+    // (the view of the slice's first row, addressed by offsets relative to h_base; never read when total = 0)
+    q.in.h_cones = t.total ? (const double*)device_view(cones + 3 * (size_t)off[0]) : (const double*)device_view(poses);
+    q.in.h_poses = (const double*)device_view(poses);
+    q.in.h_prev = prev ? (const double*)device_view(prev) : nullptr;
+  } else if (in_pinned) {
+    if (int rc = stage_inputs(c, q.in, q.stream, n, off, cones, poses, prev, t.total, t.max_cones)) return rc;
+  } else if (int rc = upload_inputs(c, q.in, q.stream, n, off, cones, poses, prev, t.total, t.max_cones)) {
+    return rc;
   }
   t.via_stage = false;
   if (n > 0) {
-    q.result_dst = out_pinned ? (fsdp_frame_result*)device_view(t.user_results) : nullptr;
+    // Results always leave the GPU inside the pass's last kernel, written over PCIe into page-locked memory: the caller's own buffer,
+    // or — for a pageable one — the ticket's block, which fsdp_collect copies out (no copy command on the stream either way).
+    fsdp_frame_result* dst = t.user_results;
+    if (!out_pinned) {
+      if (n > t.cap_stage) {
+        if (t.h_stage) (void)hipHostFree(t.h_stage);
+        t.h_stage = nullptr;
+        t.cap_stage = 0;
+        const int want = std::max(n, 64);
+        HIP_TRY(c, hipHostMalloc((void**)&t.h_stage, sizeof(fsdp_frame_result) * (size_t)want, hipHostMallocMapped));
+        t.cap_stage = want;
+      }
+      dst = t.h_stage;
+      t.via_stage = true;
+    }
+    q.result_dst = (fsdp_frame_result*)device_view(dst);
+    if (!q.result_dst) {
+      c->err = "internal: result block is not mapped into the device's address space";
+      return 2;
+    }
     q.result_compact = t.compact;
     q.trailer_idx = (int)(&t - q.tk);  // the ticket's own trailer
     const int rc = launch_pass(c, q, q.in, nullptr, force_routes, in_flight >= 0 ? in_flight : frames_in_flight(c, n, true));
-    const bool direct = q.result_dst != nullptr;
     q.result_dst = nullptr;
     q.result_compact = false;
     q.trailer_idx = SLOT_QUEUE;
@@ -1245,21 +1302,6 @@ static int enqueue_ticket(fsdp_ctx* c, Work& q, Work::Ticket& t, bool force_rout
     t.seq = q.seq;
     t.ran_big = q.ran_big;
     t.ran_retry = q.ran_retry;
-    if (!direct) {
-      fsdp_frame_result* dst = t.user_results;
-      if (!out_pinned) {
-        if (n > t.cap_stage) {
-          if (t.h_stage) (void)hipHostFree(t.h_stage);
-          t.h_stage = nullptr;
-          t.cap_stage = 0;
-          HIP_TRY(c, hipHostMalloc((void**)&t.h_stage, sizeof(fsdp_frame_result) * (size_t)n, hipHostMallocDefault));
-          t.cap_stage = n;
-        }
-        dst = t.h_stage;
-        t.via_stage = true;
-      }
-      HIP_TRY(c, hipMemcpyAsync(dst, q.d_result, t.rec_bytes() * (size_t)n, hipMemcpyDeviceToHost, q.stream));
-    }
     HIP_TRY(c, hipGetLastError());
   }
   if (!t.done) HIP_TRY(c, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));

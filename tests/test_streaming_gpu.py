@@ -260,6 +260,6 @@ def test_options_are_checked_and_a_lone_ticket_is_planned_as_a_lone_batch(pkg):
     assert "fit_kernel<16>" in ctx.stage_names(), ctx.stage_names()
     tickets = [ctx.submit(*pin) for _ in range(6)]
     assert "fit_kernel<4>" in ctx.stage_names(), ctx.stage_names()
-    for t in tickets:
-        assert _same(ctx.collect(t), ref)
+    for i, t in enumerate(tickets):
+        assert _same_fields(ctx.collect(t), ref), i  # (field by field: a NumPy copy of a record array does not carry the padding bytes)
     ctx.close()
