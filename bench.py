@@ -52,7 +52,7 @@ PASS_OVERLAP = 20  # passes in flight in the timed region (fsdp_set_overlap).  R
 # queues: 5.0 M); with 20-32 queues twenty passes in flight give 5.7-5.9 M frames/s over 20 passes and 6.3-6.4 M over 100, against
 # 5.4 / 6.1-6.2 M with ten; 24 or more passes collapse (0.7-3.6 M).  22 queues, not 32: the queues of all processes on a GPU add up,
 # and a second process next to 24+ of them crawls (the skidpad child of this script: 5.3 -> 0.5 M; it gets 8 of its own).
-STREAM_DEPTH = 10  # pass slots of the host -> host streaming leg (two tickets queue on each)
+STREAM_DEPTH = 20  # pass slots of the host -> host streaming leg (two tickets queue on each; 5.10 / 5.23 / 5.34 M frames/s at 10 / 16 / 20)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 

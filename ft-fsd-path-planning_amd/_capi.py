@@ -406,7 +406,7 @@ class Context:
         return offsets, cones, poses, n
 
     def plan_batch(self, offsets, cones, poses, prev_paths=None, out=None, compact: bool = False) -> np.ndarray:
-        """One blocking call: the batch in, its results out (a batch of 2048 frames or more is pipelined in chunks inside the
+        """One blocking call: the batch in, its results out (a batch of 16 384 frames or more is pipelined in chunks inside the
         library).  prev_paths: per-frame previous paths (plan_batch_sequential).  out: the array the results go to — a page-locked
         one (pinned_empty) is written in place by the GPU.  compact: fsdp_compact_result records (path, sorted indices, status:
         self.compact_dtype) instead of the full ones."""

@@ -572,11 +572,11 @@ static void launch_path_retry(fsdp_ctx* c, Work& q, const Inputs& in) {
 static void launch_assemble(fsdp_ctx* c, Work& q, int n, bool skid, fsdp_frame_result* dst = nullptr, hipStream_t stream = nullptr,
                             const SkidInfo* info_src = nullptr, SkidInfo* info_dst = nullptr, const int32_t* remap = nullptr,
                             const int32_t* remap_off = nullptr, bool compact = false) {
-  (void)c;
   long long blocks = ((long long)n + 3) / 4;  // one wavefront per frame, four per workgroup (grid-stride beyond the cap)
   // results that go straight to host memory leave at the link's pace: a few hundred wavefronts keep it busy, more would
   // only sit on the SIMDs' wavefront slots with their stores pending while the other slots' kernels wait for a place
-  const long long cap = dst ? 128 : 16384;
+  (void)c;
+  const long long cap = dst ? 128 : 16384;  // (32 / 128 / 512 workgroups towards host memory: 5.1 / 5.2 / 5.4 M frames/s streamed, inside the noise: profiles/r06_streaming_probe.txt)
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   q.seq++;
@@ -1494,12 +1494,16 @@ int fsdp_route_stats(fsdp_ctx* c, int* expect_big, int* expect_retry, long long*
 }
 
 // ---- blocking calls on host buffers -------------------------------------------------------------------------------------
-// A batch of PLAN_CHUNK_MIN x 2 frames or more is cut into up to PLAN_CHUNKS contiguous chunks, each a ticket on a slot of its
-// own: one chunk's transfers (in place for page-locked buffers, staged by the runtime for pageable ones — then the host
-// copies chunk k + 1 while the kernels of chunk k run) go under the other chunks' kernels, and the first chunk's results
-// are on their way back while the last one is still being planned.  The chunks know they share the GPU (in_flight = the
-// whole batch): they run the kernels the whole batch would.  Results do not depend on the chunking.
-constexpr int PLAN_CHUNKS = 4, PLAN_CHUNK_MIN = 1024;
+// A LARGE blocking call is cut into up to PLAN_CHUNKS contiguous chunks, each a ticket on a slot of its own: one chunk's transfers
+// (in place for page-locked buffers, staged by the runtime for pageable ones — then the host copies chunk k + 1 while the kernels of
+// chunk k run) go under the other chunks' kernels, and the first chunk's results are on their way back while the last one is still
+// being planned.  Measured (tools/plan_probe.py, profiles/r06_plan_probe.txt): at 4096 frames chunks only add launches to a pass that is
+// one dependent chain anyway (2.39 -> 2.73 ms page-locked, 3.11 -> 3.32 ms pageable); from 16 384 frames they pay for pageable buffers
+// (10.2 -> 8.3 ms), at 65 536 for both (36.0 -> 26.6 ms pageable, 14.8 -> 13.4 ms page-locked).  Hence: four chunks from
+// PLAN_CHUNK_FROM frames on, none below.  The chunks know they share the GPU (in_flight = the whole batch) and run the kernels the
+// whole batch would.  Results do not depend on the chunking.  Option "plan_chunks" = k forces up to k chunks of >= PLAN_CHUNK_MIN frames
+// (tests), 1 = never.
+constexpr int PLAN_CHUNKS = 4, PLAN_CHUNK_FROM = 16384, PLAN_CHUNK_MIN = 512;
 
 static int plan_blocking(fsdp_ctx* c, int n_frames, const int32_t* off, const double* cones, const double* poses, const double* prev,
                          fsdp_frame_result* results, bool compact) {
@@ -1518,7 +1522,7 @@ static int plan_blocking(fsdp_ctx* c, int n_frames, const int32_t* off, const do
   c->last_slot = 0;
   c->last_n = n_frames;
   if (n_frames == 0) return 0;
-  const int chunks = std::max(1, std::min(c->plan_chunks > 0 ? c->plan_chunks : PLAN_CHUNKS, n_frames / PLAN_CHUNK_MIN));
+  const int chunks = c->plan_chunks > 0 ? std::max(1, std::min(c->plan_chunks, n_frames / PLAN_CHUNK_MIN)) : (n_frames >= PLAN_CHUNK_FROM ? PLAN_CHUNKS : 1);
   const size_t rec = compact ? sizeof(fsdp_compact_result) : sizeof(fsdp_frame_result);
   long long ids[PLAN_CHUNKS];
   int issued = 0, rc = 0;

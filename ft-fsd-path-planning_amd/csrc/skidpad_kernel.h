@@ -645,7 +645,10 @@ __device__ __forceinline__ void skid_finish_step(SkidState* st, const SkidTables
 // no wait can be for work that is not resident or finished.  With 1024 instances three steps put three wavefronts on every
 // SIMD, where one alone issues an FP64 instruction every 8.7 cycles and four together one every 4.6; the
 // kernel is held to 168 registers for that (144 spilled: 1 % slower alone, 8 % faster three to a SIMD than two at 256).
-__global__ void __launch_bounds__(64, 3) skid_path_kernel(int n_inst, SkidGroup G, SkidState* states, SkidTables T,
+#ifndef FSDP_SKID_PATH_WAVES
+#define FSDP_SKID_PATH_WAVES 3
+#endif
+__global__ void __launch_bounds__(64, FSDP_SKID_PATH_WAVES) skid_path_kernel(int n_inst, SkidGroup G, SkidState* states, SkidTables T,
                                                           const double* __restrict__ chord, uint32_t* sync) {
   __shared__ PathShared<WAVE> S;
   __shared__ uint32_t s_ticket, s_spins;

@@ -193,9 +193,10 @@ const char* fsdp_last_error(const fsdp_ctx* ctx); /* ctx may be NULL: last creat
  * Host buffers; does H2D, the kernels of a pass and D2H on the context's stream, then synchronises. */
 int fsdp_plan_batch(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
                     const double* poses, fsdp_frame_result* results);
-/* A batch of 2048 frames or more is pipelined inside the call: it is cut into up to four contiguous chunks of at least 1024
- * frames, each on a pass slot (HIP stream) of its own, so that one chunk's transfers run under the other chunks' kernels;
- * with page-locked buffers (fsdp_host_alloc / fsdp_host_register) the chunks are read and written in place.  Results do not
+/* A batch of 16 384 frames or more is pipelined inside the call: it is cut into four contiguous chunks, each on a pass slot
+ * (HIP stream) of its own, so that one chunk's transfers run under the other chunks' kernels (pageable buffers: -18 % of the
+ * call at 16 384 frames, -26 % at 65 536; below that size chunks only add launches: profiles/r06_plan_probe.txt); with
+ * page-locked buffers (fsdp_host_alloc / fsdp_host_register) the chunks are read and written in place.  Results do not
  * depend on the chunking (frames are independent).  The same call with compact records: */
 int fsdp_plan_batch_compact(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const double* cones_xyt,
                             const double* poses, const double* prev_paths /* or NULL */, fsdp_compact_result* results);
@@ -290,7 +291,7 @@ int fsdp_route_stats(fsdp_ctx* ctx, int* expect_big, int* expect_retry, long lon
  *   "always_route"    1: sort_big_kernel and path_retry_kernel with every pass (default: only when expected, see below)
  *   "no_sort128"      1: the sorting kernel's 255-cone state also for frames of up to 128 cones
  *   "retry_pack_min"  retry lists longer than this run four frames per wavefront in path_retry_kernel (default 512)
- *   "plan_chunks"     most chunks a blocking fsdp_plan_batch call is pipelined in (default 4; 1: the batch is one pass)
+ *   "plan_chunks"     k > 1: every blocking call is cut into up to k chunks of >= 512 frames; 1: never (default: four from 16 384 frames)
  *   "skid_group"      steps per launch of a skidpad replay that submits ahead (default: from the instance count)
  *   "skid_pack_min"   (instance, step) pairs from which a group of skidpad steps takes the packed kernels (default 2048)
  * Returns 1 on an unknown name or a value outside its range, or while tickets are outstanding. */

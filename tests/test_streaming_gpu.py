@@ -218,9 +218,9 @@ def test_compact_results_are_the_full_results_fields(pkg, golden_dir, unknown):
 
 @pytest.mark.parametrize("n", [2048, 2049, 4096, 5000])
 def test_a_blocking_call_pipelined_in_chunks_equals_one_pass(pkg, n):
-    """fsdp_plan_batch cuts a batch of 2048 frames or more into up to four chunks on pass slots of their own (include/fsdp.h): same
-    bytes as the batch in one pass (option "plan_chunks" = 1), pageable and page-locked, full and compact records, with previous
-    paths, and with frames that need the route kernels in some chunks only."""
+    """fsdp_plan_batch cuts a large batch into four chunks on pass slots of their own (include/fsdp.h; here forced for small ones with
+    option "plan_chunks" = 4): same bytes as the batch in one pass (option "plan_chunks" = 1), pageable and page-locked, full and compact
+    records, with previous paths, and with frames that need the route kernels in some chunks only."""
     off, cones, poses = pkg.synth.make_replay_batch(n, 100, 0.0, seed=70 + n % 7, color=False, frame_noise=0.3, random_pose=True)
     prev = np.random.default_rng(3).normal(size=(n, 40, 4))
     prev[:, :, 0] = np.abs(prev[:, :, 0]).cumsum(axis=1)
@@ -229,7 +229,7 @@ def test_a_blocking_call_pipelined_in_chunks_equals_one_pass(pkg, n):
     ref_prev = one.plan_batch(off, cones, poses, prev_paths=prev)
     assert one.route_stats()[1]  # the noisy set leaves the packed kernels
     one.close()
-    ctx = pkg.Context(device=0)
+    ctx = pkg.Context(device=0, options={"plan_chunks": 4})
     assert _same(ctx.plan_batch(off, cones, poses), ref)
     assert _same(ctx.plan_batch(off, cones, poses, prev_paths=prev), ref_prev)
     pin = (pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64))
