@@ -492,13 +492,14 @@ class Context:
                        None if prev is None else prev.ctypes.data, out.ctypes.data, ctypes.byref(t)), "fsdp_submit")
         return Ticket(int(t.value), out, None, (offsets, cones, poses, prev))
 
-    def submit_slice(self, lo: int, hi: int, offsets, cones, poses, prev, out) -> Ticket:
+    def submit_slice(self, lo: int, hi: int, offsets, cones, poses, prev, out, compact: bool = False) -> Ticket:
         """Frames [lo, hi) of a batch that is already in the ABI's layout (int32 offsets of the WHOLE batch, (N, 3) cones,
         (F, 4) poses, optional (F, 40, 4) previous paths, self.result_dtype out of the whole batch): the slice goes to fsdp_submit as
         pointers into those arrays (include/fsdp.h: cone_offsets[0] need not be 0) — nothing is copied or rebased on the host."""
         n = hi - lo
         t = ctypes.c_longlong(-1)
-        self._check(self._lib.fsdp_submit(self._h, n, offsets.ctypes.data + 4 * lo, cones.ctypes.data if len(cones) else None,
+        fn = self._lib.fsdp_submit_compact if compact else self._lib.fsdp_submit
+        self._check(fn(self._h, n, offsets.ctypes.data + 4 * lo, cones.ctypes.data if len(cones) else None,
                                           poses.ctypes.data + 32 * lo, None if prev is None else prev.ctypes.data + prev.strides[0] * lo,
                                           out.ctypes.data + out.strides[0] * lo, ctypes.byref(t)), "fsdp_submit")
         return Ticket(int(t.value), out, None, (offsets, cones, poses, prev))

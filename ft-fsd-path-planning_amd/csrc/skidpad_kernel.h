@@ -646,7 +646,7 @@ __device__ __forceinline__ void skid_finish_step(SkidState* st, const SkidTables
 // SIMD, where one alone issues an FP64 instruction every 8.7 cycles and four together one every 4.6; the
 // kernel is held to 168 registers for that (144 spilled: 1 % slower alone, 8 % faster three to a SIMD than two at 256).
 #ifndef FSDP_SKID_PATH_WAVES
-#define FSDP_SKID_PATH_WAVES 3
+#define FSDP_SKID_PATH_WAVES 2  // (3: 168 registers, 214 of them spilled, 384 B of scratch per lane; 2: 256 registers, 36 spilled, 112 B — same frames/s, profiles/r06_kernel_resources.txt)
 #endif
 __global__ void __launch_bounds__(64, FSDP_SKID_PATH_WAVES) skid_path_kernel(int n_inst, SkidGroup G, SkidState* states, SkidTables T,
                                                           const double* __restrict__ chord, uint32_t* sync) {

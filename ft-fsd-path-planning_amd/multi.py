@@ -134,15 +134,17 @@ class MultiPlanner:
         self._pool.close()
 
     # ---- one batch --------------------------------------------------------------------------------------------------
-    def _stage_and_submit(self, g, lo, hi, offsets, cones, poses, prev, out):
+    def _stage_and_submit(self, g, lo, hi, offsets, cones, poses, prev, out, compact=False):
         st = self._stage[g][self._turn[g] % len(self._stage[g])]
         self._turn[g] += 1
         o, c, p, q = st.load(offsets[lo : hi + 1], cones[offsets[lo] : offsets[hi]], poses[lo:hi], None if prev is None else prev[lo:hi])
-        return self.ctx[g].submit(o, c, p, q, out=out[lo:hi])
+        return self.ctx[g].submit(o, c, p, q, out=out[lo:hi], compact=compact)
 
-    def submit(self, offsets, cones, poses, prev_paths=None, out: np.ndarray | None = None) -> MultiTicket:
+    def submit(self, offsets, cones, poses, prev_paths=None, out: np.ndarray | None = None, compact: bool = False) -> MultiTicket:
         """Cut the batch, enqueue every shard on its GPU, return at once.  ``out``: page-locked RESULT_DTYPE array of the
         whole batch (``pinned_empty``); every GPU writes its range of it.  Default: a block of the planner's pool.
+        ``compact``: fsdp_compact_result records (path, sorted indices, status: ``Context.compact_dtype``, 1384 instead of 2408 bytes
+        per frame over PCIe).
 
         Contract: page-locked input arrays are NOT copied (the GPUs read their slices in place) — they, and ``out``, must stay
         untouched until ``collect``.  If a shard cannot be submitted, the shards already on their GPUs are waited for before the
@@ -154,9 +156,10 @@ class MultiPlanner:
         prev = None if prev_paths is None else self.ctx[0].pad_paths(prev_paths)
         if prev is not None and len(prev) != n:
             raise ValueError("prev_paths: one (horizon, 4) path per frame")
+        dt = self.ctx[0].compact_dtype if compact else self.ctx[0].result_dtype
         if out is None:
-            out = self._pool.get(n, self.ctx[0].result_dtype)
-        assert out.dtype == self.ctx[0].result_dtype and len(out) == n and out.flags.c_contiguous
+            out = self._pool.get(n, dt)
+        assert out.dtype == dt and len(out) == n and out.flags.c_contiguous
         ranges = [(g, lo, hi) for g, (lo, hi) in enumerate(shard_ranges(n, len(self.ctx))) if hi > lo]
         zero_copy = n > 0 and _capi.is_pinned(offsets) and _capi.is_pinned(poses) and (len(cones) == 0 or _capi.is_pinned(cones)) and (
             prev is None or _capi.is_pinned(prev))
@@ -165,7 +168,7 @@ class MultiPlanner:
             if zero_copy:
                 self.zero_copy_batches += 1
                 for g, lo, hi in ranges:
-                    parts.append((g, self.ctx[g].submit_slice(lo, hi, offsets, cones, poses, prev, out)))
+                    parts.append((g, self.ctx[g].submit_slice(lo, hi, offsets, cones, poses, prev, out, compact=compact)))
             elif len(ranges) > 1 and n >= self.STAGE_THREADS_MIN_FRAMES * len(ranges):
                 # pageable input: every context's worker copies its shard into page-locked staging and submits it; the caller's
                 # arrays are his again when submit returns
@@ -174,13 +177,13 @@ class MultiPlanner:
                     from concurrent.futures import ThreadPoolExecutor
 
                     self._workers = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"fsdp-stage-{g}") for g in range(len(self.ctx))]
-                futs = [(g, self._workers[g].submit(self._stage_and_submit, g, lo, hi, offsets, cones, poses, prev, out)) for g, lo, hi in ranges]
+                futs = [(g, self._workers[g].submit(self._stage_and_submit, g, lo, hi, offsets, cones, poses, prev, out, compact)) for g, lo, hi in ranges]
                 for g, f in futs:
                     parts.append((g, f.result()))
             else:
                 self.staged_batches += 1
                 for g, lo, hi in ranges:
-                    parts.append((g, self._stage_and_submit(g, lo, hi, offsets, cones, poses, prev, out)))
+                    parts.append((g, self._stage_and_submit(g, lo, hi, offsets, cones, poses, prev, out, compact)))
         except BaseException:
             # (round-5 advisor) shards already submitted write into `out` / read the caller's arrays: wait for them — and for the
             # workers still staging — before the block can go back to the pool and the exception to the caller
@@ -193,10 +196,10 @@ class MultiPlanner:
                     pass
             self._drain(parts)
             raise
-        dt = time.perf_counter() - t0
-        self.host_seconds += dt
+        el = time.perf_counter() - t0
+        self.host_seconds += el
         self.host_frames += n
-        return MultiTicket(parts, out, dt)
+        return MultiTicket(parts, out, el)
 
     def _drain(self, parts):
         """Wait for shards whose results nobody will read (error paths): errors of the wait itself are swallowed."""
@@ -217,12 +220,12 @@ class MultiPlanner:
                 raise
         return ticket.out
 
-    def plan_batch(self, offsets, cones, poses, prev_paths=None) -> np.ndarray:
+    def plan_batch(self, offsets, cones, poses, prev_paths=None, compact: bool = False) -> np.ndarray:
         """The bytes of ``Context.plan_batch`` / ``plan_batch_sequential`` over the whole batch, planned on all GPUs."""
-        return self.collect(self.submit(offsets, cones, poses, prev_paths))
+        return self.collect(self.submit(offsets, cones, poses, prev_paths, compact=compact))
 
     # ---- a stream of batches ----------------------------------------------------------------------------------------
-    def plan_stream(self, batches, depth: int | None = None):
+    def plan_stream(self, batches, depth: int | None = None, compact: bool = False):
         """Yield the results of an iterable of batches ``(offsets, cones, poses)`` in order, `depth` batches in flight on
         every GPU (default: two per pass slot — the contexts' ticket capacity: a slot's next batch is then already queued on
         its stream when the current one ends).  Every yielded array is the page-locked block its GPUs wrote; drop it (and
@@ -233,7 +236,7 @@ class MultiPlanner:
             for b in batches:
                 if len(inflight) == depth:
                     yield self.collect(inflight.pop(0))
-                inflight.append(self.submit(*b))
+                inflight.append(self.submit(*b, compact=compact))
             while inflight:
                 yield self.collect(inflight.pop(0))
         finally:

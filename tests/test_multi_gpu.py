@@ -67,6 +67,12 @@ def test_sharded_plan_batch_equals_one_context(pkg, config):
         prev = np.repeat(one.default_path()[None], len(poses), axis=0)
         prev[:, :, 1] += np.linspace(-0.5, 0.5, len(poses))[:, None]
         assert _same(mp.plan_batch(off, cones, poses, prev_paths=prev), one.plan_batch_sequential(off, cones, poses, prev)), (config, devs)
+        # compact records (fsdp_submit_compact on every shard): the same fields, pageable and page-locked (zero-copy slices)
+        want = one.plan_batch(off, cones, poses, compact=True)
+        assert all(np.array_equal(want[f], ref[f], equal_nan=True) for f in ("path", "left_idx", "right_idx", "status"))
+        assert _same(mp.plan_batch(off, cones, poses, compact=True), want), (config, devs)
+        pin = (pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64))
+        assert _same(mp.plan_batch(*pin, compact=True), want), (config, devs)
         mp.close()
 
 

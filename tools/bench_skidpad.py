@@ -22,7 +22,9 @@ import skidpad_support as sk  # noqa: E402
 
 pkg = importlib.import_module("ft-fsd-path-planning_amd")
 
-pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
+pkg._capi.DEFAULT_OPTIONS.update(pkg._capi.options_from_env())
+if os.environ.get("AB_LIB"):  # an experiment build (tools/build_variant.sh)
+    pkg._capi.LIB_PATH = Path(os.environ["AB_LIB"])  # FSDP_PACK / FSDP_PATH_MODE / ... of this tool's shell -> fsdp_set_option
 n_total = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 comm_ctx = pkg.Context(device=local_rank, mission=4)  # carries the communicator
