@@ -310,8 +310,8 @@ __device__ __forceinline__ int cones_for_other_side(MatchShared& S, const Params
   return no;
 }
 
-constexpr int MATCH_G = (MAX_MATCH < 32) ? 32 : 64;  // lanes per frame (>= MAX_MATCH + 1: the insertion work list is walked one cone per lane; wide build: the whole wavefront)
-static_assert(MATCH_G > MAX_MATCH, "matching walks its lists one cone per lane");
+constexpr int MATCH_G = (MAX_MATCH <= 32) ? 32 : 64;  // lanes per frame: the lists (<= MAX_MATCH cones incl. the virtual ones) are walked one cone per lane
+static_assert(MATCH_G >= MAX_MATCH, "matching walks its lists one cone per lane");
 // (four wavefronts per SIMD, 126 registers: measured +2 % frames/s over the two the allocator takes unasked)
 template <int G>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FSDP_MATCH_WAVES))) match_kernel(int n_frames, const int32_t* __restrict__ cone_offsets,

@@ -1402,7 +1402,11 @@ sort_kernel(int n_frames, const int32_t* __restrict__ cone_offsets, const double
 // arrays, neighbour lists and bit masks are half as long, which makes a frame SORT128_LDS and lets a SIMD hold
 // SORT128_WAVES wavefronts.
 #ifndef SORT128_WAVES
+#ifdef FSDP_WIDE_SHAPES
+#define SORT128_WAVES 3  // (the wide shapes' frame state is 12.4 KB: three wavefronts per SIMD by LDS anyway — at four by registers it spilled 48 of them)
+#else
 #define SORT128_WAVES 4
+#endif
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SORT128_WAVES)))
 sort_kernel_128(int n_frames, const int32_t* __restrict__ cone_offsets, const double* __restrict__ cones_xyt,

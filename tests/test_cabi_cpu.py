@@ -152,3 +152,21 @@ def test_vectorised_fma_is_correctly_rounded_and_reproduces_numpy_dot():
     for i in range(200):
         assert np.array_equal(acc._rotate(pts[i], theta[i]), [x[i], y[i]])           # np.dot(1-D, 2-D): gemv
         assert np.array_equal(acc._rotate(rows[i], theta[i]), np.column_stack([rx[i], ry[i]]))  # np.dot(2-D, 2-D): gemm
+
+
+def test_compact_record_mirror_and_option_plumbing(pkg):
+    """fsdp_compact_result (include/fsdp.h) and its NumPy mirror: 1384 bytes in the standard build (the bytes SURVEY 8d counts as a frame's
+    output), field offsets as the struct lays them out; and the library has no environment switch for its behaviour — the product sources
+    call getenv once (the path of librccl), tools translate their shell's FSDP_* variables through _capi.options_from_env."""
+    c = pkg._capi.STANDARD.compact_dtype
+    assert c.itemsize == 1384 and pkg.COMPACT_DTYPE is c
+    assert [c.fields[f][1] for f in ("path", "left_idx", "right_idx", "status", "n_left", "n_right", "path_fallback", "n_dense")] == [0, 1280, 1328, 1376, 1380, 1381, 1382, 1383]
+    assert pkg._capi.WIDE.compact_dtype.itemsize == 64 * 32 + 2 * 16 * 4 + 8
+    header = (ROOT / "include" / "fsdp.h").read_text()
+    for name in pkg._capi.OPTION_NAMES:
+        assert f'"{name}"' in header, name  # every option the binding knows is documented at fsdp_set_option
+    assert pkg._capi.options_from_env({"FSDP_PACK": "1", "FSDP_PATH_MODE": "split", "FSDP_FIT_G": "8", "FSDP_ALWAYS_ROUTE": "1"}) == {
+        "pack": 2, "path_mode": 2, "fit_g": 8, "always_route": 1}
+    assert pkg._capi.options_from_env({}) == {} and pkg._capi.DEFAULT_OPTIONS == {}
+    src = "".join(p.read_text() for p in (ROOT / "ft-fsd-path-planning_amd" / "csrc").glob("*") if p.suffix in (".h", ".hip"))
+    assert re.findall(r'getenv\("(\w+)"\)', src) == ["FSDP_RCCL_LIB"]
