@@ -91,7 +91,7 @@ COMPACT_DTYPE = STANDARD.compact_dtype
 # depend on them.  The library itself reads no environment variable for this; tools that are driven from a shell translate
 # theirs with options_from_env().
 DEFAULT_OPTIONS: dict = {}
-OPTION_NAMES = ("path_mode", "pack", "fit_g", "always_route", "no_sort128", "retry_pack_min", "plan_chunks", "skid_group", "skid_pack_min")
+OPTION_NAMES = ("path_mode", "pack", "fit_g", "always_route", "no_sort128", "retry_pack_min", "plan_chunks", "poison", "skid_group", "skid_pack_min")
 
 
 def options_from_env(env=None) -> dict:
@@ -104,7 +104,7 @@ def options_from_env(env=None) -> dict:
         out["path_mode"] = 1 if env["FSDP_PATH_MODE"] == "mono" else 2
     if "FSDP_PACK" in env:
         out["pack"] = 2 if int(env["FSDP_PACK"]) else 1
-    for name in ("fit_g", "retry_pack_min", "plan_chunks", "skid_group", "skid_pack_min"):
+    for name in ("fit_g", "retry_pack_min", "plan_chunks", "poison", "skid_group", "skid_pack_min"):
         if f"FSDP_{name.upper()}" in env:
             out[name] = int(env[f"FSDP_{name.upper()}"])
     for name in ("always_route", "no_sort128"):

@@ -177,6 +177,7 @@ struct fsdp_ctx {
   // from then on the kernel is part of every pass until ROUTE_DECAY (4096) passes in a row came back with an empty list.
   bool expect_big = false, expect_retry = false;
   int clean_big = 0, clean_retry = 0;
+  bool poison = false;        // "poison": every pass first fills its intermediates and scratch with 0xFF bytes (tests: no result depends on what a buffer held before)
   int plan_chunks = 0;        // "plan_chunks": most chunks a blocking fsdp_plan_batch call is pipelined in (0: up to 4; 1: never cut)
   bool always_route = false;  // "always_route": both route kernels with every pass (tests: results never depend on the prediction)
   long long reruns = 0;  // passes re-run by verify_pass (diagnostics: fsdp_route_stats)
@@ -628,6 +629,18 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
     if (int rc = launch_filter(c, q, in_, &fin)) return rc;
   const Inputs& in = filtered ? fin : in_;
   std::string names = std::string(sort128(c, in) ? "sort_kernel_128" : "sort_kernel") + ",";
+  if (c->poison) {
+    // (tests) whatever a previous pass, another batch or the allocator left in the slot's buffers is gone: 0xFF bytes = NaNs, -1 indices
+    const size_t m = (size_t)in.n_frames;
+    (void)hipMemsetAsync(q.d_sort, 0xff, sizeof(SortOut) * m, q.stream);
+    (void)hipMemsetAsync(q.d_match, 0xff, sizeof(MatchOut) * m, q.stream);
+    (void)hipMemsetAsync(q.d_path, 0xff, sizeof(PathOut) * m, q.stream);
+    (void)hipMemsetAsync(q.d_mid, 0xff, sizeof(PathMid) * m, q.stream);
+    (void)hipMemsetAsync(q.d_arena, 0xff, sizeof(double) * (size_t)ARENA_DOUBLES * m, q.stream);
+    (void)hipMemsetAsync(q.d_result, 0xff, sizeof(fsdp_frame_result) * m, q.stream);
+    (void)hipMemsetAsync(q.d_big + 1, 0xff, sizeof(int) * m, q.stream);
+    (void)hipMemsetAsync(q.d_retry + 1, 0xff, sizeof(int) * m, q.stream);
+  }
   mark(q, t);
   launch_sort(c, q, in);
   if (with_big) {
@@ -1605,6 +1618,8 @@ int fsdp_set_option(fsdp_ctx* c, const char* name, long long v) {
     if (v < 0 || v > 0x7fffffff) return bad();
     c->params.retry_pack_min = v == 0 ? 512 : (int)v;
     HIP_TRY(c, copy_sync(c, c->d_params, &c->params, sizeof(Params), hipMemcpyHostToDevice));
+  } else if (k == "poison") {
+    c->poison = v != 0;
   } else if (k == "plan_chunks") {
     if (v < 0 || v > PLAN_CHUNKS) return bad();
     c->plan_chunks = (int)v;

@@ -233,8 +233,10 @@ int fsdp_set_global_path(fsdp_ctx* ctx, const double* xy, int n);
  * caller's buffers must stay valid and untouched from submit to collect.  For the transfers to be asynchronous they must
  * be page-locked: allocate them with fsdp_host_alloc or pin existing memory with fsdp_host_register — the batch then
  * crosses PCIe inside kernels of the slot's own stream (one reads the inputs from host memory, the last one of the pass
- * writes the results into it; no copy-engine command at all); pageable buffers are accepted (inputs are then copied
- * before fsdp_submit returns, results pass through a pinned block and a memcpy in fsdp_collect).  prev_paths: (n_frames,FSDP_PATH_POINTS,4) as for fsdp_plan_batch_sequential, or NULL.
+ * writes the results into it; no copy-engine command at all); pageable buffers are accepted (inputs of up to 256 KB — a
+ * single frame, a car's handful — are packed into the ticket's own page-locked block by the host and then read in place,
+ * larger ones are copied before fsdp_submit returns; results are written by the pass's last kernel into the ticket's
+ * page-locked block and copied out by fsdp_collect).  prev_paths: (n_frames,FSDP_PATH_POINTS,4) as for fsdp_plan_batch_sequential, or NULL.
  * While tickets are outstanding the blocking / resident entry points of the context return an error. */
 void* fsdp_host_alloc(size_t bytes);            /* page-locked host memory (hipHostMalloc), NULL on failure */
 void fsdp_host_free(void* p);
@@ -259,7 +261,8 @@ int fsdp_upload(fsdp_ctx* ctx, int n_frames, const int32_t* cone_offsets, const 
 int fsdp_run(fsdp_ctx* ctx);      /* enqueue one pass over the resident batch on the next slot's stream (async) */
 int fsdp_sync(fsdp_ctx* ctx);     /* wait for all passes in flight */
 int fsdp_resident_frames(const fsdp_ctx* ctx); /* frames of the most recent pass (what fsdp_download writes) */
-int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results);
+int fsdp_download(fsdp_ctx* ctx, fsdp_frame_result* results); /* the results of the most recent fsdp_run pass (tickets and blocking calls
+                                                                  hand their results to the caller's buffer, not to the slot's block) */
 
 /* Pass overlap: depth d (<= FSDP_MAX_OVERLAP) gives the context d pass slots (HIP stream + buffers each); fsdp_submit
  * tickets and consecutive fsdp_run passes rotate through them, so the next passes fill the compute units that the slowest
@@ -292,6 +295,8 @@ int fsdp_route_stats(fsdp_ctx* ctx, int* expect_big, int* expect_retry, long lon
  *   "no_sort128"      1: the sorting kernel's 255-cone state also for frames of up to 128 cones
  *   "retry_pack_min"  retry lists longer than this run four frames per wavefront in path_retry_kernel (default 512)
  *   "plan_chunks"     k > 1: every blocking call is cut into up to k chunks of >= 512 frames; 1: never (default: four from 16 384 frames)
+ *   "poison"          1: every pass first fills its intermediates and scratch with 0xFF bytes (tests: no result depends on what a
+ *                     buffer held before — tests/test_streaming_gpu.py)
  *   "skid_group"      steps per launch of a skidpad replay that submits ahead (default: from the instance count)
  *   "skid_pack_min"   (instance, step) pairs from which a group of skidpad steps takes the packed kernels (default 2048)
  * Returns 1 on an unknown name or a value outside its range, or while tickets are outstanding. */

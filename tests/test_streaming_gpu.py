@@ -263,3 +263,28 @@ def test_options_are_checked_and_a_lone_ticket_is_planned_as_a_lone_batch(pkg):
     for i, t in enumerate(tickets):
         assert _same_fields(ctx.collect(t), ref), i  # (field by field: a NumPy copy of a record array does not carry the padding bytes)
     ctx.close()
+
+
+@pytest.mark.parametrize("params", [None, dict(use_unknown_cones=False)])
+def test_no_result_depends_on_what_a_buffer_held_before(pkg, golden_dir, params):
+    """Option "poison": every pass first overwrites its stage records, its 94 KB of scratch per frame, its result block and its hand-off
+    lists with 0xFF bytes.  The batches of the streaming tests (all routes, empty and single-frame batches), through slots that have
+    just planned other batches of other sizes, must return the same bytes as a context that never poisons — whatever a kernel reads, it
+    (or a kernel before it in the same pass) has written."""
+    batches = _batches(pkg, golden_dir)
+    plain = pkg.Context(device=0, params=params)
+    ref = [plain.plan_batch(*b) for b in batches]
+    plain.close()
+    ctx = pkg.Context(device=0, params=params, options={"poison": 1})
+    ctx.set_overlap(2)
+    order = list(range(len(batches))) + list(range(len(batches) - 1, -1, -1))
+    for k in order:
+        assert _same_fields(ctx.plan_batch(*batches[k]), ref[k]), k
+        assert _same_fields(ctx.collect(ctx.submit(*batches[k], compact=True)), _compact_of(pkg, ref[k])), k
+    # the packed kernels (what passes in flight run) and the one-kernel path stage on the same poisoned buffers
+    for options in ({"poison": 1, "path_mode": 2, "pack": 2}, {"poison": 1, "path_mode": 1}):
+        c2 = pkg.Context(device=0, params=params, options=options)
+        for k in (0, 2, 6, 10):
+            assert _same_fields(c2.plan_batch(*batches[k]), ref[k]), (options, k)
+        c2.close()
+    ctx.close()
