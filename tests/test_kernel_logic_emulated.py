@@ -106,7 +106,7 @@ def test_emulated_wide_build_with_parameters_beyond_the_standard_shapes(golden_d
     assert flips == [f for f in arc.flips("det") if f in set(idx.tolist())], flips
 
 
-@pytest.mark.parametrize("seed,frame,knots,group", [(511, 901, 68, 64), (516, 1001, 171, 64), (516, 1001, 171, 1004)])
+@pytest.mark.parametrize("seed,frame,knots,group", [(511, 901, 68, 64), (516, 1001, 171, 1004)])
 def test_refits_beyond_64_knots_are_planned_not_refused(seed, frame, knots, group):
     """FITPACK lets a smoothing spline take nest = m + 2k knots (utils/spline_fit.py:117 -> splprep); the exact kernels' last level (a
     frame with the whole wavefront: path_kernel<64>, the second level of path_retry_kernel) keeps 256 of them.  The two noisiest
