@@ -153,15 +153,26 @@ __device__ __forceinline__ double angle_between(double ax, double ay, double bx,
 // angle_between(...) < thr and > thr for a constant threshold, from the clipped cosine c: the arc cosine is monotone, so
 // the cosine decides unless it lies within 1e-9 of cos(thr) (nine orders of magnitude above acos' rounding) — only then
 // is the arc cosine itself evaluated and compared, like the reference does.  NaN (a zero vector) compares false everywhere.
+// The slow path is a CALL (FSDP_ACOS_COLD, default on): inlined, every predicate carried its own copy of the device library's acos, and
+// the polynomial's coefficients — shared by the copies, hoisted to the top of the sorting kernel — stayed alive across the whole kernel
+// and were spilled to scratch (18 registers, re-read by eight dependent scratch loads inside every acos of the cost phase).
+#ifndef FSDP_ACOS_COLD
+#define FSDP_ACOS_COLD 1
+#endif
+#if FSDP_ACOS_COLD && !defined(FSDP_EMU)
+__device__ __attribute__((noinline)) inline double acos_cold(double c) { return acos(c); }
+#else
+__device__ __forceinline__ double acos_cold(double c) { return acos(c); }
+#endif
 __device__ __forceinline__ bool acos_less(double c, double thr, double cos_thr) {
   if (c > cos_thr + 1e-9) return true;
   if (c < cos_thr - 1e-9) return false;
-  return acos(c) < thr;
+  return acos_cold(c) < thr;
 }
 __device__ __forceinline__ bool acos_greater(double c, double thr, double cos_thr) {
   if (c < cos_thr - 1e-9) return true;
   if (c > cos_thr + 1e-9) return false;
-  return acos(c) > thr;
+  return acos_cold(c) > thr;
 }
 constexpr double COS_60DEG = 0.5, COS_85DEG = 0.087155742747658173558, COS_150DEG = -0.86602540378443864676;
 
