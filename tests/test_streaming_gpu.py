@@ -288,3 +288,28 @@ def test_no_result_depends_on_what_a_buffer_held_before(pkg, golden_dir, params)
             assert _same_fields(c2.plan_batch(*batches[k]), ref[k]), (options, k)
         c2.close()
     ctx.close()
+
+
+def test_large_blocking_calls_are_chunked_by_default_and_wide_contexts_return_compact_records(pkg):
+    """(i) From 16 384 frames on a blocking call is pipelined in four chunks without being asked to (include/fsdp.h): same bytes as one
+    pass, pageable and page-locked.  (ii) The wide build's compact record (16-cone sides, 64-row paths: 2184 bytes) holds the full
+    record's fields."""
+    n = 16384 + 37
+    off, cones, poses = pkg.synth.make_replay_batch(n, 64, 0.15, seed=11, color=True)
+    one = pkg.Context(device=0, options={"plan_chunks": 1})
+    ref = one.plan_batch(off, cones, poses)
+    one.close()
+    ctx = pkg.Context(device=0)
+    assert _same(ctx.plan_batch(off, cones, poses), ref)
+    pin = (pkg.pinned_copy(off, np.int32), pkg.pinned_copy(cones, np.float64), pkg.pinned_copy(poses, np.float64))
+    assert _same_fields(ctx.plan_batch(*pin, compact=True), _compact_of(pkg, ref))
+    ctx.close()
+    wide = pkg.Context(device=0, params=dict(max_n_neighbors=8, max_length=16, mpc_prediction_horizon=64, mpc_path_length=30))
+    assert wide.shapes is pkg.WIDE and wide.compact_dtype.itemsize == 2184
+    o, c, p = pkg.synth.make_replay_batch(700, 64, 0.15, seed=12, color=False)
+    full = wide.plan_batch(o, c, p)
+    comp = wide.plan_batch(o, c, p, compact=True)
+    for f in ("path", "left_idx", "right_idx", "status", "n_left", "n_right", "path_fallback", "n_dense"):
+        assert np.array_equal(comp[f], full[f], equal_nan=True), f
+    assert (full["status"] == 0).mean() > 0.9 and int(full["n_left"].max()) > 12
+    wide.close()
