@@ -52,7 +52,7 @@ PASS_OVERLAP = 20  # passes in flight in the timed region (fsdp_set_overlap).  R
 # queues: 5.0 M); with 20-32 queues twenty passes in flight give 5.7-5.9 M frames/s over 20 passes and 6.3-6.4 M over 100, against
 # 5.4 / 6.1-6.2 M with ten; 24 or more passes collapse (0.7-3.6 M).  22 queues, not 32: the queues of all processes on a GPU add up,
 # and a second process next to 24+ of them crawls (the skidpad child of this script: 5.3 -> 0.5 M; it gets 8 of its own).
-STREAM_DEPTH = 20  # pass slots of the host -> host streaming leg (two tickets queue on each; 5.10 / 5.23 / 5.34 M frames/s at 10 / 16 / 20)
+STREAM_DEPTH = 20  # pass slots of the host -> host streaming leg (two tickets queue on each; profiles/r06_streaming_probe.txt)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -195,6 +195,19 @@ def streaming_leg(pkg, ctx, per_gpu: int, depth: int, n_batches: int, seed0: int
     bad = int(sum(int((o["status"] != 0).sum()) for o in outs_c))
     h2d = sum(a.nbytes for a in batches[0])
     ceiling = ctx.pcie_probe(h2d, 30)
+    # The yardstick of the stream: the SAME batches resident in HBM at the same depth (every track costs the GPU differently: 5.5-6.8 M
+    # frames/s; the headline's track is one of the cheaper ones) — a sample of six of them, sixty passes each, no PCIe in the clock.
+    res_rates = []
+    ctx.set_overlap(depth)
+    for k in range(0, n_batches, max(1, n_batches // 6))[:6]:
+        ctx.upload(*batches[k])
+        ctx.time_runs(depth, collect=False)
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.time_runs(60, collect=False)
+        ctx.sync()
+        res_rates.append(per_gpu * 60 / (time.perf_counter() - t1))
+    resident_same = float(np.mean(res_rates)) if res_rates else None
     return {
         "value": per_gpu * n_batches / el, "unit": "frames/s", "batches": n_batches, "frames_per_batch": per_gpu, "depth": depth,
         "seconds": el, "result_records": "compact (fsdp_compact_result, 1384 B)",
@@ -206,6 +219,8 @@ def streaming_leg(pkg, ctx, per_gpu: int, depth: int, n_batches: int, seed0: int
         "pcie_GBps": {"h2d": h2d * n_batches / el / 1e9, "d2h": outs_c[0].nbytes * n_batches / el / 1e9},
         # what the box's link carries for page-locked copies of a batch's size (fsdp_pcie_probe: hipMemcpyAsync, 30 x 12.7 MB)
         "pcie_ceiling_GBps": ceiling,
+        "resident_rate_of_the_same_batches": resident_same,
+        "stream_over_resident_same_batches": (per_gpu * n_batches / el / resident_same) if resident_same else None,
         "last_batch_equals_serial_plan_batch": bool(same), "compact_records_equal_full_records_fields": bool(same_c),
         "frames_with_nonzero_status": bad,
         "passes_rerun_for_routes": ctx.route_stats()[2] - reruns0,

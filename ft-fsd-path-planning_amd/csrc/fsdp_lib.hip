@@ -176,6 +176,7 @@ struct fsdp_ctx {
   // that turns out to need a kernel it did not get is re-run with it before anybody sees its results (verify_pass), and
   // from then on the kernel is part of every pass until ROUTE_DECAY (4096) passes in a row came back with an empty list.
   bool expect_big = false, expect_retry = false;
+  int retry_hint = 0;  // the longest retry list a recent pass reported (decays by an eighth per pass): sizes path_retry_kernel's grid
   int clean_big = 0, clean_retry = 0;
   bool poison = false;        // "poison": every pass first fills its intermediates and scratch with 0xFF bytes (tests: no result depends on what a buffer held before)
   int plan_chunks = 0;        // "plan_chunks": most chunks a blocking fsdp_plan_batch call is pipelined in (0: up to 4; 1: never cut)
@@ -564,9 +565,15 @@ static bool launch_path(fsdp_ctx* c, Work& q, const Inputs& in, StageEvents* t, 
   names += "path_prep_kernel<" + g + ">,fit_kernel<" + std::to_string(gf) + ">,path_finish_kernel<" + g + ">,";
   return split;
 }
-static void launch_path_retry(fsdp_ctx* c, Work& q, const Inputs& in) {
+// sized: by the retry lists the context's recent passes reported (fsdp_ctx::retry_hint) instead of for the worst case.  A pass that is
+// only EXPECTED to need the kernel (one batch in thousands had a frame for it) used to launch 1024 workgroups that found an empty list:
+// nothing to compute, but on a chip full of other passes' wavefronts the last of them was dispatched ~1.7 ms later, and the pass's
+// assembly waits for it (the stream of different batches: 355 such launches, 12 % of the summed kernel time of the trace).  The kernel
+// walks its list grid-stride: any grid plans any list.
+static void launch_path_retry(fsdp_ctx* c, Work& q, const Inputs& in, bool sized = false) {
   const double* prev = in.use_prev ? in.d_prev : nullptr;
-  const int rb = in.n_frames < 1024 ? in.n_frames : 1024;  // one wavefront per SIMD at most; blocks beyond the list's length return at once
+  int rb = in.n_frames < 1024 ? in.n_frames : 1024;  // one wavefront per SIMD at most; blocks beyond the list's length return at once
+  if (sized) rb = std::max(1, std::min(rb, 16 + 2 * c->retry_hint));
   hipLaunchKernelGGL(path_retry_kernel, dim3(rb), dim3(WAVE), 0, q.stream, in.d_poses, q.d_match, c->d_default_path, prev, c->d_gpath,
                      c->n_gpath, q.d_arena, q.d_path, q.d_retry, c->d_params);
 }
@@ -656,7 +663,7 @@ static int launch_pass(fsdp_ctx* c, Work& q, const Inputs& in_, StageEvents* t =
   if (with_retry) {
     mark(q, t, after_path);
     after_path = MARK_PLAIN;
-    launch_path_retry(c, q, in);
+    launch_path_retry(c, q, in, !force_routes || c->retry_hint > 0);
     names += "path_retry_kernel,";
   }
   mark(q, t, after_path);
@@ -708,6 +715,7 @@ static int verify_pass(fsdp_ctx* c, Work& q, bool* rerun = nullptr) {
       clean = 0;
     }
   };
+  c->retry_hint = std::max(tr.n_retry, c->retry_hint - (c->retry_hint + 7) / 8);
   if (q.pass_in == &c->res) {  // the resident batch: from now on its passes carry exactly the routes it needs
     c->expect_big = tr.n_big > 0;
     c->expect_retry = tr.n_retry > 0;
@@ -1458,6 +1466,7 @@ int fsdp_collect(fsdp_ctx* c, long long ticket) {
       };
       track(tr.n_big > 0, c->expect_big, c->clean_big);
       track(tr.n_retry > 0, c->expect_retry, c->clean_retry);
+      c->retry_hint = std::max(tr.n_retry, c->retry_hint - (c->retry_hint + 7) / 8);
       if ((tr.n_big > 0 && !t.ran_big) || (tr.n_retry > 0 && !t.ran_retry)) {
         // the whole ticket once more, with both route kernels, behind whatever the slot's stream holds by now (the
         // caller's buffers are still his to leave alone: the batch is read again from them)
